@@ -1,0 +1,48 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    import oracle
+    oracle.build()
+    return oracle.Oracle()
+
+
+@pytest.fixture(scope="session")
+def reference_lib():
+    import oracle
+    if not oracle.Reference.available():
+        pytest.skip("oracle/_ref/libfreesasa_ref.so not built (needs /root/reference)")
+    ref = oracle.Reference()
+    ref.lib.freesasa_set_verbosity(2)
+    return ref
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def read_bfactor_pdb(path):
+    """xyz, radius (occupancy column) and SASA (B-factor column) of the reference's golden
+    per-atom file tests/data/1ubq.B.pdb (fixed PDB columns)."""
+    xyz, rad, sasa = [], [], []
+    with open(path) as fh:
+        for line in fh:
+            if line.startswith("ATOM"):
+                xyz.append([float(line[30:38]), float(line[38:46]), float(line[46:54])])
+                rad.append(float(line[54:60]))
+                sasa.append(float(line[60:66]))
+    return np.array(xyz), np.array(rad), np.array(sasa)
