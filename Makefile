@@ -1,0 +1,54 @@
+# Build of the MI355X SASA engine (gfx950 only).
+#   make            -> freesasa_amd/lib/libfreesasa_amd.so (stand-alone drop-in library)
+#                      freesasa_amd/lib/libfreesasa_amd_seam.a (seam objects for a drop-in
+#                      build of the reference)
+#   make emu        -> tests/emu/libsasa_emu.so  (TESTS ONLY: the kernel phase functions
+#                      driven on the CPU; never linked into the product)
+#   make oracle     -> oracle/ (TESTS ONLY) ; make tools -> tools/libsasa_synth.so
+HIPCC   ?= /opt/rocm/bin/hipcc
+CC      ?= gcc
+CXX     ?= g++
+ARCH    ?= gfx950
+CSRC     = freesasa_amd/csrc
+LIBDIR   = freesasa_amd/lib
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function
+CFLAGS   = -O2 -std=gnu99 -fPIC -ffp-contract=off -Wall
+
+all: $(LIBDIR)/libfreesasa_amd.so $(LIBDIR)/libfreesasa_amd_seam.a
+
+$(LIBDIR)/gpu_engine.o: $(CSRC)/gpu_engine.hip $(CSRC)/sasa_kernels.h include/freesasa_gpu.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIBDIR)/seam.o: $(CSRC)/seam.c include/freesasa_amd.h include/freesasa_gpu.h
+	@mkdir -p $(LIBDIR)
+	$(CC) $(CFLAGS) -c $< -o $@
+
+$(LIBDIR)/testpoints.o: $(CSRC)/testpoints.c include/freesasa_gpu.h
+	@mkdir -p $(LIBDIR)
+	$(CC) $(CFLAGS) -c $< -o $@
+
+$(LIBDIR)/api.o: $(CSRC)/api.c include/freesasa_amd.h
+	@mkdir -p $(LIBDIR)
+	$(CC) $(CFLAGS) -c $< -o $@
+
+$(LIBDIR)/libfreesasa_amd.so: $(LIBDIR)/gpu_engine.o $(LIBDIR)/seam.o $(LIBDIR)/testpoints.o $(LIBDIR)/api.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
+
+$(LIBDIR)/libfreesasa_amd_seam.a: $(LIBDIR)/gpu_engine.o $(LIBDIR)/seam.o $(LIBDIR)/testpoints.o
+	ar rcs $@ $^
+
+emu: tests/emu/libsasa_emu.so
+tests/emu/libsasa_emu.so: tests/emu/emu.cpp $(CSRC)/sasa_kernels.h
+	$(CXX) -O2 -std=c++17 -fPIC -ffp-contract=off -DSASA_EMU -shared -o $@ tests/emu/emu.cpp -lm
+
+oracle:
+	$(MAKE) -C oracle all
+tools:
+	$(MAKE) -C tools
+
+clean:
+	rm -rf $(LIBDIR) tests/emu/libsasa_emu.so
+	$(MAKE) -C oracle clean
+	$(MAKE) -C tools clean
+.PHONY: all emu oracle tools clean

@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py — atoms/sec of the Lee-Richards hot path (20 slices, probe 1.4 A) on MI355X.
+
+One "step" = one pass of the whole hot path (cell sort -> fused neighbor + L&R kernel ->
+per-atom SASA and per-structure totals) over one batch of synthetic structures that is
+already resident in HBM.  Workload: BASELINE.json configs[2]'s batch geometry (1000
+random-coil structures x 10 000 atoms, seeds 1000+k) at the metric's parameters (L&R, 20
+slices, probe 1.4 A, fp64).  Multi-GPU: every rank owns its own 1000 structures (weak
+scaling, independent structures, no collective on the data path); the timed region is
+bracketed by barrier + synchronize and the MAX over ranks is reported.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--structs S] [--atoms A]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     — achieved = ALGORITHMIC bytes (40 B/atom: x,y,z,R in, SASA out) of the dominant
+                 kernel (k_lr_tile) / its HIP-event duration measured live on the launch stream;
+  cpu_baseline — the real reference (oracle/_ref, kind "reference") or the oracle port, timed on
+                 this box's host cores on a bounded sample of the same batch.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_ATOM = 40.0  # read x,y,z,R (32 B) + write sasa (8 B), fp64
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+FP64_VECTOR_PEAK_TFLOPS = 78.6
+
+
+def cpu_baseline(xyz, r, offs, gpu_sasa, budget_s=12.0):
+    """Reference CPU path on this box's cores: one structure per host thread, n_threads=1 each
+    (the library is re-entrant; BASELINE.md §4 mode 2), on the first S structures of the batch."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    import oracle
+    cores = os.cpu_count() or 1
+    if oracle.Reference.available():
+        ref, kind = oracle.Reference(), "reference"
+
+        def run(k):
+            sl = slice(offs[k], offs[k + 1])
+            return ref.calc_coord(xyz[sl], r[sl], oracle.LEE_RICHARDS, 1.4, n_slices=20, n_threads=1)[0]
+    else:
+        orc, kind = oracle.Oracle(), "port"
+
+        def run(k):
+            sl = slice(offs[k], offs[k + 1])
+            return orc.lee_richards(xyz[sl], r[sl], 1.4, 20)
+    t0 = time.perf_counter()
+    first = run(0)
+    t1 = time.perf_counter() - t0
+    n_structs = len(offs) - 1
+    sample = int(max(1, min(n_structs, budget_s * cores / max(t1, 1e-6))))
+    workers = min(cores, sample)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        res = list(ex.map(run, range(sample)))
+    dt = time.perf_counter() - t0
+    atoms = int(offs[sample])
+    err = max(float(np.max(np.abs(res[k] - gpu_sasa[offs[k]:offs[k + 1]]))) for k in range(sample))
+    del first
+    return {"value": atoms / dt, "unit": "atoms/s", "cores": workers, "kind": kind,
+            "sample": f"first {sample} of {n_structs} structures ({atoms} atoms), one structure per "
+                      f"host thread, n_threads=1 each, L&R 20 slices; {dt:.2f} s wall; "
+                      f"single-thread rate {len(res[0]) / t1:.0f} atoms/s"}, err
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--structs", type=int, default=1000, help="structures per GPU")
+    ap.add_argument("--atoms", type=int, default=10000, help="atoms per structure")
+    ap.add_argument("--slices", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import freesasa_amd as fa
+    import tools
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    # this rank's shard: its own independent structures (seeds are disjoint across ranks)
+    xyz, r, offs = tools.coil_batch(args.structs, args.atoms, seed0=1000 + rank * args.structs)
+    n_atoms = int(offs[-1])
+    d_xyz = torch.from_numpy(xyz).to(dev)
+    d_r = torch.from_numpy(r).to(dev)
+    d_sasa = torch.empty(n_atoms, dtype=torch.float64, device=dev)
+    d_tot = torch.empty(args.structs, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    stream = torch.cuda.Stream(device=dev)      # the engine launches on this torch stream
+    torch.cuda.set_stream(stream)
+    ctx = fa.GpuContext(local_rank, stream=stream.cuda_stream, timing=True)
+
+    def step():
+        ctx.lee_richards(d_xyz.data_ptr(), d_r.data_ptr(), offs, d_sasa.data_ptr(), d_tot.data_ptr(),
+                         probe=1.4, n_slices=args.slices)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    k_ms, prep_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        st = ctx.stats()
+        k_ms.append(st["ms_kernel"])
+        prep_ms.append(st["ms_prep"])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    st = ctx.stats()
+
+    if rank == 0:
+        total_atoms = n_atoms * world * args.steps
+        value = total_atoms / elapsed
+        kern_s = float(np.mean(k_ms)) * 1e-3
+        achieved = ALGO_BYTES_PER_ATOM * n_atoms / kern_s / 1e9 if kern_s > 0 else None
+        out = {
+            "metric": "atoms/sec SASA (L&R 20 slices)" if args.slices == 20 else f"atoms/sec SASA (L&R {args.slices} slices)",
+            "value": value, "unit": "atoms/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.structs} synthetic random-coil structures x {args.atoms} atoms per GPU "
+                                   f"(BASELINE configs[2] batch geometry, seeds 1000+k), Lee-Richards "
+                                   f"{args.slices} slices, probe 1.4 A, inputs resident in HBM",
+                       "structures_per_gpu": args.structs, "atoms_per_structure": args.atoms,
+                       "n_slices": args.slices, "probe_radius": 1.4,
+                       "parallelism": f"{world} x independent structure shards (no collective)",
+                       "max_neighbors_per_atom": st["max_neighbors"], "fallback_tiles": st["fallback_tiles"],
+                       "tile_atoms": st["tile_atoms"], "block_threads": st["block_threads"],
+                       "lds_bytes_per_block": st["lds_bytes"], "cells": st["n_cells"]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": None,
+                         "kernel": "k_lr_tile", "kernel_ms": 1e3 * kern_s, "prep_ms": float(np.mean(prep_ms)),
+                         "kernel_atoms_per_s": n_atoms / kern_s if kern_s > 0 else None,
+                         "note": "nominal HBM roofline per north_star (40 B/atom); the kernel is fp64-VALU bound, "
+                                 "see DESIGN.md"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, err = cpu_baseline(xyz, r, offs, d_sasa.cpu().numpy())
+            out["cpu_baseline"] = base
+            out["max_abs_dsasa_vs_cpu"] = err
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

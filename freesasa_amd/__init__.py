@@ -1,0 +1,197 @@
+"""freesasa_amd — thin ctypes front-end of libfreesasa_amd.so (the MI355X SASA engine).
+
+The product is the C library (include/freesasa_amd.h = the reference's calculation API,
+include/freesasa_gpu.h = the additive batch API).  This module only loads it and wraps the
+C entry points for the tests, the bench and Python callers; it contains no SASA arithmetic
+and no CPU fallback — if the library or a HIP device is missing, calls fail loudly.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB_PATH = os.path.join(HERE, "lib", "libfreesasa_amd.so")
+
+LEE_RICHARDS, SHRAKE_RUPLEY = 0, 1
+SUCCESS, FAIL, WARN = 0, -1, -2
+V_NORMAL, V_NOWARNINGS, V_SILENT, V_DEBUG = 0, 1, 2, 3
+
+_dp, _ip, _lp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int64)
+
+
+class Parameters(C.Structure):
+    """freesasa_parameters (include/freesasa_amd.h; reference src/freesasa.h:232-238)."""
+    _fields_ = [("alg", C.c_int), ("probe_radius", C.c_double),
+                ("shrake_rupley_n_points", C.c_int), ("lee_richards_n_slices", C.c_int),
+                ("n_threads", C.c_int)]
+
+
+class Result(C.Structure):
+    """freesasa_result (reference src/freesasa.h:267-272)."""
+    _fields_ = [("total", C.c_double), ("sasa", _dp), ("n_atoms", C.c_int),
+                ("parameters", Parameters)]
+
+
+class CoordT(C.Structure):
+    """coord_t (reference src/coord.h:26-38)."""
+    _fields_ = [("n", C.c_int), ("is_linked", C.c_int), ("xyz", _dp)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_atoms", C.c_longlong), ("n_cells", C.c_longlong), ("n_structs", C.c_int),
+                ("max_neighbors", C.c_int), ("fallback_tiles", C.c_int), ("tile_atoms", C.c_int),
+                ("block_threads", C.c_int), ("lds_bytes", C.c_int), ("ms_prep", C.c_double),
+                ("ms_kernel", C.c_double), ("ms_total", C.c_double)]
+
+
+_lib = None
+
+
+def build():
+    """Compile the library in-tree (hipcc --offload-arch=gfx950; works without a GPU)."""
+    subprocess.run(["make", "-C", ROOT, "all"], check=True, stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OSError(f"{LIB_PATH} is not built (run `make` or __graft_entry__.build()); "
+                          "freesasa_amd has no pure-Python or CPU path")
+        L = C.CDLL(LIB_PATH)
+        L.freesasa_calc_coord.argtypes = [_dp, _dp, C.c_int, C.POINTER(Parameters)]
+        L.freesasa_calc_coord.restype = C.POINTER(Result)
+        L.freesasa_calc.argtypes = [C.POINTER(CoordT), _dp, C.POINTER(Parameters)]
+        L.freesasa_calc.restype = C.POINTER(Result)
+        L.freesasa_calc_structure.argtypes = [C.c_void_p, C.POINTER(Parameters)]
+        L.freesasa_calc_structure.restype = C.POINTER(Result)
+        L.freesasa_result_free.argtypes = [C.POINTER(Result)]
+        L.freesasa_result_free.restype = None
+        L.freesasa_lee_richards.argtypes = [_dp, C.POINTER(CoordT), _dp, C.POINTER(Parameters)]
+        L.freesasa_shrake_rupley.argtypes = [_dp, C.POINTER(CoordT), _dp, C.POINTER(Parameters)]
+        L.freesasa_set_verbosity.argtypes = [C.c_int]
+        L.freesasa_get_verbosity.restype = C.c_int
+        L.freesasa_gpu_device_count.restype = C.c_int
+        L.freesasa_gpu_ctx_create.argtypes = [C.c_int, C.c_void_p]
+        L.freesasa_gpu_ctx_create.restype = C.c_void_p
+        L.freesasa_gpu_ctx_destroy.argtypes = [C.c_void_p]
+        L.freesasa_gpu_ctx_destroy.restype = None
+        L.freesasa_gpu_ctx_set_timing.argtypes = [C.c_void_p, C.c_int]
+        L.freesasa_gpu_ctx_set_timing.restype = None
+        L.freesasa_gpu_ctx_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.freesasa_gpu_ctx_get_stats.restype = None
+        L.freesasa_gpu_ctx_last_error.argtypes = [C.c_void_p]
+        L.freesasa_gpu_ctx_last_error.restype = C.c_char_p
+        L.freesasa_gpu_lr_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, _lp, C.c_int,
+                                                C.c_double, C.c_int, C.c_void_p, C.c_void_p]
+        L.freesasa_gpu_sr_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, _lp, C.c_int,
+                                                C.c_double, C.c_int, _dp, C.c_void_p, C.c_void_p,
+                                                C.c_void_p]
+        L.freesasa_gpu_test_points.argtypes = [C.c_int, _dp]
+        L.freesasa_gpu_test_points.restype = None
+        L.freesasa_gpu_calc_batch.argtypes = [_dp, _dp, _lp, C.c_int, C.c_int, C.c_double, C.c_int,
+                                              _dp, _ip, _dp, C.c_int, C.c_char_p, C.c_int]
+        _lib = L
+    return _lib
+
+
+def device_count():
+    return lib().freesasa_gpu_device_count()
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def calc_coord(xyz, radii, alg=LEE_RICHARDS, probe=1.4, n_points=100, n_slices=20, n_threads=1):
+    """freesasa_calc_coord(): returns (per-atom sasa, total) or raises on NULL."""
+    xyz, radii = _f64(xyz).reshape(-1), _f64(radii)
+    p = Parameters(alg, probe, n_points, n_slices, n_threads)
+    res = lib().freesasa_calc_coord(xyz.ctypes.data_as(_dp), radii.ctypes.data_as(_dp),
+                                    radii.size, C.byref(p))
+    if not res:
+        raise RuntimeError("freesasa_calc_coord returned NULL (see the library's error output)")
+    sasa = np.ctypeslib.as_array(res.contents.sasa, (radii.size,)).copy()
+    total = res.contents.total
+    lib().freesasa_result_free(res)
+    return sasa, total
+
+
+def calc_batch(xyz, radii, offsets, alg=LEE_RICHARDS, probe=1.4, resolution=20, device=-1):
+    """freesasa_gpu_calc_batch() on host arrays: (sasa, counts-or-None, totals)."""
+    xyz, radii = _f64(xyz).reshape(-1), _f64(radii)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    n, ns = radii.size, offsets.size - 1
+    sasa, totals = np.empty(n), np.empty(ns)
+    counts = np.empty(n, dtype=np.int32) if alg == SHRAKE_RUPLEY else None
+    err = C.create_string_buffer(512)
+    ret = lib().freesasa_gpu_calc_batch(xyz.ctypes.data_as(_dp), radii.ctypes.data_as(_dp),
+                                        offsets.ctypes.data_as(_lp), ns, alg, probe, resolution,
+                                        sasa.ctypes.data_as(_dp),
+                                        counts.ctypes.data_as(_ip) if counts is not None else None,
+                                        totals.ctypes.data_as(_dp), device, err, 512)
+    if ret:
+        raise RuntimeError("freesasa_gpu_calc_batch: " + err.value.decode())
+    return sasa, counts, totals
+
+
+def test_points(n_points):
+    tp = np.empty(3 * n_points)
+    lib().freesasa_gpu_test_points(n_points, tp.ctypes.data_as(_dp))
+    return tp.reshape(n_points, 3)
+
+
+class GpuContext:
+    """Device-resident batches: pointers are raw device addresses (e.g. tensor.data_ptr())."""
+
+    def __init__(self, device=0, stream=None, timing=False):
+        self._h = lib().freesasa_gpu_ctx_create(device, C.c_void_p(stream) if stream else None)
+        if not self._h:
+            raise RuntimeError("freesasa_gpu_ctx_create failed: no usable HIP device "
+                               "(libfreesasa_amd has no CPU path)")
+        if timing:
+            lib().freesasa_gpu_ctx_set_timing(self._h, 1)
+        self._tp = {}
+
+    def close(self):
+        if self._h:
+            lib().freesasa_gpu_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def error(self):
+        return lib().freesasa_gpu_ctx_last_error(self._h).decode()
+
+    def stats(self):
+        s = Stats()
+        lib().freesasa_gpu_ctx_get_stats(self._h, C.byref(s))
+        return {k: getattr(s, k) for k, _ in Stats._fields_}
+
+    def lee_richards(self, d_xyz, d_radii, offsets, d_sasa, d_totals=0, probe=1.4, n_slices=20):
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        ret = lib().freesasa_gpu_lr_batch_dev(self._h, d_xyz, d_radii, offsets.ctypes.data_as(_lp),
+                                              offsets.size - 1, probe, n_slices, d_sasa,
+                                              d_totals or None)
+        if ret:
+            raise RuntimeError("freesasa_gpu_lr_batch_dev: " + self.error())
+
+    def shrake_rupley(self, d_xyz, d_radii, offsets, d_sasa, d_counts=0, d_totals=0, probe=1.4,
+                      n_points=100):
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        if n_points not in self._tp:
+            self._tp[n_points] = np.ascontiguousarray(test_points(n_points).reshape(-1))
+        tp = self._tp[n_points]
+        ret = lib().freesasa_gpu_sr_batch_dev(self._h, d_xyz, d_radii, offsets.ctypes.data_as(_lp),
+                                              offsets.size - 1, probe, n_points,
+                                              tp.ctypes.data_as(_dp), d_sasa, d_counts or None,
+                                              d_totals or None)
+        if ret:
+            raise RuntimeError("freesasa_gpu_sr_batch_dev: " + self.error())

@@ -1,0 +1,535 @@
+/*
+ * gpu_engine.hip — __global__ wrappers around the phase functions of sasa_kernels.h, the
+ * per-device workspace, the launch sequence of one batch, and the additive C-ABI of
+ * include/freesasa_gpu.h.  gfx950 only; no CPU path: without a HIP device every entry
+ * point fails with a message.
+ */
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <mutex>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "../../include/freesasa_gpu.h"
+#include "sasa_kernels.h"
+
+using namespace sasa;
+
+/* ------------------------------------------------------------------ kernels */
+
+__global__ __launch_bounds__(SASA_PIPE_B) void k_bounds(PipeArgs a)
+{
+    __shared__ double red[7 * SASA_PIPE_B];
+    bounds_phase0(a, red, blockIdx.x, threadIdx.x, SASA_PIPE_B);
+    __syncthreads();
+    bounds_phase1(a, red, blockIdx.x, threadIdx.x, SASA_PIPE_B);
+}
+
+__global__ __launch_bounds__(SASA_PIPE_B) void k_cell_base(PipeArgs a)
+{
+    __shared__ long long part[SASA_PIPE_B];
+    cellbase_phase0(a, part, threadIdx.x, SASA_PIPE_B);
+    __syncthreads();
+    cellbase_phase1(a, part, threadIdx.x, SASA_PIPE_B);
+    __syncthreads();
+    cellbase_phase2(a, part, threadIdx.x, SASA_PIPE_B);
+}
+
+__global__ __launch_bounds__(SASA_PIPE_B) void k_count(PipeArgs a)
+{
+    count_atom(a, blockIdx.x * SASA_PIPE_B + threadIdx.x);
+}
+
+__global__ __launch_bounds__(SASA_PIPE_B) void k_scan1(PipeArgs a, long long n)
+{
+    __shared__ int part[SASA_PIPE_B];
+    scan1_phase0(a, n, part, blockIdx.x, threadIdx.x, SASA_PIPE_B);
+    __syncthreads();
+    scan1_phase1(a, part, blockIdx.x, threadIdx.x, SASA_PIPE_B);
+}
+
+__global__ __launch_bounds__(SASA_PIPE_B) void k_scan2(PipeArgs a, int nblk)
+{
+    __shared__ int part[SASA_PIPE_B];
+    scan2_phase0(a, nblk, part, threadIdx.x, SASA_PIPE_B);
+    __syncthreads();
+    scan2_phase1(part, threadIdx.x, SASA_PIPE_B);
+    __syncthreads();
+    scan2_phase2(a, nblk, part, threadIdx.x, SASA_PIPE_B);
+}
+
+__global__ __launch_bounds__(SASA_PIPE_B) void k_scan3(PipeArgs a, long long n)
+{
+    __shared__ int part[SASA_PIPE_B];
+    scan3_phase0(a, n, part, blockIdx.x, threadIdx.x, SASA_PIPE_B);
+    __syncthreads();
+    scan3_phase1(part, threadIdx.x, SASA_PIPE_B);
+    __syncthreads();
+    scan3_phase2(a, n, part, blockIdx.x, threadIdx.x, SASA_PIPE_B);
+}
+
+__global__ __launch_bounds__(SASA_PIPE_B) void k_scatter(PipeArgs a)
+{
+    scatter_atom(a, blockIdx.x * SASA_PIPE_B + threadIdx.x);
+}
+
+__global__ __launch_bounds__(64) void k_totals(const double *sasa, const int64_t *offsets, int n_structs, double *totals)
+{
+    totals_struct(sasa, offsets, n_structs, totals, blockIdx.x * 64 + threadIdx.x);
+}
+
+template <int B, bool GLOBAL>
+__global__ __launch_bounds__(B) void k_lr_tile(TileArgs a, int items)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    TileMem m = tile_carve<GLOBAL>(a, smem, items, B, blockIdx.x);
+    const int n_work = GLOBAL ? *a.ovf_count : ((a.n_tiles + 7) >> 3) << 3;
+    for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
+        const int tile = GLOBAL ? a.work_tiles[w] : xcd_tile(w, a.n_tiles);
+        if (tile >= a.n_tiles) continue; /* uniform per workgroup */
+        tile_phase_load(a, m, tile, tid);
+        __syncthreads();
+        tile_phase_neighbors(a, m, tile, tid, B);
+        __syncthreads();
+        tile_phase_offsets<GLOBAL>(a, m, tile, tid);
+        __syncthreads();
+        lr_phase_beta(a, m, tid, B);
+        lr_phase_ztab(a, m, tid);
+        __syncthreads();
+        lr_phase_rank(a, m, tid, B);
+        __syncthreads();
+        lr_phase_slices(a, m, tile, tid, B);
+        __syncthreads();
+        lr_phase_store<GLOBAL>(a, m, tile, tid, B);
+        __syncthreads();
+    }
+}
+
+template <int B, bool GLOBAL>
+__global__ __launch_bounds__(B) void k_sr_tile(TileArgs a, int items)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    TileMem m = tile_carve<GLOBAL>(a, smem, items, B, blockIdx.x);
+    const int n_work = GLOBAL ? *a.ovf_count : ((a.n_tiles + 7) >> 3) << 3;
+    for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
+        const int tile = GLOBAL ? a.work_tiles[w] : xcd_tile(w, a.n_tiles);
+        if (tile >= a.n_tiles) continue;
+        tile_phase_load(a, m, tile, tid);
+        __syncthreads();
+        tile_phase_neighbors(a, m, tile, tid, B);
+        __syncthreads();
+        tile_phase_offsets<GLOBAL>(a, m, tile, tid);
+        __syncthreads();
+        sr_phase_pairs(a, m, tid, B);
+        __syncthreads();
+        sr_phase_points(a, m, tile, tid, B);
+        __syncthreads();
+        sr_phase_store(a, m, tile, tid);
+        __syncthreads();
+    }
+}
+
+/* ------------------------------------------------------------------ context */
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct freesasa_gpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool timing = false;
+    char err[512] = {0};
+    freesasa_gpu_stats stats = {};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    /* workspace */
+    DevBuf offsets, grid, ncells, sid, cell_of, rank, cell_start, blk_sums;
+    DevBuf sx, sy, sz, sr, s_orig, s_cell, s_struct;
+    DevBuf status, ovf_tiles, unit_pts, slab;
+    std::vector<int64_t> offsets_host; /* last uploaded offsets */
+    /* host staging for freesasa_gpu_calc_batch */
+    DevBuf h_xyz, h_radii, h_sasa, h_counts, h_totals;
+    long long max_cells = 1LL << 30;
+};
+
+static int ctx_fail(freesasa_gpu_ctx *c, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(c->err, sizeof c->err, fmt, ap);
+    va_end(ap);
+    return -1;
+}
+
+#define HIP_TRY(c, call)                                                                      \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return ctx_fail((c), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+static int ensure(freesasa_gpu_ctx *c, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return 0;
+    if (b.p) HIP_TRY(c, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = bytes + bytes / 4 + 256; /* slack: trajectories grow/shrink a little */
+    HIP_TRY(c, hipMalloc(&b.p, want));
+    b.cap = want;
+    return 0;
+}
+
+extern "C" int freesasa_gpu_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" freesasa_gpu_ctx *freesasa_gpu_ctx_create(int device, void *stream)
+{
+    int n = freesasa_gpu_device_count();
+    if (n <= 0 || device >= n) return nullptr;
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) return nullptr;
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    freesasa_gpu_ctx *c = new freesasa_gpu_ctx();
+    c->device = device;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete c;
+            return nullptr;
+        }
+        c->own_stream = true;
+    }
+    for (int k = 0; k < 4; ++k)
+        if (hipEventCreate(&c->ev[k]) != hipSuccess) {
+            delete c;
+            return nullptr;
+        }
+    return c;
+}
+
+extern "C" void freesasa_gpu_ctx_destroy(freesasa_gpu_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf *all[] = {&c->offsets, &c->grid, &c->ncells, &c->sid, &c->cell_of, &c->rank, &c->cell_start,
+                     &c->blk_sums, &c->sx, &c->sy, &c->sz, &c->sr, &c->s_orig, &c->s_cell, &c->s_struct,
+                     &c->status, &c->ovf_tiles, &c->unit_pts, &c->slab,
+                     &c->h_xyz, &c->h_radii, &c->h_sasa, &c->h_counts, &c->h_totals};
+    for (DevBuf *b : all)
+        if (b->p) (void)hipFree(b->p);
+    for (int k = 0; k < 4; ++k)
+        if (c->ev[k]) (void)hipEventDestroy(c->ev[k]);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" void freesasa_gpu_ctx_set_timing(freesasa_gpu_ctx *c, int enable) { c->timing = enable != 0; }
+extern "C" void freesasa_gpu_ctx_get_stats(const freesasa_gpu_ctx *c, freesasa_gpu_stats *out) { *out = c->stats; }
+extern "C" const char *freesasa_gpu_ctx_last_error(const freesasa_gpu_ctx *c) { return c ? c->err : "no context"; }
+
+/* ------------------------------------------------------------------ launch configuration */
+
+
+template <bool GLOBAL>
+static hipError_t launch_lr(const TileCfg &c, const TileArgs &t, int grid, size_t lds, hipStream_t s)
+{
+    if (c.B == 320)
+        hipLaunchKernelGGL((k_lr_tile<320, GLOBAL>), dim3(grid), dim3(320), lds, s, t, c.items);
+    else
+        hipLaunchKernelGGL((k_lr_tile<256, GLOBAL>), dim3(grid), dim3(256), lds, s, t, c.items);
+    return hipGetLastError();
+}
+template <bool GLOBAL>
+static hipError_t launch_sr(const TileCfg &c, const TileArgs &t, int grid, size_t lds, hipStream_t s)
+{
+    if (c.B == 320)
+        hipLaunchKernelGGL((k_sr_tile<320, GLOBAL>), dim3(grid), dim3(320), lds, s, t, c.items);
+    else
+        hipLaunchKernelGGL((k_sr_tile<256, GLOBAL>), dim3(grid), dim3(256), lds, s, t, c.items);
+    return hipGetLastError();
+}
+
+static const char *err_text(int code)
+{
+    switch (code) {
+    case ERR_BAD_RADIUS: return "cell size 2*max(radius+probe) is not positive and finite";
+    case ERR_GRID_TOO_BIG: return "cell list too large for the coordinate extent (out of memory in the reference)";
+    case ERR_BAD_COORD: return "non-finite coordinate";
+    case ERR_NEIGHBOR_CAP: return "an atom has more neighbors than the GPU fallback path supports (4096 per atom, 16384 per tile)";
+    case ERR_STACK_CAP: return "more disjoint arcs in one slice than the GPU fallback path supports";
+    default: return "unknown device-side error";
+    }
+}
+
+/* ------------------------------------------------------------------ one batch */
+
+static int run_batch(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, const double *d_radii,
+                     const int64_t *offsets, int n_structs, double probe, int resolution,
+                     const double *unit_points, double *d_sasa, int *d_counts, double *d_totals)
+{
+    c->err[0] = 0;
+    if (!d_xyz || !d_radii || !offsets || !d_sasa) return ctx_fail(c, "null argument");
+    if (n_structs <= 0) return ctx_fail(c, "n_structs must be > 0");
+    if (resolution <= 0) return ctx_fail(c, "resolution must be > 0");
+    if (offsets[0] != 0) return ctx_fail(c, "offsets[0] must be 0");
+    for (int s = 0; s < n_structs; ++s)
+        if (offsets[s + 1] < offsets[s]) return ctx_fail(c, "offsets must be non-decreasing");
+    const int64_t n64 = offsets[n_structs];
+    if (n64 <= 0) return ctx_fail(c, "empty batch");
+    if (n64 > (int64_t)1 << 30) return ctx_fail(c, "batch too large (max 2^30 atoms per call)");
+    const int n = (int)n64;
+
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const size_t nb = (size_t)n;
+
+    /* workspace */
+    if (ensure(c, c->offsets, sizeof(int64_t) * ((size_t)n_structs + 1)) || ensure(c, c->grid, sizeof(GridS) * (size_t)n_structs) ||
+        ensure(c, c->ncells, sizeof(long long) * ((size_t)n_structs + 1)) || ensure(c, c->sid, 4 * nb) ||
+        ensure(c, c->cell_of, 4 * nb) || ensure(c, c->rank, 4 * nb) || ensure(c, c->sx, 8 * nb) ||
+        ensure(c, c->sy, 8 * nb) || ensure(c, c->sz, 8 * nb) || ensure(c, c->sr, 8 * nb) ||
+        ensure(c, c->s_orig, 4 * nb) || ensure(c, c->s_cell, 4 * nb) || ensure(c, c->s_struct, 4 * nb) ||
+        ensure(c, c->status, sizeof(int) * ST_WORDS))
+        return -1;
+
+    /* offsets: upload only when they changed (trajectory frames reuse them) */
+    if ((int)c->offsets_host.size() != n_structs + 1 ||
+        memcmp(c->offsets_host.data(), offsets, sizeof(int64_t) * ((size_t)n_structs + 1)) != 0) {
+        c->offsets_host.assign(offsets, offsets + n_structs + 1);
+        HIP_TRY(c, hipMemcpyAsync(c->offsets.p, c->offsets_host.data(), sizeof(int64_t) * ((size_t)n_structs + 1),
+                                  hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(c, hipMemsetAsync(c->status.p, 0, sizeof(int) * ST_WORDS, st));
+    if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[0], st));
+
+    PipeArgs pa;
+    memset(&pa, 0, sizeof pa);
+    pa.xyz = d_xyz; pa.radii = d_radii; pa.offsets = (const int64_t *)c->offsets.p;
+    pa.n_structs = n_structs; pa.n_atoms = n; pa.probe = probe; pa.max_cells = c->max_cells;
+    pa.grid = (GridS *)c->grid.p; pa.ncells = (long long *)c->ncells.p;
+    pa.sid = (int *)c->sid.p; pa.cell_of = (int *)c->cell_of.p; pa.rank = (int *)c->rank.p;
+    pa.sx = (double *)c->sx.p; pa.sy = (double *)c->sy.p; pa.sz = (double *)c->sz.p; pa.sr = (double *)c->sr.p;
+    pa.s_orig = (int *)c->s_orig.p; pa.s_cell = (int *)c->s_cell.p; pa.s_struct = (int *)c->s_struct.p;
+    pa.status = (int *)c->status.p;
+
+    hipLaunchKernelGGL(k_bounds, dim3(n_structs), dim3(SASA_PIPE_B), 0, st, pa);
+    hipLaunchKernelGGL(k_cell_base, dim3(1), dim3(SASA_PIPE_B), 0, st, pa);
+    HIP_TRY(c, hipGetLastError());
+
+    /* the one mid-pipeline readback: total cells sizes the histogram */
+    long long total_cells = 0;
+    int status_h[ST_WORDS];
+    HIP_TRY(c, hipMemcpyAsync(&total_cells, (long long *)c->ncells.p + n_structs, sizeof(long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(status_h, c->status.p, sizeof status_h, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if (status_h[ST_ERROR]) return ctx_fail(c, "%s", err_text(status_h[ST_ERROR]));
+    if (total_cells <= 0 || total_cells > c->max_cells) return ctx_fail(c, "%s", err_text(ERR_GRID_TOO_BIG));
+
+    const int nblk_scan = (int)((total_cells + 1 + (long long)SASA_PIPE_B * SASA_SCAN_ITEMS - 1) / ((long long)SASA_PIPE_B * SASA_SCAN_ITEMS));
+    if (ensure(c, c->cell_start, sizeof(int) * ((size_t)total_cells + 2)) || ensure(c, c->blk_sums, sizeof(int) * ((size_t)nblk_scan + 1)))
+        return -1;
+    pa.cell_start = (int *)c->cell_start.p;
+    pa.blk_sums = (int *)c->blk_sums.p;
+    HIP_TRY(c, hipMemsetAsync(c->cell_start.p, 0, sizeof(int) * ((size_t)total_cells + 2), st));
+
+    const int nblk_atoms = (n + SASA_PIPE_B - 1) / SASA_PIPE_B;
+    hipLaunchKernelGGL(k_count, dim3(nblk_atoms), dim3(SASA_PIPE_B), 0, st, pa);
+    hipLaunchKernelGGL(k_scan1, dim3(nblk_scan), dim3(SASA_PIPE_B), 0, st, pa, total_cells);
+    hipLaunchKernelGGL(k_scan2, dim3(1), dim3(SASA_PIPE_B), 0, st, pa, nblk_scan);
+    hipLaunchKernelGGL(k_scan3, dim3(nblk_scan), dim3(SASA_PIPE_B), 0, st, pa, total_cells);
+    hipLaunchKernelGGL(k_scatter, dim3(nblk_atoms), dim3(SASA_PIPE_B), 0, st, pa);
+    HIP_TRY(c, hipGetLastError());
+    if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[1], st));
+
+    /* fused tile kernel */
+    const TileCfg cfg = choose_cfg(resolution, lr);
+    const int n_tiles = (n + cfg.TA - 1) / cfg.TA;
+    if (ensure(c, c->ovf_tiles, sizeof(int) * ((size_t)n_tiles + 1))) return -1;
+
+    TileArgs ta;
+    memset(&ta, 0, sizeof ta);
+    ta.sx = pa.sx; ta.sy = pa.sy; ta.sz = pa.sz; ta.sr = pa.sr;
+    ta.s_orig = pa.s_orig; ta.s_cell = pa.s_cell; ta.s_struct = pa.s_struct;
+    ta.grid = pa.grid; ta.cell_start = pa.cell_start;
+    ta.n_atoms = n; ta.n_tiles = n_tiles; ta.TA = cfg.TA; ta.n_res = resolution; ta.tab = cfg.tab;
+    ta.sasa = d_sasa; ta.counts = d_counts;
+    ta.cap_idx = cfg.cap_idx; ta.pool = cfg.pool; ta.ds = cfg.ds;
+    ta.ovf_count = (int *)c->status.p + ST_OVF_TILES;
+    ta.ovf_tiles = (int *)c->ovf_tiles.p;
+    ta.status = (int *)c->status.p;
+    if (!lr) {
+        if (!unit_points) return ctx_fail(c, "unit_points is null");
+        if (ensure(c, c->unit_pts, sizeof(double) * 3 * (size_t)resolution)) return -1;
+        HIP_TRY(c, hipMemcpyAsync(c->unit_pts.p, unit_points, sizeof(double) * 3 * (size_t)resolution, hipMemcpyHostToDevice, st));
+        ta.unit_pts = (const double *)c->unit_pts.p;
+    }
+
+    const int grid_main = ((n_tiles + 7) / 8) * 8;
+    hipError_t le;
+    {
+        static bool attr_done[4] = {false, false, false, false};
+        /* allow > 64 KB of dynamic LDS */
+        const int which = (lr ? 0 : 2) + (cfg.B == 320 ? 0 : 1);
+        if (!attr_done[which]) {
+            const void *fn = lr ? (cfg.B == 320 ? (const void *)k_lr_tile<320, false> : (const void *)k_lr_tile<256, false>)
+                                : (cfg.B == 320 ? (const void *)k_sr_tile<320, false> : (const void *)k_sr_tile<256, false>);
+            (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_done[which] = true;
+        }
+    }
+    le = lr ? launch_lr<false>(cfg, ta, grid_main, cfg.lds, st) : launch_sr<false>(cfg, ta, grid_main, cfg.lds, st);
+    if (le != hipSuccess) return ctx_fail(c, "tile kernel launch failed: %s", hipGetErrorString(le));
+    if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[2], st));
+
+    /* fallback launch over the tiles the main launch gave up on (normally zero: the blocks
+       read the count on the device and exit).  One atom per workgroup, lists in a slab. */
+    {
+        const TileCfg fb = fallback_cfg(cfg, lr);
+        const size_t stride = tile_slab_bytes(fb.TA, fb.cap_idx, fb.pool, fb.ds, fb.B);
+        if (ensure(c, c->slab, stride * SASA_FB_BLOCKS)) return -1;
+        TileArgs tf = ta;
+        tf.cap_idx = fb.cap_idx; tf.pool = fb.pool; tf.ds = fb.ds;
+        tf.work_tiles = (const int *)c->ovf_tiles.p;
+        tf.slab = (char *)c->slab.p;
+        tf.slab_stride = (long long)stride;
+        le = lr ? launch_lr<true>(fb, tf, SASA_FB_BLOCKS, fb.lds, st) : launch_sr<true>(fb, tf, SASA_FB_BLOCKS, fb.lds, st);
+        if (le != hipSuccess) return ctx_fail(c, "fallback kernel launch failed: %s", hipGetErrorString(le));
+    }
+
+    if (d_totals) {
+        hipLaunchKernelGGL(k_totals, dim3((n_structs + 63) / 64), dim3(64), 0, st, (const double *)d_sasa,
+                           (const int64_t *)c->offsets.p, n_structs, d_totals);
+        HIP_TRY(c, hipGetLastError());
+    }
+    if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[3], st));
+
+    HIP_TRY(c, hipMemcpyAsync(status_h, c->status.p, sizeof status_h, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+
+    freesasa_gpu_stats &S = c->stats;
+    S.n_atoms = n; S.n_cells = total_cells; S.n_structs = n_structs;
+    S.max_neighbors = status_h[ST_MAX_NN]; S.fallback_tiles = status_h[ST_OVF_TILES];
+    S.tile_atoms = cfg.TA; S.block_threads = cfg.B; S.lds_bytes = (int)cfg.lds;
+    S.ms_prep = S.ms_kernel = S.ms_total = 0;
+    if (c->timing) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) S.ms_prep = ms;
+        if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) S.ms_kernel = ms;
+        if (hipEventElapsedTime(&ms, c->ev[0], c->ev[3]) == hipSuccess) S.ms_total = ms;
+    }
+    if (status_h[ST_ERROR]) return ctx_fail(c, "%s", err_text(status_h[ST_ERROR]));
+    return 0;
+}
+
+extern "C" int freesasa_gpu_lr_batch_dev(freesasa_gpu_ctx *c, const double *d_xyz, const double *d_radii,
+                                         const int64_t *offsets, int n_structs, double probe, int n_slices,
+                                         double *d_sasa, double *d_totals)
+{
+    if (!c) return -1;
+    return run_batch(c, true, d_xyz, d_radii, offsets, n_structs, probe, n_slices, nullptr, d_sasa, nullptr, d_totals);
+}
+
+extern "C" int freesasa_gpu_sr_batch_dev(freesasa_gpu_ctx *c, const double *d_xyz, const double *d_radii,
+                                         const int64_t *offsets, int n_structs, double probe, int n_points,
+                                         const double *unit_points, double *d_sasa, int *d_counts, double *d_totals)
+{
+    if (!c) return -1;
+    return run_batch(c, false, d_xyz, d_radii, offsets, n_structs, probe, n_points, unit_points, d_sasa, d_counts, d_totals);
+}
+
+/* ------------------------------------------------------------------ host-pointer batch */
+
+/* A small pool of contexts so that concurrent host threads (the reference library is
+ * re-entrant, doc/doxy-main.md:741-756) each get their own stream and workspace. */
+static std::mutex g_pool_mu;
+static std::vector<freesasa_gpu_ctx *> g_pool;
+
+static freesasa_gpu_ctx *pool_get(int device)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (size_t k = 0; k < g_pool.size(); ++k)
+            if (device < 0 || g_pool[k]->device == device) {
+                freesasa_gpu_ctx *c = g_pool[k];
+                g_pool.erase(g_pool.begin() + k);
+                return c;
+            }
+    }
+    return freesasa_gpu_ctx_create(device, nullptr);
+}
+static void pool_put(freesasa_gpu_ctx *c)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool.push_back(c);
+}
+
+static int set_err(char *out, int len, const char *msg)
+{
+    if (out && len > 0) snprintf(out, (size_t)len, "%s", msg);
+    return -1;
+}
+
+extern "C" int freesasa_gpu_calc_batch(const double *xyz, const double *radii, const int64_t *offsets, int n_structs,
+                                       int alg, double probe, int resolution, double *sasa_out, int *counts_out,
+                                       double *totals_out, int device, char *err_out, int err_len)
+{
+    if (err_out && err_len > 0) err_out[0] = 0;
+    if (!xyz || !radii || !offsets || !sasa_out) return set_err(err_out, err_len, "null argument");
+    if (freesasa_gpu_device_count() <= 0)
+        return set_err(err_out, err_len, "no HIP device available: libfreesasa_amd has no CPU path");
+    freesasa_gpu_ctx *c = pool_get(device);
+    if (!c) return set_err(err_out, err_len, "could not create a GPU context");
+    int ret = -1;
+    do {
+        if (n_structs <= 0 || offsets[n_structs] <= 0) { ctx_fail(c, "empty batch"); break; }
+        const size_t n = (size_t)offsets[n_structs];
+        if (hipSetDevice(c->device) != hipSuccess) { ctx_fail(c, "hipSetDevice failed"); break; }
+        if (ensure(c, c->h_xyz, 24 * n) || ensure(c, c->h_radii, 8 * n) || ensure(c, c->h_sasa, 8 * n) ||
+            ensure(c, c->h_counts, 4 * n) || ensure(c, c->h_totals, 8 * (size_t)n_structs))
+            break;
+        if (hipMemcpyAsync(c->h_xyz.p, xyz, 24 * n, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            hipMemcpyAsync(c->h_radii.p, radii, 8 * n, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+            ctx_fail(c, "host-to-device copy failed");
+            break;
+        }
+        if (alg == 0) {
+            ret = run_batch(c, true, (double *)c->h_xyz.p, (double *)c->h_radii.p, offsets, n_structs, probe, resolution,
+                            nullptr, (double *)c->h_sasa.p, nullptr, totals_out ? (double *)c->h_totals.p : nullptr);
+        } else if (alg == 1) {
+            std::vector<double> tp(3 * (size_t)(resolution > 0 ? resolution : 1));
+            if (resolution > 0) freesasa_gpu_test_points(resolution, tp.data());
+            ret = run_batch(c, false, (double *)c->h_xyz.p, (double *)c->h_radii.p, offsets, n_structs, probe, resolution,
+                            tp.data(), (double *)c->h_sasa.p, counts_out ? (int *)c->h_counts.p : nullptr,
+                            totals_out ? (double *)c->h_totals.p : nullptr);
+        } else {
+            ctx_fail(c, "unknown algorithm %d", alg);
+        }
+        if (ret) break;
+        ret = -1;
+        if (hipMemcpyAsync(sasa_out, c->h_sasa.p, 8 * n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { ctx_fail(c, "device-to-host copy failed"); break; }
+        if (counts_out && alg == 1 &&
+            hipMemcpyAsync(counts_out, c->h_counts.p, 4 * n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { ctx_fail(c, "device-to-host copy failed"); break; }
+        if (totals_out &&
+            hipMemcpyAsync(totals_out, c->h_totals.p, 8 * (size_t)n_structs, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { ctx_fail(c, "device-to-host copy failed"); break; }
+        if (hipStreamSynchronize(c->stream) != hipSuccess) { ctx_fail(c, "stream synchronize failed"); break; }
+        ret = 0;
+    } while (0);
+    if (ret) set_err(err_out, err_len, c->err[0] ? c->err : "GPU batch failed");
+    pool_put(c);
+    return ret;
+}

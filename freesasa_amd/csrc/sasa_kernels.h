@@ -1,0 +1,835 @@
+/*
+ * sasa_kernels.h — device code of the MI355X SASA hot path (gfx950 / CDNA4).
+ *
+ * Every kernel is written as a sequence of barrier-separated PHASE functions
+ *     phase(args, smem-view, tile/block id, tid)
+ * so that the very same source is
+ *   (a) wrapped in __global__ kernels by gpu_engine.hip (the product), and
+ *   (b) driven thread-by-thread on a CPU by tests/emu/ (tests only, -DSASA_EMU) to check
+ *       the kernel LOGIC in the GPU-less build container.  The emulation is never linked
+ *       into libfreesasa_amd.so; the product has no CPU path.
+ *
+ * Pipeline for one batch of independent structures (xyz AoS fp64 + radii, CSR offsets):
+ *   K1 bounds      per structure: bounding box, max(R+probe) -> cell grid   (ref: src/nb.c:43-72, 543)
+ *   K2 cell_base   exclusive scan of cells-per-structure
+ *   K3 count       per atom: cell id, rank within cell (atomic)              (ref: src/nb.c:133-175)
+ *   K4 scan        exclusive scan of the cell histogram (3 launches)
+ *   K5 scatter     cell-sorted SoA copy x[],y[],z[],R[] (+ original index)
+ *   K6 lr_tile / sr_tile   fused: neighbor discovery from the 27 surrounding cells into LDS,
+ *                  then Lee-Richards slices or Shrake-Rupley test points   (ref: src/nb.c:458-522,
+ *                  src/sasa_lr.c:270-408, src/sasa_sr.c:276-338); results scattered back.
+ *
+ * Arithmetic contract: fp64 everywhere, compiled with -ffp-contract=off; every expression
+ * that reaches a result keeps the reference's operand order, so S&R counts are bit-exact and
+ * L&R differs from the reference only through the device acos/atan2 (ulps).
+ */
+#ifndef SASA_KERNELS_H
+#define SASA_KERNELS_H
+
+#include <math.h>
+#include <stdint.h>
+
+#ifdef SASA_EMU
+#define SASA_D inline
+#define SASA_HD inline
+namespace sasa_emu {
+inline int atomic_add(int *p, int v) { int o = *p; *p = o + v; return o; }
+inline int atomic_max(int *p, int v) { int o = *p; if (v > o) *p = v; return o; }
+}
+#define SASA_ATOMIC_ADD_LDS(p, v) sasa_emu::atomic_add((p), (v))
+#define SASA_ATOMIC_ADD_GLB(p, v) sasa_emu::atomic_add((p), (v))
+#define SASA_ATOMIC_MAX_GLB(p, v) sasa_emu::atomic_max((p), (v))
+#else
+#define SASA_D __device__ __forceinline__
+#define SASA_HD __host__ __device__ __forceinline__
+#define SASA_ATOMIC_ADD_LDS(p, v) atomicAdd((p), (v))
+#define SASA_ATOMIC_ADD_GLB(p, v) atomicAdd((p), (v))
+#define SASA_ATOMIC_MAX_GLB(p, v) atomicMax((p), (v))
+#endif
+
+namespace sasa {
+
+#define SASA_PI 3.14159265358979323846
+#define SASA_TWOPI (2 * SASA_PI) /* ref: src/sasa_lr.c:25 */
+
+/* status[] slots (device -> host) */
+enum {
+    ST_ERROR = 0,      /* first error code, 0 = ok */
+    ST_OVF_TILES = 1,  /* number of tiles handed to the fallback kernel */
+    ST_MAX_NN = 2,     /* max neighbors/atom seen */
+    ST_SUM_NN_LO = 3,  /* (unused) */
+    ST_FALLBACK_FAIL = 4,
+    ST_WORDS = 8
+};
+enum {
+    ERR_NONE = 0,
+    ERR_BAD_RADIUS = 1,   /* cell size 2*max(R+probe) not > 0 (ref asserts, src/nb.c:544) */
+    ERR_GRID_TOO_BIG = 2, /* nx*ny*nz over the limit (the reference would fail its malloc) */
+    ERR_BAD_COORD = 3,    /* non-finite coordinate */
+    ERR_NEIGHBOR_CAP = 4, /* an atom has more neighbors than the fallback kernel's slab holds */
+    ERR_STACK_CAP = 5     /* more disjoint arcs in one slice than the fallback stack holds */
+};
+
+struct GridS {
+    double x0, y0, z0; /* lower corner = min - d/2          (ref: src/nb.c:61-66) */
+    double d;          /* cell edge = 2*max(R+probe)        (ref: src/nb.c:543)   */
+    int nx, ny, nz;    /* cells per axis                    (ref: src/nb.c:67-69) */
+    int cell_base;     /* first cell of this structure in the batch-wide cell arrays */
+};
+
+/* ------------------------------------------------------------------------------------
+ * K1..K5: cell-sort pipeline
+ * ---------------------------------------------------------------------------------- */
+struct PipeArgs {
+    const double *xyz;      /* [3*n_atoms] x1,y1,z1,...   (ref layout: src/coord.h:26-38) */
+    const double *radii;    /* [n_atoms] atom radii WITHOUT probe */
+    const int64_t *offsets; /* [n_structs+1] first atom of each structure */
+    int n_structs;
+    int n_atoms;
+    double probe;
+    long long max_cells; /* capacity of the cell arrays */
+    /* per structure */
+    GridS *grid;
+    long long *ncells; /* [n_structs] cells of each structure; [n_structs] = total after K2 */
+    /* per atom, original order */
+    int *sid;     /* structure of atom i */
+    int *cell_of; /* batch-wide cell index */
+    int *rank;    /* arrival rank within the cell */
+    /* per cell */
+    int *cell_start; /* [total_cells+1]: histogram, then exclusive scan */
+    int *blk_sums;   /* scan scratch */
+    /* per atom, cell-sorted order */
+    double *sx, *sy, *sz, *sr; /* sr = radius + probe (ref: src/sasa_lr.c:136, sasa_sr.c:144) */
+    int *s_orig, *s_cell, *s_struct;
+    int *status;
+};
+
+#define SASA_PIPE_B 256
+
+/* K1: one workgroup per structure.  red = LDS doubles [7][B]. */
+SASA_D void bounds_phase0(const PipeArgs &a, double *red, int s, int tid, int B)
+{
+    const int64_t b = a.offsets[s], e = a.offsets[s + 1];
+    double lo0 = INFINITY, lo1 = INFINITY, lo2 = INFINITY;
+    double hi0 = -INFINITY, hi1 = -INFINITY, hi2 = -INFINITY, rmax = 0; /* ref: src/nb.c:246 */
+    for (int64_t i = b + tid; i < e; i += B) {
+        const double x = a.xyz[3 * i], y = a.xyz[3 * i + 1], z = a.xyz[3 * i + 2];
+        lo0 = fmin(x, lo0); hi0 = fmax(x, hi0);
+        lo1 = fmin(y, lo1); hi1 = fmax(y, hi1);
+        lo2 = fmin(z, lo2); hi2 = fmax(z, hi2);
+        rmax = fmax(a.radii[i] + a.probe, rmax);
+        a.sid[i] = s;
+    }
+    red[0 * B + tid] = lo0; red[1 * B + tid] = lo1; red[2 * B + tid] = lo2;
+    red[3 * B + tid] = hi0; red[4 * B + tid] = hi1; red[5 * B + tid] = hi2;
+    red[6 * B + tid] = rmax;
+}
+
+SASA_D void bounds_phase1(const PipeArgs &a, const double *red, int s, int tid, int B)
+{
+    if (tid != 0) return;
+    GridS g;
+    const int64_t n = a.offsets[s + 1] - a.offsets[s];
+    if (n <= 0) {
+        g.x0 = g.y0 = g.z0 = 0; g.d = 1; g.nx = g.ny = g.nz = 0; g.cell_base = 0;
+        a.grid[s] = g;
+        a.ncells[s] = 0;
+        return;
+    }
+    double lo[3], hi[3], rmax = 0;
+    for (int k = 0; k < 3; ++k) { lo[k] = red[k * B]; hi[k] = red[(3 + k) * B]; }
+    for (int t = 0; t < B; ++t) {
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fmin(red[k * B + t], lo[k]);
+            hi[k] = fmax(red[(3 + k) * B + t], hi[k]);
+        }
+        rmax = fmax(red[6 * B + t], rmax);
+    }
+    const double d = 2 * rmax; /* ref: src/nb.c:543 */
+    int err = ERR_NONE;
+    if (!(d > 0) || !(d < INFINITY)) err = ERR_BAD_RADIUS;
+    for (int k = 0; k < 3; ++k)
+        if (!(lo[k] > -INFINITY && hi[k] < INFINITY)) err = err ? err : ERR_BAD_COORD;
+    long long nc = 0;
+    g.d = d;
+    g.x0 = lo[0] - d / 2.; g.y0 = lo[1] - d / 2.; g.z0 = lo[2] - d / 2.; /* ref: src/nb.c:61-66 */
+    g.nx = g.ny = g.nz = 0; g.cell_base = 0;
+    if (!err) {
+        const double fx = ceil((hi[0] + d / 2. - g.x0) / d); /* ref: src/nb.c:67-69 */
+        const double fy = ceil((hi[1] + d / 2. - g.y0) / d);
+        const double fz = ceil((hi[2] + d / 2. - g.z0) / d);
+        if (!(fx * fy * fz <= (double)a.max_cells) || !(fx >= 1 && fy >= 1 && fz >= 1)) {
+            err = ERR_GRID_TOO_BIG;
+        } else {
+            g.nx = (int)fx; g.ny = (int)fy; g.nz = (int)fz;
+            nc = (long long)g.nx * g.ny * g.nz;
+        }
+    }
+    if (err) {
+        SASA_ATOMIC_MAX_GLB(&a.status[ST_ERROR], err);
+        g.nx = g.ny = g.nz = 1; g.d = 1; g.x0 = g.y0 = g.z0 = 0;
+        nc = 1; /* keep the rest of the pipeline in bounds; host discards results */
+    }
+    a.grid[s] = g;
+    a.ncells[s] = nc;
+}
+
+/* K2: one workgroup; exclusive scan of ncells[] -> grid[].cell_base, total -> ncells[n_structs].
+ * part = LDS long long [B]. */
+SASA_D void cellbase_phase0(const PipeArgs &a, long long *part, int tid, int B)
+{
+    const int per = (a.n_structs + B - 1) / B;
+    long long s = 0;
+    for (int k = tid * per; k < (tid + 1) * per && k < a.n_structs; ++k) s += a.ncells[k];
+    part[tid] = s;
+}
+SASA_D void cellbase_phase1(const PipeArgs &a, long long *part, int tid, int B)
+{
+    if (tid != 0) return;
+    long long run = 0;
+    for (int t = 0; t < B; ++t) { long long v = part[t]; part[t] = run; run += v; }
+    a.ncells[a.n_structs] = run;
+    if (run > a.max_cells) SASA_ATOMIC_MAX_GLB(&a.status[ST_ERROR], (int)ERR_GRID_TOO_BIG);
+}
+SASA_D void cellbase_phase2(const PipeArgs &a, const long long *part, int tid, int B)
+{
+    const int per = (a.n_structs + B - 1) / B;
+    long long run = part[tid];
+    for (int k = tid * per; k < (tid + 1) * per && k < a.n_structs; ++k) {
+        a.grid[k].cell_base = (int)run;
+        run += a.ncells[k];
+    }
+}
+
+SASA_D int cell_coord(double v, double v0, double d) { return (int)((v - v0) / d); } /* ref: src/nb.c:137-140 */
+
+/* K3: one thread per atom (original order). */
+SASA_D void count_atom(const PipeArgs &a, int i)
+{
+    if (i >= a.n_atoms) return;
+    const GridS g = a.grid[a.sid[i]];
+    int ix = cell_coord(a.xyz[3 * i], g.x0, g.d);
+    int iy = cell_coord(a.xyz[3 * i + 1], g.y0, g.d);
+    int iz = cell_coord(a.xyz[3 * i + 2], g.z0, g.d);
+    if (!(ix >= 0 && ix < g.nx && iy >= 0 && iy < g.ny && iz >= 0 && iz < g.nz)) {
+        /* NaN/inf coordinate (or an errored grid): park the atom in cell 0, flag */
+        if (a.status[ST_ERROR] == 0) SASA_ATOMIC_MAX_GLB(&a.status[ST_ERROR], (int)ERR_BAD_COORD);
+        ix = iy = iz = 0;
+    }
+    const int c = g.cell_base + ix + g.nx * (iy + g.ny * iz); /* ref: src/nb.c:74-83 */
+    a.cell_of[i] = c;
+    a.rank[i] = SASA_ATOMIC_ADD_GLB(&a.cell_start[c], 1);
+}
+
+/* K4: exclusive scan of cell_start[0..n) in place, n = total cells; cell_start[n] = total.
+ * Three launches: scan1 (block sums), scan2 (scan of block sums, one block), scan3 (apply).
+ * Each thread owns SCAN_ITEMS consecutive cells. */
+#define SASA_SCAN_ITEMS 8
+SASA_D void scan1_phase0(const PipeArgs &a, long long n, int *part, int blk, int tid, int B)
+{
+    const long long base = ((long long)blk * B + tid) * SASA_SCAN_ITEMS;
+    int s = 0;
+    for (int k = 0; k < SASA_SCAN_ITEMS; ++k)
+        if (base + k < n) s += a.cell_start[base + k];
+    part[tid] = s;
+}
+SASA_D void scan1_phase1(const PipeArgs &a, int *part, int blk, int tid, int B)
+{
+    if (tid != 0) return;
+    int run = 0;
+    for (int t = 0; t < B; ++t) run += part[t];
+    a.blk_sums[blk] = run;
+}
+/* one block; nblk block sums -> exclusive */
+SASA_D void scan2_phase0(const PipeArgs &a, int nblk, int *part, int tid, int B)
+{
+    const int per = (nblk + B - 1) / B;
+    int s = 0;
+    for (int k = tid * per; k < (tid + 1) * per && k < nblk; ++k) s += a.blk_sums[k];
+    part[tid] = s;
+}
+SASA_D void scan2_phase1(int *part, int tid, int B)
+{
+    if (tid != 0) return;
+    int run = 0;
+    for (int t = 0; t < B; ++t) { int v = part[t]; part[t] = run; run += v; }
+}
+SASA_D void scan2_phase2(const PipeArgs &a, int nblk, const int *part, int tid, int B)
+{
+    const int per = (nblk + B - 1) / B;
+    int run = part[tid];
+    for (int k = tid * per; k < (tid + 1) * per && k < nblk; ++k) {
+        int v = a.blk_sums[k];
+        a.blk_sums[k] = run;
+        run += v;
+    }
+}
+SASA_D void scan3_phase0(const PipeArgs &a, long long n, int *part, int blk, int tid, int B)
+{
+    scan1_phase0(a, n, part, blk, tid, B);
+}
+SASA_D void scan3_phase1(int *part, int tid, int B) { scan2_phase1(part, tid, B); }
+SASA_D void scan3_phase2(const PipeArgs &a, long long n, const int *part, int blk, int tid, int B)
+{
+    const long long base = ((long long)blk * B + tid) * SASA_SCAN_ITEMS;
+    int run = a.blk_sums[blk] + part[tid];
+    for (int k = 0; k < SASA_SCAN_ITEMS; ++k)
+        if (base + k < n) {
+            int v = a.cell_start[base + k];
+            a.cell_start[base + k] = run;
+            run += v;
+        }
+    if (base <= n && n < base + SASA_SCAN_ITEMS) a.cell_start[n] = run; /* sentinel = n_atoms */
+}
+
+/* K5: one thread per atom: scatter into cell-sorted SoA. */
+SASA_D void scatter_atom(const PipeArgs &a, int i)
+{
+    if (i >= a.n_atoms) return;
+    const int c = a.cell_of[i];
+    const int p = a.cell_start[c] + a.rank[i];
+    a.sx[p] = a.xyz[3 * i];
+    a.sy[p] = a.xyz[3 * i + 1];
+    a.sz[p] = a.xyz[3 * i + 2];
+    a.sr[p] = a.radii[i] + a.probe; /* ref: src/sasa_lr.c:136, src/sasa_sr.c:144 */
+    a.s_orig[p] = i;
+    a.s_cell[p] = c;
+    a.s_struct[p] = a.sid[i];
+}
+
+/* ------------------------------------------------------------------------------------
+ * K6: fused tile kernels
+ * ---------------------------------------------------------------------------------- */
+struct Pair { /* one neighbor of one tile atom, 32 B */
+    double a, b, c, d;
+    /* L&R: a = beta, b = z_j, c = R_j, d = xy-distance d_ij   (ref: src/nb.c:438-448)
+       S&R: a = x_j,  b = y_j, c = z_j, d = R_j^2              (ref: src/sasa_sr.c:146) */
+};
+struct Arc { double s, e; };
+
+struct TileArgs {
+    const double *sx, *sy, *sz, *sr;
+    const int *s_orig, *s_cell, *s_struct;
+    const GridS *grid;
+    const int *cell_start;
+    int n_atoms;
+    int n_tiles;
+    int TA;      /* atoms per tile */
+    int n_res;   /* L&R: slices per atom; S&R: test points */
+    int tab;     /* 1: z table + per-slice contributions in LDS, summed in slice order */
+    const double *unit_pts; /* S&R: [3*n_res] unit test points (host libm, ref: src/sasa_sr.c:56-90) */
+    double *sasa; /* [n_atoms] original order */
+    int *counts;  /* S&R: exposed points per atom (original order), may be null */
+    /* capacities of the per-tile lists */
+    int cap_idx; /* neighbor indices per atom */
+    int pool;    /* Pair entries per tile */
+    int ds;      /* spilled stack levels per thread (L&R) */
+    /* overflow hand-off to the fallback launch */
+    int *ovf_count;
+    int *ovf_tiles;
+    const int *work_tiles; /* fallback launch: tile ids to (re)do; null in the main launch */
+    /* fallback launch: lists live in a global slab, one slice per workgroup */
+    char *slab;
+    long long slab_stride;
+    int *status;
+};
+
+/* LDS / slab views */
+struct TileMem {
+    double *ax, *ay, *az, *aR; /* [TA] tile atoms */
+    int *acnt;                 /* [TA] neighbors found */
+    int *aoff;                 /* [TA+1] offsets into pool */
+    int *aexp;                 /* [TA] S&R exposed-point counters */
+    int *flags;                /* [4] flags[0]=tile overflow */
+    double *ztab;              /* [TA*n_res] slice mid-planes (tab mode) */
+    double *contrib;           /* [TA*n_res] slice areas (tab mode) / [B] partials */
+    int *idx;                  /* [TA*cap_idx] neighbor candidates (sorted positions) */
+    double *tb;                /* [pool] beta of each pair before ranking */
+    Pair *pool;                /* [pool] */
+    Arc *stack;                /* [ds][B] spilled components */
+};
+
+SASA_HD size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+/* Bytes of LDS needed.  In the LDS variant idx+tb (phases N..N2) alias the stack (phase L). */
+SASA_HD size_t tile_fixed_bytes(int TA, int items)
+{
+    return align16(sizeof(double) * 4 * TA) + align16(sizeof(int) * (3 * TA + 1 + 4)) +
+           align16(sizeof(double) * items) * 2;
+}
+SASA_HD size_t tile_union_bytes(int TA, int cap_idx, int pool, int ds, int B)
+{
+    size_t u1 = align16(sizeof(int) * (size_t)TA * cap_idx) + align16(sizeof(double) * (size_t)pool);
+    size_t u2 = sizeof(Arc) * (size_t)ds * B;
+    return u1 > u2 ? u1 : u2;
+}
+SASA_HD size_t tile_list_bytes(int TA, int cap_idx, int pool, int ds, int B)
+{
+    return tile_union_bytes(TA, cap_idx, pool, ds, B) + align16(sizeof(Pair) * (size_t)pool);
+}
+/* fallback slab (no aliasing) */
+SASA_HD size_t tile_slab_bytes(int TA, int cap_idx, int pool, int ds, int B)
+{
+    return align16(sizeof(int) * (size_t)TA * cap_idx) + align16(sizeof(double) * (size_t)pool) +
+           align16(sizeof(Arc) * (size_t)ds * B) + align16(sizeof(Pair) * (size_t)pool);
+}
+
+template <bool GLOBAL>
+SASA_D TileMem tile_carve(const TileArgs &a, char *smem, int items, int B, int blk)
+{
+    TileMem m;
+    char *p = smem;
+    m.ax = (double *)p; m.ay = m.ax + a.TA; m.az = m.ay + a.TA; m.aR = m.az + a.TA;
+    p += align16(sizeof(double) * 4 * a.TA);
+    m.acnt = (int *)p; m.aoff = m.acnt + a.TA; m.aexp = m.aoff + a.TA + 1; m.flags = m.aexp + a.TA;
+    p += align16(sizeof(int) * (3 * a.TA + 1 + 4));
+    m.ztab = (double *)p; p += align16(sizeof(double) * items);
+    m.contrib = (double *)p; p += align16(sizeof(double) * items);
+    if (GLOBAL) {
+        char *q = a.slab + (long long)blk * a.slab_stride;
+        m.idx = (int *)q; q += align16(sizeof(int) * (size_t)a.TA * a.cap_idx);
+        m.tb = (double *)q; q += align16(sizeof(double) * (size_t)a.pool);
+        m.stack = (Arc *)q; q += align16(sizeof(Arc) * (size_t)a.ds * B);
+        m.pool = (Pair *)q;
+    } else {
+        m.idx = (int *)p;
+        m.tb = (double *)(p + align16(sizeof(int) * (size_t)a.TA * a.cap_idx));
+        m.stack = (Arc *)p;
+        p += tile_union_bytes(a.TA, a.cap_idx, a.pool, a.ds, B);
+        m.pool = (Pair *)p;
+    }
+    return m;
+}
+
+SASA_D int tile_first_atom(const TileArgs &a, int tile) { return tile * a.TA; }
+SASA_D int tile_atoms(const TileArgs &a, int tile)
+{
+    int n = a.n_atoms - tile * a.TA;
+    return n < a.TA ? n : a.TA;
+}
+
+/* phase A: load the tile's atoms, reset counters */
+SASA_D void tile_phase_load(const TileArgs &a, TileMem &m, int tile, int tid)
+{
+    const int na = tile_atoms(a, tile), p0 = tile_first_atom(a, tile);
+    if (tid < a.TA) {
+        if (tid < na) {
+            m.ax[tid] = a.sx[p0 + tid]; m.ay[tid] = a.sy[p0 + tid];
+            m.az[tid] = a.sz[p0 + tid]; m.aR[tid] = a.sr[p0 + tid];
+        } else {
+            m.ax[tid] = m.ay[tid] = m.az[tid] = 0; m.aR[tid] = 1;
+        }
+        m.acnt[tid] = 0;
+        m.aexp[tid] = 0;
+    }
+    if (tid < 4) m.flags[tid] = 0;
+}
+
+/* phase N: neighbor discovery.  SUB = B/TA lanes share one atom and stride over the atoms of
+ * its 27 surrounding cells (9 contiguous runs in cell-sorted order).  Contact test is the
+ * reference's, operand for operand (ref: src/nb.c:483-492). */
+SASA_D void tile_phase_neighbors(const TileArgs &a, TileMem &m, int tile, int tid, int B)
+{
+    const int na = tile_atoms(a, tile), p0 = tile_first_atom(a, tile);
+    const int SUB = B / a.TA;
+    const int la = tid / SUB, sub = tid - la * SUB;
+    if (la >= na) return;
+    const int p = p0 + la;
+    const GridS g = a.grid[a.s_struct[p]];
+    const int lc = a.s_cell[p] - g.cell_base;
+    const int ix = lc % g.nx, iy = (lc / g.nx) % g.ny, iz = lc / (g.nx * g.ny);
+    const double xi = m.ax[la], yi = m.ay[la], zi = m.az[la], ri = m.aR[la];
+    const int x_lo = ix > 0 ? ix - 1 : 0, x_hi = ix < g.nx - 1 ? ix + 1 : ix;
+
+    for (int cz = iz - 1; cz <= iz + 1; ++cz) {
+        if (cz < 0 || cz >= g.nz) continue;
+        for (int cy = iy - 1; cy <= iy + 1; ++cy) {
+            if (cy < 0 || cy >= g.ny) continue;
+            const int row = g.cell_base + g.nx * (cy + g.ny * cz);
+            const int q_lo = a.cell_start[row + x_lo], q_hi = a.cell_start[row + x_hi + 1];
+            for (int q = q_lo + sub; q < q_hi; q += SUB) {
+                if (q == p) continue;
+                const double rj = a.sr[q];
+                const double cut2 = (ri + rj) * (ri + rj);
+                const double dx = a.sx[q] - xi, dy = a.sy[q] - yi, dz = a.sz[q] - zi;
+                if (dx * dx + dy * dy + dz * dz < cut2) {
+                    const int slot = SASA_ATOMIC_ADD_LDS(&m.acnt[la], 1);
+                    if (slot < a.cap_idx) m.idx[la * a.cap_idx + slot] = q;
+                }
+            }
+        }
+    }
+}
+
+/* phase O: offsets into the pool; overflow -> hand the tile to the fallback launch */
+template <bool GLOBAL>
+SASA_D void tile_phase_offsets(const TileArgs &a, TileMem &m, int tile, int tid)
+{
+    if (tid != 0) return;
+    int run = 0, ovf = 0, mx = 0;
+    for (int k = 0; k < a.TA; ++k) {
+        const int c = m.acnt[k];
+        if (c > a.cap_idx) ovf = 1;
+        if (c > mx) mx = c;
+        m.aoff[k] = run;
+        run += c;
+    }
+    m.aoff[a.TA] = run;
+    if (run > a.pool) ovf = 1;
+    SASA_ATOMIC_MAX_GLB(&a.status[ST_MAX_NN], mx);
+    if (ovf) {
+        m.flags[0] = 1;
+        if (GLOBAL) {
+            SASA_ATOMIC_MAX_GLB(&a.status[ST_ERROR], (int)ERR_NEIGHBOR_CAP);
+        } else {
+            const int w = SASA_ATOMIC_ADD_GLB(a.ovf_count, 1);
+            a.ovf_tiles[w] = tile;
+        }
+    }
+}
+
+/* ---------------------------------------------------------------- Lee & Richards */
+
+/* phase P1: beta = atan2(yd, xd) + pi for every (atom, neighbor) pair (ref: src/sasa_lr.c:337;
+ * the reference recomputes it per slice, it only depends on the pair). */
+SASA_D void lr_phase_beta(const TileArgs &a, TileMem &m, int tid, int B)
+{
+    if (m.flags[0]) return;
+    const int total = m.aoff[a.TA];
+    for (int gp = tid; gp < total; gp += B) {
+        int la = 0;
+        while (m.aoff[la + 1] <= gp) ++la;
+        const int q = m.idx[la * a.cap_idx + (gp - m.aoff[la])];
+        const double xd = a.sx[q] - m.ax[la], yd = a.sy[q] - m.ay[la]; /* ref: src/nb.c:445-448 */
+        m.tb[gp] = atan2(yd, xd) + SASA_PI;
+    }
+}
+
+/* phase P2: rank each pair by beta inside its atom's list and write the pair record at its
+ * sorted position.  Sorting by the arc mid-angle is what lets the slice loop merge arcs with
+ * a stack instead of the reference's per-slice insertion sort (DESIGN.md §L&R). */
+SASA_D void lr_phase_rank(const TileArgs &a, TileMem &m, int tid, int B)
+{
+    if (m.flags[0]) return;
+    const int total = m.aoff[a.TA];
+    for (int gp = tid; gp < total; gp += B) {
+        int la = 0;
+        while (m.aoff[la + 1] <= gp) ++la;
+        const int o = m.aoff[la], nn = m.aoff[la + 1] - o, k = gp - o;
+        const double beta = m.tb[gp];
+        int rank = 0;
+        for (int t = 0; t < nn; ++t) {
+            const double bt = m.tb[o + t];
+            rank += (bt < beta || (bt == beta && t < k)) ? 1 : 0;
+        }
+        const int q = m.idx[la * a.cap_idx + k];
+        const double xd = a.sx[q] - m.ax[la], yd = a.sy[q] - m.ay[la];
+        Pair pr;
+        pr.a = beta;
+        pr.b = a.sz[q];
+        pr.c = a.sr[q];
+        pr.d = sqrt(xd * xd + yd * yd); /* ref: src/nb.c:438 */
+        m.pool[o + rank] = pr;
+    }
+}
+
+/* phase Z: slice mid-planes, accumulated exactly like the reference (ref: src/sasa_lr.c:304-307) */
+SASA_D void lr_phase_ztab(const TileArgs &a, TileMem &m, int tid)
+{
+    if (!a.tab || tid >= a.TA) return;
+    const double Ri = m.aR[tid], zi = m.az[tid];
+    const double delta = 2 * Ri / a.n_res;
+    double z = zi - Ri - 0.5 * delta;
+    for (int s = 0; s < a.n_res; ++s) {
+        z += delta;
+        m.ztab[tid * a.n_res + s] = z;
+    }
+}
+
+/* One slice of one atom: exposed arc length of circle i at height z, or -1 if the slice is
+ * skipped/buried (contributes nothing).  P = the atom's pairs sorted by beta.
+ * Arc union: arcs arrive ordered by mid-angle beta, so disjoint components form a stack —
+ * a new arc either overlaps the top component (merge, then keep popping while the merged
+ * start reaches the next one down) or lies entirely to its right (push).  Arcs that wrap
+ * through 0 only extend a covered prefix [0,W] / suffix [V,2pi].  End points are only ever
+ * compared and copied, never recomputed, and gaps are summed in ascending order, so the
+ * result equals the reference's sort + sweep (src/sasa_lr.c:367-408) bit for bit given the
+ * same inf/sup values. */
+SASA_D double lr_slice(const Pair *P, int nn, double zi, double Ri, double z,
+                       Arc *stk, int stride, int ds, int *err)
+{
+    const double di = fabs(zi - z);                 /* ref: src/sasa_lr.c:308 */
+    const double Ri_p2 = Ri * Ri - di * di;
+    if (Ri_p2 < 0) return -1;                       /* ref: :310 */
+    const double Ri_p = sqrt(Ri_p2);
+    if (Ri_p <= 0) return -1;                       /* ref: :312 */
+
+    double W = 0, V = SASA_TWOPI, ts = 0, te = 0;
+    int depth = 0, wrap = 0;
+
+    for (int k = 0; k < nn; ++k) {
+        const Pair p = P[k];
+        const double dj = fabs(p.b - z);            /* ref: :318 */
+        if (!(dj < p.c)) continue;                  /* ref: :320 */
+        const double Rj_p2 = p.c * p.c - dj * dj;
+        const double Rj_p = sqrt(Rj_p2);
+        const double dij = p.d;
+        if (dij >= Ri_p + Rj_p) continue;           /* ref: :324 */
+        if (dij + Ri_p < Rj_p) return -1;           /* ref: :327-330 buried */
+        if (dij + Rj_p < Ri_p) continue;            /* ref: :331 */
+        if (dij == 0) continue; /* guard: the reference evaluates acos(0/0) = NaN here (measure zero) */
+        double ca = (Ri_p2 + dij * dij - Rj_p2) / (2.0 * Ri_p * dij); /* ref: :335 */
+        ca = ca > 1.0 ? 1.0 : (ca < -1.0 ? -1.0 : ca); /* guard: rounding past +-1 is NaN in the reference */
+        const double alpha = acos(ca);
+        double inf = p.a - alpha, sup = p.a + alpha; /* ref: :338-339 */
+        if (inf < 0) inf += SASA_TWOPI;              /* ref: :340 */
+        if (sup > SASA_TWOPI) sup -= SASA_TWOPI;     /* ref: :341 */
+        if (sup < inf) {                             /* ref: :344-351 arc passes the origin */
+            wrap = 1;
+            W = sup > W ? sup : W;
+            V = inf < V ? inf : V;
+        } else if (inf <= p.a && p.a <= sup) {       /* (false only for a zero-length arc at alpha == pi) */
+            if (depth == 0) {
+                ts = inf; te = sup; depth = 1;
+            } else if (inf <= te) {
+                ts = inf < ts ? inf : ts;
+                te = sup > te ? sup : te;
+                while (depth > 1) {
+                    const Arc lo = stk[(depth - 2) * stride];
+                    if (lo.e < ts) break;
+                    ts = lo.s < ts ? lo.s : ts;
+                    te = lo.e > te ? lo.e : te;
+                    --depth;
+                }
+            } else {
+                if (depth - 1 < ds) {
+                    Arc t; t.s = ts; t.e = te;
+                    stk[(depth - 1) * stride] = t;
+                    ts = inf; te = sup; ++depth;
+                } else {
+                    *err = 1;
+                }
+            }
+        }
+    }
+    /* sweep, ref: src/sasa_lr.c:396-407 with sum = arc[0] == (0 < arc[0] ? arc[0] - 0 : 0) */
+    double sum = 0, sup = W;
+    for (int c = 0; c < depth; ++c) {
+        Arc cur;
+        if (c == depth - 1) { cur.s = ts; cur.e = te; } else cur = stk[c * stride];
+        if (wrap && cur.s >= V) break; /* sorted behind the [V,2pi] piece: fully covered */
+        if (sup < cur.s) sum += cur.s - sup;
+        if (cur.e > sup) sup = cur.e;
+    }
+    if (wrap) {
+        if (sup < V) sum += V - sup;
+        sup = SASA_TWOPI;
+    }
+    return sum + SASA_TWOPI - sup; /* ref: :407 */
+}
+
+/* phase L: work items = (atom, slice) */
+SASA_D void lr_phase_slices(const TileArgs &a, TileMem &m, int tile, int tid, int B)
+{
+    if (m.flags[0]) return;
+    const int na = tile_atoms(a, tile);
+    const int ns = a.n_res;
+    Arc *stk = m.stack + tid;
+    int err = 0;
+    if (a.tab) {
+        const int items = na * ns;
+        for (int it = tid; it < items; it += B) {
+            const int la = it / ns;
+            const double Ri = m.aR[la];
+            const double delta = 2 * Ri / ns;
+            const int o = m.aoff[la];
+            const double ex = lr_slice(m.pool + o, m.aoff[la + 1] - o, m.az[la], Ri, m.ztab[it],
+                                       stk, B, a.ds, &err);
+            m.contrib[it] = ex < 0 ? 0.0 : delta * Ri * ex; /* ref: src/sasa_lr.c:360 */
+        }
+    } else {
+        /* many slices per atom (TA == 1): strided partial sums, z by direct formula */
+        const double Ri = m.aR[0], zi = m.az[0];
+        const double delta = 2 * Ri / ns;
+        const double z0 = zi - Ri - 0.5 * delta;
+        double part = 0;
+        for (int s = tid; s < ns; s += B) {
+            const double z = z0 + (double)(s + 1) * delta;
+            const double ex = lr_slice(m.pool, m.aoff[1], zi, Ri, z, stk, B, a.ds, &err);
+            if (!(ex < 0)) part += delta * Ri * ex;
+        }
+        m.contrib[tid] = part;
+    }
+    if (err) m.flags[1] = 1;
+}
+
+/* phase S: per-atom sum in slice order (ref: src/sasa_lr.c:305-361 accumulates sasa += ...) */
+template <bool GLOBAL>
+SASA_D void lr_phase_store(const TileArgs &a, TileMem &m, int tile, int tid, int B)
+{
+    if (m.flags[0]) return;
+    const int na = tile_atoms(a, tile), p0 = tile_first_atom(a, tile);
+    if (m.flags[1]) { /* a stack overflowed: redo the tile in the fallback launch */
+        if (tid == 0) {
+            if (GLOBAL) {
+                SASA_ATOMIC_MAX_GLB(&a.status[ST_ERROR], (int)ERR_STACK_CAP);
+            } else {
+                const int w = SASA_ATOMIC_ADD_GLB(a.ovf_count, 1);
+                a.ovf_tiles[w] = tile;
+            }
+        }
+        return;
+    }
+    if (a.tab) {
+        if (tid < na) {
+            double s = 0;
+            for (int k = 0; k < a.n_res; ++k) s += m.contrib[tid * a.n_res + k];
+            a.sasa[a.s_orig[p0 + tid]] = s;
+        }
+    } else if (tid == 0) {
+        double s = 0;
+        for (int t = 0; t < B; ++t) s += m.contrib[t];
+        a.sasa[a.s_orig[p0]] = s;
+    }
+}
+
+/* ---------------------------------------------------------------- Shrake & Rupley */
+
+/* phase P: neighbor records (x, y, z, R^2) */
+SASA_D void sr_phase_pairs(const TileArgs &a, TileMem &m, int tid, int B)
+{
+    if (m.flags[0]) return;
+    const int total = m.aoff[a.TA];
+    for (int gp = tid; gp < total; gp += B) {
+        int la = 0;
+        while (m.aoff[la + 1] <= gp) ++la;
+        const int q = m.idx[la * a.cap_idx + (gp - m.aoff[la])];
+        const double rj = a.sr[q];
+        Pair pr;
+        pr.a = a.sx[q]; pr.b = a.sy[q]; pr.c = a.sz[q];
+        pr.d = rj * rj; /* ref: src/sasa_sr.c:146 */
+        m.pool[gp] = pr;
+    }
+}
+
+/* phase L: work items = (atom, test point).  A point is exposed iff no neighbor covers it
+ * (ref: src/sasa_sr.c:311-330; the reference's "last hit first" order does not change the
+ * outcome, which is an OR over neighbors). */
+SASA_D void sr_phase_points(const TileArgs &a, TileMem &m, int tile, int tid, int B)
+{
+    if (m.flags[0]) return;
+    const int na = tile_atoms(a, tile);
+    const int np = a.n_res, items = na * np;
+    for (int it = tid; it < items; it += B) {
+        const int la = it / np, pt = it - la * np;
+        const double ri = m.aR[la];
+        /* test point = unit * ri, then + centre: two rounded steps (ref: src/coord.c:331-342, 314-329) */
+        double tx = a.unit_pts[3 * pt] * ri, ty = a.unit_pts[3 * pt + 1] * ri, tz = a.unit_pts[3 * pt + 2] * ri;
+        tx += m.ax[la]; ty += m.ay[la]; tz += m.az[la];
+        const Pair *P = m.pool + m.aoff[la];
+        const int nn = m.aoff[la + 1] - m.aoff[la];
+        int covered = 0;
+        for (int k = 0; k < nn; ++k) {
+            const Pair p = P[k];
+            const double dx = tx - p.a, dy = ty - p.b, dz = tz - p.c;
+            if (dx * dx + dy * dy + dz * dz <= p.d) { covered = 1; break; } /* ref: src/sasa_sr.c:324 */
+        }
+        if (!covered) SASA_ATOMIC_ADD_LDS(&m.aexp[la], 1);
+    }
+}
+
+SASA_D void sr_phase_store(const TileArgs &a, TileMem &m, int tile, int tid)
+{
+    if (m.flags[0]) return;
+    const int na = tile_atoms(a, tile), p0 = tile_first_atom(a, tile);
+    if (tid < na) {
+        const double ri = m.aR[tid];
+        const int n_surface = m.aexp[tid];
+        const int i = a.s_orig[p0 + tid];
+        a.sasa[i] = (4.0 * SASA_PI * ri * ri * n_surface) / a.n_res; /* ref: src/sasa_sr.c:337 */
+        if (a.counts) a.counts[i] = n_surface;
+    }
+}
+
+/* ---------------------------------------------------------------- per-structure totals */
+/* one thread per structure, atom order (ref: src/freesasa.c:113-116) */
+SASA_D void totals_struct(const double *sasa, const int64_t *offsets, int n_structs, double *totals, int s)
+{
+    if (s >= n_structs) return;
+    double t = 0;
+    for (int64_t i = offsets[s]; i < offsets[s + 1]; ++i) t += sasa[i];
+    totals[s] = t;
+}
+
+/* Workgroup b runs on XCD b % 8 (observed dispatch order).  Give each XCD one contiguous
+ * eighth of the cell-sorted tiles so that the candidate cells a tile reads were, with high
+ * probability, last touched through the same XCD's L2.  Speed only; any mapping is correct.
+ * The main launch uses a grid of 8*ceil(n_tiles/8) workgroups. */
+SASA_D int xcd_tile(int b, int n_tiles)
+{
+    const int per = (n_tiles + 7) >> 3;
+    return (b & 7) * per + (b >> 3);
+}
+
+/* ------------------------------------------------------------------------------------
+ * launch configuration (host side; shared by gpu_engine.hip and the test emulation)
+ * ---------------------------------------------------------------------------------- */
+struct TileCfg {
+    int B, TA, tab, items, cap_idx, pool, ds;
+    size_t lds;
+};
+
+#define SASA_ITEMS_CAP 640
+#define SASA_TA_MAX 16
+/* fallback launch: same tiling, lists in a global slab, far larger capacities */
+#define SASA_FB_BLOCKS 64
+#define SASA_FB_CAP 4096   /* neighbors per atom */
+#define SASA_FB_POOL 16384 /* neighbors per tile */
+#define SASA_FB_DS 96      /* spilled stack levels */
+
+/* Pick workgroup size and atoms per tile so that TA*resolution work items fill whole rounds
+ * of B threads (resolution 20 -> 16 atoms x 20 slices = 320 threads, one round). */
+static inline TileCfg choose_cfg(int resolution, bool lr)
+{
+    TileCfg c;
+    c.tab = 1;
+    /* L&R keeps a z table and a per-slice area table in LDS (TA*resolution <= SASA_ITEMS_CAP);
+       S&R has no per-item state, its tile is only bounded by the neighbor pool */
+    const int items_cap = lr ? SASA_ITEMS_CAP : 4096;
+    const int ta_max = lr ? SASA_TA_MAX : 8;
+    if (resolution > items_cap) {
+        c.B = 256;
+        c.TA = 1;
+        if (lr) c.tab = 0;
+    } else {
+        double best = -1;
+        c.B = 256; c.TA = 1;
+        const int Bs[2] = {320, 256};
+        for (int bi = 0; bi < 2; ++bi)
+            for (int ta = 1; ta <= ta_max && ta * resolution <= items_cap; ++ta) {
+                const int items = ta * resolution, B = Bs[bi];
+                const double eff = (double)items / (double)(((items + B - 1) / B) * B);
+                const double score = eff + 0.002 * ta; /* prefer bigger tiles at equal efficiency */
+                if (score > best) { best = score; c.B = B; c.TA = ta; }
+            }
+    }
+    c.items = lr ? (c.tab ? c.TA * resolution : c.B) : 1;
+    c.cap_idx = 128;
+    c.pool = 64 * c.TA < 128 ? 128 : 64 * c.TA;
+    c.ds = lr ? 4 : 0;
+    c.lds = tile_fixed_bytes(c.TA, c.items) + tile_list_bytes(c.TA, c.cap_idx, c.pool, c.ds, c.B);
+    return c;
+}
+
+static inline TileCfg fallback_cfg(const TileCfg &main_cfg, bool lr)
+{
+    TileCfg fb = main_cfg;
+    fb.cap_idx = SASA_FB_CAP;
+    fb.pool = SASA_FB_POOL;
+    fb.ds = lr ? SASA_FB_DS : 0;
+    fb.lds = tile_fixed_bytes(fb.TA, fb.items);
+    return fb;
+}
+
+} /* namespace sasa */
+#endif

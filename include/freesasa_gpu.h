@@ -1,0 +1,82 @@
+/*
+ * freesasa_gpu.h — ADDITIVE C-ABI of the MI355X engine (nothing here exists in the
+ * reference; freesasa_amd.h stays byte-compatible with the reference's freesasa.h).
+ *
+ * The reference computes one structure per call (src/freesasa.c:76-120) and parallelises
+ * with <= 16 pthreads inside it (src/sasa_lr.c:219-253).  A GPU needs many structures per
+ * launch, so the engine's native unit is a BATCH of independent structures in CSR form.
+ * Plain pointers and sizes only; no torch / HIP types in any signature (a stream is passed
+ * as void*).
+ */
+#ifndef FREESASA_GPU_H
+#define FREESASA_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct freesasa_gpu_ctx freesasa_gpu_ctx;
+
+/* Per-call statistics of the last batch run on a context. */
+typedef struct freesasa_gpu_stats {
+    long long n_atoms;      /* atoms processed */
+    long long n_cells;      /* cells of the batch-wide cell list */
+    int n_structs;
+    int max_neighbors;      /* largest neighbor count of any atom */
+    int fallback_tiles;     /* tiles re-done by the large-capacity fallback launch */
+    int tile_atoms;         /* launch configuration of the fused kernel */
+    int block_threads;
+    int lds_bytes;
+    double ms_prep;         /* HIP-event time of the cell-sort pipeline (0 unless timing on) */
+    double ms_kernel;       /* HIP-event time of the fused L&R / S&R kernel */
+    double ms_total;        /* HIP-event time of the whole call on the stream */
+} freesasa_gpu_stats;
+
+/* Number of usable HIP devices (0 when there is none; never fails). */
+int freesasa_gpu_device_count(void);
+
+/* A context owns one device's workspace.  stream: a hipStream_t to launch on (e.g. torch's
+   current stream) or NULL for a private stream.  Returns NULL on failure. */
+freesasa_gpu_ctx *freesasa_gpu_ctx_create(int device, void *stream);
+void freesasa_gpu_ctx_destroy(freesasa_gpu_ctx *ctx);
+/* Record HIP events around the pipeline stages (adds two syncs per call). */
+void freesasa_gpu_ctx_set_timing(freesasa_gpu_ctx *ctx, int enable);
+void freesasa_gpu_ctx_get_stats(const freesasa_gpu_ctx *ctx, freesasa_gpu_stats *out);
+/* Text of the last error on this context ("" if none). */
+const char *freesasa_gpu_ctx_last_error(const freesasa_gpu_ctx *ctx);
+
+/* Device-resident batch.  d_* are DEVICE pointers, offsets is a HOST array [n_structs+1]
+   (first atom of each structure; offsets[0] == 0).  d_xyz: x1,y1,z1,... (3 * n_atoms),
+   d_radii without probe.  d_sasa [n_atoms] per-atom areas in input order; d_totals
+   [n_structs] per-structure sums in atom order (may be NULL).  Work is enqueued on the
+   context's stream; the call returns after the results are complete on that stream
+   (it synchronises the stream once to size the cell list and once to read the status).
+   Returns FREESASA_SUCCESS (0) or FREESASA_FAIL (-1). */
+int freesasa_gpu_lr_batch_dev(freesasa_gpu_ctx *ctx, const double *d_xyz, const double *d_radii,
+                              const int64_t *offsets, int n_structs, double probe_radius,
+                              int n_slices, double *d_sasa, double *d_totals);
+/* unit_points: HOST array [3*n_points] of unit test points (generate with
+   freesasa_gpu_test_points for bit-exact parity with the reference).  d_counts [n_atoms]
+   exposed points per atom (may be NULL). */
+int freesasa_gpu_sr_batch_dev(freesasa_gpu_ctx *ctx, const double *d_xyz, const double *d_radii,
+                              const int64_t *offsets, int n_structs, double probe_radius,
+                              int n_points, const double *unit_points, double *d_sasa,
+                              int *d_counts, double *d_totals);
+
+/* Golden-spiral unit test points on the host, host libm (src/sasa_sr.c:56-90). */
+void freesasa_gpu_test_points(int n_points, double *unit_points);
+
+/* Host-pointer batch on a pooled per-thread context of `device` (-1: current default).
+   alg/probe/resolution as in freesasa_parameters; counts_out may be NULL (S&R only);
+   totals_out may be NULL.  Thread-safe.  Returns 0 / -1; message via err_out (>= len 1). */
+int freesasa_gpu_calc_batch(const double *xyz, const double *radii, const int64_t *offsets,
+                            int n_structs, int alg, double probe_radius, int resolution,
+                            double *sasa_out, int *counts_out, double *totals_out,
+                            int device, char *err_out, int err_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FREESASA_GPU_H */

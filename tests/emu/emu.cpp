@@ -1,0 +1,155 @@
+/*
+ * emu.cpp — TESTS ONLY.  Drives the phase functions of freesasa_amd/csrc/sasa_kernels.h on the
+ * CPU, one "thread" at a time, in the same launch sequence as gpu_engine.hip::run_batch, so the
+ * kernel logic (indexing, capacities, overflow hand-off, arithmetic order) can be checked against
+ * the oracle in the GPU-less build container.  Built as tests/emu/libsasa_emu.so by `make emu`;
+ * never linked into libfreesasa_amd.so.  With host libm the emulated L&R must equal the oracle
+ * bit for bit, which pins everything except the device's acos/atan2.
+ */
+#define SASA_EMU 1
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "../../freesasa_amd/csrc/sasa_kernels.h"
+
+using namespace sasa;
+
+template <bool GLOBAL>
+static void emu_tile_kernel(bool lr, const TileCfg &cfg, TileArgs a, int grid)
+{
+    const int B = cfg.B;
+    std::vector<char> smem(cfg.lds + 64);
+    for (int blk = 0; blk < grid; ++blk) {
+        TileMem m = tile_carve<GLOBAL>(a, smem.data(), cfg.items, B, blk);
+        const int n_work = GLOBAL ? *a.ovf_count : ((a.n_tiles + 7) >> 3) << 3;
+        for (int w = blk; w < n_work; w += grid) {
+            const int tile = GLOBAL ? a.work_tiles[w] : xcd_tile(w, a.n_tiles);
+            if (tile >= a.n_tiles) continue;
+#define PHASE(call) for (int tid = 0; tid < B; ++tid) { call; }
+            PHASE(tile_phase_load(a, m, tile, tid));
+            PHASE(tile_phase_neighbors(a, m, tile, tid, B));
+            PHASE(tile_phase_offsets<GLOBAL>(a, m, tile, tid));
+            if (lr) {
+                PHASE(lr_phase_beta(a, m, tid, B); lr_phase_ztab(a, m, tid));
+                PHASE(lr_phase_rank(a, m, tid, B));
+                PHASE(lr_phase_slices(a, m, tile, tid, B));
+                PHASE(lr_phase_store<GLOBAL>(a, m, tile, tid, B));
+            } else {
+                PHASE(sr_phase_pairs(a, m, tid, B));
+                PHASE(sr_phase_points(a, m, tile, tid, B));
+                PHASE(sr_phase_store(a, m, tile, tid));
+            }
+#undef PHASE
+        }
+    }
+}
+
+/* force_*: <= 0 keeps the production launch configuration; positive values shrink the
+ * capacities so that small inputs exercise the overflow -> fallback path.
+ * stats_out[8]: error, fallback tiles, max nn, TA, B, lds, total cells, items. */
+extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, const int64_t *offsets,
+                             int n_structs, double probe, int resolution, const double *unit_pts,
+                             double *sasa, int *counts, double *totals, long long *stats_out,
+                             int force_cap_idx, int force_pool, int force_ds, int fb_cap_idx,
+                             int fb_pool, int fb_ds)
+{
+    const int n = (int)offsets[n_structs];
+    const int PB = SASA_PIPE_B;
+    std::vector<GridS> grid(n_structs);
+    std::vector<long long> ncells(n_structs + 1);
+    std::vector<int> sid(n), cell_of(n), rank(n), s_orig(n), s_cell(n), s_struct(n), status(ST_WORDS, 0);
+    std::vector<double> sx(n), sy(n), sz(n), sr(n);
+
+    PipeArgs pa;
+    memset(&pa, 0, sizeof pa);
+    pa.xyz = xyz; pa.radii = radii; pa.offsets = offsets; pa.n_structs = n_structs; pa.n_atoms = n;
+    pa.probe = probe; pa.max_cells = 1LL << 28;
+    pa.grid = grid.data(); pa.ncells = ncells.data(); pa.sid = sid.data(); pa.cell_of = cell_of.data();
+    pa.rank = rank.data(); pa.sx = sx.data(); pa.sy = sy.data(); pa.sz = sz.data(); pa.sr = sr.data();
+    pa.s_orig = s_orig.data(); pa.s_cell = s_cell.data(); pa.s_struct = s_struct.data(); pa.status = status.data();
+
+    { /* k_bounds */
+        std::vector<double> red(7 * PB);
+        for (int s = 0; s < n_structs; ++s) {
+            for (int t = 0; t < PB; ++t) bounds_phase0(pa, red.data(), s, t, PB);
+            for (int t = 0; t < PB; ++t) bounds_phase1(pa, red.data(), s, t, PB);
+        }
+    }
+    { /* k_cell_base */
+        std::vector<long long> part(PB);
+        for (int t = 0; t < PB; ++t) cellbase_phase0(pa, part.data(), t, PB);
+        for (int t = 0; t < PB; ++t) cellbase_phase1(pa, part.data(), t, PB);
+        for (int t = 0; t < PB; ++t) cellbase_phase2(pa, part.data(), t, PB);
+    }
+    stats_out[0] = status[ST_ERROR];
+    if (status[ST_ERROR]) return -1;
+    const long long total_cells = ncells[n_structs];
+    const int nblk_scan = (int)((total_cells + 1 + (long long)PB * SASA_SCAN_ITEMS - 1) / ((long long)PB * SASA_SCAN_ITEMS));
+    std::vector<int> cell_start(total_cells + 2, 0), blk_sums(nblk_scan + 1);
+    pa.cell_start = cell_start.data(); pa.blk_sums = blk_sums.data();
+
+    const int nblk_atoms = (n + PB - 1) / PB;
+    for (int b = 0; b < nblk_atoms; ++b)
+        for (int t = 0; t < PB; ++t) count_atom(pa, b * PB + t);
+    {
+        std::vector<int> part(PB);
+        for (int b = 0; b < nblk_scan; ++b) {
+            for (int t = 0; t < PB; ++t) scan1_phase0(pa, total_cells, part.data(), b, t, PB);
+            for (int t = 0; t < PB; ++t) scan1_phase1(pa, part.data(), b, t, PB);
+        }
+        for (int t = 0; t < PB; ++t) scan2_phase0(pa, nblk_scan, part.data(), t, PB);
+        for (int t = 0; t < PB; ++t) scan2_phase1(part.data(), t, PB);
+        for (int t = 0; t < PB; ++t) scan2_phase2(pa, nblk_scan, part.data(), t, PB);
+        for (int b = 0; b < nblk_scan; ++b) {
+            for (int t = 0; t < PB; ++t) scan3_phase0(pa, total_cells, part.data(), b, t, PB);
+            for (int t = 0; t < PB; ++t) scan3_phase1(part.data(), t, PB);
+            for (int t = 0; t < PB; ++t) scan3_phase2(pa, total_cells, part.data(), b, t, PB);
+        }
+    }
+    for (int b = 0; b < nblk_atoms; ++b)
+        for (int t = 0; t < PB; ++t) scatter_atom(pa, b * PB + t);
+
+    TileCfg cfg = choose_cfg(resolution, lr != 0);
+    if (force_cap_idx > 0) cfg.cap_idx = force_cap_idx;
+    if (force_pool > 0) cfg.pool = force_pool;
+    if (force_ds >= 0 && lr) cfg.ds = force_ds;
+    cfg.lds = tile_fixed_bytes(cfg.TA, cfg.items) + tile_list_bytes(cfg.TA, cfg.cap_idx, cfg.pool, cfg.ds, cfg.B);
+    const int n_tiles = (n + cfg.TA - 1) / cfg.TA;
+    std::vector<int> ovf_tiles(n_tiles + 1);
+
+    TileArgs ta;
+    memset(&ta, 0, sizeof ta);
+    ta.sx = pa.sx; ta.sy = pa.sy; ta.sz = pa.sz; ta.sr = pa.sr;
+    ta.s_orig = pa.s_orig; ta.s_cell = pa.s_cell; ta.s_struct = pa.s_struct;
+    ta.grid = pa.grid; ta.cell_start = pa.cell_start;
+    ta.n_atoms = n; ta.n_tiles = n_tiles; ta.TA = cfg.TA; ta.n_res = resolution; ta.tab = cfg.tab;
+    ta.unit_pts = unit_pts; ta.sasa = sasa; ta.counts = counts;
+    ta.cap_idx = cfg.cap_idx; ta.pool = cfg.pool; ta.ds = cfg.ds;
+    ta.ovf_count = status.data() + ST_OVF_TILES; ta.ovf_tiles = ovf_tiles.data(); ta.status = status.data();
+
+    emu_tile_kernel<false>(lr != 0, cfg, ta, ((n_tiles + 7) / 8) * 8);
+
+    {
+        TileCfg fb = fallback_cfg(cfg, lr != 0);
+        if (fb_cap_idx > 0) fb.cap_idx = fb_cap_idx;
+        if (fb_pool > 0) fb.pool = fb_pool;
+        if (fb_ds > 0 && lr) fb.ds = fb_ds;
+        const size_t stride = tile_slab_bytes(fb.TA, fb.cap_idx, fb.pool, fb.ds, fb.B);
+        const int fb_blocks = 3; /* fewer than SASA_FB_BLOCKS so that the work loop wraps */
+        std::vector<char> slab(stride * fb_blocks + 64);
+        TileArgs tf = ta;
+        tf.cap_idx = fb.cap_idx; tf.pool = fb.pool; tf.ds = fb.ds;
+        tf.work_tiles = ovf_tiles.data();
+        tf.slab = slab.data(); tf.slab_stride = (long long)stride;
+        emu_tile_kernel<true>(lr != 0, fb, tf, fb_blocks);
+    }
+    if (totals)
+        for (int s = 0; s < n_structs; ++s) totals_struct(sasa, offsets, n_structs, totals, s);
+
+    stats_out[0] = status[ST_ERROR]; stats_out[1] = status[ST_OVF_TILES]; stats_out[2] = status[ST_MAX_NN];
+    stats_out[3] = cfg.TA; stats_out[4] = cfg.B; stats_out[5] = (long long)cfg.lds; stats_out[6] = total_cells;
+    stats_out[7] = cfg.items;
+    return status[ST_ERROR] ? -1 : 0;
+}

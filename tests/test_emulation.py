@@ -1,0 +1,133 @@
+"""CPU tests of the KERNEL LOGIC: the phase functions of freesasa_amd/csrc/sasa_kernels.h are
+driven thread-by-thread by tests/emu (never shipped) in the production launch sequence and
+compared with the oracle.  With host libm the emulated L&R must be bit-identical to the
+oracle, which leaves the device's acos/atan2 as the only untested ingredient on this box."""
+import numpy as np
+import pytest
+
+import tools
+from conftest import load_golden
+from emu import run_batch
+
+
+def _sr(oracle_lib, xyz, r, n_points=100, probe=1.4, **kw):
+    return run_batch(False, xyz, r, probe=probe, resolution=n_points,
+                     unit_pts=oracle_lib.test_points(n_points), **kw)
+
+
+@pytest.mark.parametrize("name", ["1ubq", "3bzd_trimmed"])
+def test_golden_structures(oracle_lib, name):
+    g = load_golden(name)
+    sasa, _, tot, st = run_batch(True, g["xyz"], g["radii"], resolution=20)
+    assert np.array_equal(sasa, g["lr20"]) and tot[0] == float(g["lr20_total"])
+    sasa, counts, tot, _ = _sr(oracle_lib, g["xyz"], g["radii"])
+    assert np.array_equal(counts, g["sr100_counts"])
+    assert np.array_equal(sasa, g["sr100"]) and tot[0] == float(g["sr100_total"])
+
+
+def test_lr100_and_probe_sweep(oracle_lib):
+    g = load_golden("1ubq")
+    sasa, *_ = run_batch(True, g["xyz"], g["radii"], resolution=100)
+    assert np.array_equal(sasa, g["lr100"])
+    for probe in (1.0, 2.0):
+        sasa, *_ = run_batch(True, g["xyz"], g["radii"], probe=probe, resolution=20)
+        assert np.array_equal(sasa, g[f"lr20_p{probe}"])
+        _, c, _, _ = _sr(oracle_lib, g["xyz"], g["radii"], probe=probe)
+        assert np.array_equal(c, g[f"sr100_p{probe}_counts"])
+    for npts in (20, 1000):
+        _, c, _, _ = _sr(oracle_lib, g["xyz"], g["radii"], n_points=npts)
+        assert np.array_equal(c, g[f"sr{npts}_counts"])
+
+
+def test_ragged_batch_with_empty_and_single_atom_structures(oracle_lib):
+    parts = [tools.coil(700, 1), tools.globule(333, 2), (np.zeros((0, 3)), np.zeros(0)),
+             (np.array([[5.0, 5.0, 5.0]]), np.array([1.7])), tools.coil(64, 3),
+             tools.globule(250, 4, 2.05)]
+    xyz = np.concatenate([p[0] for p in parts])
+    # translate every structure to the same place: neighbors must never cross structures
+    r = np.concatenate([p[1] for p in parts])
+    offsets = np.concatenate([[0], np.cumsum([len(p[1]) for p in parts])])
+    lr, _, tot, st = run_batch(True, xyz, r, offsets)
+    sr, cnt, stot, _ = _sr(oracle_lib, xyz, r, offsets=offsets)
+    for k, (px, pr) in enumerate(parts):
+        sl = slice(offsets[k], offsets[k + 1])
+        if len(pr) == 0:
+            assert tot[k] == 0.0
+            continue
+        want = oracle_lib.lee_richards(px, pr)
+        assert np.array_equal(lr[sl], want) and tot[k] == oracle_lib.total(want)
+        ws, wc = oracle_lib.shrake_rupley(px, pr)
+        assert np.array_equal(cnt[sl], wc) and np.array_equal(sr[sl], ws)
+    # isolated atom: L&R = slices of a free sphere, S&R = all points (defined; reference is UB)
+    assert cnt[offsets[3]] == 100
+
+
+def test_many_slices_strided_mode(oracle_lib):
+    """resolution > 640 switches to one atom per workgroup with strided partial sums and
+    z = z0 + (k+1)*delta: no longer bit-identical, must stay at rounding level."""
+    g = load_golden("synthetic")
+    for tag in ("two_x", "two_y", "two_z"):
+        sasa, *_ = run_batch(True, g[tag + "_xyz"], g[tag + "_radii"], resolution=20000)
+        assert np.max(np.abs(sasa - g[tag + "_lr20000"])) < 1e-9
+        _, c, _, _ = _sr(oracle_lib, g[tag + "_xyz"], g[tag + "_radii"], n_points=5000)
+        assert np.array_equal(c, g[tag + "_sr5000_counts"])
+
+
+def test_edge_fixtures(oracle_lib):
+    g = load_golden("synthetic")
+    for tag in ("touch", "buried", "nbkat", "four"):
+        sasa, *_ = run_batch(True, g[tag + "_xyz"], g[tag + "_radii"])
+        assert np.array_equal(sasa, g[tag + "_lr20"]), tag
+    sasa, *_ = run_batch(True, g["buried_xyz"], g["buried_radii"])
+    assert sasa[1] == 0.0
+
+
+def test_overflow_goes_to_fallback_and_matches(oracle_lib):
+    """Shrunken capacities: most tiles overflow (neighbor list, pool, arc stack) and are
+    redone by the slab-backed fallback launch; results must not change."""
+    xyz, r = tools.globule(900, 5)
+    want = oracle_lib.lee_richards(xyz, r)
+    for kw in (dict(cap_idx=24), dict(pool=300), dict(ds=0), dict(ds=1)):
+        sasa, _, _, st = run_batch(True, xyz, r, **kw)
+        assert st["fallback_tiles"] > 0, kw
+        assert np.array_equal(sasa, want), kw
+    ws, wc = oracle_lib.shrake_rupley(xyz, r)
+    _, c, _, st = _sr(oracle_lib, xyz, r, cap_idx=24)
+    assert st["fallback_tiles"] > 0 and np.array_equal(c, wc)
+
+
+def test_fallback_capacity_errors_are_reported(oracle_lib):
+    xyz, r = tools.globule(300, 6)
+    _, _, _, st = run_batch(True, xyz, r, cap_idx=8, fb_cap_idx=16, check=False)
+    assert st["error"] == 4          # ERR_NEIGHBOR_CAP
+    xyz, r = tools.coil(400, 8)
+    _, _, _, st = run_batch(True, xyz, r, ds=0, fb_ds=1, check=False)
+    assert st["error"] in (0, 5)     # ERR_STACK_CAP only if some slice needs depth > 2
+
+
+def test_bad_inputs_flag_errors():
+    xyz, r = tools.coil(50, 1)
+    bad = xyz.copy()
+    bad[7, 1] = np.nan
+    assert run_batch(True, bad, r, check=False)[3]["error"] == 3    # ERR_BAD_COORD
+    assert run_batch(True, xyz, -2.0 * np.ones(50), check=False)[3]["error"] == 1  # ERR_BAD_RADIUS
+    far = xyz.copy()
+    far[0, 0] = 1e12
+    assert run_batch(True, far, r, check=False)[3]["error"] == 2    # ERR_GRID_TOO_BIG
+
+
+def test_launch_configurations():
+    """Every branch of the launch-configuration chooser on one small structure."""
+    import oracle
+    o = oracle.Oracle()
+    xyz, r = tools.globule(150, 9)
+    for ns in (1, 3, 7, 20, 33, 64, 100, 333, 640, 641):
+        sasa, _, _, st = run_batch(True, xyz, r, resolution=ns)
+        want = o.lee_richards(xyz, r, 1.4, ns)
+        if ns <= 640:
+            assert np.array_equal(sasa, want), (ns, st)
+        else:
+            assert np.max(np.abs(sasa - want)) < 1e-10
+    for npts in (1, 13, 100, 257, 4096, 4097):
+        _, c, _, st = run_batch(False, xyz, r, resolution=npts, unit_pts=o.test_points(npts))
+        assert np.array_equal(c, o.shrake_rupley(xyz, r, 1.4, npts)[1]), (npts, st)

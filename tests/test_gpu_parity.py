@@ -1,0 +1,251 @@
+"""GPU parity tests (run by the driver on a real MI355X with -m gpu).  Everything goes through
+the C-ABI of libfreesasa_amd.so.  Bars: S&R bit-exact (integer counts AND the fp64 areas derived
+from them); L&R within LR_TOL of the reference (north_star allows 1e-4 A^2; the only source of
+difference is the device's acos/atan2, so the test holds the kernel to 1e-9)."""
+import threading
+
+import numpy as np
+import pytest
+
+import tools
+from conftest import GOLDEN, load_golden, read_bfactor_pdb
+
+pytestmark = pytest.mark.gpu
+
+LR_TOL = 1e-9          # A^2 per atom, asserted
+LR_TOL_NORTH_STAR = 1e-4
+STRUCTS = ["1ubq", "1a0q", "3bzd_trimmed", "1d3z", "1d3z_H"]
+
+
+@pytest.fixture(scope="module")
+def fa():
+    import freesasa_amd
+    assert freesasa_amd.device_count() > 0, "no HIP device: the GPU tests cannot run"
+    return freesasa_amd
+
+
+@pytest.mark.parametrize("name", STRUCTS)
+def test_calc_coord_golden_structures(fa, name):
+    g = load_golden(name)
+    sr, tot = fa.calc_coord(g["xyz"], g["radii"], fa.SHRAKE_RUPLEY, n_points=100)
+    assert np.array_equal(sr, g["sr100"])                   # bit-exact per atom
+    assert tot == float(g["sr100_total"])                   # and the sequential total
+    for ns in (20, 100):
+        lr, tot = fa.calc_coord(g["xyz"], g["radii"], fa.LEE_RICHARDS, n_slices=ns)
+        assert np.max(np.abs(lr - g[f"lr{ns}"])) < LR_TOL
+        assert abs(tot - float(g[f"lr{ns}_total"])) < 1e-7
+
+
+def test_reference_published_totals(fa):
+    """tests/test_freesasa.c:161,175,305,442,451 with the reference's own tolerance 1e-5."""
+    g = load_golden("1ubq")
+    assert abs(fa.calc_coord(g["xyz"], g["radii"], fa.LEE_RICHARDS)[1] - 4804.055641) < 1e-5
+    assert abs(fa.calc_coord(g["xyz"], g["radii"], fa.SHRAKE_RUPLEY)[1] - 4834.716265) < 1e-5
+    g = load_golden("3bzd_trimmed")
+    assert abs(fa.calc_coord(g["xyz"], g["radii"], fa.SHRAKE_RUPLEY)[1] - 16133.867124) < 1e-5
+    assert abs(fa.calc_coord(load_golden("1d3z")["xyz"], load_golden("1d3z")["radii"], fa.SHRAKE_RUPLEY)[1] - 5000.340175) < 1e-5
+
+
+def test_1ubq_B_pdb_golden_file(fa):
+    import os
+    xyz, rad, sasa_ref = read_bfactor_pdb(os.path.join(GOLDEN, "1ubq.B.pdb"))
+    sasa, _ = fa.calc_coord(xyz, rad, fa.SHRAKE_RUPLEY, n_points=100)
+    assert np.max(np.abs(sasa - sasa_ref)) <= 0.005 + 1e-9
+
+
+def test_parameter_sweep(fa):
+    g = load_golden("1ubq")
+    for probe in (1.0, 2.0):
+        lr, _ = fa.calc_coord(g["xyz"], g["radii"], fa.LEE_RICHARDS, probe=probe)
+        assert np.max(np.abs(lr - g[f"lr20_p{probe}"])) < LR_TOL
+        _, counts, _ = fa.calc_batch(g["xyz"], g["radii"], [0, 602], fa.SHRAKE_RUPLEY, probe, 100)
+        assert np.array_equal(counts, g[f"sr100_p{probe}_counts"])
+    for npts in (20, 1000):
+        _, counts, _ = fa.calc_batch(g["xyz"], g["radii"], [0, 602], fa.SHRAKE_RUPLEY, 1.4, npts)
+        assert np.array_equal(counts, g[f"sr{npts}_counts"])
+    lr, _ = fa.calc_coord(g["xyz"], g["radii"], fa.LEE_RICHARDS, n_slices=5)
+    assert np.max(np.abs(lr - g["lr5"])) < LR_TOL
+
+
+def test_synthetic_and_edge_fixtures(fa):
+    g = load_golden("synthetic")
+    tags = sorted({k[:-4] for k in g.files if k.endswith("_xyz")})
+    for tag in tags:
+        xyz, radii = g[tag + "_xyz"], g[tag + "_radii"]
+        for k in g.files:
+            if not k.startswith(tag + "_") or k.endswith(("_xyz", "_radii")):
+                continue
+            what = k[len(tag) + 1:]
+            if what.startswith("lr"):
+                lr, _ = fa.calc_coord(xyz, radii, fa.LEE_RICHARDS, n_slices=int(what[2:]))
+                assert np.max(np.abs(lr - g[k])) < LR_TOL, k
+            else:
+                n = int(what[2:].split("_")[0])
+                _, counts, _ = fa.calc_batch(xyz, radii, [0, len(radii)], fa.SHRAKE_RUPLEY, 1.4, n)
+                assert np.array_equal(counts, g[k]), k
+
+
+def test_analytic_two_spheres(fa):
+    r1, r2, d = 2.4, 3.4, 2.0
+    hidden = np.pi / d * (r1 * (r2 * r2 - (d - r1) ** 2) + r2 * (r1 * r1 - (d - r2) ** 2))
+    exact = 4 * np.pi * (r1 * r1 + r2 * r2) - hidden
+    for axis in range(3):
+        xyz = np.zeros((2, 3))
+        xyz[1, axis] = d
+        _, tot = fa.calc_coord(xyz, [1.0, 2.0], fa.LEE_RICHARDS, n_slices=20000)
+        assert abs(tot - exact) / (tot + exact) < 1e-5
+        _, tot = fa.calc_coord(xyz, [1.0, 2.0], fa.SHRAKE_RUPLEY, n_points=5000)
+        assert abs(tot - exact) / (tot + exact) < 1e-3
+
+
+def test_single_and_isolated_atoms(fa):
+    R = 2.4
+    lr, tot = fa.calc_coord([[1.0, 2.0, 3.0]], [1.0], fa.LEE_RICHARDS)
+    assert abs(lr[0] - 4 * np.pi * R * R) < 1e-10 and tot == lr[0]
+    sr, _ = fa.calc_coord([[1.0, 2.0, 3.0]], [1.0], fa.SHRAKE_RUPLEY)
+    assert sr[0] == (4.0 * np.pi * R * R * 100) / 100
+
+
+def test_ragged_batch_matches_oracle(fa, oracle_lib):
+    parts = [tools.coil(1500, 21), tools.globule(777, 22), (np.zeros((0, 3)), np.zeros(0)),
+             (np.array([[5.0, 5.0, 5.0]]), np.array([1.7])), tools.coil(33, 23),
+             tools.globule(400, 24, 2.05), tools.globule(2500, 25)]
+    xyz = np.concatenate([p[0] for p in parts])
+    r = np.concatenate([p[1] for p in parts])
+    offsets = np.concatenate([[0], np.cumsum([len(p[1]) for p in parts])])
+    lr, _, ltot = fa.calc_batch(xyz, r, offsets, fa.LEE_RICHARDS, 1.4, 20)
+    sr, cnt, stot = fa.calc_batch(xyz, r, offsets, fa.SHRAKE_RUPLEY, 1.4, 100)
+    for k, (px, pr) in enumerate(parts):
+        sl = slice(offsets[k], offsets[k + 1])
+        if len(pr) == 0:
+            assert ltot[k] == 0 and stot[k] == 0
+            continue
+        want = oracle_lib.lee_richards(px, pr)
+        assert np.max(np.abs(lr[sl] - want)) < LR_TOL
+        assert ltot[k] == oracle_lib.total(lr[sl])          # device total = sequential sum
+        ws, wc = oracle_lib.shrake_rupley(px, pr)
+        assert np.array_equal(cnt[sl], wc) and np.array_equal(sr[sl], ws)
+        assert stot[k] == oracle_lib.total(ws)
+
+
+def test_dense_packing_uses_fallback_and_stays_exact(fa, oracle_lib):
+    """Spacing 1.6 A: ~170 neighbors/atom, beyond the LDS capacities -> slab-backed launch."""
+    xyz, r = tools.globule(1200, 31, 1.6)
+    lr, _ = fa.calc_coord(xyz, r, fa.LEE_RICHARDS)
+    assert np.max(np.abs(lr - oracle_lib.lee_richards(xyz, r))) < LR_TOL
+    sr, _ = fa.calc_coord(xyz, r, fa.SHRAKE_RUPLEY)
+    assert np.array_equal(sr, oracle_lib.shrake_rupley(xyz, r)[0])
+
+
+def test_large_single_structure_config1_proxy(fa, oracle_lib):
+    """BASELINE configs[1] proxy (4V6X is not available offline): 200k-atom globule, S&R 100."""
+    xyz, r = tools.globule(200_000, 77)
+    sr, cnt, _ = fa.calc_batch(xyz, r, [0, len(r)], fa.SHRAKE_RUPLEY, 1.4, 100)
+    ws, wc = oracle_lib.shrake_rupley(xyz, r)
+    assert np.array_equal(cnt, wc) and np.array_equal(sr, ws)
+    lr, _, _ = fa.calc_batch(xyz, r, [0, len(r)], fa.LEE_RICHARDS, 1.4, 20)
+    assert np.max(np.abs(lr - oracle_lib.lee_richards(xyz, r))) < LR_TOL
+
+
+def test_device_resident_batch_full_size_properties(fa, oracle_lib):
+    """BASELINE configs[2] geometry at full size (1000 coils x 10k atoms) through the
+    device-pointer API on torch's stream: size-independent properties + oracle on a sample."""
+    import torch
+    n_structs, n_at = 1000, 10_000
+    xyz, r, offs = tools.coil_batch(n_structs, n_at, seed0=1000)
+    dev = torch.device("cuda:0")
+    d_xyz, d_r = torch.from_numpy(xyz).to(dev), torch.from_numpy(r).to(dev)
+    d_out = torch.empty(len(r), dtype=torch.float64, device=dev)
+    d_tot = torch.empty(n_structs, dtype=torch.float64, device=dev)
+    ctx = fa.GpuContext(0, stream=torch.cuda.current_stream().cuda_stream)
+    ctx.lee_richards(d_xyz.data_ptr(), d_r.data_ptr(), offs, d_out.data_ptr(), d_tot.data_ptr())
+    a = d_out.cpu().numpy()
+    tot = d_tot.cpu().numpy()
+    assert ctx.stats()["fallback_tiles"] < 0.01 * (len(r) / 16)
+    # 1. bounds: 0 <= sasa <= area of the free sphere
+    R = r + 1.4
+    assert np.all(a >= 0) and np.all(a <= 4 * np.pi * R * R * (1 + 1e-12))
+    # 2. oracle on a sample of whole structures
+    for k in (0, 1, 499, 998, 999):
+        sl = slice(offs[k], offs[k + 1])
+        assert np.max(np.abs(a[sl] - oracle_lib.lee_richards(xyz[sl], r[sl]))) < LR_TOL
+        assert tot[k] == oracle_lib.total(a[sl])
+    # 3. determinism: same input twice -> identical bits
+    ctx.lee_richards(d_xyz.data_ptr(), d_r.data_ptr(), offs, d_out.data_ptr(), d_tot.data_ptr())
+    assert np.array_equal(a, d_out.cpu().numpy())
+    # 4. batch independence: reversing the structure order permutes the results, bit for bit
+    perm = np.arange(n_structs)[::-1]
+    idx = (perm[:, None] * n_at + np.arange(n_at)[None, :]).reshape(-1)
+    d_xyz2, d_r2 = torch.from_numpy(xyz[idx]).to(dev), torch.from_numpy(r[idx]).to(dev)
+    ctx.lee_richards(d_xyz2.data_ptr(), d_r2.data_ptr(), offs, d_out.data_ptr(), d_tot.data_ptr())
+    assert np.array_equal(d_out.cpu().numpy(), a[idx])
+    # 5. S&R on the same batch: counts within [0, N], oracle on a sample, areas consistent
+    d_cnt = torch.empty(len(r), dtype=torch.int32, device=dev)
+    ctx.shrake_rupley(d_xyz.data_ptr(), d_r.data_ptr(), offs, d_out.data_ptr(), d_cnt.data_ptr())
+    c = d_cnt.cpu().numpy()
+    s = d_out.cpu().numpy()
+    assert c.min() >= 0 and c.max() <= 100
+    assert np.array_equal(s, (4.0 * np.pi * R * R * c) / 100)
+    for k in (3, 777):
+        sl = slice(offs[k], offs[k + 1])
+        assert np.array_equal(c[sl], oracle_lib.shrake_rupley(xyz[sl], r[sl])[1])
+    ctx.close()
+
+
+def test_lr100_batch_config2(fa, oracle_lib):
+    """BASELINE configs[2] parameters (L&R 100 slices) on a slice of the batch."""
+    xyz, r, offs = tools.coil_batch(20, 10_000, seed0=1000)
+    lr, _, _ = fa.calc_batch(xyz, r, offs, fa.LEE_RICHARDS, 1.4, 100)
+    for k in (0, 19):
+        sl = slice(offs[k], offs[k + 1])
+        assert np.max(np.abs(lr[sl] - oracle_lib.lee_richards(xyz[sl], r[sl], 1.4, 100))) < LR_TOL
+
+
+def test_trajectory_frames_config4_proxy(fa, oracle_lib):
+    """configs[4] proxy: one system, jittered frames, radii/offsets constant across calls."""
+    base, r = tools.globule(20_000, 5)
+    for f in range(3):
+        xyz = tools.jitter(base, 100 + f, 0.3)
+        lr, _ = fa.calc_coord(xyz, r, fa.LEE_RICHARDS)
+        if f != 1:
+            assert np.max(np.abs(lr - oracle_lib.lee_richards(xyz, r))) < LR_TOL
+
+
+def test_thread_count_is_ignored_and_calls_are_reentrant(fa):
+    g = load_golden("1ubq")
+    a1, _ = fa.calc_coord(g["xyz"], g["radii"], fa.LEE_RICHARDS, n_threads=1)
+    a16, _ = fa.calc_coord(g["xyz"], g["radii"], fa.LEE_RICHARDS, n_threads=16)
+    assert np.array_equal(a1, a16)
+    out = [None] * 6
+
+    def work(k):
+        alg = fa.LEE_RICHARDS if k % 2 else fa.SHRAKE_RUPLEY
+        out[k] = fa.calc_coord(g["xyz"], g["radii"], alg)[0]
+    th = [threading.Thread(target=work, args=(k,)) for k in range(6)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for k in range(6):
+        assert np.array_equal(out[k], a1 if k % 2 else g["sr100"])
+
+
+def test_errors_return_null_not_garbage(fa):
+    L = fa.lib()
+    L.freesasa_set_verbosity(fa.V_SILENT)
+    try:
+        xyz, r = tools.coil(100, 1)
+        bad = xyz.copy()
+        bad[5, 2] = np.inf
+        with pytest.raises(RuntimeError):
+            fa.calc_coord(bad, r)
+        far = xyz.copy()
+        far[0, 0] = 1e13
+        with pytest.raises(RuntimeError):
+            fa.calc_coord(far, r)
+        with pytest.raises(RuntimeError):
+            fa.calc_coord(xyz, r, n_threads=17)
+        with pytest.raises(RuntimeError):
+            fa.calc_coord(xyz, r, n_slices=0)
+        # the library is still healthy afterwards
+        assert np.isfinite(fa.calc_coord(xyz, r)[1])
+    finally:
+        L.freesasa_set_verbosity(fa.V_NORMAL)
