@@ -55,12 +55,33 @@ def build():
     subprocess.run(["make", "-C", ROOT, "all"], check=True, stdout=subprocess.DEVNULL)
 
 
+def _preload_torch_hip_runtime():
+    """libfreesasa_amd.so needs libamdhip64.so.7.  PyTorch-ROCm wheels bundle their own copy under
+    the same soname; a process must not end up with ROCm's copy loaded first and torch's other
+    runtime libraries later ("No HIP GPUs are available").  If torch is installed and not yet
+    imported, load ITS libamdhip64 first so that both this library and a later `import torch`
+    share one runtime.  Pure C callers are unaffected (no torch in the process)."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("FREESASA_AMD_NO_TORCH_PRELOAD"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.origin:
+            cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise OSError(f"{LIB_PATH} is not built (run `make` or __graft_entry__.build()); "
                           "freesasa_amd has no pure-Python or CPU path")
+        _preload_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         L.freesasa_calc_coord.argtypes = [_dp, _dp, C.c_int, C.POINTER(Parameters)]
         L.freesasa_calc_coord.restype = C.POINTER(Result)
