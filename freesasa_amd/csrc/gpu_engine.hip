@@ -80,7 +80,10 @@ __global__ __launch_bounds__(SASA_PIPE_B) void k_scatter(PipeArgs a)
 
 __global__ __launch_bounds__(64) void k_totals(const double *sasa, const int64_t *offsets, int n_structs, double *totals)
 {
-    totals_struct(sasa, offsets, n_structs, totals, blockIdx.x * 64 + threadIdx.x);
+    __shared__ double part[64];
+    totals_phase0(sasa, offsets, part, blockIdx.x, threadIdx.x);
+    __syncthreads();
+    totals_phase1(part, totals, blockIdx.x, threadIdx.x);
 }
 
 template <int B, bool GLOBAL>
@@ -93,14 +96,14 @@ __global__ __launch_bounds__(B) void k_lr_tile(TileArgs a, int items)
     for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
         const int tile = GLOBAL ? a.work_tiles[w] : xcd_tile(w, a.n_tiles);
         if (tile >= a.n_tiles) continue; /* uniform per workgroup */
-        tile_phase_load(a, m, tile, tid);
+        tile_phase_load(a, m, tile, tid, B);
         __syncthreads();
         tile_phase_neighbors(a, m, tile, tid, B);
         __syncthreads();
-        tile_phase_offsets<GLOBAL>(a, m, tile, tid);
+        tile_phase_offsets(a, m, tid);
         __syncthreads();
+        tile_report<GLOBAL>(a, m, tile, tid);
         lr_phase_beta(a, m, tid, B);
-        lr_phase_ztab(a, m, tid);
         __syncthreads();
         lr_phase_rank(a, m, tid, B);
         __syncthreads();
@@ -121,12 +124,13 @@ __global__ __launch_bounds__(B) void k_sr_tile(TileArgs a, int items)
     for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
         const int tile = GLOBAL ? a.work_tiles[w] : xcd_tile(w, a.n_tiles);
         if (tile >= a.n_tiles) continue;
-        tile_phase_load(a, m, tile, tid);
+        tile_phase_load(a, m, tile, tid, B);
         __syncthreads();
         tile_phase_neighbors(a, m, tile, tid, B);
         __syncthreads();
-        tile_phase_offsets<GLOBAL>(a, m, tile, tid);
+        tile_phase_offsets(a, m, tid);
         __syncthreads();
+        tile_report<GLOBAL>(a, m, tile, tid);
         sr_phase_pairs(a, m, tid, B);
         __syncthreads();
         sr_phase_points(a, m, tile, tid, B);
@@ -250,8 +254,12 @@ static hipError_t launch_lr(const TileCfg &c, const TileArgs &t, int grid, size_
 {
     if (c.B == 320)
         hipLaunchKernelGGL((k_lr_tile<320, GLOBAL>), dim3(grid), dim3(320), lds, s, t, c.items);
-    else
+    else if (c.B == 256)
         hipLaunchKernelGGL((k_lr_tile<256, GLOBAL>), dim3(grid), dim3(256), lds, s, t, c.items);
+    else if (c.B == 128)
+        hipLaunchKernelGGL((k_lr_tile<128, GLOBAL>), dim3(grid), dim3(128), lds, s, t, c.items);
+    else
+        hipLaunchKernelGGL((k_lr_tile<64, GLOBAL>), dim3(grid), dim3(64), lds, s, t, c.items);
     return hipGetLastError();
 }
 template <bool GLOBAL>
@@ -259,8 +267,12 @@ static hipError_t launch_sr(const TileCfg &c, const TileArgs &t, int grid, size_
 {
     if (c.B == 320)
         hipLaunchKernelGGL((k_sr_tile<320, GLOBAL>), dim3(grid), dim3(320), lds, s, t, c.items);
-    else
+    else if (c.B == 256)
         hipLaunchKernelGGL((k_sr_tile<256, GLOBAL>), dim3(grid), dim3(256), lds, s, t, c.items);
+    else if (c.B == 128)
+        hipLaunchKernelGGL((k_sr_tile<128, GLOBAL>), dim3(grid), dim3(128), lds, s, t, c.items);
+    else
+        hipLaunchKernelGGL((k_sr_tile<64, GLOBAL>), dim3(grid), dim3(64), lds, s, t, c.items);
     return hipGetLastError();
 }
 
@@ -357,7 +369,16 @@ static int run_batch(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, const do
     if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[1], st));
 
     /* fused tile kernel */
-    const TileCfg cfg = choose_cfg(resolution, lr);
+    TileCfg cfg = choose_cfg(resolution, lr);
+    if (const char *e = getenv("FREESASA_AMD_CFG")) { /* tuning aid: "B,TA,pool,ds" */
+        int b = 0, t = 0, pl = 0, d = 0;
+        if (sscanf(e, "%d,%d,%d,%d", &b, &t, &pl, &d) == 4 && (b == 64 || b == 128 || b == 256 || b == 320) && t >= 1 && t <= b &&
+            (!lr || !cfg.tab || t * resolution <= 4096)) {
+            cfg.B = b; cfg.TA = t; cfg.pool = pl; cfg.ds = lr ? d : 0;
+            cfg.items = lr ? (cfg.tab ? cfg.TA * resolution : cfg.B) : 1;
+            cfg.lds = tile_fixed_bytes(cfg.TA, cfg.items) + tile_list_bytes(cfg.TA, cfg.cap_idx, cfg.pool, cfg.npw, cfg.ds, cfg.B);
+        }
+    }
     const int n_tiles = (n + cfg.TA - 1) / cfg.TA;
     if (ensure(c, c->ovf_tiles, sizeof(int) * ((size_t)n_tiles + 1))) return -1;
 
@@ -368,7 +389,7 @@ static int run_batch(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, const do
     ta.grid = pa.grid; ta.cell_start = pa.cell_start;
     ta.n_atoms = n; ta.n_tiles = n_tiles; ta.TA = cfg.TA; ta.n_res = resolution; ta.tab = cfg.tab;
     ta.sasa = d_sasa; ta.counts = d_counts;
-    ta.cap_idx = cfg.cap_idx; ta.pool = cfg.pool; ta.ds = cfg.ds;
+    ta.cap_idx = cfg.cap_idx; ta.pool = cfg.pool; ta.npw = cfg.npw; ta.ds = cfg.ds;
     ta.ovf_count = (int *)c->status.p + ST_OVF_TILES;
     ta.ovf_tiles = (int *)c->ovf_tiles.p;
     ta.status = (int *)c->status.p;
@@ -382,14 +403,14 @@ static int run_batch(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, const do
     const int grid_main = ((n_tiles + 7) / 8) * 8;
     hipError_t le;
     {
-        static bool attr_done[4] = {false, false, false, false};
-        /* allow > 64 KB of dynamic LDS */
-        const int which = (lr ? 0 : 2) + (cfg.B == 320 ? 0 : 1);
-        if (!attr_done[which]) {
-            const void *fn = lr ? (cfg.B == 320 ? (const void *)k_lr_tile<320, false> : (const void *)k_lr_tile<256, false>)
-                                : (cfg.B == 320 ? (const void *)k_sr_tile<320, false> : (const void *)k_sr_tile<256, false>);
-            (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_done[which] = true;
+        static bool attr_done = false; /* allow > 64 KB of dynamic LDS */
+        if (!attr_done) {
+            const void *fns[] = {(const void *)k_lr_tile<320, false>, (const void *)k_lr_tile<256, false>,
+                                 (const void *)k_lr_tile<128, false>, (const void *)k_lr_tile<64, false>,
+                                 (const void *)k_sr_tile<320, false>, (const void *)k_sr_tile<256, false>,
+                                 (const void *)k_sr_tile<128, false>, (const void *)k_sr_tile<64, false>};
+            for (const void *fn : fns) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_done = true;
         }
     }
     le = lr ? launch_lr<false>(cfg, ta, grid_main, cfg.lds, st) : launch_sr<false>(cfg, ta, grid_main, cfg.lds, st);
@@ -400,7 +421,7 @@ static int run_batch(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, const do
        read the count on the device and exit).  One atom per workgroup, lists in a slab. */
     {
         const TileCfg fb = fallback_cfg(cfg, lr);
-        const size_t stride = tile_slab_bytes(fb.TA, fb.cap_idx, fb.pool, fb.ds, fb.B);
+        const size_t stride = tile_slab_bytes(fb.TA, fb.cap_idx, fb.pool, fb.npw, fb.ds, fb.B);
         if (ensure(c, c->slab, stride * SASA_FB_BLOCKS)) return -1;
         TileArgs tf = ta;
         tf.cap_idx = fb.cap_idx; tf.pool = fb.pool; tf.ds = fb.ds;
@@ -412,7 +433,7 @@ static int run_batch(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, const do
     }
 
     if (d_totals) {
-        hipLaunchKernelGGL(k_totals, dim3((n_structs + 63) / 64), dim3(64), 0, st, (const double *)d_sasa,
+        hipLaunchKernelGGL(k_totals, dim3(n_structs), dim3(64), 0, st, (const double *)d_sasa,
                            (const int64_t *)c->offsets.p, n_structs, d_totals);
         HIP_TRY(c, hipGetLastError());
     }

@@ -39,12 +39,16 @@ inline int atomic_max(int *p, int v) { int o = *p; if (v > o) *p = v; return o; 
 #define SASA_ATOMIC_ADD_LDS(p, v) sasa_emu::atomic_add((p), (v))
 #define SASA_ATOMIC_ADD_GLB(p, v) sasa_emu::atomic_add((p), (v))
 #define SASA_ATOMIC_MAX_GLB(p, v) sasa_emu::atomic_max((p), (v))
+#define SASA_ATOMIC_MAX_LDS(p, v) sasa_emu::atomic_max((p), (v))
+#define SASA_RSQ(x) (1.0 / sqrt(x))
 #else
 #define SASA_D __device__ __forceinline__
 #define SASA_HD __host__ __device__ __forceinline__
 #define SASA_ATOMIC_ADD_LDS(p, v) atomicAdd((p), (v))
 #define SASA_ATOMIC_ADD_GLB(p, v) atomicAdd((p), (v))
 #define SASA_ATOMIC_MAX_GLB(p, v) atomicMax((p), (v))
+#define SASA_ATOMIC_MAX_LDS(p, v) atomicMax((p), (v))
+#define SASA_RSQ(x) __builtin_amdgcn_rsq(x)
 #endif
 
 namespace sasa {
@@ -300,11 +304,6 @@ SASA_D void scatter_atom(const PipeArgs &a, int i)
 /* ------------------------------------------------------------------------------------
  * K6: fused tile kernels
  * ---------------------------------------------------------------------------------- */
-struct Pair { /* one neighbor of one tile atom, 32 B */
-    double a, b, c, d;
-    /* L&R: a = beta, b = z_j, c = R_j, d = xy-distance d_ij   (ref: src/nb.c:438-448)
-       S&R: a = x_j,  b = y_j, c = z_j, d = R_j^2              (ref: src/sasa_sr.c:146) */
-};
 struct Arc { double s, e; };
 
 struct TileArgs {
@@ -316,13 +315,14 @@ struct TileArgs {
     int n_tiles;
     int TA;      /* atoms per tile */
     int n_res;   /* L&R: slices per atom; S&R: test points */
-    int tab;     /* 1: z table + per-slice contributions in LDS, summed in slice order */
+    int tab;     /* 1: per-slice areas kept in LDS and summed in slice order */
     const double *unit_pts; /* S&R: [3*n_res] unit test points (host libm, ref: src/sasa_sr.c:56-90) */
     double *sasa; /* [n_atoms] original order */
     int *counts;  /* S&R: exposed points per atom (original order), may be null */
     /* capacities of the per-tile lists */
     int cap_idx; /* neighbor indices per atom */
-    int pool;    /* Pair entries per tile */
+    int pool;    /* neighbor records per tile */
+    int npw;     /* doubles per neighbor record: 5 (L&R) or 4 (S&R) */
     int ds;      /* spilled stack levels per thread (L&R) */
     /* overflow hand-off to the fallback launch */
     int *ovf_count;
@@ -334,44 +334,50 @@ struct TileArgs {
     int *status;
 };
 
-/* LDS / slab views */
+/* One neighbor record, 32 B, read with two ds_read_b128:
+ *   L&R: x = z_j, y = R_j^2, z = D = xd^2+yd^2, w = 1/sqrt(D)   (+ beta in a separate array)
+ *   S&R: x = x_j, y = y_j,   z = z_j,           w = R_j^2
+ * In the L&R pool every atom's list is padded to a multiple of 4 records with dummies
+ * (R_j^2 = 0: never overlaps a slice) so the screening loop runs 4 neighbors per trip. */
+struct __attribute__((aligned(16))) Quad { double x, y, z, w; };
 struct TileMem {
     double *ax, *ay, *az, *aR; /* [TA] tile atoms */
     int *acnt;                 /* [TA] neighbors found */
     int *aoff;                 /* [TA+1] offsets into pool */
     int *aexp;                 /* [TA] S&R exposed-point counters */
-    int *flags;                /* [4] flags[0]=tile overflow */
-    double *ztab;              /* [TA*n_res] slice mid-planes (tab mode) */
+    int *flags;                /* [4] 0: tile overflow, 1: stack overflow, 2: max neighbor count */
+    int *rowlo, *rowcnt;       /* [TA*9] candidate runs: first sorted position, length */
     double *contrib;           /* [TA*n_res] slice areas (tab mode) / [B] partials */
     int *idx;                  /* [TA*cap_idx] neighbor candidates (sorted positions) */
     double *tb;                /* [pool] beta of each pair before ranking */
-    Pair *pool;                /* [pool] */
+    Quad *pq;                  /* [pool] neighbor records */
+    double *pb;                /* [pool] L&R: beta, sorted */
     Arc *stack;                /* [ds][B] spilled components */
 };
 
 SASA_HD size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
-/* Bytes of LDS needed.  In the LDS variant idx+tb (phases N..N2) alias the stack (phase L). */
+/* Bytes of LDS needed.  In the LDS variant idx+tb (phases N..P) alias the stack (phase L). */
 SASA_HD size_t tile_fixed_bytes(int TA, int items)
 {
-    return align16(sizeof(double) * 4 * TA) + align16(sizeof(int) * (3 * TA + 1 + 4)) +
-           align16(sizeof(double) * items) * 2;
+    return align16(sizeof(double) * 4 * TA) + align16(sizeof(int) * (3 * TA + 1 + 4 + 18 * TA)) +
+           align16(sizeof(double) * items);
 }
-SASA_HD size_t tile_union_bytes(int TA, int cap_idx, int pool, int ds, int B)
+SASA_HD size_t tile_union_bytes(int TA, int cap_idx, int pool, int ds, int B, bool lr)
 {
-    size_t u1 = align16(sizeof(int) * (size_t)TA * cap_idx) + align16(sizeof(double) * (size_t)pool);
+    size_t u1 = align16(sizeof(int) * (size_t)TA * cap_idx) + (lr ? align16(sizeof(double) * (size_t)pool) : 0);
     size_t u2 = sizeof(Arc) * (size_t)ds * B;
     return u1 > u2 ? u1 : u2;
 }
-SASA_HD size_t tile_list_bytes(int TA, int cap_idx, int pool, int ds, int B)
+SASA_HD size_t tile_list_bytes(int TA, int cap_idx, int pool, int npw, int ds, int B)
 {
-    return tile_union_bytes(TA, cap_idx, pool, ds, B) + align16(sizeof(Pair) * (size_t)pool);
+    return tile_union_bytes(TA, cap_idx, pool, ds, B, npw == 5) + align16(sizeof(double) * (size_t)pool) * npw;
 }
 /* fallback slab (no aliasing) */
-SASA_HD size_t tile_slab_bytes(int TA, int cap_idx, int pool, int ds, int B)
+SASA_HD size_t tile_slab_bytes(int TA, int cap_idx, int pool, int npw, int ds, int B)
 {
     return align16(sizeof(int) * (size_t)TA * cap_idx) + align16(sizeof(double) * (size_t)pool) +
-           align16(sizeof(Arc) * (size_t)ds * B) + align16(sizeof(Pair) * (size_t)pool);
+           align16(sizeof(Arc) * (size_t)ds * B) + align16(sizeof(double) * (size_t)pool) * npw;
 }
 
 template <bool GLOBAL>
@@ -382,22 +388,24 @@ SASA_D TileMem tile_carve(const TileArgs &a, char *smem, int items, int B, int b
     m.ax = (double *)p; m.ay = m.ax + a.TA; m.az = m.ay + a.TA; m.aR = m.az + a.TA;
     p += align16(sizeof(double) * 4 * a.TA);
     m.acnt = (int *)p; m.aoff = m.acnt + a.TA; m.aexp = m.aoff + a.TA + 1; m.flags = m.aexp + a.TA;
-    p += align16(sizeof(int) * (3 * a.TA + 1 + 4));
-    m.ztab = (double *)p; p += align16(sizeof(double) * items);
+    m.rowlo = m.flags + 4; m.rowcnt = m.rowlo + 9 * a.TA;
+    p += align16(sizeof(int) * (3 * a.TA + 1 + 4 + 18 * a.TA));
     m.contrib = (double *)p; p += align16(sizeof(double) * items);
+    const size_t pw = align16(sizeof(double) * (size_t)a.pool);
+    char *q;
     if (GLOBAL) {
-        char *q = a.slab + (long long)blk * a.slab_stride;
+        q = a.slab + (long long)blk * a.slab_stride;
         m.idx = (int *)q; q += align16(sizeof(int) * (size_t)a.TA * a.cap_idx);
-        m.tb = (double *)q; q += align16(sizeof(double) * (size_t)a.pool);
+        m.tb = (double *)q; q += pw;
         m.stack = (Arc *)q; q += align16(sizeof(Arc) * (size_t)a.ds * B);
-        m.pool = (Pair *)q;
     } else {
         m.idx = (int *)p;
         m.tb = (double *)(p + align16(sizeof(int) * (size_t)a.TA * a.cap_idx));
         m.stack = (Arc *)p;
-        p += tile_union_bytes(a.TA, a.cap_idx, a.pool, a.ds, B);
-        m.pool = (Pair *)p;
+        q = p + tile_union_bytes(a.TA, a.cap_idx, a.pool, a.ds, B, a.npw == 5);
     }
+    m.pq = (Quad *)q;
+    m.pb = (double *)(q + 4 * pw);
     return m;
 }
 
@@ -408,8 +416,11 @@ SASA_D int tile_atoms(const TileArgs &a, int tile)
     return n < a.TA ? n : a.TA;
 }
 
-/* phase A: load the tile's atoms, reset counters */
-SASA_D void tile_phase_load(const TileArgs &a, TileMem &m, int tile, int tid)
+/* phase A: load the tile's atoms and, one thread per (atom, dy, dz), the 9 runs of
+ * cell-sorted atoms that cover its 27 surrounding cells (x-adjacent cells are contiguous).
+ * Every thread has one short chain s_struct/s_cell -> grid -> cell_start, and the chains of
+ * all threads run concurrently, so the whole tile pays about three memory round trips. */
+SASA_D void tile_phase_load(const TileArgs &a, TileMem &m, int tile, int tid, int B)
 {
     const int na = tile_atoms(a, tile), p0 = tile_first_atom(a, tile);
     if (tid < a.TA) {
@@ -423,11 +434,43 @@ SASA_D void tile_phase_load(const TileArgs &a, TileMem &m, int tile, int tid)
         m.aexp[tid] = 0;
     }
     if (tid < 4) m.flags[tid] = 0;
+    for (int t = tid; t < 9 * a.TA; t += B) {
+        const int la = t / 9, r = t - 9 * la;
+        int lo = 0, cnt = 0;
+        if (la < na) {
+            const int p = p0 + la;
+            const GridS g = a.grid[a.s_struct[p]];
+            const int lc = a.s_cell[p] - g.cell_base;
+            const int ix = lc % g.nx, iy = (lc / g.nx) % g.ny, iz = lc / (g.nx * g.ny);
+            const int cy = iy + (r % 3) - 1, cz = iz + (r / 3) - 1;
+            if (cy >= 0 && cy < g.ny && cz >= 0 && cz < g.nz) {
+                const int x_lo = ix > 0 ? ix - 1 : 0, x_hi = ix < g.nx - 1 ? ix + 1 : ix;
+                const int row = g.cell_base + g.nx * (cy + g.ny * cz);
+                lo = a.cell_start[row + x_lo];
+                cnt = a.cell_start[row + x_hi + 1] - lo;
+            }
+        }
+        m.rowlo[t] = lo;
+        m.rowcnt[t] = cnt;
+    }
 }
 
-/* phase N: neighbor discovery.  SUB = B/TA lanes share one atom and stride over the atoms of
- * its 27 surrounding cells (9 contiguous runs in cell-sorted order).  Contact test is the
- * reference's, operand for operand (ref: src/nb.c:483-492). */
+/* Contact test of the reference, operand for operand (ref: src/nb.c:483-492). */
+SASA_D void nb_test(const TileArgs &a, TileMem &m, int la, int p, int q, double xi, double yi,
+                    double zi, double ri, double xq, double yq, double zq, double rq)
+{
+    if (q == p) return;
+    const double cut2 = (ri + rq) * (ri + rq);
+    const double dx = xq - xi, dy = yq - yi, dz = zq - zi;
+    if (dx * dx + dy * dy + dz * dz < cut2) {
+        const int slot = SASA_ATOMIC_ADD_LDS(&m.acnt[la], 1);
+        if (slot < a.cap_idx) m.idx[la * a.cap_idx + slot] = q;
+    }
+}
+
+/* phase N: neighbor discovery.  SUB = B/TA lanes share one atom and stride over the
+ * concatenation of its 9 candidate runs, two candidates per trip so that eight loads are in
+ * flight before the first test. */
 SASA_D void tile_phase_neighbors(const TileArgs &a, TileMem &m, int tile, int tid, int B)
 {
     const int na = tile_atoms(a, tile), p0 = tile_first_atom(a, tile);
@@ -435,50 +478,52 @@ SASA_D void tile_phase_neighbors(const TileArgs &a, TileMem &m, int tile, int ti
     const int la = tid / SUB, sub = tid - la * SUB;
     if (la >= na) return;
     const int p = p0 + la;
-    const GridS g = a.grid[a.s_struct[p]];
-    const int lc = a.s_cell[p] - g.cell_base;
-    const int ix = lc % g.nx, iy = (lc / g.nx) % g.ny, iz = lc / (g.nx * g.ny);
     const double xi = m.ax[la], yi = m.ay[la], zi = m.az[la], ri = m.aR[la];
-    const int x_lo = ix > 0 ? ix - 1 : 0, x_hi = ix < g.nx - 1 ? ix + 1 : ix;
-
-    for (int cz = iz - 1; cz <= iz + 1; ++cz) {
-        if (cz < 0 || cz >= g.nz) continue;
-        for (int cy = iy - 1; cy <= iy + 1; ++cy) {
-            if (cy < 0 || cy >= g.ny) continue;
-            const int row = g.cell_base + g.nx * (cy + g.ny * cz);
-            const int q_lo = a.cell_start[row + x_lo], q_hi = a.cell_start[row + x_hi + 1];
-            for (int q = q_lo + sub; q < q_hi; q += SUB) {
-                if (q == p) continue;
-                const double rj = a.sr[q];
-                const double cut2 = (ri + rj) * (ri + rj);
-                const double dx = a.sx[q] - xi, dy = a.sy[q] - yi, dz = a.sz[q] - zi;
-                if (dx * dx + dy * dy + dz * dz < cut2) {
-                    const int slot = SASA_ATOMIC_ADD_LDS(&m.acnt[la], 1);
-                    if (slot < a.cap_idx) m.idx[la * a.cap_idx + slot] = q;
-                }
-            }
+    const int *rl = m.rowlo + 9 * la, *rc = m.rowcnt + 9 * la;
+    int total = 0;
+    for (int r = 0; r < 9; ++r) total += rc[r];
+    int r = 0, base = 0, cnt = rc[0];
+    for (int f = sub; f < total; f += 2 * SUB) {
+        while (f >= base + cnt) { base += cnt; ++r; cnt = rc[r]; }
+        const int q0 = rl[r] + (f - base);
+        const int f1 = f + SUB;
+        const bool has1 = f1 < total;
+        int q1 = q0;
+        if (has1) {
+            while (f1 >= base + cnt) { base += cnt; ++r; cnt = rc[r]; }
+            q1 = rl[r] + (f1 - base);
         }
+        const double x0 = a.sx[q0], y0 = a.sy[q0], z0 = a.sz[q0], r0 = a.sr[q0];
+        const double x1 = a.sx[q1], y1 = a.sy[q1], z1 = a.sz[q1], r1 = a.sr[q1];
+        nb_test(a, m, la, p, q0, xi, yi, zi, ri, x0, y0, z0, r0);
+        if (has1) nb_test(a, m, la, p, q1, xi, yi, zi, ri, x1, y1, z1, r1);
     }
 }
 
-/* phase O: offsets into the pool; overflow -> hand the tile to the fallback launch */
+/* phase O: offsets into the pool (each of the first TA threads sums the counts before it) */
+SASA_D int pad4(int c, int npw) { return npw == 5 ? (c + 3) & ~3 : c; }
+SASA_D void tile_phase_offsets(const TileArgs &a, TileMem &m, int tid)
+{
+    if (tid >= a.TA) return;
+    int off = 0;
+    for (int k = 0; k < tid; ++k) off += pad4(m.acnt[k], a.npw);
+    const int c = m.acnt[tid];
+    m.aoff[tid] = off;
+    if (c > a.cap_idx) m.flags[0] = 1;
+    if (tid == a.TA - 1) {
+        m.aoff[a.TA] = off + pad4(c, a.npw);
+        if (off + pad4(c, a.npw) > a.pool) m.flags[0] = 1;
+    }
+    SASA_ATOMIC_MAX_LDS(&m.flags[2], c);
+}
+
+/* first thing after the barrier that follows phase O: overflow -> fallback launch */
 template <bool GLOBAL>
-SASA_D void tile_phase_offsets(const TileArgs &a, TileMem &m, int tile, int tid)
+SASA_D void tile_report(const TileArgs &a, TileMem &m, int tile, int tid)
 {
     if (tid != 0) return;
-    int run = 0, ovf = 0, mx = 0;
-    for (int k = 0; k < a.TA; ++k) {
-        const int c = m.acnt[k];
-        if (c > a.cap_idx) ovf = 1;
-        if (c > mx) mx = c;
-        m.aoff[k] = run;
-        run += c;
-    }
-    m.aoff[a.TA] = run;
-    if (run > a.pool) ovf = 1;
-    SASA_ATOMIC_MAX_GLB(&a.status[ST_MAX_NN], mx);
-    if (ovf) {
-        m.flags[0] = 1;
+    SASA_ATOMIC_MAX_GLB(&a.status[ST_MAX_NN], m.flags[2]);
+    if (m.flags[0]) {
         if (GLOBAL) {
             SASA_ATOMIC_MAX_GLB(&a.status[ST_ERROR], (int)ERR_NEIGHBOR_CAP);
         } else {
@@ -486,6 +531,57 @@ SASA_D void tile_phase_offsets(const TileArgs &a, TileMem &m, int tile, int tid)
             a.ovf_tiles[w] = tile;
         }
     }
+}
+
+/* ---------------------------------------------------------------- fp64 helpers */
+
+/* g ~ sqrt(x), h ~ 0.5/sqrt(x) for normal positive x: hardware reciprocal-sqrt seed, one
+ * coupled Goldschmidt step, two residual corrections (~1 ulp; not correctly rounded). */
+SASA_D void sqrt_rh(double x, double &g, double &h)
+{
+    const double y = SASA_RSQ(x);
+    g = x * y;
+    h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    r = fma(-h, g, 0.5);
+    h = fma(h, r, h);
+    d = fma(-g, g, x);
+    g = fma(d, h, g);
+}
+
+/* acos on (-1,1): fdlibm's range reduction (|x| <= 0.5: pi/2 - asin x; else 2 asin sqrt((1-|x|)/2)),
+ * asin u = u + u z P(z), z = u^2 <= 0.25, P = degree-11 interpolant at Chebyshev nodes
+ * (max relative error of asin 5.6e-17, fitted with mpmath).  Branch-free. */
+SASA_D double acos_fast(double x)
+{
+    const double ax = fabs(x);
+    const bool big = ax > 0.5;
+    const double z = big ? (1.0 - ax) * 0.5 : x * x;
+    double p = 0x1.cd864394d2ff2p-6;
+    p = fma(p, z, -0x1.603991d6060e0p-7);
+    p = fma(p, z, 0x1.06b9d26d10838p-6);
+    p = fma(p, z, 0x1.ff5fc4d14c735p-8);
+    p = fma(p, z, 0x1.8522ddffa6208p-7);
+    p = fma(p, z, 0x1.c87265d47ef49p-7);
+    p = fma(p, z, 0x1.1c593c7b1d958p-6);
+    p = fma(p, z, 0x1.6e8b2b3b10be4p-6);
+    p = fma(p, z, 0x1.f1c71f95269afp-6);
+    p = fma(p, z, 0x1.6db6db684b6a1p-5);
+    p = fma(p, z, 0x1.3333333336da5p-4);
+    p = fma(p, z, 0x1.555555555554fp-3);
+    double s, hh;
+    sqrt_rh(big ? z : 1.0, s, hh);
+    const double u = big ? s : x;      /* asin argument */
+    const double t = fma(u * z, p, u); /* asin(u) */
+    const double pio2_hi = 0x1.921fb54442d18p+0, pio2_lo = 0x1.1a62633145c07p-54; /* pi/2 = hi + lo */
+    const double small_r = pio2_hi - (t - pio2_lo);
+    const double big_pos = 2.0 * t;
+    const double big_neg = 2.0 * pio2_hi - (2.0 * t - 2.0 * pio2_lo);
+    return big ? (x > 0 ? big_pos : big_neg) : small_r;
 }
 
 /* ---------------------------------------------------------------- Lee & Richards */
@@ -499,7 +595,9 @@ SASA_D void lr_phase_beta(const TileArgs &a, TileMem &m, int tid, int B)
     for (int gp = tid; gp < total; gp += B) {
         int la = 0;
         while (m.aoff[la + 1] <= gp) ++la;
-        const int q = m.idx[la * a.cap_idx + (gp - m.aoff[la])];
+        const int k = gp - m.aoff[la];
+        if (k >= m.acnt[la]) continue; /* padding slot */
+        const int q = m.idx[la * a.cap_idx + k];
         const double xd = a.sx[q] - m.ax[la], yd = a.sy[q] - m.ay[la]; /* ref: src/nb.c:445-448 */
         m.tb[gp] = atan2(yd, xd) + SASA_PI;
     }
@@ -507,7 +605,7 @@ SASA_D void lr_phase_beta(const TileArgs &a, TileMem &m, int tid, int B)
 
 /* phase P2: rank each pair by beta inside its atom's list and write the pair record at its
  * sorted position.  Sorting by the arc mid-angle is what lets the slice loop merge arcs with
- * a stack instead of the reference's per-slice insertion sort (DESIGN.md §L&R). */
+ * a stack instead of the reference's per-slice insertion sort. */
 SASA_D void lr_phase_rank(const TileArgs &a, TileMem &m, int tid, int B)
 {
     if (m.flags[0]) return;
@@ -515,7 +613,13 @@ SASA_D void lr_phase_rank(const TileArgs &a, TileMem &m, int tid, int B)
     for (int gp = tid; gp < total; gp += B) {
         int la = 0;
         while (m.aoff[la + 1] <= gp) ++la;
-        const int o = m.aoff[la], nn = m.aoff[la + 1] - o, k = gp - o;
+        const int o = m.aoff[la], nn = m.acnt[la], k = gp - o;
+        if (k >= nn) { /* padding slot: a record that never overlaps any slice */
+            Quad d; d.x = 0; d.y = 0; d.z = 1; d.w = 1;
+            m.pq[gp] = d;
+            m.pb[gp] = 0;
+            continue;
+        }
         const double beta = m.tb[gp];
         int rank = 0;
         for (int t = 0; t < nn; ++t) {
@@ -524,85 +628,106 @@ SASA_D void lr_phase_rank(const TileArgs &a, TileMem &m, int tid, int B)
         }
         const int q = m.idx[la * a.cap_idx + k];
         const double xd = a.sx[q] - m.ax[la], yd = a.sy[q] - m.ay[la];
-        Pair pr;
-        pr.a = beta;
-        pr.b = a.sz[q];
-        pr.c = a.sr[q];
-        pr.d = sqrt(xd * xd + yd * yd); /* ref: src/nb.c:438 */
-        m.pool[o + rank] = pr;
+        const double rj = a.sr[q];
+        const double D = xd * xd + yd * yd; /* = d_ij^2 (ref: src/nb.c:438) */
+        double g = 0, h = 0;
+        if (D > 0) sqrt_rh(D, g, h);
+        Quad rec;
+        rec.x = a.sz[q];
+        rec.y = rj * rj;
+        rec.z = D;
+        rec.w = D > 0 ? 2.0 * h : INFINITY; /* 1/d_ij; coincident xy: see lr_cos */
+        m.pq[o + rank] = rec;
+        m.pb[o + rank] = beta;
     }
 }
 
-/* phase Z: slice mid-planes, accumulated exactly like the reference (ref: src/sasa_lr.c:304-307) */
-SASA_D void lr_phase_ztab(const TileArgs &a, TileMem &m, int tid)
+/* cos(alpha) of the arc that circle j cuts out of circle i in the slice, or a value outside
+ * (-1,1).  With A = Ri'^2, B = Rj'^2, D = dij^2 the reference's three geometric tests
+ * (src/sasa_lr.c:324-331) are exactly c >= 1 (no contact, or j inside i: no arc) and
+ * c <= -1 (i inside j: slice buried) for c = (A + D - B)/(2 Ri' dij) (ref: :335), so neither
+ * sqrt(Rj'^2) nor a division is needed per (pair, slice): h2 = 1/(2 Ri') is per slice, 1/dij
+ * per pair.  dij == 0: c = +-inf decides inside/buried like the reference; 0*inf = NaN (the
+ * reference's acos(0/0) case, two coincident equal circles) compares false -> no arc. */
+SASA_D double lr_cos(double A, double h2, double dj2, double R2, double D, double ginv)
 {
-    if (!a.tab || tid >= a.TA) return;
-    const double Ri = m.aR[tid], zi = m.az[tid];
-    const double delta = 2 * Ri / a.n_res;
-    double z = zi - Ri - 0.5 * delta;
-    for (int s = 0; s < a.n_res; ++s) {
-        z += delta;
-        m.ztab[tid * a.n_res + s] = z;
-    }
+    const double Bq = R2 - dj2;
+    return Bq > 0 ? ((A + D) - Bq) * (ginv * h2) : 2.0; /* ref: src/sasa_lr.c:320 dj < Rj */
 }
 
 /* One slice of one atom: exposed arc length of circle i at height z, or -1 if the slice is
- * skipped/buried (contributes nothing).  P = the atom's pairs sorted by beta.
+ * skipped/buried (contributes nothing).  The atom's pairs are sorted by beta.
+ *
+ * Pass 1 (cheap) screens all neighbors: z-overlap and |cos alpha| < 1, buried -> done; the
+ * survivors of each group of 64 go into a bit mask.  Pass 2 visits only the set bits, in beta
+ * order: acos, arc end points, union.
+ *
  * Arc union: arcs arrive ordered by mid-angle beta, so disjoint components form a stack —
  * a new arc either overlaps the top component (merge, then keep popping while the merged
  * start reaches the next one down) or lies entirely to its right (push).  Arcs that wrap
  * through 0 only extend a covered prefix [0,W] / suffix [V,2pi].  End points are only ever
- * compared and copied, never recomputed, and gaps are summed in ascending order, so the
- * result equals the reference's sort + sweep (src/sasa_lr.c:367-408) bit for bit given the
- * same inf/sup values. */
-SASA_D double lr_slice(const Pair *P, int nn, double zi, double Ri, double z,
+ * compared and copied, and gaps are summed in ascending order, so given the same inf/sup
+ * values the result equals the reference's sort + sweep (src/sasa_lr.c:367-408) bit for bit. */
+SASA_D double lr_slice(const TileMem &m, int o, int nn, double zi, double Ri, double z,
                        Arc *stk, int stride, int ds, int *err)
 {
     const double di = fabs(zi - z);                 /* ref: src/sasa_lr.c:308 */
-    const double Ri_p2 = Ri * Ri - di * di;
-    if (Ri_p2 < 0) return -1;                       /* ref: :310 */
-    const double Ri_p = sqrt(Ri_p2);
-    if (Ri_p <= 0) return -1;                       /* ref: :312 */
+    const double A = Ri * Ri - di * di;             /* Ri'^2 */
+    if (!(A > 0)) return -1;                        /* ref: :310-312 */
+    double Rip, h2;
+    sqrt_rh(A, Rip, h2);                            /* h2 = 1/(2 Ri') */
 
     double W = 0, V = SASA_TWOPI, ts = 0, te = 0;
     int depth = 0, wrap = 0;
 
-    for (int k = 0; k < nn; ++k) {
-        const Pair p = P[k];
-        const double dj = fabs(p.b - z);            /* ref: :318 */
-        if (!(dj < p.c)) continue;                  /* ref: :320 */
-        const double Rj_p2 = p.c * p.c - dj * dj;
-        const double Rj_p = sqrt(Rj_p2);
-        const double dij = p.d;
-        if (dij >= Ri_p + Rj_p) continue;           /* ref: :324 */
-        if (dij + Ri_p < Rj_p) return -1;           /* ref: :327-330 buried */
-        if (dij + Rj_p < Ri_p) continue;            /* ref: :331 */
-        if (dij == 0) continue; /* guard: the reference evaluates acos(0/0) = NaN here (measure zero) */
-        double ca = (Ri_p2 + dij * dij - Rj_p2) / (2.0 * Ri_p * dij); /* ref: :335 */
-        ca = ca > 1.0 ? 1.0 : (ca < -1.0 ? -1.0 : ca); /* guard: rounding past +-1 is NaN in the reference */
-        const double alpha = acos(ca);
-        double inf = p.a - alpha, sup = p.a + alpha; /* ref: :338-339 */
-        if (inf < 0) inf += SASA_TWOPI;              /* ref: :340 */
-        if (sup > SASA_TWOPI) sup -= SASA_TWOPI;     /* ref: :341 */
-        if (sup < inf) {                             /* ref: :344-351 arc passes the origin */
-            wrap = 1;
-            W = sup > W ? sup : W;
-            V = inf < V ? inf : V;
-        } else if (inf <= p.a && p.a <= sup) {       /* (false only for a zero-length arc at alpha == pi) */
-            if (depth == 0) {
-                ts = inf; te = sup; depth = 1;
-            } else if (inf <= te) {
-                ts = inf < ts ? inf : ts;
-                te = sup > te ? sup : te;
-                while (depth > 1) {
-                    const Arc lo = stk[(depth - 2) * stride];
-                    if (lo.e < ts) break;
-                    ts = lo.s < ts ? lo.s : ts;
-                    te = lo.e > te ? lo.e : te;
-                    --depth;
-                }
-            } else {
-                if (depth - 1 < ds) {
+    for (int base = 0; base < nn; base += 64) { /* nn is a multiple of 4 (padded) */
+        const int lim = nn - base < 64 ? nn - base : 64;
+        const Quad *PQ = m.pq + o + base;
+        const double *PB = m.pb + o + base;
+        unsigned long long mask = 0;
+        int buried = 0;
+        for (int k = 0; k < lim; k += 4) {
+            const Quad q0 = PQ[k], q1 = PQ[k + 1], q2 = PQ[k + 2], q3 = PQ[k + 3];
+            const double d0 = q0.x - z, d1 = q1.x - z, d2 = q2.x - z, d3 = q3.x - z;
+            const double c0 = lr_cos(A, h2, d0 * d0, q0.y, q0.z, q0.w);
+            const double c1 = lr_cos(A, h2, d1 * d1, q1.y, q1.z, q1.w);
+            const double c2 = lr_cos(A, h2, d2 * d2, q2.y, q2.z, q2.w);
+            const double c3 = lr_cos(A, h2, d3 * d3, q3.y, q3.z, q3.w);
+            const unsigned b0 = c0 < 1.0, b1 = c1 < 1.0, b2 = c2 < 1.0, b3 = c3 < 1.0;
+            /* c <= -1 (or -inf): circle i lies inside circle j -> slice buried (ref: :327-330) */
+            buried |= (b0 & !(c0 > -1.0)) | (b1 & !(c1 > -1.0)) | (b2 & !(c2 > -1.0)) | (b3 & !(c3 > -1.0));
+            mask |= (unsigned long long)(b0 | (b1 << 1) | (b2 << 2) | (b3 << 3)) << k;
+        }
+        if (buried) return -1;
+        while (mask) {
+            const int k = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const Quad q = PQ[k];
+            const double dj = q.x - z;
+            const double c = lr_cos(A, h2, dj * dj, q.y, q.z, q.w);
+            const double alpha = acos_fast(c);       /* ref: :335 */
+            const double beta = PB[k];
+            double inf = beta - alpha, sup = beta + alpha; /* ref: :338-339 */
+            if (inf < 0) inf += SASA_TWOPI;          /* ref: :340 */
+            if (sup > SASA_TWOPI) sup -= SASA_TWOPI; /* ref: :341 */
+            if (sup < inf) {                         /* ref: :344-351 arc passes the origin */
+                wrap = 1;
+                W = sup > W ? sup : W;
+                V = inf < V ? inf : V;
+            } else if (inf <= beta && beta <= sup) { /* (false only for a zero-length arc at alpha == pi) */
+                if (depth == 0) {
+                    ts = inf; te = sup; depth = 1;
+                } else if (inf <= te) {
+                    ts = inf < ts ? inf : ts;
+                    te = sup > te ? sup : te;
+                    while (depth > 1) {
+                        const Arc lo = stk[(depth - 2) * stride];
+                        if (lo.e < ts) break;
+                        ts = lo.s < ts ? lo.s : ts;
+                        te = lo.e > te ? lo.e : te;
+                        --depth;
+                    }
+                } else if (depth - 1 < ds) {
                     Arc t; t.s = ts; t.e = te;
                     stk[(depth - 1) * stride] = t;
                     ts = inf; te = sup; ++depth;
@@ -639,13 +764,14 @@ SASA_D void lr_phase_slices(const TileArgs &a, TileMem &m, int tile, int tid, in
     if (a.tab) {
         const int items = na * ns;
         for (int it = tid; it < items; it += B) {
-            const int la = it / ns;
-            const double Ri = m.aR[la];
-            const double delta = 2 * Ri / ns;
+            const int la = it / ns, s = it - la * ns;
+            const double Ri = m.aR[la], zi = m.az[la];
+            const double delta = 2 * Ri / ns;       /* ref: src/sasa_lr.c:304 */
+            double z = zi - Ri - 0.5 * delta;
+            for (int k = 0; k <= s; ++k) z += delta; /* accumulated like the reference, :307 */
             const int o = m.aoff[la];
-            const double ex = lr_slice(m.pool + o, m.aoff[la + 1] - o, m.az[la], Ri, m.ztab[it],
-                                       stk, B, a.ds, &err);
-            m.contrib[it] = ex < 0 ? 0.0 : delta * Ri * ex; /* ref: src/sasa_lr.c:360 */
+            const double ex = lr_slice(m, o, m.aoff[la + 1] - o, zi, Ri, z, stk, B, a.ds, &err); /* padded count */
+            m.contrib[it] = ex < 0 ? 0.0 : delta * Ri * ex; /* ref: :360 */
         }
     } else {
         /* many slices per atom (TA == 1): strided partial sums, z by direct formula */
@@ -655,7 +781,7 @@ SASA_D void lr_phase_slices(const TileArgs &a, TileMem &m, int tile, int tid, in
         double part = 0;
         for (int s = tid; s < ns; s += B) {
             const double z = z0 + (double)(s + 1) * delta;
-            const double ex = lr_slice(m.pool, m.aoff[1], zi, Ri, z, stk, B, a.ds, &err);
+            const double ex = lr_slice(m, 0, m.aoff[1], zi, Ri, z, stk, B, a.ds, &err);
             if (!(ex < 0)) part += delta * Ri * ex;
         }
         m.contrib[tid] = part;
@@ -705,10 +831,10 @@ SASA_D void sr_phase_pairs(const TileArgs &a, TileMem &m, int tid, int B)
         while (m.aoff[la + 1] <= gp) ++la;
         const int q = m.idx[la * a.cap_idx + (gp - m.aoff[la])];
         const double rj = a.sr[q];
-        Pair pr;
-        pr.a = a.sx[q]; pr.b = a.sy[q]; pr.c = a.sz[q];
-        pr.d = rj * rj; /* ref: src/sasa_sr.c:146 */
-        m.pool[gp] = pr;
+        Quad rec;
+        rec.x = a.sx[q]; rec.y = a.sy[q]; rec.z = a.sz[q];
+        rec.w = rj * rj; /* ref: src/sasa_sr.c:146 */
+        m.pq[gp] = rec;
     }
 }
 
@@ -726,13 +852,12 @@ SASA_D void sr_phase_points(const TileArgs &a, TileMem &m, int tile, int tid, in
         /* test point = unit * ri, then + centre: two rounded steps (ref: src/coord.c:331-342, 314-329) */
         double tx = a.unit_pts[3 * pt] * ri, ty = a.unit_pts[3 * pt + 1] * ri, tz = a.unit_pts[3 * pt + 2] * ri;
         tx += m.ax[la]; ty += m.ay[la]; tz += m.az[la];
-        const Pair *P = m.pool + m.aoff[la];
-        const int nn = m.aoff[la + 1] - m.aoff[la];
+        const int o = m.aoff[la], nn = m.aoff[la + 1] - o;
         int covered = 0;
         for (int k = 0; k < nn; ++k) {
-            const Pair p = P[k];
-            const double dx = tx - p.a, dy = ty - p.b, dz = tz - p.c;
-            if (dx * dx + dy * dy + dz * dz <= p.d) { covered = 1; break; } /* ref: src/sasa_sr.c:324 */
+            const Quad q = m.pq[o + k];
+            const double dx = tx - q.x, dy = ty - q.y, dz = tz - q.z;
+            if (dx * dx + dy * dy + dz * dz <= q.w) { covered = 1; break; } /* ref: src/sasa_sr.c:324 */
         }
         if (!covered) SASA_ATOMIC_ADD_LDS(&m.aexp[la], 1);
     }
@@ -752,12 +877,24 @@ SASA_D void sr_phase_store(const TileArgs &a, TileMem &m, int tile, int tid)
 }
 
 /* ---------------------------------------------------------------- per-structure totals */
-/* one thread per structure, atom order (ref: src/freesasa.c:113-116) */
-SASA_D void totals_struct(const double *sasa, const int64_t *offsets, int n_structs, double *totals, int s)
+/* One 64-lane wave per structure: each lane sums a contiguous chunk in atom order, lane 0 adds
+ * the 64 partials in order.  Deterministic; equals the reference's sequential sum
+ * (src/freesasa.c:113-116) up to fp64 reassociation (the drop-in freesasa_calc sums on the
+ * host in exact reference order). */
+SASA_D void totals_phase0(const double *sasa, const int64_t *offsets, double *part, int s, int lane)
 {
-    if (s >= n_structs) return;
+    const int64_t b = offsets[s], e = offsets[s + 1];
+    const int64_t per = (e - b + 63) / 64;
+    const int64_t lo = b + lane * per, hi = lo + per < e ? lo + per : e;
     double t = 0;
-    for (int64_t i = offsets[s]; i < offsets[s + 1]; ++i) t += sasa[i];
+    for (int64_t i = lo; i < hi; ++i) t += sasa[i];
+    part[lane] = t;
+}
+SASA_D void totals_phase1(const double *part, double *totals, int s, int lane)
+{
+    if (lane != 0) return;
+    double t = 0;
+    for (int k = 0; k < 64; ++k) t += part[k];
     totals[s] = t;
 }
 
@@ -775,7 +912,7 @@ SASA_D int xcd_tile(int b, int n_tiles)
  * launch configuration (host side; shared by gpu_engine.hip and the test emulation)
  * ---------------------------------------------------------------------------------- */
 struct TileCfg {
-    int B, TA, tab, items, cap_idx, pool, ds;
+    int B, TA, tab, items, cap_idx, pool, npw, ds;
     size_t lds;
 };
 
@@ -793,8 +930,10 @@ static inline TileCfg choose_cfg(int resolution, bool lr)
 {
     TileCfg c;
     c.tab = 1;
-    /* L&R keeps a z table and a per-slice area table in LDS (TA*resolution <= SASA_ITEMS_CAP);
-       S&R has no per-item state, its tile is only bounded by the neighbor pool */
+    /* Small tiles win (measured, profiles/): with two-wave workgroups many independent tiles
+       are resident per CU, so one tile's memory round trips and barriers overlap another's
+       arithmetic.  TA*resolution work items should fill whole rounds of B threads
+       (resolution 20 -> 6 atoms x 20 slices = 120 of 128 threads). */
     const int items_cap = lr ? SASA_ITEMS_CAP : 4096;
     const int ta_max = lr ? SASA_TA_MAX : 8;
     if (resolution > items_cap) {
@@ -803,21 +942,25 @@ static inline TileCfg choose_cfg(int resolution, bool lr)
         if (lr) c.tab = 0;
     } else {
         double best = -1;
-        c.B = 256; c.TA = 1;
-        const int Bs[2] = {320, 256};
-        for (int bi = 0; bi < 2; ++bi)
+        c.B = 128; c.TA = 1;
+        const int Bs[3] = {128, 256, 64};
+        for (int bi = 0; bi < 3; ++bi)
             for (int ta = 1; ta <= ta_max && ta * resolution <= items_cap; ++ta) {
                 const int items = ta * resolution, B = Bs[bi];
-                const double eff = (double)items / (double)(((items + B - 1) / B) * B);
-                const double score = eff + 0.002 * ta; /* prefer bigger tiles at equal efficiency */
-                if (score > best) { best = score; c.B = B; c.TA = ta; }
+                if (ta > B / 4) continue; /* keep >= 4 lanes per atom for the neighbor search */
+                const int rounds = (items + B - 1) / B;
+                if (rounds > 8 && ta > 1) continue;
+                const double eff = (double)items / (double)(rounds * B);
+                const double score = eff - 0.01 * (rounds - 1) - (B == 256 ? 0.02 : 0.0) - (B == 64 ? 0.03 : 0.0);
+                if (score > best + 1e-9) { best = score; c.B = B; c.TA = ta; }
             }
     }
     c.items = lr ? (c.tab ? c.TA * resolution : c.B) : 1;
+    c.npw = lr ? 5 : 4;
     c.cap_idx = 128;
     c.pool = 64 * c.TA < 128 ? 128 : 64 * c.TA;
     c.ds = lr ? 4 : 0;
-    c.lds = tile_fixed_bytes(c.TA, c.items) + tile_list_bytes(c.TA, c.cap_idx, c.pool, c.ds, c.B);
+    c.lds = tile_fixed_bytes(c.TA, c.items) + tile_list_bytes(c.TA, c.cap_idx, c.pool, c.npw, c.ds, c.B);
     return c;
 }
 

@@ -28,16 +28,16 @@ static void emu_tile_kernel(bool lr, const TileCfg &cfg, TileArgs a, int grid)
             const int tile = GLOBAL ? a.work_tiles[w] : xcd_tile(w, a.n_tiles);
             if (tile >= a.n_tiles) continue;
 #define PHASE(call) for (int tid = 0; tid < B; ++tid) { call; }
-            PHASE(tile_phase_load(a, m, tile, tid));
+            PHASE(tile_phase_load(a, m, tile, tid, B));
             PHASE(tile_phase_neighbors(a, m, tile, tid, B));
-            PHASE(tile_phase_offsets<GLOBAL>(a, m, tile, tid));
+            PHASE(tile_phase_offsets(a, m, tid));
             if (lr) {
-                PHASE(lr_phase_beta(a, m, tid, B); lr_phase_ztab(a, m, tid));
+                PHASE(tile_report<GLOBAL>(a, m, tile, tid); lr_phase_beta(a, m, tid, B));
                 PHASE(lr_phase_rank(a, m, tid, B));
                 PHASE(lr_phase_slices(a, m, tile, tid, B));
                 PHASE(lr_phase_store<GLOBAL>(a, m, tile, tid, B));
             } else {
-                PHASE(sr_phase_pairs(a, m, tid, B));
+                PHASE(tile_report<GLOBAL>(a, m, tile, tid); sr_phase_pairs(a, m, tid, B));
                 PHASE(sr_phase_points(a, m, tile, tid, B));
                 PHASE(sr_phase_store(a, m, tile, tid));
             }
@@ -115,7 +115,7 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
     if (force_cap_idx > 0) cfg.cap_idx = force_cap_idx;
     if (force_pool > 0) cfg.pool = force_pool;
     if (force_ds >= 0 && lr) cfg.ds = force_ds;
-    cfg.lds = tile_fixed_bytes(cfg.TA, cfg.items) + tile_list_bytes(cfg.TA, cfg.cap_idx, cfg.pool, cfg.ds, cfg.B);
+    cfg.lds = tile_fixed_bytes(cfg.TA, cfg.items) + tile_list_bytes(cfg.TA, cfg.cap_idx, cfg.pool, cfg.npw, cfg.ds, cfg.B);
     const int n_tiles = (n + cfg.TA - 1) / cfg.TA;
     std::vector<int> ovf_tiles(n_tiles + 1);
 
@@ -126,7 +126,7 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
     ta.grid = pa.grid; ta.cell_start = pa.cell_start;
     ta.n_atoms = n; ta.n_tiles = n_tiles; ta.TA = cfg.TA; ta.n_res = resolution; ta.tab = cfg.tab;
     ta.unit_pts = unit_pts; ta.sasa = sasa; ta.counts = counts;
-    ta.cap_idx = cfg.cap_idx; ta.pool = cfg.pool; ta.ds = cfg.ds;
+    ta.cap_idx = cfg.cap_idx; ta.pool = cfg.pool; ta.npw = cfg.npw; ta.ds = cfg.ds;
     ta.ovf_count = status.data() + ST_OVF_TILES; ta.ovf_tiles = ovf_tiles.data(); ta.status = status.data();
 
     emu_tile_kernel<false>(lr != 0, cfg, ta, ((n_tiles + 7) / 8) * 8);
@@ -136,7 +136,7 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
         if (fb_cap_idx > 0) fb.cap_idx = fb_cap_idx;
         if (fb_pool > 0) fb.pool = fb_pool;
         if (fb_ds > 0 && lr) fb.ds = fb_ds;
-        const size_t stride = tile_slab_bytes(fb.TA, fb.cap_idx, fb.pool, fb.ds, fb.B);
+        const size_t stride = tile_slab_bytes(fb.TA, fb.cap_idx, fb.pool, fb.npw, fb.ds, fb.B);
         const int fb_blocks = 3; /* fewer than SASA_FB_BLOCKS so that the work loop wraps */
         std::vector<char> slab(stride * fb_blocks + 64);
         TileArgs tf = ta;
@@ -145,8 +145,13 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
         tf.slab = slab.data(); tf.slab_stride = (long long)stride;
         emu_tile_kernel<true>(lr != 0, fb, tf, fb_blocks);
     }
-    if (totals)
-        for (int s = 0; s < n_structs; ++s) totals_struct(sasa, offsets, n_structs, totals, s);
+    if (totals) {
+        double part[64];
+        for (int s = 0; s < n_structs; ++s) {
+            for (int l = 0; l < 64; ++l) totals_phase0(sasa, offsets, part, s, l);
+            for (int l = 0; l < 64; ++l) totals_phase1(part, totals, s, l);
+        }
+    }
 
     stats_out[0] = status[ST_ERROR]; stats_out[1] = status[ST_OVF_TILES]; stats_out[2] = status[ST_MAX_NN];
     stats_out[3] = cfg.TA; stats_out[4] = cfg.B; stats_out[5] = (long long)cfg.lds; stats_out[6] = total_cells;

@@ -1,13 +1,21 @@
 """CPU tests of the KERNEL LOGIC: the phase functions of freesasa_amd/csrc/sasa_kernels.h are
 driven thread-by-thread by tests/emu (never shipped) in the production launch sequence and
-compared with the oracle.  With host libm the emulated L&R must be bit-identical to the
-oracle, which leaves the device's acos/atan2 as the only untested ingredient on this box."""
+compared with the oracle.  S&R must be bit-identical.  L&R shares the reference's arc-union
+result bit for bit given equal arc end points, but computes cos(alpha) with reciprocals and
+acos with its own polynomial, so it is held to LR_TOL = 1e-11 A^2 per atom here (observed
+~2e-14); on this box only the device's atan2 and v_rsq_f64 seed remain untested."""
 import numpy as np
 import pytest
 
 import tools
 from conftest import load_golden
 from emu import run_batch
+
+LR_TOL = 1e-11
+
+
+def close(a, b, tol=LR_TOL):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b))) <= tol
 
 
 def _sr(oracle_lib, xyz, r, n_points=100, probe=1.4, **kw):
@@ -19,19 +27,19 @@ def _sr(oracle_lib, xyz, r, n_points=100, probe=1.4, **kw):
 def test_golden_structures(oracle_lib, name):
     g = load_golden(name)
     sasa, _, tot, st = run_batch(True, g["xyz"], g["radii"], resolution=20)
-    assert np.array_equal(sasa, g["lr20"]) and tot[0] == float(g["lr20_total"])
+    assert close(sasa, g["lr20"]) and abs(tot[0] - float(g["lr20_total"])) < 1e-9
     sasa, counts, tot, _ = _sr(oracle_lib, g["xyz"], g["radii"])
     assert np.array_equal(counts, g["sr100_counts"])
-    assert np.array_equal(sasa, g["sr100"]) and tot[0] == float(g["sr100_total"])
+    assert np.array_equal(sasa, g["sr100"]) and abs(tot[0] - float(g["sr100_total"])) < 1e-9
 
 
 def test_lr100_and_probe_sweep(oracle_lib):
     g = load_golden("1ubq")
     sasa, *_ = run_batch(True, g["xyz"], g["radii"], resolution=100)
-    assert np.array_equal(sasa, g["lr100"])
+    assert close(sasa, g["lr100"])
     for probe in (1.0, 2.0):
         sasa, *_ = run_batch(True, g["xyz"], g["radii"], probe=probe, resolution=20)
-        assert np.array_equal(sasa, g[f"lr20_p{probe}"])
+        assert close(sasa, g[f"lr20_p{probe}"])
         _, c, _, _ = _sr(oracle_lib, g["xyz"], g["radii"], probe=probe)
         assert np.array_equal(c, g[f"sr100_p{probe}_counts"])
     for npts in (20, 1000):
@@ -55,7 +63,7 @@ def test_ragged_batch_with_empty_and_single_atom_structures(oracle_lib):
             assert tot[k] == 0.0
             continue
         want = oracle_lib.lee_richards(px, pr)
-        assert np.array_equal(lr[sl], want) and tot[k] == oracle_lib.total(want)
+        assert close(lr[sl], want) and abs(tot[k] - oracle_lib.total(want)) < 1e-9
         ws, wc = oracle_lib.shrake_rupley(px, pr)
         assert np.array_equal(cnt[sl], wc) and np.array_equal(sr[sl], ws)
     # isolated atom: L&R = slices of a free sphere, S&R = all points (defined; reference is UB)
@@ -77,7 +85,7 @@ def test_edge_fixtures(oracle_lib):
     g = load_golden("synthetic")
     for tag in ("touch", "buried", "nbkat", "four"):
         sasa, *_ = run_batch(True, g[tag + "_xyz"], g[tag + "_radii"])
-        assert np.array_equal(sasa, g[tag + "_lr20"]), tag
+        assert close(sasa, g[tag + "_lr20"]), tag
     sasa, *_ = run_batch(True, g["buried_xyz"], g["buried_radii"])
     assert sasa[1] == 0.0
 
@@ -90,7 +98,7 @@ def test_overflow_goes_to_fallback_and_matches(oracle_lib):
     for kw in (dict(cap_idx=24), dict(pool=300), dict(ds=0), dict(ds=1)):
         sasa, _, _, st = run_batch(True, xyz, r, **kw)
         assert st["fallback_tiles"] > 0, kw
-        assert np.array_equal(sasa, want), kw
+        assert close(sasa, want), kw
     ws, wc = oracle_lib.shrake_rupley(xyz, r)
     _, c, _, st = _sr(oracle_lib, xyz, r, cap_idx=24)
     assert st["fallback_tiles"] > 0 and np.array_equal(c, wc)
@@ -124,10 +132,7 @@ def test_launch_configurations():
     for ns in (1, 3, 7, 20, 33, 64, 100, 333, 640, 641):
         sasa, _, _, st = run_batch(True, xyz, r, resolution=ns)
         want = o.lee_richards(xyz, r, 1.4, ns)
-        if ns <= 640:
-            assert np.array_equal(sasa, want), (ns, st)
-        else:
-            assert np.max(np.abs(sasa - want)) < 1e-10
+        assert close(sasa, want, 1e-10), (ns, st)
     for npts in (1, 13, 100, 257, 4096, 4097):
         _, c, _, st = run_batch(False, xyz, r, resolution=npts, unit_pts=o.test_points(npts))
         assert np.array_equal(c, o.shrake_rupley(xyz, r, 1.4, npts)[1]), (npts, st)
