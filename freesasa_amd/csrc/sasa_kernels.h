@@ -35,12 +35,15 @@
 namespace sasa_emu {
 inline int atomic_add(int *p, int v) { int o = *p; *p = o + v; return o; }
 inline int atomic_max(int *p, int v) { int o = *p; if (v > o) *p = v; return o; }
+static long long uncertain_slices = 0, crosscheck_failures = 0;
 }
 #define SASA_ATOMIC_ADD_LDS(p, v) sasa_emu::atomic_add((p), (v))
 #define SASA_ATOMIC_ADD_GLB(p, v) sasa_emu::atomic_add((p), (v))
 #define SASA_ATOMIC_MAX_GLB(p, v) sasa_emu::atomic_max((p), (v))
 #define SASA_ATOMIC_MAX_LDS(p, v) sasa_emu::atomic_max((p), (v))
 #define SASA_RSQ(x) (1.0 / sqrt(x))
+#define SASA_SQRTF(x) sqrtf(x)
+#define SASA_COUNT_UNCERTAIN() (sasa_emu::uncertain_slices++)
 #else
 #define SASA_D __device__ __forceinline__
 #define SASA_HD __host__ __device__ __forceinline__
@@ -49,6 +52,8 @@ inline int atomic_max(int *p, int v) { int o = *p; if (v > o) *p = v; return o; 
 #define SASA_ATOMIC_MAX_GLB(p, v) atomicMax((p), (v))
 #define SASA_ATOMIC_MAX_LDS(p, v) atomicMax((p), (v))
 #define SASA_RSQ(x) __builtin_amdgcn_rsq(x)
+#define SASA_SQRTF(x) __builtin_amdgcn_sqrtf(x)
+#define SASA_COUNT_UNCERTAIN() ((void)0)
 #endif
 
 namespace sasa {
@@ -655,12 +660,61 @@ SASA_D double lr_cos(double A, double h2, double dj2, double R2, double D, doubl
     return Bq > 0 ? ((A + D) - Bq) * (ginv * h2) : 2.0; /* ref: src/sasa_lr.c:320 dj < Rj */
 }
 
-/* One slice of one atom: exposed arc length of circle i at height z, or -1 if the slice is
- * skipped/buried (contributes nothing).  The atom's pairs are sorted by beta.
- *
- * Pass 1 (cheap) screens all neighbors: z-overlap and |cos alpha| < 1, buried -> done; the
- * survivors of each group of 64 go into a bit mask.  Pass 2 visits only the set bits, in beta
- * order: acos, arc end points, union.
+/* Screening pass over up to 64 neighbors (lim is a multiple of 4, lists are padded): bit k of
+ * the mask is set when neighbor k cuts an arc out of circle i (|cos alpha| < 1).  Returns 1 if
+ * some neighbor's circle contains circle i entirely (slice buried, ref: src/sasa_lr.c:327-330). */
+SASA_D int lr_screen(const Quad *PQ, int lim, double A, double h2, double z, unsigned long long &mask)
+{
+    int buried = 0;
+    mask = 0;
+    for (int k = 0; k < lim; k += 4) {
+        const Quad q0 = PQ[k], q1 = PQ[k + 1], q2 = PQ[k + 2], q3 = PQ[k + 3];
+        const double d0 = q0.x - z, d1 = q1.x - z, d2 = q2.x - z, d3 = q3.x - z;
+        const double c0 = lr_cos(A, h2, d0 * d0, q0.y, q0.z, q0.w);
+        const double c1 = lr_cos(A, h2, d1 * d1, q1.y, q1.z, q1.w);
+        const double c2 = lr_cos(A, h2, d2 * d2, q2.y, q2.z, q2.w);
+        const double c3 = lr_cos(A, h2, d3 * d3, q3.y, q3.z, q3.w);
+        const unsigned b0 = c0 < 1.0, b1 = c1 < 1.0, b2 = c2 < 1.0, b3 = c3 < 1.0;
+        buried |= (b0 & !(c0 > -1.0)) | (b1 & !(c1 > -1.0)) | (b2 & !(c2 > -1.0)) | (b3 & !(c3 > -1.0));
+        mask |= (unsigned long long)(b0 | (b1 << 1) | (b2 << 2) | (b3 << 3)) << k;
+    }
+    return buried;
+}
+
+/* End points of the arc neighbor record q (mid-angle beta) buries on circle i, normalised to
+ * [0,2pi) exactly as the reference does (src/sasa_lr.c:335-341); sup < inf means it wraps. */
+SASA_D void lr_arc(const Quad q, double beta, double A, double h2, double z, double &inf, double &sup)
+{
+    const double dj = q.x - z;
+    const double c = lr_cos(A, h2, dj * dj, q.y, q.z, q.w);
+    const double alpha = acos_fast(c);
+    inf = beta - alpha;
+    sup = beta + alpha;
+    if (inf < 0) inf += SASA_TWOPI;
+    if (sup > SASA_TWOPI) sup -= SASA_TWOPI;
+}
+
+/* Sum of the exposed gaps given the disjoint components in ascending order (component c is
+ * comp(c)), the covered prefix [0,W] and suffix [V,2pi] of the arcs that wrap.
+ * ref: src/sasa_lr.c:396-407 with sum = arc[0] == (0 < arc[0] ? arc[0] - 0 : 0). */
+#define LR_SWEEP(depth, wrap, W, V, COMP_S, COMP_E, result)                                   \
+    do {                                                                                     \
+        double sum_ = 0, sup_ = (W);                                                         \
+        for (int c_ = 0; c_ < (depth); ++c_) {                                               \
+            const double cs_ = COMP_S(c_), ce_ = COMP_E(c_);                                  \
+            if ((wrap) && cs_ >= (V)) break; /* sorted behind the [V,2pi] piece: covered */   \
+            if (sup_ < cs_) sum_ += cs_ - sup_;                                              \
+            if (ce_ > sup_) sup_ = ce_;                                                      \
+        }                                                                                    \
+        if (wrap) {                                                                          \
+            if (sup_ < (V)) sum_ += (V) - sup_;                                              \
+            sup_ = SASA_TWOPI;                                                               \
+        }                                                                                    \
+        (result) = sum_ + SASA_TWOPI - sup_; /* ref: :407 */                                 \
+    } while (0)
+
+/* EXACT path.  One slice of one atom: exposed arc length of circle i at height z, or -1 if the
+ * slice is buried.  The atom's neighbor records are sorted by beta.
  *
  * Arc union: arcs arrive ordered by mid-angle beta, so disjoint components form a stack —
  * a new arc either overlaps the top component (merge, then keep popping while the merged
@@ -668,48 +722,23 @@ SASA_D double lr_cos(double A, double h2, double dj2, double R2, double D, doubl
  * through 0 only extend a covered prefix [0,W] / suffix [V,2pi].  End points are only ever
  * compared and copied, and gaps are summed in ascending order, so given the same inf/sup
  * values the result equals the reference's sort + sweep (src/sasa_lr.c:367-408) bit for bit. */
-SASA_D double lr_slice(const TileMem &m, int o, int nn, double zi, double Ri, double z,
-                       Arc *stk, int stride, int ds, int *err)
+SASA_D double lr_union_exact(const TileMem &m, int o, int nn, double A, double h2, double z,
+                             Arc *stk, int stride, int ds, int *err)
 {
-    const double di = fabs(zi - z);                 /* ref: src/sasa_lr.c:308 */
-    const double A = Ri * Ri - di * di;             /* Ri'^2 */
-    if (!(A > 0)) return -1;                        /* ref: :310-312 */
-    double Rip, h2;
-    sqrt_rh(A, Rip, h2);                            /* h2 = 1/(2 Ri') */
-
     double W = 0, V = SASA_TWOPI, ts = 0, te = 0;
     int depth = 0, wrap = 0;
-
     for (int base = 0; base < nn; base += 64) { /* nn is a multiple of 4 (padded) */
         const int lim = nn - base < 64 ? nn - base : 64;
         const Quad *PQ = m.pq + o + base;
         const double *PB = m.pb + o + base;
-        unsigned long long mask = 0;
-        int buried = 0;
-        for (int k = 0; k < lim; k += 4) {
-            const Quad q0 = PQ[k], q1 = PQ[k + 1], q2 = PQ[k + 2], q3 = PQ[k + 3];
-            const double d0 = q0.x - z, d1 = q1.x - z, d2 = q2.x - z, d3 = q3.x - z;
-            const double c0 = lr_cos(A, h2, d0 * d0, q0.y, q0.z, q0.w);
-            const double c1 = lr_cos(A, h2, d1 * d1, q1.y, q1.z, q1.w);
-            const double c2 = lr_cos(A, h2, d2 * d2, q2.y, q2.z, q2.w);
-            const double c3 = lr_cos(A, h2, d3 * d3, q3.y, q3.z, q3.w);
-            const unsigned b0 = c0 < 1.0, b1 = c1 < 1.0, b2 = c2 < 1.0, b3 = c3 < 1.0;
-            /* c <= -1 (or -inf): circle i lies inside circle j -> slice buried (ref: :327-330) */
-            buried |= (b0 & !(c0 > -1.0)) | (b1 & !(c1 > -1.0)) | (b2 & !(c2 > -1.0)) | (b3 & !(c3 > -1.0));
-            mask |= (unsigned long long)(b0 | (b1 << 1) | (b2 << 2) | (b3 << 3)) << k;
-        }
-        if (buried) return -1;
+        unsigned long long mask;
+        if (lr_screen(PQ, lim, A, h2, z, mask)) return -1;
         while (mask) {
             const int k = __builtin_ctzll(mask);
             mask &= mask - 1;
-            const Quad q = PQ[k];
-            const double dj = q.x - z;
-            const double c = lr_cos(A, h2, dj * dj, q.y, q.z, q.w);
-            const double alpha = acos_fast(c);       /* ref: :335 */
             const double beta = PB[k];
-            double inf = beta - alpha, sup = beta + alpha; /* ref: :338-339 */
-            if (inf < 0) inf += SASA_TWOPI;          /* ref: :340 */
-            if (sup > SASA_TWOPI) sup -= SASA_TWOPI; /* ref: :341 */
+            double inf, sup;
+            lr_arc(PQ[k], beta, A, h2, z, inf, sup);
             if (sup < inf) {                         /* ref: :344-351 arc passes the origin */
                 wrap = 1;
                 W = sup > W ? sup : W;
@@ -737,20 +766,170 @@ SASA_D double lr_slice(const TileMem &m, int o, int nn, double zi, double Ri, do
             }
         }
     }
-    /* sweep, ref: src/sasa_lr.c:396-407 with sum = arc[0] == (0 < arc[0] ? arc[0] - 0 : 0) */
+    double res;
+#define CS_(c) ((c) == depth - 1 ? ts : stk[(c) * stride].s)
+#define CE_(c) ((c) == depth - 1 ? te : stk[(c) * stride].e)
+    LR_SWEEP(depth, wrap, W, V, CS_, CE_, res);
+#undef CS_
+#undef CE_
+    return res;
+}
+
+/* FILTERED path: the same union, with the TOPOLOGY (which arcs wrap, which components exist,
+ * which arc end point bounds each component) decided in fp32 and only the end points that
+ * bound a component evaluated in fp64.
+ *
+ * Every fp32 end point is within LR_EPS of its fp64 value (error budget in DESIGN.md), and a
+ * decision is taken only when the fp32 operands differ by more than 2*LR_EPS; otherwise the
+ * slice is reported LR_UNCERTAIN and redone by lr_union_exact.  All decisions taken therefore
+ * agree with the exact path, the components are bounded by the same arcs, and the final sweep
+ * adds the same fp64 numbers in the same order: the result is bit-identical to
+ * lr_union_exact's, at a fraction of the fp64 transcendental work (most arcs are interior
+ * to a component and never need an exact angle). */
+#define LR_EPS 6.0e-6f
+#define LR_UNCERTAIN (-2.0)
+struct ArcF { float s, e; int ids, ide; }; /* 16 B: shares the Arc spill slots */
+
+/* 2*asin(sqrt(zf)), zf in (0, 0.5]: degree-6 interpolant, relative error < 1e-7 */
+SASA_D float asin2_f32(float zf)
+{
+    const float s = SASA_SQRTF(zf);
+    float p = 0.08429820090532303f;
+    p = fmaf(p, zf, -0.047614749521017075f);
+    p = fmaf(p, zf, 0.04787879064679146f);
+    p = fmaf(p, zf, 0.025548843666911125f);
+    p = fmaf(p, zf, 0.045064494013786316f);
+    p = fmaf(p, zf, 0.0749865174293518f);
+    p = fmaf(p, zf, 0.16666673123836517f);
+    const float s2 = s + s;
+    return fmaf(s2 * zf, p, s2);
+}
+
+SASA_D double lr_union_filtered(const TileMem &m, int o, int nn, double A, double h2, double z,
+                                Arc *stk_, int stride, int ds)
+{
+    ArcF *stk = (ArcF *)stk_;
+    const float PI_F = 3.14159274f, TWOPI_F = 6.28318548f, E1 = LR_EPS, E2 = 2.0f * LR_EPS;
+    float W32 = 0, V32 = 0, ts = 0, te = 0;
+    int idW = -1, idV = -1, ids = 0, ide = 0, depth = 0, unc = 0;
+
+    for (int base = 0; base < nn; base += 64) {
+        const int lim = nn - base < 64 ? nn - base : 64;
+        const Quad *PQ = m.pq + o + base;
+        const double *PB = m.pb + o + base;
+        unsigned long long mask;
+        if (lr_screen(PQ, lim, A, h2, z, mask)) return -1; /* fp64 test: certain */
+        while (mask) {
+            const int k = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const Quad q = PQ[k];
+            const double dj = q.x - z;
+            const double c = lr_cos(A, h2, dj * dj, q.y, q.z, q.w);
+            /* alpha = acos c = 2 asin sqrt((1-c)/2) for c >= 0, pi - 2 asin sqrt((1+c)/2) else:
+               the argument is formed in fp64, so alpha has a uniform RELATIVE fp32 error */
+            const float zf = (float)(0.5 * (1.0 - fabs(c)));
+            const float hh = asin2_f32(zf);
+            const float af = c >= 0 ? hh : PI_F - hh;
+            const float bf = (float)PB[k];
+            float inf = bf - af, sup = bf + af;
+            const int j = base + k;
+            const bool lo_w = inf < 0, hi_w = sup > TWOPI_F;
+            if (fabsf(inf) <= E1 || fabsf(sup - TWOPI_F) <= E1) unc = 1; /* wrap or not? */
+            if (lo_w || hi_w) {
+                if (af > PI_F - E2) unc = 1; /* alpha ~ pi: degenerate full circle */
+                if (lo_w) inf += TWOPI_F; else sup -= TWOPI_F;
+                if (idW < 0) {
+                    W32 = sup; idW = j; V32 = inf; idV = j;
+                } else {
+                    const float dw = sup - W32, dv = inf - V32;
+                    if (fabsf(dw) <= E2 || fabsf(dv) <= E2) unc = 1;
+                    if (dw > 0) { W32 = sup; idW = j; }
+                    if (dv < 0) { V32 = inf; idV = j; }
+                }
+            } else if (depth == 0) {
+                ts = inf; te = sup; ids = ide = j; depth = 1;
+            } else {
+                const float d = inf - te;
+                if (fabsf(d) <= E2) unc = 1;
+                if (d < 0) { /* overlaps the top component */
+                    const float d1 = inf - ts, d2 = sup - te;
+                    if (fabsf(d1) <= E2 || fabsf(d2) <= E2) unc = 1;
+                    if (d1 < 0) { ts = inf; ids = j; }
+                    if (d2 > 0) { te = sup; ide = j; }
+                    while (depth > 1) {
+                        const ArcF lo = stk[(depth - 2) * stride];
+                        const float g = lo.e - ts;
+                        if (fabsf(g) <= E2) unc = 1;
+                        if (g < 0) break;
+                        const float g1 = lo.s - ts, g2 = lo.e - te;
+                        if (fabsf(g1) <= E2 || fabsf(g2) <= E2) unc = 1;
+                        if (g1 < 0) { ts = lo.s; ids = lo.ids; }
+                        if (g2 > 0) { te = lo.e; ide = lo.ide; }
+                        --depth;
+                    }
+                } else if (depth - 1 < ds) {
+                    ArcF t; t.s = ts; t.e = te; t.ids = ids; t.ide = ide;
+                    stk[(depth - 1) * stride] = t;
+                    ts = inf; te = sup; ids = ide = j; ++depth;
+                } else {
+                    unc = 1; /* deeper than the spill area: let the exact path flag it */
+                }
+            }
+        }
+    }
+    if (unc) return LR_UNCERTAIN;
+
+    /* fp64 end points of the arcs that bound something, then the reference's sweep */
+    const int wrap = idW >= 0;
+    double W = 0, V = SASA_TWOPI, dummy;
+    if (wrap) {
+        lr_arc(m.pq[o + idW], m.pb[o + idW], A, h2, z, dummy, W);
+        if (idV == idW) V = dummy; else lr_arc(m.pq[o + idV], m.pb[o + idV], A, h2, z, V, dummy);
+    }
     double sum = 0, sup = W;
     for (int c = 0; c < depth; ++c) {
-        Arc cur;
-        if (c == depth - 1) { cur.s = ts; cur.e = te; } else cur = stk[c * stride];
-        if (wrap && cur.s >= V) break; /* sorted behind the [V,2pi] piece: fully covered */
-        if (sup < cur.s) sum += cur.s - sup;
-        if (cur.e > sup) sup = cur.e;
+        int is, ie;
+        if (c == depth - 1) { is = ids; ie = ide; } else { const ArcF t = stk[c * stride]; is = t.ids; ie = t.ide; }
+        double cs, ce;
+        lr_arc(m.pq[o + is], m.pb[o + is], A, h2, z, cs, ce);
+        if (ie != is) lr_arc(m.pq[o + ie], m.pb[o + ie], A, h2, z, dummy, ce);
+        if (wrap && cs >= V) break;
+        if (sup < cs) sum += cs - sup;
+        if (ce > sup) sup = ce;
     }
     if (wrap) {
         if (sup < V) sum += V - sup;
         sup = SASA_TWOPI;
     }
-    return sum + SASA_TWOPI - sup; /* ref: :407 */
+    return sum + SASA_TWOPI - sup;
+}
+
+/* One slice of one atom: exposed arc length, or a negative value if it contributes nothing. */
+SASA_D double lr_slice(const TileMem &m, int o, int nn, double zi, double Ri, double z,
+                       Arc *stk, int stride, int ds, int *err)
+{
+    const double di = fabs(zi - z);                 /* ref: src/sasa_lr.c:308 */
+    const double A = Ri * Ri - di * di;             /* Ri'^2 */
+    if (!(A > 0)) return -1;                        /* ref: :310-312 */
+    double Rip, h2;
+    sqrt_rh(A, Rip, h2);                            /* h2 = 1/(2 Ri') */
+#ifdef SASA_LR_EXACT_ONLY
+    return lr_union_exact(m, o, nn, A, h2, z, stk, stride, ds, err);
+#else
+    double ex = lr_union_filtered(m, o, nn, A, h2, z, stk, stride, ds);
+    if (ex == LR_UNCERTAIN) {
+        SASA_COUNT_UNCERTAIN();
+        ex = lr_union_exact(m, o, nn, A, h2, z, stk, stride, ds, err);
+    }
+#ifdef SASA_EMU_CROSSCHECK
+    else {
+        int e2 = 0;
+        const double chk = lr_union_exact(m, o, nn, A, h2, z, stk, stride, ds, &e2);
+        if (!e2 && !(chk == ex)) sasa_emu::crosscheck_failures++;
+    }
+#endif
+    return ex;
+#endif
 }
 
 /* phase L: work items = (atom, slice) */

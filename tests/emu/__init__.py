@@ -33,7 +33,7 @@ def run_batch(lr, xyz, radii, offsets=None, probe=1.4, resolution=20, unit_pts=N
     sasa = np.full(n, np.nan)
     counts = np.full(n, -1, dtype=np.int32)
     totals = np.zeros(offsets.size - 1)
-    stats = (C.c_longlong * 8)()
+    stats = (C.c_longlong * 10)()
     up = None
     if unit_pts is not None:
         up = np.ascontiguousarray(unit_pts, dtype=np.float64).reshape(-1)
@@ -43,7 +43,7 @@ def run_batch(lr, xyz, radii, offsets=None, probe=1.4, resolution=20, unit_pts=N
                                 sasa.ctypes.data_as(_dp), counts.ctypes.data_as(_ip),
                                 totals.ctypes.data_as(_dp), stats, cap_idx, pool, ds,
                                 fb_cap_idx, fb_pool, fb_ds)
-    st = dict(zip(("error", "fallback_tiles", "max_nn", "TA", "B", "lds", "cells", "items"), list(stats)))
+    st = dict(zip(("error", "fallback_tiles", "max_nn", "TA", "B", "lds", "cells", "items", "uncertain", "crosscheck_failures"), list(stats)))
     if check and ret:
         raise RuntimeError(f"emulated batch failed: {st}")
     return sasa, counts, totals, st

@@ -7,6 +7,7 @@
  * bit for bit, which pins everything except the device's acos/atan2.
  */
 #define SASA_EMU 1
+#define SASA_EMU_CROSSCHECK 1 /* every filtered slice is re-done exactly and compared bit for bit */
 #include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
@@ -48,7 +49,8 @@ static void emu_tile_kernel(bool lr, const TileCfg &cfg, TileArgs a, int grid)
 
 /* force_*: <= 0 keeps the production launch configuration; positive values shrink the
  * capacities so that small inputs exercise the overflow -> fallback path.
- * stats_out[8]: error, fallback tiles, max nn, TA, B, lds, total cells, items. */
+ * stats_out[10]: error, fallback tiles, max nn, TA, B, lds, total cells, items, slices that
+ * needed the exact path, filtered-vs-exact cross-check failures. */
 extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, const int64_t *offsets,
                              int n_structs, double probe, int resolution, const double *unit_pts,
                              double *sasa, int *counts, double *totals, long long *stats_out,
@@ -156,5 +158,7 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
     stats_out[0] = status[ST_ERROR]; stats_out[1] = status[ST_OVF_TILES]; stats_out[2] = status[ST_MAX_NN];
     stats_out[3] = cfg.TA; stats_out[4] = cfg.B; stats_out[5] = (long long)cfg.lds; stats_out[6] = total_cells;
     stats_out[7] = cfg.items;
+    stats_out[8] = sasa_emu::uncertain_slices; stats_out[9] = sasa_emu::crosscheck_failures;
+    sasa_emu::uncertain_slices = 0; sasa_emu::crosscheck_failures = 0;
     return status[ST_ERROR] ? -1 : 0;
 }
