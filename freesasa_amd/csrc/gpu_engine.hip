@@ -86,8 +86,10 @@ __global__ __launch_bounds__(64) void k_totals(const double *sasa, const int64_t
     totals_phase1(part, totals, blockIdx.x, threadIdx.x);
 }
 
+/* 4 waves per SIMD (<= 128 VGPRs): the kernel hides its LDS/global latency and the barriers of
+ * one tile behind other resident tiles, so occupancy is worth a 16-byte spill (measured). */
 template <int B, bool GLOBAL>
-__global__ __launch_bounds__(B) void k_lr_tile(TileArgs a, int items)
+__global__ __launch_bounds__(B) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lr_tile(TileArgs a, int items)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -163,6 +165,8 @@ struct freesasa_gpu_ctx {
     /* host staging for freesasa_gpu_calc_batch */
     DevBuf h_xyz, h_radii, h_sasa, h_counts, h_totals;
     long long max_cells = 1LL << 30;
+    /* adaptive neighbor-pool size, per algorithm: (resolution, TA) it was learnt for and the value */
+    int hint_res[2] = {0, 0}, hint_ta[2] = {0, 0}, hint_pool[2] = {0, 0};
 };
 
 static int ctx_fail(freesasa_gpu_ctx *c, const char *fmt, ...)
@@ -369,7 +373,8 @@ static int run_batch(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, const do
     if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[1], st));
 
     /* fused tile kernel */
-    TileCfg cfg = choose_cfg(resolution, lr);
+    const int hi = lr ? 0 : 1;
+    TileCfg cfg = choose_cfg(resolution, lr, c->hint_res[hi] == resolution ? c->hint_pool[hi] : 0);
     if (const char *e = getenv("FREESASA_AMD_CFG")) { /* tuning aid: "B,TA,pool,ds" */
         int b = 0, t = 0, pl = 0, d = 0;
         if (sscanf(e, "%d,%d,%d,%d", &b, &t, &pl, &d) == 4 && (b == 64 || b == 128 || b == 256 || b == 320) && t >= 1 && t <= b &&
@@ -454,6 +459,10 @@ static int run_batch(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, const do
         if (hipEventElapsedTime(&ms, c->ev[0], c->ev[3]) == hipSuccess) S.ms_total = ms;
     }
     if (status_h[ST_ERROR]) return ctx_fail(c, "%s", err_text(status_h[ST_ERROR]));
+    /* learn the pool size for the next batch of this kind (trajectory frames, sweeps) */
+    c->hint_res[hi] = resolution;
+    c->hint_ta[hi] = cfg.TA;
+    c->hint_pool[hi] = pool_from_hist(status_h + ST_HIST, cfg.TA);
     return 0;
 }
 

@@ -35,15 +35,13 @@
 namespace sasa_emu {
 inline int atomic_add(int *p, int v) { int o = *p; *p = o + v; return o; }
 inline int atomic_max(int *p, int v) { int o = *p; if (v > o) *p = v; return o; }
-static long long uncertain_slices = 0, crosscheck_failures = 0;
 }
 #define SASA_ATOMIC_ADD_LDS(p, v) sasa_emu::atomic_add((p), (v))
 #define SASA_ATOMIC_ADD_GLB(p, v) sasa_emu::atomic_add((p), (v))
 #define SASA_ATOMIC_MAX_GLB(p, v) sasa_emu::atomic_max((p), (v))
 #define SASA_ATOMIC_MAX_LDS(p, v) sasa_emu::atomic_max((p), (v))
 #define SASA_RSQ(x) (1.0 / sqrt(x))
-#define SASA_SQRTF(x) sqrtf(x)
-#define SASA_COUNT_UNCERTAIN() (sasa_emu::uncertain_slices++)
+#define SASA_FMA_K(p, z, k) fma((p), (z), (k))
 #else
 #define SASA_D __device__ __forceinline__
 #define SASA_HD __host__ __device__ __forceinline__
@@ -52,8 +50,16 @@ static long long uncertain_slices = 0, crosscheck_failures = 0;
 #define SASA_ATOMIC_MAX_GLB(p, v) atomicMax((p), (v))
 #define SASA_ATOMIC_MAX_LDS(p, v) atomicMax((p), (v))
 #define SASA_RSQ(x) __builtin_amdgcn_rsq(x)
-#define SASA_SQRTF(x) __builtin_amdgcn_sqrtf(x)
-#define SASA_COUNT_UNCERTAIN() ((void)0)
+/* p*z + k with the constant k held in an SGPR pair: one v_fma_f64 per Horner step and no VGPRs
+   spent on coefficients (hipcc otherwise copies each coefficient into a VGPR pair and issues
+   v_mov + v_fmac) */
+__device__ __forceinline__ double sasa_fma_k(double p, double z, double k)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(z), "s"(k));
+    return r;
+}
+#define SASA_FMA_K(p, z, k) sasa_fma_k((p), (z), (k))
 #endif
 
 namespace sasa {
@@ -68,7 +74,8 @@ enum {
     ST_MAX_NN = 2,     /* max neighbors/atom seen */
     ST_SUM_NN_LO = 3,  /* (unused) */
     ST_FALLBACK_FAIL = 4,
-    ST_WORDS = 8
+    ST_HIST = 8,       /* [64] tiles by neighbor records needed, bins of 16 */
+    ST_WORDS = 72
 };
 enum {
     ERR_NONE = 0,
@@ -528,6 +535,10 @@ SASA_D void tile_report(const TileArgs &a, TileMem &m, int tile, int tid)
 {
     if (tid != 0) return;
     SASA_ATOMIC_MAX_GLB(&a.status[ST_MAX_NN], m.flags[2]);
+    if (!GLOBAL) { /* demand histogram: the host sizes the next batch's pool from it */
+        const int need = m.aoff[a.TA] >> 4;
+        SASA_ATOMIC_ADD_GLB(&a.status[ST_HIST + (need < 63 ? need : 63)], 1);
+    }
     if (m.flags[0]) {
         if (GLOBAL) {
             SASA_ATOMIC_MAX_GLB(&a.status[ST_ERROR], (int)ERR_NEIGHBOR_CAP);
@@ -567,17 +578,17 @@ SASA_D double acos_fast(double x)
     const bool big = ax > 0.5;
     const double z = big ? (1.0 - ax) * 0.5 : x * x;
     double p = 0x1.cd864394d2ff2p-6;
-    p = fma(p, z, -0x1.603991d6060e0p-7);
-    p = fma(p, z, 0x1.06b9d26d10838p-6);
-    p = fma(p, z, 0x1.ff5fc4d14c735p-8);
-    p = fma(p, z, 0x1.8522ddffa6208p-7);
-    p = fma(p, z, 0x1.c87265d47ef49p-7);
-    p = fma(p, z, 0x1.1c593c7b1d958p-6);
-    p = fma(p, z, 0x1.6e8b2b3b10be4p-6);
-    p = fma(p, z, 0x1.f1c71f95269afp-6);
-    p = fma(p, z, 0x1.6db6db684b6a1p-5);
-    p = fma(p, z, 0x1.3333333336da5p-4);
-    p = fma(p, z, 0x1.555555555554fp-3);
+    p = SASA_FMA_K(p, z, -0x1.603991d6060e0p-7);
+    p = SASA_FMA_K(p, z, 0x1.06b9d26d10838p-6);
+    p = SASA_FMA_K(p, z, 0x1.ff5fc4d14c735p-8);
+    p = SASA_FMA_K(p, z, 0x1.8522ddffa6208p-7);
+    p = SASA_FMA_K(p, z, 0x1.c87265d47ef49p-7);
+    p = SASA_FMA_K(p, z, 0x1.1c593c7b1d958p-6);
+    p = SASA_FMA_K(p, z, 0x1.6e8b2b3b10be4p-6);
+    p = SASA_FMA_K(p, z, 0x1.f1c71f95269afp-6);
+    p = SASA_FMA_K(p, z, 0x1.6db6db684b6a1p-5);
+    p = SASA_FMA_K(p, z, 0x1.3333333336da5p-4);
+    p = SASA_FMA_K(p, z, 0x1.555555555554fp-3);
     double s, hh;
     sqrt_rh(big ? z : 1.0, s, hh);
     const double u = big ? s : x;      /* asin argument */
@@ -667,16 +678,14 @@ SASA_D int lr_screen(const Quad *PQ, int lim, double A, double h2, double z, uns
 {
     int buried = 0;
     mask = 0;
-    for (int k = 0; k < lim; k += 4) {
-        const Quad q0 = PQ[k], q1 = PQ[k + 1], q2 = PQ[k + 2], q3 = PQ[k + 3];
-        const double d0 = q0.x - z, d1 = q1.x - z, d2 = q2.x - z, d3 = q3.x - z;
+    for (int k = 0; k < lim; k += 2) {
+        const Quad q0 = PQ[k], q1 = PQ[k + 1];
+        const double d0 = q0.x - z, d1 = q1.x - z;
         const double c0 = lr_cos(A, h2, d0 * d0, q0.y, q0.z, q0.w);
         const double c1 = lr_cos(A, h2, d1 * d1, q1.y, q1.z, q1.w);
-        const double c2 = lr_cos(A, h2, d2 * d2, q2.y, q2.z, q2.w);
-        const double c3 = lr_cos(A, h2, d3 * d3, q3.y, q3.z, q3.w);
-        const unsigned b0 = c0 < 1.0, b1 = c1 < 1.0, b2 = c2 < 1.0, b3 = c3 < 1.0;
-        buried |= (b0 & !(c0 > -1.0)) | (b1 & !(c1 > -1.0)) | (b2 & !(c2 > -1.0)) | (b3 & !(c3 > -1.0));
-        mask |= (unsigned long long)(b0 | (b1 << 1) | (b2 << 2) | (b3 << 3)) << k;
+        const unsigned b0 = c0 < 1.0, b1 = c1 < 1.0;
+        buried |= (b0 & !(c0 > -1.0)) | (b1 & !(c1 > -1.0));
+        mask |= (unsigned long long)(b0 | (b1 << 1)) << k;
     }
     return buried;
 }
@@ -713,7 +722,7 @@ SASA_D void lr_arc(const Quad q, double beta, double A, double h2, double z, dou
         (result) = sum_ + SASA_TWOPI - sup_; /* ref: :407 */                                 \
     } while (0)
 
-/* EXACT path.  One slice of one atom: exposed arc length of circle i at height z, or -1 if the
+/* One slice of one atom: exposed arc length of circle i at height z, or -1 if the
  * slice is buried.  The atom's neighbor records are sorted by beta.
  *
  * Arc union: arcs arrive ordered by mid-angle beta, so disjoint components form a stack —
@@ -775,135 +784,6 @@ SASA_D double lr_union_exact(const TileMem &m, int o, int nn, double A, double h
     return res;
 }
 
-/* FILTERED path: the same union, with the TOPOLOGY (which arcs wrap, which components exist,
- * which arc end point bounds each component) decided in fp32 and only the end points that
- * bound a component evaluated in fp64.
- *
- * Every fp32 end point is within LR_EPS of its fp64 value (error budget in DESIGN.md), and a
- * decision is taken only when the fp32 operands differ by more than 2*LR_EPS; otherwise the
- * slice is reported LR_UNCERTAIN and redone by lr_union_exact.  All decisions taken therefore
- * agree with the exact path, the components are bounded by the same arcs, and the final sweep
- * adds the same fp64 numbers in the same order: the result is bit-identical to
- * lr_union_exact's, at a fraction of the fp64 transcendental work (most arcs are interior
- * to a component and never need an exact angle). */
-#define LR_EPS 6.0e-6f
-#define LR_UNCERTAIN (-2.0)
-struct ArcF { float s, e; int ids, ide; }; /* 16 B: shares the Arc spill slots */
-
-/* 2*asin(sqrt(zf)), zf in (0, 0.5]: degree-6 interpolant, relative error < 1e-7 */
-SASA_D float asin2_f32(float zf)
-{
-    const float s = SASA_SQRTF(zf);
-    float p = 0.08429820090532303f;
-    p = fmaf(p, zf, -0.047614749521017075f);
-    p = fmaf(p, zf, 0.04787879064679146f);
-    p = fmaf(p, zf, 0.025548843666911125f);
-    p = fmaf(p, zf, 0.045064494013786316f);
-    p = fmaf(p, zf, 0.0749865174293518f);
-    p = fmaf(p, zf, 0.16666673123836517f);
-    const float s2 = s + s;
-    return fmaf(s2 * zf, p, s2);
-}
-
-SASA_D double lr_union_filtered(const TileMem &m, int o, int nn, double A, double h2, double z,
-                                Arc *stk_, int stride, int ds)
-{
-    ArcF *stk = (ArcF *)stk_;
-    const float PI_F = 3.14159274f, TWOPI_F = 6.28318548f, E1 = LR_EPS, E2 = 2.0f * LR_EPS;
-    float W32 = 0, V32 = 0, ts = 0, te = 0;
-    int idW = -1, idV = -1, ids = 0, ide = 0, depth = 0, unc = 0;
-
-    for (int base = 0; base < nn; base += 64) {
-        const int lim = nn - base < 64 ? nn - base : 64;
-        const Quad *PQ = m.pq + o + base;
-        const double *PB = m.pb + o + base;
-        unsigned long long mask;
-        if (lr_screen(PQ, lim, A, h2, z, mask)) return -1; /* fp64 test: certain */
-        while (mask) {
-            const int k = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            const Quad q = PQ[k];
-            const double dj = q.x - z;
-            const double c = lr_cos(A, h2, dj * dj, q.y, q.z, q.w);
-            /* alpha = acos c = 2 asin sqrt((1-c)/2) for c >= 0, pi - 2 asin sqrt((1+c)/2) else:
-               the argument is formed in fp64, so alpha has a uniform RELATIVE fp32 error */
-            const float zf = (float)(0.5 * (1.0 - fabs(c)));
-            const float hh = asin2_f32(zf);
-            const float af = c >= 0 ? hh : PI_F - hh;
-            const float bf = (float)PB[k];
-            float inf = bf - af, sup = bf + af;
-            const int j = base + k;
-            const bool lo_w = inf < 0, hi_w = sup > TWOPI_F;
-            if (fabsf(inf) <= E1 || fabsf(sup - TWOPI_F) <= E1) unc = 1; /* wrap or not? */
-            if (lo_w || hi_w) {
-                if (af > PI_F - E2) unc = 1; /* alpha ~ pi: degenerate full circle */
-                if (lo_w) inf += TWOPI_F; else sup -= TWOPI_F;
-                if (idW < 0) {
-                    W32 = sup; idW = j; V32 = inf; idV = j;
-                } else {
-                    const float dw = sup - W32, dv = inf - V32;
-                    if (fabsf(dw) <= E2 || fabsf(dv) <= E2) unc = 1;
-                    if (dw > 0) { W32 = sup; idW = j; }
-                    if (dv < 0) { V32 = inf; idV = j; }
-                }
-            } else if (depth == 0) {
-                ts = inf; te = sup; ids = ide = j; depth = 1;
-            } else {
-                const float d = inf - te;
-                if (fabsf(d) <= E2) unc = 1;
-                if (d < 0) { /* overlaps the top component */
-                    const float d1 = inf - ts, d2 = sup - te;
-                    if (fabsf(d1) <= E2 || fabsf(d2) <= E2) unc = 1;
-                    if (d1 < 0) { ts = inf; ids = j; }
-                    if (d2 > 0) { te = sup; ide = j; }
-                    while (depth > 1) {
-                        const ArcF lo = stk[(depth - 2) * stride];
-                        const float g = lo.e - ts;
-                        if (fabsf(g) <= E2) unc = 1;
-                        if (g < 0) break;
-                        const float g1 = lo.s - ts, g2 = lo.e - te;
-                        if (fabsf(g1) <= E2 || fabsf(g2) <= E2) unc = 1;
-                        if (g1 < 0) { ts = lo.s; ids = lo.ids; }
-                        if (g2 > 0) { te = lo.e; ide = lo.ide; }
-                        --depth;
-                    }
-                } else if (depth - 1 < ds) {
-                    ArcF t; t.s = ts; t.e = te; t.ids = ids; t.ide = ide;
-                    stk[(depth - 1) * stride] = t;
-                    ts = inf; te = sup; ids = ide = j; ++depth;
-                } else {
-                    unc = 1; /* deeper than the spill area: let the exact path flag it */
-                }
-            }
-        }
-    }
-    if (unc) return LR_UNCERTAIN;
-
-    /* fp64 end points of the arcs that bound something, then the reference's sweep */
-    const int wrap = idW >= 0;
-    double W = 0, V = SASA_TWOPI, dummy;
-    if (wrap) {
-        lr_arc(m.pq[o + idW], m.pb[o + idW], A, h2, z, dummy, W);
-        if (idV == idW) V = dummy; else lr_arc(m.pq[o + idV], m.pb[o + idV], A, h2, z, V, dummy);
-    }
-    double sum = 0, sup = W;
-    for (int c = 0; c < depth; ++c) {
-        int is, ie;
-        if (c == depth - 1) { is = ids; ie = ide; } else { const ArcF t = stk[c * stride]; is = t.ids; ie = t.ide; }
-        double cs, ce;
-        lr_arc(m.pq[o + is], m.pb[o + is], A, h2, z, cs, ce);
-        if (ie != is) lr_arc(m.pq[o + ie], m.pb[o + ie], A, h2, z, dummy, ce);
-        if (wrap && cs >= V) break;
-        if (sup < cs) sum += cs - sup;
-        if (ce > sup) sup = ce;
-    }
-    if (wrap) {
-        if (sup < V) sum += V - sup;
-        sup = SASA_TWOPI;
-    }
-    return sum + SASA_TWOPI - sup;
-}
-
 /* One slice of one atom: exposed arc length, or a negative value if it contributes nothing. */
 SASA_D double lr_slice(const TileMem &m, int o, int nn, double zi, double Ri, double z,
                        Arc *stk, int stride, int ds, int *err)
@@ -913,23 +793,7 @@ SASA_D double lr_slice(const TileMem &m, int o, int nn, double zi, double Ri, do
     if (!(A > 0)) return -1;                        /* ref: :310-312 */
     double Rip, h2;
     sqrt_rh(A, Rip, h2);                            /* h2 = 1/(2 Ri') */
-#ifdef SASA_LR_EXACT_ONLY
     return lr_union_exact(m, o, nn, A, h2, z, stk, stride, ds, err);
-#else
-    double ex = lr_union_filtered(m, o, nn, A, h2, z, stk, stride, ds);
-    if (ex == LR_UNCERTAIN) {
-        SASA_COUNT_UNCERTAIN();
-        ex = lr_union_exact(m, o, nn, A, h2, z, stk, stride, ds, err);
-    }
-#ifdef SASA_EMU_CROSSCHECK
-    else {
-        int e2 = 0;
-        const double chk = lr_union_exact(m, o, nn, A, h2, z, stk, stride, ds, &e2);
-        if (!e2 && !(chk == ex)) sasa_emu::crosscheck_failures++;
-    }
-#endif
-    return ex;
-#endif
 }
 
 /* phase L: work items = (atom, slice) */
@@ -941,16 +805,18 @@ SASA_D void lr_phase_slices(const TileArgs &a, TileMem &m, int tile, int tid, in
     Arc *stk = m.stack + tid;
     int err = 0;
     if (a.tab) {
+        /* slice-major items: a wave holds a few ADJACENT slices of every atom of the tile, so
+           its lanes have similar arc counts (polar slices cut few arcs, equatorial many) */
         const int items = na * ns;
         for (int it = tid; it < items; it += B) {
-            const int la = it / ns, s = it - la * ns;
+            const int s = it / na, la = it - s * na;
             const double Ri = m.aR[la], zi = m.az[la];
             const double delta = 2 * Ri / ns;       /* ref: src/sasa_lr.c:304 */
             double z = zi - Ri - 0.5 * delta;
             for (int k = 0; k <= s; ++k) z += delta; /* accumulated like the reference, :307 */
             const int o = m.aoff[la];
             const double ex = lr_slice(m, o, m.aoff[la + 1] - o, zi, Ri, z, stk, B, a.ds, &err); /* padded count */
-            m.contrib[it] = ex < 0 ? 0.0 : delta * Ri * ex; /* ref: :360 */
+            m.contrib[la * ns + s] = ex < 0 ? 0.0 : delta * Ri * ex; /* ref: :360 */
         }
     } else {
         /* many slices per atom (TA == 1): strided partial sums, z by direct formula */
@@ -1105,7 +971,7 @@ struct TileCfg {
 
 /* Pick workgroup size and atoms per tile so that TA*resolution work items fill whole rounds
  * of B threads (resolution 20 -> 16 atoms x 20 slices = 320 threads, one round). */
-static inline TileCfg choose_cfg(int resolution, bool lr)
+static inline TileCfg choose_cfg(int resolution, bool lr, int pool_hint = 0)
 {
     TileCfg c;
     c.tab = 1;
@@ -1138,9 +1004,30 @@ static inline TileCfg choose_cfg(int resolution, bool lr)
     c.npw = lr ? 5 : 4;
     c.cap_idx = 128;
     c.pool = 64 * c.TA < 128 ? 128 : 64 * c.TA;
+    if (pool_hint > 0) c.pool = pool_hint;
     c.ds = lr ? 4 : 0;
     c.lds = tile_fixed_bytes(c.TA, c.items) + tile_list_bytes(c.TA, c.cap_idx, c.pool, c.npw, c.ds, c.B);
     return c;
+}
+
+/* Pool size for the NEXT batch on this context from the demand histogram of the last one: the
+ * smallest multiple of 16 records that would have kept all but ~0.05% of the tiles out of the
+ * (slow) fallback launch, plus one bin of headroom.  Less LDS per tile = more resident tiles. */
+static inline int pool_from_hist(const int *hist, int TA)
+{
+    long long total = 0;
+    for (int k = 0; k < 64; ++k) total += hist[k];
+    if (total <= 0) return 0;
+    long long allowed = total / 2000, acc = 0;
+    int k = 63;
+    for (; k > 0; --k) {
+        acc += hist[k];
+        if (acc > allowed) break;
+    }
+    if (k >= 63) return 0; /* demand beyond the histogram: keep the default */
+    int pool = (k + 2) * 16;
+    if (pool < 128) pool = 128;
+    return pool;
 }
 
 static inline TileCfg fallback_cfg(const TileCfg &main_cfg, bool lr)

