@@ -42,8 +42,8 @@ emu: tests/emu/libsasa_emu.so
 tests/emu/libsasa_emu.so: tests/emu/emu.cpp $(CSRC)/sasa_kernels.h
 	$(CXX) -O2 -std=c++17 -fPIC -ffp-contract=off -DSASA_EMU -shared -o $@ tests/emu/emu.cpp -lm
 
-oracle:
-	$(MAKE) -C oracle all
+oracle: $(LIBDIR)/libfreesasa_amd_seam.a
+	$(MAKE) -C oracle all dropin
 tools:
 	$(MAKE) -C tools
 

@@ -72,6 +72,27 @@ def cpu_baseline(xyz, r, offs, gpu_sasa, budget_s=12.0):
                       f"single-thread rate {len(res[0]) / t1:.0f} atoms/s"}, err
 
 
+def profiled_traffic(args):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this same command, KB units;
+    for this kernel's 8-byte gathers FETCH_SIZE needs no x2 correction — calibrated on
+    k_scatter's known byte count).  Only valid for the default workload."""
+    if (args.structs, args.atoms, args.slices) != (1000, 10000, 20):
+        return None, None
+    best = None
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles"))) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
+        if name.endswith("_hbm_counters.json"):
+            best = name
+    if not best:
+        return None, None
+    with open(os.path.join(ROOT, "profiles", best)) as fh:
+        d = json.load(fh)
+    for k, v in d.items():
+        if "k_lr_tile" in k and "false" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            return (v["FETCH_SIZE"]["per_launch_KB"] + v["WRITE_SIZE"]["per_launch_KB"]) * 1024.0, "profiles/" + best
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,6 +166,7 @@ def main():
         value = total_atoms / elapsed
         kern_s = float(np.mean(k_ms)) * 1e-3
         achieved = ALGO_BYTES_PER_ATOM * n_atoms / kern_s / 1e9 if kern_s > 0 else None
+        traffic, traffic_src = profiled_traffic(args)
         out = {
             "metric": "atoms/sec SASA (L&R 20 slices)" if args.slices == 20 else f"atoms/sec SASA (L&R {args.slices} slices)",
             "value": value, "unit": "atoms/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -160,7 +182,9 @@ def main():
                        "tile_atoms": st["tile_atoms"], "block_threads": st["block_threads"],
                        "lds_bytes_per_block": st["lds_bytes"], "cells": st["n_cells"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,
+                         "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ATOM * n_atoms,
                          "kernel": "k_lr_tile", "kernel_ms": 1e3 * kern_s, "prep_ms": float(np.mean(prep_ms)),
                          "kernel_atoms_per_s": n_atoms / kern_s if kern_s > 0 else None,
                          "note": "nominal HBM roofline per north_star (40 B/atom); the kernel is fp64-VALU bound, "
