@@ -101,6 +101,10 @@ def main():
     ap.add_argument("--structs", type=int, default=1000, help="structures per GPU")
     ap.add_argument("--atoms", type=int, default=10000, help="atoms per structure")
     ap.add_argument("--slices", type=int, default=20)
+    ap.add_argument("--workload", default="coil_lr", choices=["coil_lr", "globule_sr"],
+                    help="coil_lr: the headline metric (default).  globule_sr: BASELINE configs[1] proxy, "
+                         "ONE 200k-atom globule per GPU, Shrake-Rupley 100 points (secondary line)")
+    ap.add_argument("--points", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -121,8 +125,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    # this rank's shard: its own independent structures (seeds are disjoint across ranks)
-    xyz, r, offs = tools.coil_batch(args.structs, args.atoms, seed0=1000 + rank * args.structs)
+    sr = args.workload == "globule_sr"
+    if sr:
+        args.structs, args.atoms = 1, 200_000
+        xyz, r = tools.globule(args.atoms, 77 + rank)
+        offs = np.array([0, args.atoms], dtype=np.int64)
+    else:
+        # this rank's shard: its own independent structures (seeds are disjoint across ranks)
+        xyz, r, offs = tools.coil_batch(args.structs, args.atoms, seed0=1000 + rank * args.structs)
     n_atoms = int(offs[-1])
     d_xyz = torch.from_numpy(xyz).to(dev)
     d_r = torch.from_numpy(r).to(dev)
@@ -133,9 +143,15 @@ def main():
     torch.cuda.set_stream(stream)
     ctx = fa.GpuContext(local_rank, stream=stream.cuda_stream, timing=True)
 
+    d_cnt = torch.empty(n_atoms, dtype=torch.int32, device=dev) if sr else None
+
     def step():
-        ctx.lee_richards(d_xyz.data_ptr(), d_r.data_ptr(), offs, d_sasa.data_ptr(), d_tot.data_ptr(),
-                         probe=1.4, n_slices=args.slices)
+        if sr:
+            ctx.shrake_rupley(d_xyz.data_ptr(), d_r.data_ptr(), offs, d_sasa.data_ptr(), d_cnt.data_ptr(),
+                              d_tot.data_ptr(), probe=1.4, n_points=args.points)
+        else:
+            ctx.lee_richards(d_xyz.data_ptr(), d_r.data_ptr(), offs, d_sasa.data_ptr(), d_tot.data_ptr(),
+                             probe=1.4, n_slices=args.slices)
 
     def barrier():
         torch.cuda.synchronize()
@@ -167,14 +183,22 @@ def main():
         kern_s = float(np.mean(k_ms)) * 1e-3
         achieved = ALGO_BYTES_PER_ATOM * n_atoms / kern_s / 1e9 if kern_s > 0 else None
         traffic, traffic_src = profiled_traffic(args)
+        if sr:
+            traffic = None
+            metric = f"atoms/sec SASA (S&R {args.points} points)"
+            wl = (f"one synthetic {args.atoms}-atom globule per GPU (BASELINE configs[1] proxy: 4V6X is not available "
+                  f"offline), Shrake-Rupley {args.points} test points, probe 1.4 A, inputs resident in HBM")
+        else:
+            metric = "atoms/sec SASA (L&R 20 slices)" if args.slices == 20 else f"atoms/sec SASA (L&R {args.slices} slices)"
+            wl = (f"{args.structs} synthetic random-coil structures x {args.atoms} atoms per GPU "
+                  f"(BASELINE configs[2] batch geometry, seeds 1000+k), Lee-Richards "
+                  f"{args.slices} slices, probe 1.4 A, inputs resident in HBM")
         out = {
-            "metric": "atoms/sec SASA (L&R 20 slices)" if args.slices == 20 else f"atoms/sec SASA (L&R {args.slices} slices)",
+            "metric": metric,
             "value": value, "unit": "atoms/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.structs} synthetic random-coil structures x {args.atoms} atoms per GPU "
-                                   f"(BASELINE configs[2] batch geometry, seeds 1000+k), Lee-Richards "
-                                   f"{args.slices} slices, probe 1.4 A, inputs resident in HBM",
+            "config": {"workload": wl,
                        "structures_per_gpu": args.structs, "atoms_per_structure": args.atoms,
                        "n_slices": args.slices, "probe_radius": 1.4,
                        "parallelism": f"{world} x independent structure shards (no collective)",
@@ -185,12 +209,12 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,
                          "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ATOM * n_atoms,
-                         "kernel": "k_lr_tile", "kernel_ms": 1e3 * kern_s, "prep_ms": float(np.mean(prep_ms)),
+                         "kernel": "k_sr_tile" if sr else "k_lr_tile", "kernel_ms": 1e3 * kern_s, "prep_ms": float(np.mean(prep_ms)),
                          "kernel_atoms_per_s": n_atoms / kern_s if kern_s > 0 else None,
                          "note": "nominal HBM roofline per north_star (40 B/atom); the kernel is fp64-VALU bound, "
                                  "see DESIGN.md"},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not sr:
             base, err = cpu_baseline(xyz, r, offs, d_sasa.cpu().numpy())
             out["cpu_baseline"] = base
             out["max_abs_dsasa_vs_cpu"] = err

@@ -78,9 +78,9 @@ __global__ __launch_bounds__(SASA_PIPE_B) void k_scatter(PipeArgs a)
     scatter_atom(a, blockIdx.x * SASA_PIPE_B + threadIdx.x);
 }
 
-__global__ __launch_bounds__(64) void k_totals(const double *sasa, const int64_t *offsets, int n_structs, double *totals)
+__global__ __launch_bounds__(SASA_TOT_B) void k_totals(const double *sasa, const int64_t *offsets, int n_structs, double *totals)
 {
-    __shared__ double part[64];
+    __shared__ double part[SASA_TOT_B];
     totals_phase0(sasa, offsets, part, blockIdx.x, threadIdx.x);
     __syncthreads();
     totals_phase1(part, totals, blockIdx.x, threadIdx.x);
@@ -162,8 +162,10 @@ struct freesasa_gpu_ctx {
     DevBuf sx, sy, sz, sr, s_orig, s_cell, s_struct;
     DevBuf status, ovf_tiles, unit_pts, slab;
     std::vector<int64_t> offsets_host; /* last uploaded offsets */
+    std::vector<double> unit_host;     /* last uploaded S&R unit points */
     /* host staging for freesasa_gpu_calc_batch */
     DevBuf h_xyz, h_radii, h_sasa, h_counts, h_totals;
+    int *pinned = nullptr; /* page-locked host words for the small device->host readbacks */
     long long max_cells = 1LL << 30;
     /* adaptive neighbor-pool size, per algorithm: (resolution, TA) it was learnt for and the value */
     int hint_res[2] = {0, 0}, hint_ta[2] = {0, 0}, hint_pool[2] = {0, 0};
@@ -226,6 +228,10 @@ extern "C" freesasa_gpu_ctx *freesasa_gpu_ctx_create(int device, void *stream)
             delete c;
             return nullptr;
         }
+    if (hipHostMalloc((void **)&c->pinned, sizeof(int) * (ST_WORDS + 4), hipHostMallocDefault) != hipSuccess) {
+        delete c;
+        return nullptr;
+    }
     return c;
 }
 
@@ -242,6 +248,7 @@ extern "C" void freesasa_gpu_ctx_destroy(freesasa_gpu_ctx *c)
         if (b->p) (void)hipFree(b->p);
     for (int k = 0; k < 4; ++k)
         if (c->ev[k]) (void)hipEventDestroy(c->ev[k]);
+    if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -348,11 +355,12 @@ static int run_batch(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, const do
     HIP_TRY(c, hipGetLastError());
 
     /* the one mid-pipeline readback: total cells sizes the histogram */
-    long long total_cells = 0;
-    int status_h[ST_WORDS];
-    HIP_TRY(c, hipMemcpyAsync(&total_cells, (long long *)c->ncells.p + n_structs, sizeof(long long), hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(status_h, c->status.p, sizeof status_h, hipMemcpyDeviceToHost, st));
+    int *status_h = c->pinned;
+    long long *total_cells_p = (long long *)(c->pinned + ST_WORDS + 2);
+    HIP_TRY(c, hipMemcpyAsync(total_cells_p, (long long *)c->ncells.p + n_structs, sizeof(long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(status_h, c->status.p, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
+    const long long total_cells = *total_cells_p;
     if (status_h[ST_ERROR]) return ctx_fail(c, "%s", err_text(status_h[ST_ERROR]));
     if (total_cells <= 0 || total_cells > c->max_cells) return ctx_fail(c, "%s", err_text(ERR_GRID_TOO_BIG));
 
@@ -401,7 +409,12 @@ static int run_batch(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, const do
     if (!lr) {
         if (!unit_points) return ctx_fail(c, "unit_points is null");
         if (ensure(c, c->unit_pts, sizeof(double) * 3 * (size_t)resolution)) return -1;
-        HIP_TRY(c, hipMemcpyAsync(c->unit_pts.p, unit_points, sizeof(double) * 3 * (size_t)resolution, hipMemcpyHostToDevice, st));
+        /* pageable host-to-device copies stall the stream: upload the points only when they change */
+        if (c->unit_host.size() != 3 * (size_t)resolution ||
+            memcmp(c->unit_host.data(), unit_points, sizeof(double) * 3 * (size_t)resolution) != 0) {
+            c->unit_host.assign(unit_points, unit_points + 3 * (size_t)resolution);
+            HIP_TRY(c, hipMemcpyAsync(c->unit_pts.p, c->unit_host.data(), sizeof(double) * 3 * (size_t)resolution, hipMemcpyHostToDevice, st));
+        }
         ta.unit_pts = (const double *)c->unit_pts.p;
     }
 
@@ -438,13 +451,13 @@ static int run_batch(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, const do
     }
 
     if (d_totals) {
-        hipLaunchKernelGGL(k_totals, dim3(n_structs), dim3(64), 0, st, (const double *)d_sasa,
+        hipLaunchKernelGGL(k_totals, dim3(n_structs), dim3(SASA_TOT_B), 0, st, (const double *)d_sasa,
                            (const int64_t *)c->offsets.p, n_structs, d_totals);
         HIP_TRY(c, hipGetLastError());
     }
     if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[3], st));
 
-    HIP_TRY(c, hipMemcpyAsync(status_h, c->status.p, sizeof status_h, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(status_h, c->status.p, sizeof(int) * ST_WORDS, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
 
     freesasa_gpu_stats &S = c->stats;

@@ -534,8 +534,10 @@ template <bool GLOBAL>
 SASA_D void tile_report(const TileArgs &a, TileMem &m, int tile, int tid)
 {
     if (tid != 0) return;
-    SASA_ATOMIC_MAX_GLB(&a.status[ST_MAX_NN], m.flags[2]);
-    if (!GLOBAL) { /* demand histogram: the host sizes the next batch's pool from it */
+    /* statistics must not serialise half a million tiles on one L2 atomic unit: the maximum is
+       only pushed when it beats the value already there, the demand histogram samples 1 tile in 32 */
+    if (m.flags[2] > a.status[ST_MAX_NN]) SASA_ATOMIC_MAX_GLB(&a.status[ST_MAX_NN], m.flags[2]);
+    if (!GLOBAL && (tile & 31) == 0) {
         const int need = m.aoff[a.TA] >> 4;
         SASA_ATOMIC_ADD_GLB(&a.status[ST_HIST + (need < 63 ? need : 63)], 1);
     }
@@ -922,24 +924,30 @@ SASA_D void sr_phase_store(const TileArgs &a, TileMem &m, int tile, int tid)
 }
 
 /* ---------------------------------------------------------------- per-structure totals */
-/* One 64-lane wave per structure: each lane sums a contiguous chunk in atom order, lane 0 adds
- * the 64 partials in order.  Deterministic; equals the reference's sequential sum
- * (src/freesasa.c:113-116) up to fp64 reassociation (the drop-in freesasa_calc sums on the
- * host in exact reference order). */
-SASA_D void totals_phase0(const double *sasa, const int64_t *offsets, double *part, int s, int lane)
+/* One workgroup of SASA_TOT_B threads per structure: each thread sums a contiguous chunk in
+ * atom order (4 loads in flight), thread 0 adds the partials in order.  Deterministic; equals the
+ * reference's sequential sum (src/freesasa.c:113-116) up to fp64 reassociation (the drop-in
+ * freesasa_calc sums on the host in exact reference order). */
+#define SASA_TOT_B 256
+SASA_D void totals_phase0(const double *sasa, const int64_t *offsets, double *part, int s, int tid)
 {
     const int64_t b = offsets[s], e = offsets[s + 1];
-    const int64_t per = (e - b + 63) / 64;
-    const int64_t lo = b + lane * per, hi = lo + per < e ? lo + per : e;
+    const int64_t per = (e - b + SASA_TOT_B - 1) / SASA_TOT_B;
+    const int64_t lo = b + tid * per, hi = lo + per < e ? lo + per : e;
     double t = 0;
-    for (int64_t i = lo; i < hi; ++i) t += sasa[i];
-    part[lane] = t;
+    int64_t i = lo;
+    for (; i + 4 <= hi; i += 4) {
+        const double v0 = sasa[i], v1 = sasa[i + 1], v2 = sasa[i + 2], v3 = sasa[i + 3];
+        t += v0; t += v1; t += v2; t += v3;
+    }
+    for (; i < hi; ++i) t += sasa[i];
+    part[tid] = t;
 }
-SASA_D void totals_phase1(const double *part, double *totals, int s, int lane)
+SASA_D void totals_phase1(const double *part, double *totals, int s, int tid)
 {
-    if (lane != 0) return;
+    if (tid != 0) return;
     double t = 0;
-    for (int k = 0; k < 64; ++k) t += part[k];
+    for (int k = 0; k < SASA_TOT_B; ++k) t += part[k];
     totals[s] = t;
 }
 
@@ -1018,7 +1026,7 @@ static inline int pool_from_hist(const int *hist, int TA)
     long long total = 0;
     for (int k = 0; k < 64; ++k) total += hist[k];
     if (total <= 0) return 0;
-    long long allowed = total / 2000, acc = 0;
+    long long allowed = total / 1000, acc = 0; /* (the histogram is a 1-in-32 sample) */
     int k = 63;
     for (; k > 0; --k) {
         acc += hist[k];

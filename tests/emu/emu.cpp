@@ -147,10 +147,10 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
         emu_tile_kernel<true>(lr != 0, fb, tf, fb_blocks);
     }
     if (totals) {
-        double part[64];
+        double part[SASA_TOT_B];
         for (int s = 0; s < n_structs; ++s) {
-            for (int l = 0; l < 64; ++l) totals_phase0(sasa, offsets, part, s, l);
-            for (int l = 0; l < 64; ++l) totals_phase1(part, totals, s, l);
+            for (int l = 0; l < SASA_TOT_B; ++l) totals_phase0(sasa, offsets, part, s, l);
+            for (int l = 0; l < SASA_TOT_B; ++l) totals_phase1(part, totals, s, l);
         }
     }
 
