@@ -13,7 +13,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-LIB_PATH = os.path.join(HERE, "lib", "libfreesasa_amd.so")
+LIB_PATH = os.environ.get("FREESASA_AMD_LIB") or os.path.join(HERE, "lib", "libfreesasa_amd.so")
 
 LEE_RICHARDS, SHRAKE_RUPLEY = 0, 1
 SUCCESS, FAIL, WARN = 0, -1, -2

@@ -94,9 +94,9 @@ __global__ __launch_bounds__(B) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     TileMem m = tile_carve<GLOBAL>(a, smem, items, B, blockIdx.x);
-    const int n_work = GLOBAL ? *a.ovf_count : ((a.n_tiles + 7) >> 3) << 3;
+    const int n_work = a.work_tiles ? *a.work_count : ((a.n_tiles + 7) >> 3) << 3;
     for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
-        const int tile = GLOBAL ? a.work_tiles[w] : xcd_tile(w, a.n_tiles);
+        const int tile = a.work_tiles ? a.work_tiles[w] : xcd_tile(w, a.n_tiles);
         if (tile >= a.n_tiles) continue; /* uniform per workgroup */
         tile_phase_load(a, m, tile, tid, B);
         __syncthreads();
@@ -122,9 +122,9 @@ __global__ __launch_bounds__(B) void k_sr_tile(TileArgs a, int items)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     TileMem m = tile_carve<GLOBAL>(a, smem, items, B, blockIdx.x);
-    const int n_work = GLOBAL ? *a.ovf_count : ((a.n_tiles + 7) >> 3) << 3;
+    const int n_work = a.work_tiles ? *a.work_count : ((a.n_tiles + 7) >> 3) << 3;
     for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
-        const int tile = GLOBAL ? a.work_tiles[w] : xcd_tile(w, a.n_tiles);
+        const int tile = a.work_tiles ? a.work_tiles[w] : xcd_tile(w, a.n_tiles);
         if (tile >= a.n_tiles) continue;
         tile_phase_load(a, m, tile, tid, B);
         __syncthreads();
@@ -160,7 +160,7 @@ struct freesasa_gpu_ctx {
     /* workspace */
     DevBuf offsets, grid, ncells, sid, cell_of, rank, cell_start, blk_sums;
     DevBuf sx, sy, sz, sr, s_orig, s_cell, s_struct;
-    DevBuf status, ovf_tiles, unit_pts, slab;
+    DevBuf status, ovf_tiles, ovf_tiles2, unit_pts, slab;
     std::vector<int64_t> offsets_host; /* last uploaded offsets */
     std::vector<double> unit_host;     /* last uploaded S&R unit points */
     /* host staging for freesasa_gpu_calc_batch */
@@ -242,7 +242,7 @@ extern "C" void freesasa_gpu_ctx_destroy(freesasa_gpu_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->offsets, &c->grid, &c->ncells, &c->sid, &c->cell_of, &c->rank, &c->cell_start,
                      &c->blk_sums, &c->sx, &c->sy, &c->sz, &c->sr, &c->s_orig, &c->s_cell, &c->s_struct,
-                     &c->status, &c->ovf_tiles, &c->unit_pts, &c->slab,
+                     &c->status, &c->ovf_tiles, &c->ovf_tiles2, &c->unit_pts, &c->slab,
                      &c->h_xyz, &c->h_radii, &c->h_sasa, &c->h_counts, &c->h_totals};
     for (DevBuf *b : all)
         if (b->p) (void)hipFree(b->p);
@@ -393,7 +393,7 @@ static int run_batch(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, const do
         }
     }
     const int n_tiles = (n + cfg.TA - 1) / cfg.TA;
-    if (ensure(c, c->ovf_tiles, sizeof(int) * ((size_t)n_tiles + 1))) return -1;
+    if (ensure(c, c->ovf_tiles, sizeof(int) * ((size_t)n_tiles + 1)) || ensure(c, c->ovf_tiles2, sizeof(int) * ((size_t)n_tiles + 1))) return -1;
 
     TileArgs ta;
     memset(&ta, 0, sizeof ta);
@@ -405,6 +405,8 @@ static int run_batch(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, const do
     ta.cap_idx = cfg.cap_idx; ta.pool = cfg.pool; ta.npw = cfg.npw; ta.ds = cfg.ds;
     ta.ovf_count = (int *)c->status.p + ST_OVF_TILES;
     ta.ovf_tiles = (int *)c->ovf_tiles.p;
+    ta.work_tiles = nullptr;
+    ta.work_count = nullptr;
     ta.status = (int *)c->status.p;
     if (!lr) {
         if (!unit_points) return ctx_fail(c, "unit_points is null");
@@ -435,15 +437,31 @@ static int run_batch(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, const do
     if (le != hipSuccess) return ctx_fail(c, "tile kernel launch failed: %s", hipGetErrorString(le));
     if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[2], st));
 
-    /* fallback launch over the tiles the main launch gave up on (normally zero: the blocks
-       read the count on the device and exit).  One atom per workgroup, lists in a slab. */
+    /* second launch: the tiles whose lists did not fit the small LDS capacities (the blocks read
+       the count on the device; normally a fraction of a percent of the tiles) */
+    {
+        const TileCfg mc = mid_cfg(cfg, lr);
+        TileArgs tm = ta;
+        tm.cap_idx = mc.cap_idx; tm.pool = mc.pool; tm.ds = mc.ds;
+        tm.work_tiles = (const int *)c->ovf_tiles.p;
+        tm.work_count = (const int *)c->status.p + ST_OVF_TILES;
+        tm.ovf_tiles = (int *)c->ovf_tiles2.p;
+        tm.ovf_count = (int *)c->status.p + ST_OVF2_TILES;
+        const int grid_mid = n_tiles < SASA_MID_BLOCKS ? n_tiles : SASA_MID_BLOCKS;
+        le = lr ? launch_lr<false>(mc, tm, grid_mid, mc.lds, st) : launch_sr<false>(mc, tm, grid_mid, mc.lds, st);
+        if (le != hipSuccess) return ctx_fail(c, "second tile launch failed: %s", hipGetErrorString(le));
+    }
+    /* third launch: whatever is left (pathological densities), lists in a global slab */
     {
         const TileCfg fb = fallback_cfg(cfg, lr);
         const size_t stride = tile_slab_bytes(fb.TA, fb.cap_idx, fb.pool, fb.npw, fb.ds, fb.B);
         if (ensure(c, c->slab, stride * SASA_FB_BLOCKS)) return -1;
         TileArgs tf = ta;
         tf.cap_idx = fb.cap_idx; tf.pool = fb.pool; tf.ds = fb.ds;
-        tf.work_tiles = (const int *)c->ovf_tiles.p;
+        tf.work_tiles = (const int *)c->ovf_tiles2.p;
+        tf.work_count = (const int *)c->status.p + ST_OVF2_TILES;
+        tf.ovf_tiles = nullptr;
+        tf.ovf_count = nullptr;
         tf.slab = (char *)c->slab.p;
         tf.slab_stride = (long long)stride;
         le = lr ? launch_lr<true>(fb, tf, SASA_FB_BLOCKS, fb.lds, st) : launch_sr<true>(fb, tf, SASA_FB_BLOCKS, fb.lds, st);

@@ -70,9 +70,9 @@ namespace sasa {
 /* status[] slots (device -> host) */
 enum {
     ST_ERROR = 0,      /* first error code, 0 = ok */
-    ST_OVF_TILES = 1,  /* number of tiles handed to the fallback kernel */
+    ST_OVF_TILES = 1,  /* tiles handed to the second (large-LDS) launch */
     ST_MAX_NN = 2,     /* max neighbors/atom seen */
-    ST_SUM_NN_LO = 3,  /* (unused) */
+    ST_OVF2_TILES = 3, /* tiles handed on to the third (slab) launch */
     ST_FALLBACK_FAIL = 4,
     ST_HIST = 8,       /* [64] tiles by neighbor records needed, bins of 16 */
     ST_WORDS = 72
@@ -336,10 +336,12 @@ struct TileArgs {
     int pool;    /* neighbor records per tile */
     int npw;     /* doubles per neighbor record: 5 (L&R) or 4 (S&R) */
     int ds;      /* spilled stack levels per thread (L&R) */
-    /* overflow hand-off to the fallback launch */
+    /* overflow hand-off: a tile that does not fit this launch's capacities is appended to the
+       next launch's work list (null in the last launch: error) */
     int *ovf_count;
     int *ovf_tiles;
-    const int *work_tiles; /* fallback launch: tile ids to (re)do; null in the main launch */
+    const int *work_tiles; /* tile ids to (re)do; null in the main launch (all tiles) */
+    const int *work_count;
     /* fallback launch: lists live in a global slab, one slice per workgroup */
     char *slab;
     long long slab_stride;
@@ -537,12 +539,12 @@ SASA_D void tile_report(const TileArgs &a, TileMem &m, int tile, int tid)
     /* statistics must not serialise half a million tiles on one L2 atomic unit: the maximum is
        only pushed when it beats the value already there, the demand histogram samples 1 tile in 32 */
     if (m.flags[2] > a.status[ST_MAX_NN]) SASA_ATOMIC_MAX_GLB(&a.status[ST_MAX_NN], m.flags[2]);
-    if (!GLOBAL && (tile & 31) == 0) {
+    if (!a.work_tiles && (tile & 31) == 0) {
         const int need = m.aoff[a.TA] >> 4;
         SASA_ATOMIC_ADD_GLB(&a.status[ST_HIST + (need < 63 ? need : 63)], 1);
     }
     if (m.flags[0]) {
-        if (GLOBAL) {
+        if (!a.ovf_tiles) {
             SASA_ATOMIC_MAX_GLB(&a.status[ST_ERROR], (int)ERR_NEIGHBOR_CAP);
         } else {
             const int w = SASA_ATOMIC_ADD_GLB(a.ovf_count, 1);
@@ -811,7 +813,11 @@ SASA_D void lr_phase_slices(const TileArgs &a, TileMem &m, int tile, int tid, in
            its lanes have similar arc counts (polar slices cut few arcs, equatorial many) */
         const int items = na * ns;
         for (int it = tid; it < items; it += B) {
+#ifdef SASA_ATOM_MAJOR
+            const int la = it / ns, s = it - la * ns;
+#else
             const int s = it / na, la = it - s * na;
+#endif
             const double Ri = m.aR[la], zi = m.az[la];
             const double delta = 2 * Ri / ns;       /* ref: src/sasa_lr.c:304 */
             double z = zi - Ri - 0.5 * delta;
@@ -844,7 +850,7 @@ SASA_D void lr_phase_store(const TileArgs &a, TileMem &m, int tile, int tid, int
     const int na = tile_atoms(a, tile), p0 = tile_first_atom(a, tile);
     if (m.flags[1]) { /* a stack overflowed: redo the tile in the fallback launch */
         if (tid == 0) {
-            if (GLOBAL) {
+            if (!a.ovf_tiles) {
                 SASA_ATOMIC_MAX_GLB(&a.status[ST_ERROR], (int)ERR_STACK_CAP);
             } else {
                 const int w = SASA_ATOMIC_ADD_GLB(a.ovf_count, 1);
@@ -971,7 +977,10 @@ struct TileCfg {
 
 #define SASA_ITEMS_CAP 640
 #define SASA_TA_MAX 16
-/* fallback launch: same tiling, lists in a global slab, far larger capacities */
+/* Three launches share one tiling.  1: small LDS lists sized for the typical tile (most
+ * resident tiles per CU).  2: the tiles that overflowed, with 2x-4x larger LDS lists.  3: what
+ * still overflows, lists in a global slab, far larger capacities. */
+#define SASA_MID_BLOCKS 2048
 #define SASA_FB_BLOCKS 64
 #define SASA_FB_CAP 4096   /* neighbors per atom */
 #define SASA_FB_POOL 16384 /* neighbors per tile */
@@ -996,7 +1005,7 @@ static inline TileCfg choose_cfg(int resolution, bool lr, int pool_hint = 0)
     } else {
         double best = -1;
         c.B = 128; c.TA = 1;
-        const int Bs[3] = {128, 256, 64};
+        const int Bs[3] = {64, 128, 256};
         for (int bi = 0; bi < 3; ++bi)
             for (int ta = 1; ta <= ta_max && ta * resolution <= items_cap; ++ta) {
                 const int items = ta * resolution, B = Bs[bi];
@@ -1004,7 +1013,7 @@ static inline TileCfg choose_cfg(int resolution, bool lr, int pool_hint = 0)
                 const int rounds = (items + B - 1) / B;
                 if (rounds > 8 && ta > 1) continue;
                 const double eff = (double)items / (double)(rounds * B);
-                const double score = eff - 0.01 * (rounds - 1) - (B == 256 ? 0.02 : 0.0) - (B == 64 ? 0.03 : 0.0);
+                const double score = eff - 0.05 * (rounds - 1) - (B == 256 ? 0.04 : 0.0) - (B == 128 ? 0.02 : 0.0);
                 if (score > best + 1e-9) { best = score; c.B = B; c.TA = ta; }
             }
     }
@@ -1013,7 +1022,7 @@ static inline TileCfg choose_cfg(int resolution, bool lr, int pool_hint = 0)
     c.cap_idx = 128;
     c.pool = 64 * c.TA < 128 ? 128 : 64 * c.TA;
     if (pool_hint > 0) c.pool = pool_hint;
-    c.ds = lr ? 4 : 0;
+    c.ds = lr ? 3 : 0; /* deeper arc stacks are rare: those tiles go to the second launch */
     c.lds = tile_fixed_bytes(c.TA, c.items) + tile_list_bytes(c.TA, c.cap_idx, c.pool, c.npw, c.ds, c.B);
     return c;
 }
@@ -1026,7 +1035,7 @@ static inline int pool_from_hist(const int *hist, int TA)
     long long total = 0;
     for (int k = 0; k < 64; ++k) total += hist[k];
     if (total <= 0) return 0;
-    long long allowed = total / 1000, acc = 0; /* (the histogram is a 1-in-32 sample) */
+    long long allowed = total / 300, acc = 0; /* ~0.3% of tiles may spill to the second launch (1-in-32 sample) */
     int k = 63;
     for (; k > 0; --k) {
         acc += hist[k];
@@ -1034,8 +1043,19 @@ static inline int pool_from_hist(const int *hist, int TA)
     }
     if (k >= 63) return 0; /* demand beyond the histogram: keep the default */
     int pool = (k + 2) * 16;
-    if (pool < 128) pool = 128;
+    if (pool < 64) pool = 64;
     return pool;
+}
+
+static inline TileCfg mid_cfg(const TileCfg &main_cfg, bool lr)
+{
+    TileCfg c = main_cfg;
+    c.cap_idx = 256;
+    c.pool = 160 * c.TA < 512 ? 512 : 160 * c.TA;
+    if (c.pool > 2560) c.pool = 2560;
+    c.ds = lr ? 10 : 0;
+    c.lds = tile_fixed_bytes(c.TA, c.items) + tile_list_bytes(c.TA, c.cap_idx, c.pool, c.npw, c.ds, c.B);
+    return c;
 }
 
 static inline TileCfg fallback_cfg(const TileCfg &main_cfg, bool lr)

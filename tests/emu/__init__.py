@@ -18,12 +18,13 @@ def _load():
         subprocess.run(["make", "-C", ROOT, "emu"], check=True, stdout=subprocess.DEVNULL)
         _lib = C.CDLL(_SO)
         _lib.emu_run_batch.argtypes = [C.c_int, _dp, _dp, _lp, C.c_int, C.c_double, C.c_int, _dp,
-                                       _dp, _ip, _dp, C.POINTER(C.c_longlong)] + [C.c_int] * 6
+                                       _dp, _ip, _dp, C.POINTER(C.c_longlong)] + [C.c_int] * 9
     return _lib
 
 
 def run_batch(lr, xyz, radii, offsets=None, probe=1.4, resolution=20, unit_pts=None,
-              cap_idx=0, pool=0, ds=-1, fb_cap_idx=0, fb_pool=0, fb_ds=0, check=True):
+              cap_idx=0, pool=0, ds=-1, fb_cap_idx=0, fb_pool=0, fb_ds=0, mid_cap_idx=0, mid_pool=0,
+              mid_ds=-1, check=True):
     xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1)
     radii = np.ascontiguousarray(radii, dtype=np.float64)
     n = radii.size
@@ -42,8 +43,8 @@ def run_batch(lr, xyz, radii, offsets=None, probe=1.4, resolution=20, unit_pts=N
                                 up.ctypes.data_as(_dp) if up is not None else None,
                                 sasa.ctypes.data_as(_dp), counts.ctypes.data_as(_ip),
                                 totals.ctypes.data_as(_dp), stats, cap_idx, pool, ds,
-                                fb_cap_idx, fb_pool, fb_ds)
-    st = dict(zip(("error", "fallback_tiles", "max_nn", "TA", "B", "lds", "cells", "items", "uncertain", "crosscheck_failures"), list(stats)))
+                                fb_cap_idx, fb_pool, fb_ds, mid_cap_idx, mid_pool, mid_ds)
+    st = dict(zip(("error", "fallback_tiles", "max_nn", "TA", "B", "lds", "cells", "items", "slab_tiles", "unused"), list(stats)))
     if check and ret:
         raise RuntimeError(f"emulated batch failed: {st}")
     return sasa, counts, totals, st

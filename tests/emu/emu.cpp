@@ -23,9 +23,9 @@ static void emu_tile_kernel(bool lr, const TileCfg &cfg, TileArgs a, int grid)
     std::vector<char> smem(cfg.lds + 64);
     for (int blk = 0; blk < grid; ++blk) {
         TileMem m = tile_carve<GLOBAL>(a, smem.data(), cfg.items, B, blk);
-        const int n_work = GLOBAL ? *a.ovf_count : ((a.n_tiles + 7) >> 3) << 3;
+        const int n_work = a.work_tiles ? *a.work_count : ((a.n_tiles + 7) >> 3) << 3;
         for (int w = blk; w < n_work; w += grid) {
-            const int tile = GLOBAL ? a.work_tiles[w] : xcd_tile(w, a.n_tiles);
+            const int tile = a.work_tiles ? a.work_tiles[w] : xcd_tile(w, a.n_tiles);
             if (tile >= a.n_tiles) continue;
 #define PHASE(call) for (int tid = 0; tid < B; ++tid) { call; }
             PHASE(tile_phase_load(a, m, tile, tid, B));
@@ -54,7 +54,7 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
                              int n_structs, double probe, int resolution, const double *unit_pts,
                              double *sasa, int *counts, double *totals, long long *stats_out,
                              int force_cap_idx, int force_pool, int force_ds, int fb_cap_idx,
-                             int fb_pool, int fb_ds)
+                             int fb_pool, int fb_ds, int mid_cap_idx, int mid_pool, int mid_ds)
 {
     const int n = (int)offsets[n_structs];
     const int PB = SASA_PIPE_B;
@@ -130,8 +130,22 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
     ta.cap_idx = cfg.cap_idx; ta.pool = cfg.pool; ta.npw = cfg.npw; ta.ds = cfg.ds;
     ta.ovf_count = status.data() + ST_OVF_TILES; ta.ovf_tiles = ovf_tiles.data(); ta.status = status.data();
 
+    ta.work_tiles = nullptr; ta.work_count = nullptr;
     emu_tile_kernel<false>(lr != 0, cfg, ta, ((n_tiles + 7) / 8) * 8);
 
+    std::vector<int> ovf_tiles2(n_tiles + 1);
+    {
+        TileCfg mc = mid_cfg(cfg, lr != 0);
+        if (mid_cap_idx > 0) mc.cap_idx = mid_cap_idx;
+        if (mid_pool > 0) mc.pool = mid_pool;
+        if (mid_ds >= 0 && lr) mc.ds = mid_ds;
+        mc.lds = tile_fixed_bytes(mc.TA, mc.items) + tile_list_bytes(mc.TA, mc.cap_idx, mc.pool, mc.npw, mc.ds, mc.B);
+        TileArgs tm = ta;
+        tm.cap_idx = mc.cap_idx; tm.pool = mc.pool; tm.ds = mc.ds;
+        tm.work_tiles = ovf_tiles.data(); tm.work_count = status.data() + ST_OVF_TILES;
+        tm.ovf_tiles = ovf_tiles2.data(); tm.ovf_count = status.data() + ST_OVF2_TILES;
+        emu_tile_kernel<false>(lr != 0, mc, tm, 5); /* fewer blocks than work items: the loop wraps */
+    }
     {
         TileCfg fb = fallback_cfg(cfg, lr != 0);
         if (fb_cap_idx > 0) fb.cap_idx = fb_cap_idx;
@@ -142,7 +156,8 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
         std::vector<char> slab(stride * fb_blocks + 64);
         TileArgs tf = ta;
         tf.cap_idx = fb.cap_idx; tf.pool = fb.pool; tf.ds = fb.ds;
-        tf.work_tiles = ovf_tiles.data();
+        tf.work_tiles = ovf_tiles2.data(); tf.work_count = status.data() + ST_OVF2_TILES;
+        tf.ovf_tiles = nullptr; tf.ovf_count = nullptr;
         tf.slab = slab.data(); tf.slab_stride = (long long)stride;
         emu_tile_kernel<true>(lr != 0, fb, tf, fb_blocks);
     }
@@ -157,6 +172,6 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
     stats_out[0] = status[ST_ERROR]; stats_out[1] = status[ST_OVF_TILES]; stats_out[2] = status[ST_MAX_NN];
     stats_out[3] = cfg.TA; stats_out[4] = cfg.B; stats_out[5] = (long long)cfg.lds; stats_out[6] = total_cells;
     stats_out[7] = cfg.items;
-    stats_out[8] = 0; stats_out[9] = 0;
+    stats_out[8] = status[ST_OVF2_TILES]; stats_out[9] = 0;
     return status[ST_ERROR] ? -1 : 0;
 }

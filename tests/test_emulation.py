@@ -90,26 +90,31 @@ def test_edge_fixtures(oracle_lib):
     assert sasa[1] == 0.0
 
 
-def test_overflow_goes_to_fallback_and_matches(oracle_lib):
-    """Shrunken capacities: most tiles overflow (neighbor list, pool, arc stack) and are
-    redone by the slab-backed fallback launch; results must not change."""
+def test_overflow_goes_to_later_launches_and_matches(oracle_lib):
+    """Shrunken capacities: most tiles overflow (neighbor list, pool, arc stack) in the first
+    launch and are redone by the second (larger LDS lists) and, when that is shrunk too, by the
+    third (slab-backed) launch; results must not change."""
     xyz, r = tools.globule(900, 5)
     want = oracle_lib.lee_richards(xyz, r)
-    for kw in (dict(cap_idx=24), dict(pool=300), dict(ds=0), dict(ds=1)):
+    for kw in (dict(cap_idx=24), dict(pool=100), dict(ds=0), dict(ds=1)):
         sasa, _, _, st = run_batch(True, xyz, r, **kw)
-        assert st["fallback_tiles"] > 0, kw
+        assert st["fallback_tiles"] > 0 and st["slab_tiles"] == 0, kw
+        assert close(sasa, want), kw
+    for kw in (dict(cap_idx=24, mid_cap_idx=30), dict(pool=100, mid_pool=120), dict(ds=0, mid_ds=0)):
+        sasa, _, _, st = run_batch(True, xyz, r, **kw)
+        assert st["fallback_tiles"] > 0 and st["slab_tiles"] > 0, kw
         assert close(sasa, want), kw
     ws, wc = oracle_lib.shrake_rupley(xyz, r)
-    _, c, _, st = _sr(oracle_lib, xyz, r, cap_idx=24)
-    assert st["fallback_tiles"] > 0 and np.array_equal(c, wc)
+    _, c, _, st = _sr(oracle_lib, xyz, r, cap_idx=24, mid_cap_idx=30)
+    assert st["slab_tiles"] > 0 and np.array_equal(c, wc)
 
 
-def test_fallback_capacity_errors_are_reported(oracle_lib):
+def test_last_launch_capacity_errors_are_reported(oracle_lib):
     xyz, r = tools.globule(300, 6)
-    _, _, _, st = run_batch(True, xyz, r, cap_idx=8, fb_cap_idx=16, check=False)
+    _, _, _, st = run_batch(True, xyz, r, cap_idx=8, mid_cap_idx=12, fb_cap_idx=16, check=False)
     assert st["error"] == 4          # ERR_NEIGHBOR_CAP
     xyz, r = tools.coil(400, 8)
-    _, _, _, st = run_batch(True, xyz, r, ds=0, fb_ds=1, check=False)
+    _, _, _, st = run_batch(True, xyz, r, ds=0, mid_ds=0, fb_ds=1, check=False)
     assert st["error"] in (0, 5)     # ERR_STACK_CAP only if some slice needs depth > 2
 
 
