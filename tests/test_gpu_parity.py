@@ -249,3 +249,32 @@ def test_errors_return_null_not_garbage(fa):
         assert np.isfinite(fa.calc_coord(xyz, r)[1])
     finally:
         L.freesasa_set_verbosity(fa.V_NORMAL)
+
+
+def test_randomized_sweep_against_oracle(fa, oracle_lib):
+    """Seeded random sweep over generator, size, probe and resolution (both algorithms),
+    including sizes that are not multiples of the tile, tiny structures and dense packings
+    that exercise the second and third launches."""
+    rng = np.random.default_rng(12345)
+    worst = 0.0
+    for trial in range(40):
+        kind = rng.integers(0, 3)
+        n = int(rng.choice([1, 2, 3, 5, 17, 64, 100, 333, 1000, 2500]))
+        seed = int(rng.integers(1, 10_000))
+        if kind == 0:
+            xyz, r = tools.coil(n, seed)
+        elif kind == 1:
+            xyz, r = tools.globule(n, seed, float(rng.choice([2.6, 2.2, 1.8])))
+        else:
+            xyz, r = tools.globule(n, seed, 3.4)           # sparse: many atoms with few neighbors
+        probe = float(rng.choice([0.0, 0.7, 1.4, 2.5]))
+        ns = int(rng.choice([1, 2, 7, 20, 33, 100, 700]))
+        npts = int(rng.choice([1, 10, 100, 333, 1000]))
+        lr, _, _ = fa.calc_batch(xyz, r, [0, n], fa.LEE_RICHARDS, probe, ns)
+        want = oracle_lib.lee_richards(xyz, r, probe, ns)
+        worst = max(worst, float(np.max(np.abs(lr - want))))
+        assert np.max(np.abs(lr - want)) < LR_TOL, (trial, kind, n, seed, probe, ns)
+        if n > 1 and kind != 2:
+            _, cnt, _ = fa.calc_batch(xyz, r, [0, n], fa.SHRAKE_RUPLEY, probe, npts)
+            assert np.array_equal(cnt, oracle_lib.shrake_rupley(xyz, r, probe, npts)[1]), (trial, n, seed, probe, npts)
+    assert worst < LR_TOL
