@@ -88,7 +88,8 @@ __global__ __launch_bounds__(SASA_TOT_B) void k_totals(const double *sasa, const
 
 /* 4 waves per SIMD (<= 128 VGPRs): the kernel hides its LDS/global latency and the barriers of
  * one tile behind other resident tiles, so occupancy is worth a 16-byte spill (measured). */
-template <int B, bool GLOBAL>
+/* TIER only names the launch (0 main, 1 second, 2 slab) so that profiles list them separately. */
+template <int B, bool GLOBAL, int TIER>
 __global__ __launch_bounds__(B) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lr_tile(TileArgs a, int items)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(B) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     }
 }
 
-template <int B, bool GLOBAL>
+template <int B, bool GLOBAL, int TIER>
 __global__ __launch_bounds__(B) void k_sr_tile(TileArgs a, int items)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -260,30 +261,30 @@ extern "C" const char *freesasa_gpu_ctx_last_error(const freesasa_gpu_ctx *c) { 
 /* ------------------------------------------------------------------ launch configuration */
 
 
-template <bool GLOBAL>
+template <bool GLOBAL, int TIER>
 static hipError_t launch_lr(const TileCfg &c, const TileArgs &t, int grid, size_t lds, hipStream_t s)
 {
     if (c.B == 320)
-        hipLaunchKernelGGL((k_lr_tile<320, GLOBAL>), dim3(grid), dim3(320), lds, s, t, c.items);
+        hipLaunchKernelGGL((k_lr_tile<320, GLOBAL, TIER>), dim3(grid), dim3(320), lds, s, t, c.items);
     else if (c.B == 256)
-        hipLaunchKernelGGL((k_lr_tile<256, GLOBAL>), dim3(grid), dim3(256), lds, s, t, c.items);
+        hipLaunchKernelGGL((k_lr_tile<256, GLOBAL, TIER>), dim3(grid), dim3(256), lds, s, t, c.items);
     else if (c.B == 128)
-        hipLaunchKernelGGL((k_lr_tile<128, GLOBAL>), dim3(grid), dim3(128), lds, s, t, c.items);
+        hipLaunchKernelGGL((k_lr_tile<128, GLOBAL, TIER>), dim3(grid), dim3(128), lds, s, t, c.items);
     else
-        hipLaunchKernelGGL((k_lr_tile<64, GLOBAL>), dim3(grid), dim3(64), lds, s, t, c.items);
+        hipLaunchKernelGGL((k_lr_tile<64, GLOBAL, TIER>), dim3(grid), dim3(64), lds, s, t, c.items);
     return hipGetLastError();
 }
-template <bool GLOBAL>
+template <bool GLOBAL, int TIER>
 static hipError_t launch_sr(const TileCfg &c, const TileArgs &t, int grid, size_t lds, hipStream_t s)
 {
     if (c.B == 320)
-        hipLaunchKernelGGL((k_sr_tile<320, GLOBAL>), dim3(grid), dim3(320), lds, s, t, c.items);
+        hipLaunchKernelGGL((k_sr_tile<320, GLOBAL, TIER>), dim3(grid), dim3(320), lds, s, t, c.items);
     else if (c.B == 256)
-        hipLaunchKernelGGL((k_sr_tile<256, GLOBAL>), dim3(grid), dim3(256), lds, s, t, c.items);
+        hipLaunchKernelGGL((k_sr_tile<256, GLOBAL, TIER>), dim3(grid), dim3(256), lds, s, t, c.items);
     else if (c.B == 128)
-        hipLaunchKernelGGL((k_sr_tile<128, GLOBAL>), dim3(grid), dim3(128), lds, s, t, c.items);
+        hipLaunchKernelGGL((k_sr_tile<128, GLOBAL, TIER>), dim3(grid), dim3(128), lds, s, t, c.items);
     else
-        hipLaunchKernelGGL((k_sr_tile<64, GLOBAL>), dim3(grid), dim3(64), lds, s, t, c.items);
+        hipLaunchKernelGGL((k_sr_tile<64, GLOBAL, TIER>), dim3(grid), dim3(64), lds, s, t, c.items);
     return hipGetLastError();
 }
 
@@ -425,15 +426,19 @@ static int run_batch(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, const do
     {
         static bool attr_done = false; /* allow > 64 KB of dynamic LDS */
         if (!attr_done) {
-            const void *fns[] = {(const void *)k_lr_tile<320, false>, (const void *)k_lr_tile<256, false>,
-                                 (const void *)k_lr_tile<128, false>, (const void *)k_lr_tile<64, false>,
-                                 (const void *)k_sr_tile<320, false>, (const void *)k_sr_tile<256, false>,
-                                 (const void *)k_sr_tile<128, false>, (const void *)k_sr_tile<64, false>};
+            const void *fns[] = {(const void *)k_lr_tile<320, false, 0>, (const void *)k_lr_tile<256, false, 0>,
+                                 (const void *)k_lr_tile<128, false, 0>, (const void *)k_lr_tile<64, false, 0>,
+                                 (const void *)k_sr_tile<320, false, 0>, (const void *)k_sr_tile<256, false, 0>,
+                                 (const void *)k_sr_tile<128, false, 0>, (const void *)k_sr_tile<64, false, 0>,
+                                 (const void *)k_lr_tile<320, false, 1>, (const void *)k_lr_tile<256, false, 1>,
+                                 (const void *)k_lr_tile<128, false, 1>, (const void *)k_lr_tile<64, false, 1>,
+                                 (const void *)k_sr_tile<320, false, 1>, (const void *)k_sr_tile<256, false, 1>,
+                                 (const void *)k_sr_tile<128, false, 1>, (const void *)k_sr_tile<64, false, 1>};
             for (const void *fn : fns) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_done = true;
         }
     }
-    le = lr ? launch_lr<false>(cfg, ta, grid_main, cfg.lds, st) : launch_sr<false>(cfg, ta, grid_main, cfg.lds, st);
+    le = lr ? launch_lr<false, 0>(cfg, ta, grid_main, cfg.lds, st) : launch_sr<false, 0>(cfg, ta, grid_main, cfg.lds, st);
     if (le != hipSuccess) return ctx_fail(c, "tile kernel launch failed: %s", hipGetErrorString(le));
     if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[2], st));
 
@@ -448,7 +453,7 @@ static int run_batch(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, const do
         tm.ovf_tiles = (int *)c->ovf_tiles2.p;
         tm.ovf_count = (int *)c->status.p + ST_OVF2_TILES;
         const int grid_mid = n_tiles < SASA_MID_BLOCKS ? n_tiles : SASA_MID_BLOCKS;
-        le = lr ? launch_lr<false>(mc, tm, grid_mid, mc.lds, st) : launch_sr<false>(mc, tm, grid_mid, mc.lds, st);
+        le = lr ? launch_lr<false, 1>(mc, tm, grid_mid, mc.lds, st) : launch_sr<false, 1>(mc, tm, grid_mid, mc.lds, st);
         if (le != hipSuccess) return ctx_fail(c, "second tile launch failed: %s", hipGetErrorString(le));
     }
     /* third launch: whatever is left (pathological densities), lists in a global slab */
@@ -464,7 +469,7 @@ static int run_batch(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, const do
         tf.ovf_count = nullptr;
         tf.slab = (char *)c->slab.p;
         tf.slab_stride = (long long)stride;
-        le = lr ? launch_lr<true>(fb, tf, SASA_FB_BLOCKS, fb.lds, st) : launch_sr<true>(fb, tf, SASA_FB_BLOCKS, fb.lds, st);
+        le = lr ? launch_lr<true, 2>(fb, tf, SASA_FB_BLOCKS, fb.lds, st) : launch_sr<true, 2>(fb, tf, SASA_FB_BLOCKS, fb.lds, st);
         if (le != hipSuccess) return ctx_fail(c, "fallback kernel launch failed: %s", hipGetErrorString(le));
     }
 
