@@ -351,8 +351,8 @@ struct TileArgs {
 /* One neighbor record, 32 B, read with two ds_read_b128:
  *   L&R: x = z_j, y = R_j^2, z = D = xd^2+yd^2, w = 1/sqrt(D)   (+ beta in a separate array)
  *   S&R: x = x_j, y = y_j,   z = z_j,           w = R_j^2
- * In the L&R pool every atom's list is padded to a multiple of 4 records with dummies
- * (R_j^2 = 0: never overlaps a slice) so the screening loop runs 4 neighbors per trip. */
+ * In the L&R pool every atom's list is padded to an even number of records with a dummy
+ * (R_j^2 = 0: never overlaps a slice) so the screening loop runs 2 neighbors per trip. */
 struct __attribute__((aligned(16))) Quad { double x, y, z, w; };
 struct TileMem {
     double *ax, *ay, *az, *aR; /* [TA] tile atoms */
@@ -515,7 +515,7 @@ SASA_D void tile_phase_neighbors(const TileArgs &a, TileMem &m, int tile, int ti
 }
 
 /* phase O: offsets into the pool (each of the first TA threads sums the counts before it) */
-SASA_D int pad4(int c, int npw) { return npw == 5 ? (c + 3) & ~3 : c; }
+SASA_D int pad4(int c, int npw) { return npw == 5 ? (c + 1) & ~1 : c; } /* L&R lists: even length */
 SASA_D void tile_phase_offsets(const TileArgs &a, TileMem &m, int tid)
 {
     if (tid >= a.TA) return;
@@ -642,9 +642,12 @@ SASA_D void lr_phase_rank(const TileArgs &a, TileMem &m, int tid, int B)
         }
         const double beta = m.tb[gp];
         int rank = 0;
-        for (int t = 0; t < nn; ++t) {
-            const double bt = m.tb[o + t];
-            rank += (bt < beta || (bt == beta && t < k)) ? 1 : 0;
+        /* two betas per LDS read (o is even, so the pair is 16-byte aligned); the slot after an
+           odd-length list is padding and is excluded by t + 1 < nn */
+        for (int t = 0; t < nn; t += 2) {
+            const Arc bb = *(const Arc *)(m.tb + o + t);
+            rank += (bb.s < beta || (bb.s == beta && t < k)) ? 1 : 0;
+            rank += (t + 1 < nn && (bb.e < beta || (bb.e == beta && t + 1 < k))) ? 1 : 0;
         }
         const int q = m.idx[la * a.cap_idx + k];
         const double xd = a.sx[q] - m.ax[la], yd = a.sy[q] - m.ay[la];
@@ -675,7 +678,7 @@ SASA_D double lr_cos(double A, double h2, double dj2, double R2, double D, doubl
     return Bq > 0 ? ((A + D) - Bq) * (ginv * h2) : 2.0; /* ref: src/sasa_lr.c:320 dj < Rj */
 }
 
-/* Screening pass over up to 64 neighbors (lim is a multiple of 4, lists are padded): bit k of
+/* Screening pass over up to 64 neighbors (lim is even, lists are padded): bit k of
  * the mask is set when neighbor k cuts an arc out of circle i (|cos alpha| < 1).  Returns 1 if
  * some neighbor's circle contains circle i entirely (slice buried, ref: src/sasa_lr.c:327-330). */
 SASA_D int lr_screen(const Quad *PQ, int lim, double A, double h2, double z, unsigned long long &mask)
@@ -740,7 +743,7 @@ SASA_D double lr_union_exact(const TileMem &m, int o, int nn, double A, double h
 {
     double W = 0, V = SASA_TWOPI, ts = 0, te = 0;
     int depth = 0, wrap = 0;
-    for (int base = 0; base < nn; base += 64) { /* nn is a multiple of 4 (padded) */
+    for (int base = 0; base < nn; base += 64) { /* nn is even (padded) */
         const int lim = nn - base < 64 ? nn - base : 64;
         const Quad *PQ = m.pq + o + base;
         const double *PB = m.pb + o + base;
