@@ -161,7 +161,7 @@ struct freesasa_gpu_ctx {
     /* workspace */
     DevBuf offsets, grid, ncells, sid, cell_of, rank, cell_start, blk_sums;
     DevBuf sx, sy, sz, sr, s_orig, s_cell, s_struct;
-    DevBuf status, ovf_tiles, ovf_tiles2, unit_pts, slab;
+    DevBuf status, ovf_tiles, ovf_tiles2, unit_pts, slab, seg;
     std::vector<int64_t> offsets_host; /* last uploaded offsets */
     std::vector<double> unit_host;     /* last uploaded S&R unit points */
     /* host staging for freesasa_gpu_calc_batch */
@@ -243,7 +243,7 @@ extern "C" void freesasa_gpu_ctx_destroy(freesasa_gpu_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->offsets, &c->grid, &c->ncells, &c->sid, &c->cell_of, &c->rank, &c->cell_start,
                      &c->blk_sums, &c->sx, &c->sy, &c->sz, &c->sr, &c->s_orig, &c->s_cell, &c->s_struct,
-                     &c->status, &c->ovf_tiles, &c->ovf_tiles2, &c->unit_pts, &c->slab,
+                     &c->status, &c->ovf_tiles, &c->ovf_tiles2, &c->unit_pts, &c->slab, &c->seg,
                      &c->h_xyz, &c->h_radii, &c->h_sasa, &c->h_counts, &c->h_totals};
     for (DevBuf *b : all)
         if (b->p) (void)hipFree(b->p);
@@ -516,6 +516,23 @@ extern "C" int freesasa_gpu_sr_batch_dev(freesasa_gpu_ctx *c, const double *d_xy
 {
     if (!c) return -1;
     return run_batch(c, false, d_xyz, d_radii, offsets, n_structs, probe, n_points, unit_points, d_sasa, d_counts, d_totals);
+}
+
+extern "C" int freesasa_gpu_segment_sums_dev(freesasa_gpu_ctx *c, const double *d_sasa, const int64_t *seg,
+                                             int n_segs, double *d_out)
+{
+    if (!c) return -1;
+    c->err[0] = 0;
+    if (!d_sasa || !seg || !d_out || n_segs <= 0) return ctx_fail(c, "bad argument");
+    for (int k = 0; k < n_segs; ++k)
+        if (seg[k + 1] < seg[k]) return ctx_fail(c, "segment offsets must be non-decreasing");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (ensure(c, c->seg, sizeof(int64_t) * ((size_t)n_segs + 1))) return -1;
+    HIP_TRY(c, hipMemcpyAsync(c->seg.p, seg, sizeof(int64_t) * ((size_t)n_segs + 1), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_totals, dim3(n_segs), dim3(SASA_TOT_B), 0, c->stream, d_sasa, (const int64_t *)c->seg.p, n_segs, d_out);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
 }
 
 /* ------------------------------------------------------------------ host-pointer batch */

@@ -65,6 +65,13 @@ int freesasa_gpu_sr_batch_dev(freesasa_gpu_ctx *ctx, const double *d_xyz, const 
                               int n_points, const double *unit_points, double *d_sasa,
                               int *d_counts, double *d_totals);
 
+/* Segmented sums of per-atom areas on the device: out[k] = sum of d_sasa[seg[k] .. seg[k+1]) in
+   atom order, for k < n_segs.  seg is a HOST array [n_segs+1] of atom offsets (residues, chains
+   or structures: the per-residue / per-chain totals that the reference's result tree computes on
+   the host, src/node.c:150-176).  d_out [n_segs] is a device pointer.  Returns 0 / -1. */
+int freesasa_gpu_segment_sums_dev(freesasa_gpu_ctx *ctx, const double *d_sasa, const int64_t *seg,
+                                  int n_segs, double *d_out);
+
 /* Golden-spiral unit test points on the host, host libm (src/sasa_sr.c:56-90). */
 void freesasa_gpu_test_points(int n_points, double *unit_points);
 

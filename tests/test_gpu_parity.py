@@ -278,3 +278,31 @@ def test_randomized_sweep_against_oracle(fa, oracle_lib):
             _, cnt, _ = fa.calc_batch(xyz, r, [0, n], fa.SHRAKE_RUPLEY, probe, npts)
             assert np.array_equal(cnt, oracle_lib.shrake_rupley(xyz, r, probe, npts)[1]), (trial, n, seed, probe, npts)
     assert worst < LR_TOL
+
+
+def test_per_residue_sums_match_the_references_sequence_file(fa):
+    """SURVEY §8(f) N2, first step: per-residue totals on the device.  Pinned to the reference's
+    own per-residue S&R output for 1UBQ (tests/data/seq.reference, tests/test-cli.in:298-299)."""
+    import os
+    import torch
+    xyz, rad, _ = read_bfactor_pdb(os.path.join(GOLDEN, "1ubq.B.pdb"))
+    resnum, want = [], []
+    with open(os.path.join(GOLDEN, "1ubq.B.pdb")) as fh:
+        resnum = [int(l[22:26]) for l in fh if l.startswith("ATOM")]
+    with open(os.path.join(GOLDEN, "seq.reference")) as fh:
+        for l in fh:
+            if l.startswith("SEQ"):
+                want.append(float(l.split(":")[1]))
+    resnum = np.array(resnum)
+    starts = np.concatenate([[0], np.nonzero(np.diff(resnum))[0] + 1, [len(resnum)]])
+    assert len(starts) - 1 == len(want) == 76
+    dev = torch.device("cuda:0")
+    d_xyz, d_r = torch.from_numpy(xyz).to(dev), torch.from_numpy(rad).to(dev)
+    d_sasa = torch.empty(len(rad), dtype=torch.float64, device=dev)
+    d_res = torch.empty(76, dtype=torch.float64, device=dev)
+    ctx = fa.GpuContext(0)
+    ctx.shrake_rupley(d_xyz.data_ptr(), d_r.data_ptr(), [0, len(rad)], d_sasa.data_ptr())
+    ctx.segment_sums(d_sasa.data_ptr(), starts, d_res.data_ptr())
+    got = d_res.cpu().numpy()
+    assert np.max(np.abs(got - np.array(want))) <= 0.005 + 1e-9     # the file has two decimals
+    ctx.close()

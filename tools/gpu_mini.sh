@@ -29,3 +29,14 @@ for alg in ('lr', 'sr'):
     st = ctx.stats()
     print('globule100x10k %s: %.4g atoms/s  kernel_ms %.3f prep_ms %.3f fallback %d lds %d maxnn %d' % (alg, len(r)/dt, st['ms_kernel'], st['ms_prep'], st['fallback_tiles'], st['lds_bytes'], st['max_neighbors']))
 PY
+python - <<'PY' 2>&1 | tail -4
+import sys, time, numpy as np
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import freesasa_amd as fa
+g = np.load('tests/golden/1ubq.npz')
+for alg, name in ((fa.LEE_RICHARDS, 'L&R-20'), (fa.SHRAKE_RUPLEY, 'S&R-100')):
+    fa.calc_coord(g['xyz'], g['radii'], alg)
+    t0 = time.perf_counter()
+    for _ in range(50): fa.calc_coord(g['xyz'], g['radii'], alg)
+    print('1UBQ freesasa_calc_coord %s: %.0f us per call (host arrays in, host result out)' % (name, (time.perf_counter() - t0) / 50 * 1e6))
+PY
