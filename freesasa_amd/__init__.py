@@ -116,6 +116,8 @@ def lib():
         L.freesasa_gpu_test_points.restype = None
         L.freesasa_gpu_calc_batch.argtypes = [_dp, _dp, _lp, C.c_int, C.c_int, C.c_double, C.c_int,
                                               _dp, _ip, _dp, C.c_int, C.c_char_p, C.c_int]
+        L.freesasa_gpu_trajectory.argtypes = [_dp, _dp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
+                                              C.c_int, _dp, _dp, C.c_int, C.c_char_p, C.c_int]
         _lib = L
     return _lib
 
@@ -158,6 +160,27 @@ def calc_batch(xyz, radii, offsets, alg=LEE_RICHARDS, probe=1.4, resolution=20, 
     if ret:
         raise RuntimeError("freesasa_gpu_calc_batch: " + err.value.decode())
     return sasa, counts, totals
+
+
+def trajectory(xyz_frames, radii, alg=LEE_RICHARDS, probe=1.4, resolution=20, frames_per_batch=0,
+               per_atom=True, device=-1):
+    """freesasa_gpu_trajectory() on host arrays: xyz_frames [n_frames, n_atoms, 3] -> (totals
+    [n_frames], per-atom [n_frames, n_atoms] or None)."""
+    xyz_frames = np.ascontiguousarray(xyz_frames, dtype=np.float64)
+    radii = _f64(radii)
+    n_frames, n_atoms = xyz_frames.shape[0], radii.size
+    assert xyz_frames.size == n_frames * n_atoms * 3
+    totals = np.empty(n_frames)
+    sasa = np.empty((n_frames, n_atoms)) if per_atom else None
+    err = C.create_string_buffer(512)
+    ret = lib().freesasa_gpu_trajectory(xyz_frames.ctypes.data_as(_dp), radii.ctypes.data_as(_dp), n_atoms,
+                                        n_frames, alg, probe, resolution, frames_per_batch,
+                                        totals.ctypes.data_as(_dp),
+                                        sasa.ctypes.data_as(_dp) if sasa is not None else None,
+                                        device, err, 512)
+    if ret:
+        raise RuntimeError("freesasa_gpu_trajectory: " + err.value.decode())
+    return totals, sasa
 
 
 def test_points(n_points):

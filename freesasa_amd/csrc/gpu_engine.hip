@@ -616,3 +616,109 @@ extern "C" int freesasa_gpu_calc_batch(const double *xyz, const double *radii, c
     pool_put(c);
     return ret;
 }
+
+/* ------------------------------------------------------------------ trajectory driver */
+
+namespace {
+struct Pinned { /* pin a caller's buffer in place for the duration of the call; best effort */
+    void *p = nullptr;
+    bool ok = false;
+    Pinned(const void *ptr, size_t bytes)
+    {
+        if (ptr && bytes && hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterDefault) == hipSuccess) {
+            p = const_cast<void *>(ptr);
+            ok = true;
+        } else {
+            (void)hipGetLastError(); /* pageable copies still work, only slower */
+        }
+    }
+    ~Pinned() { if (ok) (void)hipHostUnregister(p); }
+};
+}
+
+extern "C" int freesasa_gpu_trajectory(const double *xyz_frames, const double *radii, int n_atoms, int n_frames,
+                                       int alg, double probe, int resolution, int frames_per_batch,
+                                       double *totals_out, double *sasa_out, int device, char *err_out, int err_len)
+{
+    if (err_out && err_len > 0) err_out[0] = 0;
+    if (!xyz_frames || !radii || !totals_out) return set_err(err_out, err_len, "null argument");
+    if (n_atoms <= 0 || n_frames <= 0) return set_err(err_out, err_len, "n_atoms and n_frames must be > 0");
+    if (alg != 0 && alg != 1) return set_err(err_out, err_len, "unknown algorithm");
+    if (freesasa_gpu_device_count() <= 0)
+        return set_err(err_out, err_len, "no HIP device available: libfreesasa_amd has no CPU path");
+    if (frames_per_batch <= 0) frames_per_batch = (int)(2000000 / n_atoms) + 1;
+    if (frames_per_batch > n_frames) frames_per_batch = n_frames;
+    if ((long long)frames_per_batch * n_atoms > (1LL << 30)) return set_err(err_out, err_len, "batch too large");
+
+    freesasa_gpu_ctx *c = pool_get(device);
+    if (!c) return set_err(err_out, err_len, "could not create a GPU context");
+    const size_t n = (size_t)n_atoms, FB = (size_t)frames_per_batch;
+    hipStream_t copy = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr};
+    double *d_xyz[2] = {nullptr, nullptr}, *d_sasa[2] = {nullptr, nullptr}, *d_tot[2] = {nullptr, nullptr}, *d_rad = nullptr;
+    int ret = -1;
+    std::vector<int64_t> offs(FB + 1);
+    for (size_t k = 0; k <= FB; ++k) offs[k] = (int64_t)(k * n);
+    std::vector<double> tp;
+    if (alg == 1 && resolution > 0) {
+        tp.resize(3 * (size_t)resolution);
+        freesasa_gpu_test_points(resolution, tp.data());
+    }
+    do {
+        if (hipSetDevice(c->device) != hipSuccess) { ctx_fail(c, "hipSetDevice failed"); break; }
+        if (hipStreamCreateWithFlags(&copy, hipStreamNonBlocking) != hipSuccess) { ctx_fail(c, "stream create failed"); break; }
+        bool ok = true;
+        for (int b = 0; b < 2 && ok; ++b)
+            ok = hipEventCreateWithFlags(&ev_in[b], hipEventDisableTiming) == hipSuccess &&
+                 hipMalloc((void **)&d_xyz[b], 24 * n * FB) == hipSuccess && hipMalloc((void **)&d_sasa[b], 8 * n * FB) == hipSuccess &&
+                 hipMalloc((void **)&d_tot[b], 8 * FB) == hipSuccess;
+        ok = ok && hipMalloc((void **)&d_rad, 8 * n * FB) == hipSuccess;
+        if (!ok) { ctx_fail(c, "out of device memory for the trajectory buffers"); break; }
+        /* radii: one copy per frame slot of a batch (the batch API takes per-atom radii) */
+        for (size_t k = 0; k < FB && ok; ++k)
+            ok = hipMemcpyAsync(d_rad + k * n, radii, 8 * n, hipMemcpyHostToDevice, copy) == hipSuccess;
+        if (!ok) { ctx_fail(c, "radii upload failed"); break; }
+
+        Pinned pin_in(xyz_frames, 24 * n * (size_t)n_frames);
+        Pinned pin_tot(totals_out, 8 * (size_t)n_frames);
+        Pinned pin_out(sasa_out, sasa_out ? 8 * n * (size_t)n_frames : 0);
+
+        const int n_batches = (n_frames + frames_per_batch - 1) / frames_per_batch;
+        auto frames_in = [&](int k) { int f0 = k * frames_per_batch; return n_frames - f0 < frames_per_batch ? n_frames - f0 : frames_per_batch; };
+        /* prologue: batch 0 in */
+        ok = hipMemcpyAsync(d_xyz[0], xyz_frames, 24 * n * (size_t)frames_in(0), hipMemcpyHostToDevice, copy) == hipSuccess &&
+             hipEventRecord(ev_in[0], copy) == hipSuccess;
+        for (int k = 0; k < n_batches && ok; ++k) {
+            const int b = k & 1, nf = frames_in(k);
+            const size_t f0 = (size_t)k * FB;
+            ok = hipStreamWaitEvent(c->stream, ev_in[b], 0) == hipSuccess;
+            if (ok && k + 1 < n_batches) /* next batch in, while this one computes */
+                ok = hipMemcpyAsync(d_xyz[b ^ 1], xyz_frames + 3 * n * (f0 + FB), 24 * n * (size_t)frames_in(k + 1), hipMemcpyHostToDevice, copy) == hipSuccess &&
+                     hipEventRecord(ev_in[b ^ 1], copy) == hipSuccess;
+            if (!ok) { ctx_fail(c, "host-to-device copy failed"); break; }
+            const int rc = run_batch(c, alg == 0, d_xyz[b], d_rad, offs.data(), nf, probe, resolution,
+                                     alg == 1 ? tp.data() : nullptr, d_sasa[b], nullptr, d_tot[b]);
+            if (rc) { ok = false; break; }
+            /* results out on the copy stream: overlaps the next batch's kernels */
+            ok = hipMemcpyAsync(totals_out + f0, d_tot[b], 8 * (size_t)nf, hipMemcpyDeviceToHost, copy) == hipSuccess;
+            if (ok && sasa_out)
+                ok = hipMemcpyAsync(sasa_out + n * f0, d_sasa[b], 8 * n * (size_t)nf, hipMemcpyDeviceToHost, copy) == hipSuccess;
+            if (!ok) ctx_fail(c, "device-to-host copy failed");
+            /* the copy stream is in order: by the time batch k+2 wants this slot again, these
+               copies have completed (batch k+2's upload is enqueued behind them) */
+        }
+        if (hipStreamSynchronize(copy) != hipSuccess) { ctx_fail(c, "stream synchronize failed"); ok = false; }
+        if (ok) ret = 0;
+    } while (0);
+    if (ret) set_err(err_out, err_len, c->err[0] ? c->err : "trajectory run failed");
+    if (copy) { (void)hipStreamSynchronize(copy); (void)hipStreamDestroy(copy); }
+    for (int b = 0; b < 2; ++b) {
+        if (ev_in[b]) (void)hipEventDestroy(ev_in[b]);
+        if (d_xyz[b]) (void)hipFree(d_xyz[b]);
+        if (d_sasa[b]) (void)hipFree(d_sasa[b]);
+        if (d_tot[b]) (void)hipFree(d_tot[b]);
+    }
+    if (d_rad) (void)hipFree(d_rad);
+    pool_put(c);
+    return ret;
+}

@@ -83,6 +83,19 @@ int freesasa_gpu_calc_batch(const double *xyz, const double *radii, const int64_
                             double *sasa_out, int *counts_out, double *totals_out,
                             int device, char *err_out, int err_len);
 
+/* Trajectory driver (BASELINE configs[4]): n_frames frames of the SAME n_atoms
+   atoms, frame f at xyz_frames + f*3*n_atoms in HOST memory, radii constant.  Frames are
+   processed frames_per_batch at a time as independent structures (<= 0: chosen so that a batch
+   holds about 2M atoms); the host->device copy of batch k+1 and the device->host copy of batch
+   k-1 run on a second HIP stream while batch k computes, from/to buffers pinned in place
+   (hipHostRegister).  totals_out [n_frames] per-frame totals; sasa_out NULL or
+   [n_frames*n_atoms] per-atom areas.  alg/probe/resolution as in freesasa_parameters.
+   Returns 0 / -1 (message in err_out). */
+int freesasa_gpu_trajectory(const double *xyz_frames, const double *radii, int n_atoms, int n_frames,
+                            int alg, double probe_radius, int resolution, int frames_per_batch,
+                            double *totals_out, double *sasa_out, int device,
+                            char *err_out, int err_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,7 +34,8 @@ def test_exports_every_declared_symbol(L):
     declared = _declared_symbols("freesasa_amd.h") | _declared_symbols("freesasa_gpu.h")
     assert {"freesasa_calc_coord", "freesasa_calc_structure", "freesasa_result_free",
             "freesasa_default_parameters", "FREESASA_DEF_NUMBER_THREADS", "freesasa_lee_richards",
-            "freesasa_shrake_rupley", "freesasa_gpu_lr_batch_dev", "freesasa_gpu_calc_batch"} <= declared
+            "freesasa_shrake_rupley", "freesasa_gpu_lr_batch_dev", "freesasa_gpu_calc_batch",
+            "freesasa_gpu_trajectory", "freesasa_gpu_segment_sums_dev"} <= declared
     missing = declared - exported
     assert not missing, f"declared in include/ but not exported: {sorted(missing)}"
 
@@ -128,6 +129,8 @@ def test_no_gpu_means_loud_failure_not_a_cpu_path(L):
             fa.calc_batch(np.zeros((2, 3)), np.ones(2), [0, 2])
         with pytest.raises(RuntimeError):
             fa.GpuContext(0)
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            fa.trajectory(np.zeros((2, 3, 3)), np.ones(3))
     finally:
         L.freesasa_set_verbosity(fa.V_NORMAL)
 

@@ -306,3 +306,23 @@ def test_per_residue_sums_match_the_references_sequence_file(fa):
     got = d_res.cpu().numpy()
     assert np.max(np.abs(got - np.array(want))) <= 0.005 + 1e-9     # the file has two decimals
     ctx.close()
+
+
+def test_trajectory_driver_matches_per_frame_calls(fa, oracle_lib):
+    """SURVEY §8(f) N3 / BASELINE configs[4] proxy: frames streamed from host memory in batches
+    with copy/compute overlap must equal frame-by-frame calls bit for bit (and the oracle)."""
+    base, r = tools.globule(6000, 9)
+    n_frames = 11
+    frames = np.stack([tools.jitter(base, 700 + f, 0.3) for f in range(n_frames)])
+    for alg, res in ((fa.LEE_RICHARDS, 20), (fa.SHRAKE_RUPLEY, 100)):
+        for fpb in (0, 1, 4):                      # default batch, single frames, ragged last batch
+            totals, sasa = fa.trajectory(frames, r, alg, 1.4, res, frames_per_batch=fpb)
+            for f in (0, 5, n_frames - 1):
+                a, tot = fa.calc_coord(frames[f], r, alg, n_points=100, n_slices=20)
+                assert np.array_equal(sasa[f], a)
+                assert abs(totals[f] - tot) < 1e-9 * tot
+        totals2, none = fa.trajectory(frames, r, alg, 1.4, res, per_atom=False)
+        assert none is None and np.array_equal(totals2, totals)
+    want = oracle_lib.lee_richards(frames[3], r)
+    _, sasa = fa.trajectory(frames, r)
+    assert np.max(np.abs(sasa[3] - want)) < LR_TOL
