@@ -30,6 +30,11 @@ __global__ __launch_bounds__(SASA_PIPE_B) void k_bounds(PipeArgs a)
     bounds_phase1(a, red, blockIdx.x, threadIdx.x, SASA_PIPE_B);
 }
 
+__global__ __launch_bounds__(64) void k_grid(PipeArgs a)
+{
+    grid_struct(a, blockIdx.x * 64 + threadIdx.x);
+}
+
 __global__ __launch_bounds__(SASA_PIPE_B) void k_cell_base(PipeArgs a)
 {
     __shared__ long long part[SASA_PIPE_B];
@@ -160,6 +165,8 @@ struct freesasa_gpu_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     /* workspace */
     DevBuf offsets, grid, ncells, sid, cell_of, rank, cell_start, blk_sums;
+    DevBuf chunk_struct, chunk_begin, chunk_len, struct_chunk0, bpart;
+    int n_chunks = 0;
     DevBuf sx, sy, sz, sr, s_orig, s_cell, s_struct;
     DevBuf status, ovf_tiles, ovf_tiles2, unit_pts, slab, seg;
     std::vector<int64_t> offsets_host; /* last uploaded offsets */
@@ -241,7 +248,7 @@ extern "C" void freesasa_gpu_ctx_destroy(freesasa_gpu_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->offsets, &c->grid, &c->ncells, &c->sid, &c->cell_of, &c->rank, &c->cell_start,
+    DevBuf *all[] = {&c->chunk_struct, &c->chunk_begin, &c->chunk_len, &c->struct_chunk0, &c->bpart, &c->offsets, &c->grid, &c->ncells, &c->sid, &c->cell_of, &c->rank, &c->cell_start,
                      &c->blk_sums, &c->sx, &c->sy, &c->sz, &c->sr, &c->s_orig, &c->s_cell, &c->s_struct,
                      &c->status, &c->ovf_tiles, &c->ovf_tiles2, &c->unit_pts, &c->slab, &c->seg,
                      &c->h_xyz, &c->h_radii, &c->h_sasa, &c->h_counts, &c->h_totals};
@@ -331,12 +338,31 @@ static int run_batch(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, const do
         ensure(c, c->status, sizeof(int) * ST_WORDS))
         return -1;
 
-    /* offsets: upload only when they changed (trajectory frames reuse them) */
+    /* offsets and the chunk table derived from them: upload only when they changed
+       (trajectory frames and repeated batches reuse them) */
     if ((int)c->offsets_host.size() != n_structs + 1 ||
         memcmp(c->offsets_host.data(), offsets, sizeof(int64_t) * ((size_t)n_structs + 1)) != 0) {
         c->offsets_host.assign(offsets, offsets + n_structs + 1);
-        HIP_TRY(c, hipMemcpyAsync(c->offsets.p, c->offsets_host.data(), sizeof(int64_t) * ((size_t)n_structs + 1),
-                                  hipMemcpyHostToDevice, st));
+        std::vector<int> cs, cl, sc0((size_t)n_structs + 1);
+        std::vector<int64_t> cb;
+        for (int s = 0; s < n_structs; ++s) {
+            sc0[s] = (int)cs.size();
+            for (int64_t b = offsets[s]; b < offsets[s + 1]; b += SASA_BOUNDS_CHUNK) {
+                const int64_t e = b + SASA_BOUNDS_CHUNK < offsets[s + 1] ? b + SASA_BOUNDS_CHUNK : offsets[s + 1];
+                cs.push_back(s); cb.push_back(b); cl.push_back((int)(e - b));
+            }
+        }
+        sc0[n_structs] = (int)cs.size();
+        c->n_chunks = (int)cs.size();
+        const size_t nc = cs.size();
+        if (ensure(c, c->chunk_struct, 4 * nc) || ensure(c, c->chunk_begin, 8 * nc) || ensure(c, c->chunk_len, 4 * nc) ||
+            ensure(c, c->struct_chunk0, 4 * ((size_t)n_structs + 1)) || ensure(c, c->bpart, 56 * nc))
+            return -1;
+        HIP_TRY(c, hipMemcpy(c->offsets.p, c->offsets_host.data(), sizeof(int64_t) * ((size_t)n_structs + 1), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->chunk_struct.p, cs.data(), 4 * nc, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->chunk_begin.p, cb.data(), 8 * nc, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->chunk_len.p, cl.data(), 4 * nc, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->struct_chunk0.p, sc0.data(), 4 * ((size_t)n_structs + 1), hipMemcpyHostToDevice));
     }
     HIP_TRY(c, hipMemsetAsync(c->status.p, 0, sizeof(int) * ST_WORDS, st));
     if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[0], st));
@@ -345,13 +371,16 @@ static int run_batch(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, const do
     memset(&pa, 0, sizeof pa);
     pa.xyz = d_xyz; pa.radii = d_radii; pa.offsets = (const int64_t *)c->offsets.p;
     pa.n_structs = n_structs; pa.n_atoms = n; pa.probe = probe; pa.max_cells = c->max_cells;
+    pa.n_chunks = c->n_chunks; pa.chunk_struct = (const int *)c->chunk_struct.p; pa.chunk_begin = (const int64_t *)c->chunk_begin.p;
+    pa.chunk_len = (const int *)c->chunk_len.p; pa.struct_chunk0 = (const int *)c->struct_chunk0.p; pa.bpart = (double *)c->bpart.p;
     pa.grid = (GridS *)c->grid.p; pa.ncells = (long long *)c->ncells.p;
     pa.sid = (int *)c->sid.p; pa.cell_of = (int *)c->cell_of.p; pa.rank = (int *)c->rank.p;
     pa.sx = (double *)c->sx.p; pa.sy = (double *)c->sy.p; pa.sz = (double *)c->sz.p; pa.sr = (double *)c->sr.p;
     pa.s_orig = (int *)c->s_orig.p; pa.s_cell = (int *)c->s_cell.p; pa.s_struct = (int *)c->s_struct.p;
     pa.status = (int *)c->status.p;
 
-    hipLaunchKernelGGL(k_bounds, dim3(n_structs), dim3(SASA_PIPE_B), 0, st, pa);
+    hipLaunchKernelGGL(k_bounds, dim3(c->n_chunks), dim3(SASA_PIPE_B), 0, st, pa);
+    hipLaunchKernelGGL(k_grid, dim3((n_structs + 63) / 64), dim3(64), 0, st, pa);
     hipLaunchKernelGGL(k_cell_base, dim3(1), dim3(SASA_PIPE_B), 0, st, pa);
     HIP_TRY(c, hipGetLastError());
 

@@ -10,7 +10,7 @@
  *       into libfreesasa_amd.so; the product has no CPU path.
  *
  * Pipeline for one batch of independent structures (xyz AoS fp64 + radii, CSR offsets):
- *   K1 bounds      per structure: bounding box, max(R+probe) -> cell grid   (ref: src/nb.c:43-72, 543)
+ *   K1 bounds/grid per 4096-atom chunk: bounding box, max(R+probe); per structure -> cell grid (ref: src/nb.c:43-72, 543)
  *   K2 cell_base   exclusive scan of cells-per-structure
  *   K3 count       per atom: cell id, rank within cell (atomic)              (ref: src/nb.c:133-175)
  *   K4 scan        exclusive scan of the cell histogram (3 launches)
@@ -104,6 +104,13 @@ struct PipeArgs {
     int n_atoms;
     double probe;
     long long max_cells; /* capacity of the cell arrays */
+    /* per chunk of <= SASA_BOUNDS_CHUNK atoms (host-built from offsets) */
+    int n_chunks;
+    const int *chunk_struct;
+    const int64_t *chunk_begin;
+    const int *chunk_len;
+    const int *struct_chunk0; /* [n_structs+1] first chunk of each structure */
+    double *bpart;            /* [n_chunks*7] per-chunk min xyz, max xyz, max radius */
     /* per structure */
     GridS *grid;
     long long *ncells; /* [n_structs] cells of each structure; [n_structs] = total after K2 */
@@ -122,10 +129,14 @@ struct PipeArgs {
 
 #define SASA_PIPE_B 256
 
-/* K1: one workgroup per structure.  red = LDS doubles [7][B]. */
-SASA_D void bounds_phase0(const PipeArgs &a, double *red, int s, int tid, int B)
+/* K1a: one workgroup per CHUNK of at most SASA_BOUNDS_CHUNK atoms of one structure (a 200k-atom
+ * structure is 49 chunks, not one serial workgroup).  red = LDS doubles [7][B]; the chunk's
+ * min/max/max-radius go to bpart[chunk*7 ..]. */
+#define SASA_BOUNDS_CHUNK 4096
+SASA_D void bounds_phase0(const PipeArgs &a, double *red, int chunk, int tid, int B)
 {
-    const int64_t b = a.offsets[s], e = a.offsets[s + 1];
+    const int s = a.chunk_struct[chunk];
+    const int64_t b = a.chunk_begin[chunk], e = a.chunk_begin[chunk] + a.chunk_len[chunk];
     double lo0 = INFINITY, lo1 = INFINITY, lo2 = INFINITY;
     double hi0 = -INFINITY, hi1 = -INFINITY, hi2 = -INFINITY, rmax = 0; /* ref: src/nb.c:246 */
     for (int64_t i = b + tid; i < e; i += B) {
@@ -141,25 +152,34 @@ SASA_D void bounds_phase0(const PipeArgs &a, double *red, int s, int tid, int B)
     red[6 * B + tid] = rmax;
 }
 
-SASA_D void bounds_phase1(const PipeArgs &a, const double *red, int s, int tid, int B)
+SASA_D void bounds_phase1(const PipeArgs &a, const double *red, int chunk, int tid, int B)
 {
-    if (tid != 0) return;
+    if (tid >= 7) return;
+    double v = red[tid * B];
+    for (int t = 1; t < B; ++t) {
+        const double w = red[tid * B + t];
+        v = tid < 3 ? fmin(w, v) : fmax(w, v);
+    }
+    a.bpart[(size_t)chunk * 7 + tid] = v;
+}
+
+/* K1b: one thread per structure: combine its chunks, derive the cell grid. */
+SASA_D void grid_struct(const PipeArgs &a, int s)
+{
+    if (s >= a.n_structs) return;
     GridS g;
-    const int64_t n = a.offsets[s + 1] - a.offsets[s];
-    if (n <= 0) {
+    const int c0 = a.struct_chunk0[s], c1 = a.struct_chunk0[s + 1];
+    if (c1 <= c0) { /* empty structure */
         g.x0 = g.y0 = g.z0 = 0; g.d = 1; g.nx = g.ny = g.nz = 0; g.cell_base = 0;
         a.grid[s] = g;
         a.ncells[s] = 0;
         return;
     }
-    double lo[3], hi[3], rmax = 0;
-    for (int k = 0; k < 3; ++k) { lo[k] = red[k * B]; hi[k] = red[(3 + k) * B]; }
-    for (int t = 0; t < B; ++t) {
-        for (int k = 0; k < 3; ++k) {
-            lo[k] = fmin(red[k * B + t], lo[k]);
-            hi[k] = fmax(red[(3 + k) * B + t], hi[k]);
-        }
-        rmax = fmax(red[6 * B + t], rmax);
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, rmax = 0;
+    for (int c = c0; c < c1; ++c) {
+        const double *q = a.bpart + (size_t)c * 7;
+        for (int k = 0; k < 3; ++k) { lo[k] = fmin(q[k], lo[k]); hi[k] = fmax(q[3 + k], hi[k]); }
+        rmax = fmax(q[6], rmax);
     }
     const double d = 2 * rmax; /* ref: src/nb.c:543 */
     int err = ERR_NONE;

@@ -71,12 +71,27 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
     pa.rank = rank.data(); pa.sx = sx.data(); pa.sy = sy.data(); pa.sz = sz.data(); pa.sr = sr.data();
     pa.s_orig = s_orig.data(); pa.s_cell = s_cell.data(); pa.s_struct = s_struct.data(); pa.status = status.data();
 
-    { /* k_bounds */
-        std::vector<double> red(7 * PB);
-        for (int s = 0; s < n_structs; ++s) {
-            for (int t = 0; t < PB; ++t) bounds_phase0(pa, red.data(), s, t, PB);
-            for (int t = 0; t < PB; ++t) bounds_phase1(pa, red.data(), s, t, PB);
+    /* chunk table, as gpu_engine.hip builds it */
+    std::vector<int> cs, cl, sc0(n_structs + 1);
+    std::vector<int64_t> cb;
+    for (int s = 0; s < n_structs; ++s) {
+        sc0[s] = (int)cs.size();
+        for (int64_t b = offsets[s]; b < offsets[s + 1]; b += SASA_BOUNDS_CHUNK) {
+            const int64_t e = b + SASA_BOUNDS_CHUNK < offsets[s + 1] ? b + SASA_BOUNDS_CHUNK : offsets[s + 1];
+            cs.push_back(s); cb.push_back(b); cl.push_back((int)(e - b));
         }
+    }
+    sc0[n_structs] = (int)cs.size();
+    std::vector<double> bpart(7 * cs.size() + 7);
+    pa.n_chunks = (int)cs.size(); pa.chunk_struct = cs.data(); pa.chunk_begin = cb.data(); pa.chunk_len = cl.data();
+    pa.struct_chunk0 = sc0.data(); pa.bpart = bpart.data();
+    { /* k_bounds + k_grid */
+        std::vector<double> red(7 * PB);
+        for (int ch = 0; ch < pa.n_chunks; ++ch) {
+            for (int t = 0; t < PB; ++t) bounds_phase0(pa, red.data(), ch, t, PB);
+            for (int t = 0; t < PB; ++t) bounds_phase1(pa, red.data(), ch, t, PB);
+        }
+        for (int s = 0; s < n_structs; ++s) grid_struct(pa, s);
     }
     { /* k_cell_base */
         std::vector<long long> part(PB);

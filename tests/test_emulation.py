@@ -50,7 +50,7 @@ def test_lr100_and_probe_sweep(oracle_lib):
 def test_ragged_batch_with_empty_and_single_atom_structures(oracle_lib):
     parts = [tools.coil(700, 1), tools.globule(333, 2), (np.zeros((0, 3)), np.zeros(0)),
              (np.array([[5.0, 5.0, 5.0]]), np.array([1.7])), tools.coil(64, 3),
-             tools.globule(250, 4, 2.05)]
+             tools.globule(250, 4, 2.05), tools.coil(9000, 5)]   # the last one spans 3 bounds chunks
     xyz = np.concatenate([p[0] for p in parts])
     # translate every structure to the same place: neighbors must never cross structures
     r = np.concatenate([p[1] for p in parts])
