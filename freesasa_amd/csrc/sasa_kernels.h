@@ -511,6 +511,9 @@ SASA_D void tile_phase_neighbors(const TileArgs &a, TileMem &m, int tile, int ti
     const int SUB = B / a.TA;
     const int la = tid / SUB, sub = tid - la * SUB;
     if (la >= na) return;
+#ifdef SASA_ABLATE_NB
+    return;
+#endif
     const int p = p0 + la;
     const double xi = m.ax[la], yi = m.ay[la], zi = m.az[la], ri = m.aR[la];
     const int *rl = m.rowlo + 9 * la, *rc = m.rowcnt + 9 * la;
@@ -631,6 +634,9 @@ SASA_D double acos_fast(double x)
 SASA_D void lr_phase_beta(const TileArgs &a, TileMem &m, int tid, int B)
 {
     if (m.flags[0]) return;
+#ifdef SASA_ABLATE_PAIRS
+    return;
+#endif
     const int total = m.aoff[a.TA];
     for (int gp = tid; gp < total; gp += B) {
         int la = 0;
@@ -649,6 +655,9 @@ SASA_D void lr_phase_beta(const TileArgs &a, TileMem &m, int tid, int B)
 SASA_D void lr_phase_rank(const TileArgs &a, TileMem &m, int tid, int B)
 {
     if (m.flags[0]) return;
+#ifdef SASA_ABLATE_PAIRS
+    return;
+#endif
     const int total = m.aoff[a.TA];
     for (int gp = tid; gp < total; gp += B) {
         int la = 0;
@@ -769,6 +778,9 @@ SASA_D double lr_union_exact(const TileMem &m, int o, int nn, double A, double h
         const double *PB = m.pb + o + base;
         unsigned long long mask;
         if (lr_screen(PQ, lim, A, h2, z, mask)) return -1;
+#ifdef SASA_ABLATE_ARCS /* timing attribution only: tools/build_variant.sh, never in the product */
+        mask = 0;
+#endif
         while (mask) {
             const int k = __builtin_ctzll(mask);
             mask &= mask - 1;
@@ -820,6 +832,9 @@ SASA_D double lr_slice(const TileMem &m, int o, int nn, double zi, double Ri, do
     if (!(A > 0)) return -1;                        /* ref: :310-312 */
     double Rip, h2;
     sqrt_rh(A, Rip, h2);                            /* h2 = 1/(2 Ri') */
+#ifdef SASA_ABLATE_SLICES
+    return h2;
+#endif
     return lr_union_exact(m, o, nn, A, h2, z, stk, stride, ds, err);
 }
 
