@@ -326,3 +326,38 @@ def test_trajectory_driver_matches_per_frame_calls(fa, oracle_lib):
     want = oracle_lib.lee_richards(frames[3], r)
     _, sasa = fa.trajectory(frames, r)
     assert np.max(np.abs(sasa[3] - want)) < LR_TOL
+
+
+def test_stress_shapes(fa, oracle_lib):
+    """Batch shapes far from the bench's: very many tiny ragged structures, and one multi-million
+    atom structure (int32 index ranges, chunk tables, grid of launches)."""
+    rng = np.random.default_rng(7)
+    # (a) 60 000 structures of 1..40 atoms (about 1.2M atoms), built from slices of one coil
+    base, rbase = tools.coil(50_000, 99)
+    sizes = rng.integers(1, 41, size=60_000)
+    starts = rng.integers(0, 50_000 - 41, size=60_000)
+    idx = np.concatenate([np.arange(s, s + n) for s, n in zip(starts, sizes)])
+    xyz, r = base[idx], rbase[idx]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    lr, _, ltot = fa.calc_batch(xyz, r, offs, fa.LEE_RICHARDS, 1.4, 20)
+    sr, cnt, _ = fa.calc_batch(xyz, r, offs, fa.SHRAKE_RUPLEY, 1.4, 100)
+    for k in list(rng.integers(0, 60_000, size=300)) + [0, 59_999]:
+        sl = slice(offs[k], offs[k + 1])
+        assert np.max(np.abs(lr[sl] - oracle_lib.lee_richards(xyz[sl], r[sl]))) < LR_TOL
+        assert abs(ltot[k] - lr[sl].sum()) < 1e-9 * max(1.0, ltot[k])
+        if sizes[k] > 1:
+            got = cnt[sl]
+            want = oracle_lib.shrake_rupley(xyz[sl], r[sl])[1]
+            # atoms without any neighbor are defined (100 exposed points) here, UB in the reference
+            assert np.array_equal(got, want)
+    # (b) one 3M-atom globule: results of two sampled sub-blocks must match the oracle run on a
+    #     neighborhood that contains all their neighbors
+    xyz, r = tools.globule(3_000_000, 3)
+    lr, _, _ = fa.calc_batch(xyz, r, [0, len(r)], fa.LEE_RICHARDS, 1.4, 20)
+    assert np.all(np.isfinite(lr)) and lr.min() >= 0
+    centre = xyz[1_500_000]
+    near = np.nonzero(np.max(np.abs(xyz - centre), axis=1) < 30.0)[0]
+    inner = np.nonzero(np.max(np.abs(xyz[near] - centre), axis=1) < 15.0)[0]
+    want = oracle_lib.lee_richards(xyz[near], r[near])
+    assert len(inner) > 500
+    assert np.max(np.abs(lr[near][inner] - want[inner])) < LR_TOL
