@@ -18,10 +18,15 @@
  *   K6 lr_tile / sr_tile   fused: neighbor discovery from the 27 surrounding cells into LDS,
  *                  then Lee-Richards slices or Shrake-Rupley test points   (ref: src/nb.c:458-522,
  *                  src/sasa_lr.c:270-408, src/sasa_sr.c:276-338); results scattered back.
+ *                  Launched up to three times over one tiling (small LDS lists, larger LDS lists
+ *                  for the tiles that overflowed, global slab for the rest).
+ *   K7 totals      per-structure (or per-residue) sums
  *
- * Arithmetic contract: fp64 everywhere, compiled with -ffp-contract=off; every expression
- * that reaches a result keeps the reference's operand order, so S&R counts are bit-exact and
- * L&R differs from the reference only through the device acos/atan2 (ulps).
+ * Arithmetic contract: fp64 everywhere, compiled with -ffp-contract=off (fma only where written
+ * explicitly).  The neighbor predicate and the whole S&R path keep the reference's operand order:
+ * S&R counts and areas are bit-exact.  L&R reproduces the reference's arc union exactly for equal
+ * arc end points, but computes cos(alpha) with reciprocals and acos/atan2/sqrt with device
+ * routines: per-atom differences ~1e-13 A^2 (tolerance 1e-4 in north_star, 1e-9 in the tests).
  */
 #ifndef SASA_KERNELS_H
 #define SASA_KERNELS_H
@@ -73,7 +78,6 @@ enum {
     ST_OVF_TILES = 1,  /* tiles handed to the second (large-LDS) launch */
     ST_MAX_NN = 2,     /* max neighbors/atom seen */
     ST_OVF2_TILES = 3, /* tiles handed on to the third (slab) launch */
-    ST_FALLBACK_FAIL = 4,
     ST_HIST = 8,       /* [64] tiles by neighbor records needed, bins of 16 */
     ST_WORDS = 72
 };
@@ -82,8 +86,8 @@ enum {
     ERR_BAD_RADIUS = 1,   /* cell size 2*max(R+probe) not > 0 (ref asserts, src/nb.c:544) */
     ERR_GRID_TOO_BIG = 2, /* nx*ny*nz over the limit (the reference would fail its malloc) */
     ERR_BAD_COORD = 3,    /* non-finite coordinate */
-    ERR_NEIGHBOR_CAP = 4, /* an atom has more neighbors than the fallback kernel's slab holds */
-    ERR_STACK_CAP = 5     /* more disjoint arcs in one slice than the fallback stack holds */
+    ERR_NEIGHBOR_CAP = 4, /* an atom has more neighbors than the last (slab) launch holds */
+    ERR_STACK_CAP = 5     /* more disjoint arcs in one slice than the last launch's stack holds */
 };
 
 struct GridS {
@@ -362,7 +366,7 @@ struct TileArgs {
     int *ovf_tiles;
     const int *work_tiles; /* tile ids to (re)do; null in the main launch (all tiles) */
     const int *work_count;
-    /* fallback launch: lists live in a global slab, one slice per workgroup */
+    /* third launch: lists live in a global slab, one slice per workgroup */
     char *slab;
     long long slab_stride;
     int *status;
@@ -407,7 +411,7 @@ SASA_HD size_t tile_list_bytes(int TA, int cap_idx, int pool, int npw, int ds, i
 {
     return tile_union_bytes(TA, cap_idx, pool, ds, B, npw == 5) + align16(sizeof(double) * (size_t)pool) * npw;
 }
-/* fallback slab (no aliasing) */
+/* slab of the third launch (no aliasing) */
 SASA_HD size_t tile_slab_bytes(int TA, int cap_idx, int pool, int npw, int ds, int B)
 {
     return align16(sizeof(int) * (size_t)TA * cap_idx) + align16(sizeof(double) * (size_t)pool) +
@@ -554,7 +558,7 @@ SASA_D void tile_phase_offsets(const TileArgs &a, TileMem &m, int tid)
     SASA_ATOMIC_MAX_LDS(&m.flags[2], c);
 }
 
-/* first thing after the barrier that follows phase O: overflow -> fallback launch */
+/* first thing after the barrier that follows phase O: overflow -> next launch's work list */
 template <bool GLOBAL>
 SASA_D void tile_report(const TileArgs &a, TileMem &m, int tile, int tid)
 {
@@ -886,7 +890,7 @@ SASA_D void lr_phase_store(const TileArgs &a, TileMem &m, int tile, int tid, int
 {
     if (m.flags[0]) return;
     const int na = tile_atoms(a, tile), p0 = tile_first_atom(a, tile);
-    if (m.flags[1]) { /* a stack overflowed: redo the tile in the fallback launch */
+    if (m.flags[1]) { /* a stack overflowed: redo the tile in the next launch */
         if (tid == 0) {
             if (!a.ovf_tiles) {
                 SASA_ATOMIC_MAX_GLB(&a.status[ST_ERROR], (int)ERR_STACK_CAP);
@@ -1067,7 +1071,7 @@ static inline TileCfg choose_cfg(int resolution, bool lr, int pool_hint = 0)
 
 /* Pool size for the NEXT batch on this context from the demand histogram of the last one: the
  * smallest multiple of 16 records that would have kept all but ~0.05% of the tiles out of the
- * (slow) fallback launch, plus one bin of headroom.  Less LDS per tile = more resident tiles. */
+ * second launch, plus one bin of headroom.  Less LDS per tile = more resident tiles. */
 static inline int pool_from_hist(const int *hist, int TA)
 {
     long long total = 0;
