@@ -190,3 +190,13 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
     stats_out[8] = status[ST_OVF2_TILES]; stats_out[9] = 0;
     return status[ST_ERROR] ? -1 : 0;
 }
+
+/* scalar device math helpers, exposed for unit tests */
+extern "C" void emu_acos_fast(const double *x, double *out, int n)
+{
+    for (int i = 0; i < n; ++i) out[i] = acos_fast(x[i]);
+}
+extern "C" void emu_sqrt_rh(const double *x, double *g, double *h, int n)
+{
+    for (int i = 0; i < n; ++i) sqrt_rh(x[i], g[i], h[i]);
+}

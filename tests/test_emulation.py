@@ -141,3 +141,30 @@ def test_launch_configurations():
     for npts in (1, 13, 100, 257, 4096, 4097):
         _, c, _, st = run_batch(False, xyz, r, resolution=npts, unit_pts=o.test_points(npts))
         assert np.array_equal(c, o.shrake_rupley(xyz, r, 1.4, npts)[1]), (npts, st)
+
+
+def test_device_math_helpers_accuracy():
+    """acos_fast / sqrt_rh (the only transcendental code of the L&R arc pass besides atan2) against
+    correctly rounded references: <= 2 ulp everywhere on (-1,1), including next to +-1 and +-0.5."""
+    import ctypes as C
+    import emu
+    lib = emu._load()
+    dp = C.POINTER(C.c_double)
+    lib.emu_acos_fast.argtypes = [dp, dp, C.c_int]
+    lib.emu_sqrt_rh.argtypes = [dp, dp, dp, C.c_int]
+    rng = np.random.default_rng(3)
+    edge = np.concatenate([1 - np.logspace(-16, -1, 400), -(1 - np.logspace(-16, -1, 400)),
+                           0.5 + np.linspace(-1e-9, 1e-9, 101), -0.5 + np.linspace(-1e-9, 1e-9, 101),
+                           np.linspace(-1e-9, 1e-9, 101)])
+    x = np.concatenate([rng.uniform(-1, 1, 200_000), edge])
+    x = x[(x > -1) & (x < 1)]
+    out = np.empty_like(x)
+    lib.emu_acos_fast(x.ctypes.data_as(dp), out.ctypes.data_as(dp), x.size)
+    want = np.arccos(x)
+    ulp = np.spacing(want)
+    assert np.max(np.abs(out - want) / ulp) <= 2.0
+    v = np.concatenate([rng.uniform(1e-12, 1e4, 100_000), np.logspace(-30, 30, 1000)])
+    g, h = np.empty_like(v), np.empty_like(v)
+    lib.emu_sqrt_rh(v.ctypes.data_as(dp), g.ctypes.data_as(dp), h.ctypes.data_as(dp), v.size)
+    assert np.max(np.abs(g - np.sqrt(v)) / np.spacing(np.sqrt(v))) <= 1.0
+    assert np.max(np.abs(h - 0.5 / np.sqrt(v)) / np.spacing(0.5 / np.sqrt(v))) <= 2.0
