@@ -38,7 +38,9 @@ typedef struct freesasa_gpu_stats {
 int freesasa_gpu_device_count(void);
 
 /* A context owns one device's workspace.  stream: a hipStream_t to launch on (e.g. torch's
-   current stream) or NULL for a private stream.  Returns NULL on failure. */
+   current stream) or NULL for a private non-blocking stream.  Work is ordered only with respect
+   to THAT stream: device inputs produced asynchronously on another stream must be complete
+   (synchronise, or create the context on the producing stream).  Returns NULL on failure. */
 freesasa_gpu_ctx *freesasa_gpu_ctx_create(int device, void *stream);
 void freesasa_gpu_ctx_destroy(freesasa_gpu_ctx *ctx);
 /* Record HIP events around the pipeline stages (adds two syncs per call). */
