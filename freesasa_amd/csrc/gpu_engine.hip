@@ -93,9 +93,11 @@ __global__ __launch_bounds__(SASA_TOT_B) void k_totals(const double *sasa, const
 
 /* 4 waves per SIMD (<= 128 VGPRs): the kernel hides its LDS/global latency and the barriers of
  * one tile behind other resident tiles, so occupancy is worth a 16-byte spill (measured). */
-/* TIER only names the launch (0 main, 1 second, 2 slab) so that profiles list them separately. */
-template <int B, bool GLOBAL, int TIER>
-__global__ __launch_bounds__(B) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lr_tile(TileArgs a, int items)
+/* TIER only names the launch (0 main, 1 second, 2 slab) so that profiles list them separately.
+ * WPE = waves per SIMD the register allocation is capped for: 4 (128 VGPRs), or 5 (96 VGPRs, no
+ * spill since atan2_fast) when the tile's LDS footprint lets more than 16 one-wave tiles reside. */
+template <int B, bool GLOBAL, int TIER, int WPE>
+__global__ __launch_bounds__(B) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lr_tile(TileArgs a, int items)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -271,14 +273,17 @@ extern "C" const char *freesasa_gpu_ctx_last_error(const freesasa_gpu_ctx *c) { 
 template <bool GLOBAL, int TIER>
 static hipError_t launch_lr(const TileCfg &c, const TileArgs &t, int grid, size_t lds, hipStream_t s)
 {
+    /* 160 KB of LDS per CU: more than 16 resident one-wave tiles only pay off with <= 96 VGPRs */
+    const bool wpe5 = TIER == 0 && !GLOBAL && c.B == 64 && lds * 17 <= 160 * 1024;
     if (c.B == 320)
-        hipLaunchKernelGGL((k_lr_tile<320, GLOBAL, TIER>), dim3(grid), dim3(320), lds, s, t, c.items);
+        hipLaunchKernelGGL((k_lr_tile<320, GLOBAL, TIER, 4>), dim3(grid), dim3(320), lds, s, t, c.items);
     else if (c.B == 256)
-        hipLaunchKernelGGL((k_lr_tile<256, GLOBAL, TIER>), dim3(grid), dim3(256), lds, s, t, c.items);
+        hipLaunchKernelGGL((k_lr_tile<256, GLOBAL, TIER, 4>), dim3(grid), dim3(256), lds, s, t, c.items);
     else if (c.B == 128)
-        hipLaunchKernelGGL((k_lr_tile<128, GLOBAL, TIER>), dim3(grid), dim3(128), lds, s, t, c.items);
+        hipLaunchKernelGGL((k_lr_tile<128, GLOBAL, TIER, 4>), dim3(grid), dim3(128), lds, s, t, c.items);
     else
-        hipLaunchKernelGGL((k_lr_tile<64, GLOBAL, TIER>), dim3(grid), dim3(64), lds, s, t, c.items);
+        { if (wpe5) hipLaunchKernelGGL((k_lr_tile<64, GLOBAL, TIER, 5>), dim3(grid), dim3(64), lds, s, t, c.items);
+          else hipLaunchKernelGGL((k_lr_tile<64, GLOBAL, TIER, 4>), dim3(grid), dim3(64), lds, s, t, c.items); }
     return hipGetLastError();
 }
 template <bool GLOBAL, int TIER>
@@ -455,12 +460,12 @@ static int run_batch(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, const do
     {
         static bool attr_done = false; /* allow > 64 KB of dynamic LDS */
         if (!attr_done) {
-            const void *fns[] = {(const void *)k_lr_tile<320, false, 0>, (const void *)k_lr_tile<256, false, 0>,
-                                 (const void *)k_lr_tile<128, false, 0>, (const void *)k_lr_tile<64, false, 0>,
+            const void *fns[] = {(const void *)k_lr_tile<320, false, 0, 4>, (const void *)k_lr_tile<256, false, 0, 4>,
+                                 (const void *)k_lr_tile<128, false, 0, 4>, (const void *)k_lr_tile<64, false, 0, 4>,
                                  (const void *)k_sr_tile<320, false, 0>, (const void *)k_sr_tile<256, false, 0>,
                                  (const void *)k_sr_tile<128, false, 0>, (const void *)k_sr_tile<64, false, 0>,
-                                 (const void *)k_lr_tile<320, false, 1>, (const void *)k_lr_tile<256, false, 1>,
-                                 (const void *)k_lr_tile<128, false, 1>, (const void *)k_lr_tile<64, false, 1>,
+                                 (const void *)k_lr_tile<320, false, 1, 4>, (const void *)k_lr_tile<256, false, 1, 4>,
+                                 (const void *)k_lr_tile<128, false, 1, 4>, (const void *)k_lr_tile<64, false, 1, 4>,
                                  (const void *)k_sr_tile<320, false, 1>, (const void *)k_sr_tile<256, false, 1>,
                                  (const void *)k_sr_tile<128, false, 1>, (const void *)k_sr_tile<64, false, 1>};
             for (const void *fn : fns) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -47,6 +47,7 @@ inline int atomic_max(int *p, int v) { int o = *p; if (v > o) *p = v; return o; 
 #define SASA_ATOMIC_MAX_LDS(p, v) sasa_emu::atomic_max((p), (v))
 #define SASA_RSQ(x) (1.0 / sqrt(x))
 #define SASA_FMA_K(p, z, k) fma((p), (z), (k))
+#define SASA_RCP(x) (1.0 / (x))
 #else
 #define SASA_D __device__ __forceinline__
 #define SASA_HD __host__ __device__ __forceinline__
@@ -65,6 +66,7 @@ __device__ __forceinline__ double sasa_fma_k(double p, double z, double k)
     return r;
 }
 #define SASA_FMA_K(p, z, k) sasa_fma_k((p), (z), (k))
+#define SASA_RCP(x) __builtin_amdgcn_rcp(x)
 #endif
 
 namespace sasa {
@@ -78,7 +80,7 @@ enum {
     ST_OVF_TILES = 1,  /* tiles handed to the second (large-LDS) launch */
     ST_MAX_NN = 2,     /* max neighbors/atom seen */
     ST_OVF2_TILES = 3, /* tiles handed on to the third (slab) launch */
-    ST_HIST = 8,       /* [64] tiles by neighbor records needed, bins of 16 */
+    ST_HIST = 8,       /* [64] tiles by neighbor records needed, bins of hist_bin_width(TA) */
     ST_WORDS = 72
 };
 enum {
@@ -558,6 +560,8 @@ SASA_D void tile_phase_offsets(const TileArgs &a, TileMem &m, int tid)
     SASA_ATOMIC_MAX_LDS(&m.flags[2], c);
 }
 
+SASA_HD int hist_bin_width(int TA) { return 2 * TA + 2; }
+
 /* first thing after the barrier that follows phase O: overflow -> next launch's work list */
 template <bool GLOBAL>
 SASA_D void tile_report(const TileArgs &a, TileMem &m, int tile, int tid)
@@ -567,7 +571,7 @@ SASA_D void tile_report(const TileArgs &a, TileMem &m, int tile, int tid)
        only pushed when it beats the value already there, the demand histogram samples 1 tile in 32 */
     if (m.flags[2] > a.status[ST_MAX_NN]) SASA_ATOMIC_MAX_GLB(&a.status[ST_MAX_NN], m.flags[2]);
     if (!a.work_tiles && (tile & 31) == 0) {
-        const int need = m.aoff[a.TA] >> 4;
+        const int need = m.aoff[a.TA] / hist_bin_width(a.TA);
         SASA_ATOMIC_ADD_GLB(&a.status[ST_HIST + (need < 63 ? need : 63)], 1);
     }
     if (m.flags[0]) {
@@ -631,6 +635,46 @@ SASA_D double acos_fast(double x)
     return big ? (x > 0 ? big_pos : big_neg) : small_r;
 }
 
+/* atan2(y, x) for finite arguments: ONE division (hardware reciprocal seed + two Newton steps + a
+ * residual correction) shared by both reductions — u = mn/mx, or (mn-mx)/(mn+mx) with a pi/4
+ * offset when mn/mx > tan(pi/8) — then atan u = u + u s P(s), s = u^2 <= 0.1716, P a degree-10
+ * interpolant at Chebyshev nodes (max relative error 5e-18, fitted with mpmath).  ~2 ulp.
+ * Replaces ocml's atan2, whose register footprint (not its speed) capped the kernel at 4 waves
+ * per SIMD. */
+SASA_D double atan2_fast(double y, double x)
+{
+    const double ax = fabs(x), ay = fabs(y);
+    const bool swap = ay > ax;
+    const double mx = swap ? ay : ax, mn = swap ? ax : ay;
+    if (!(mx > 0)) return 0.0;
+    const bool red = mn > 0x1.a827999fcef32p-2 * mx; /* tan(pi/8) */
+    const double num = red ? mn - mx : mn;
+    const double den = red ? mn + mx : mx;
+    double r = SASA_RCP(den);
+    r = fma(fma(-den, r, 1.0), r, r);
+    r = fma(fma(-den, r, 1.0), r, r);
+    double u = num * r;
+    u = fma(fma(-den, u, num), r, u);
+    const double s2 = u * u;
+    double p = -0x1.3a31b1c0fd3b7p-6;
+    p = SASA_FMA_K(p, s2, 0x1.4162c02b1dda3p-5);
+    p = SASA_FMA_K(p, s2, -0x1.a0999c632b6edp-5);
+    p = SASA_FMA_K(p, s2, 0x1.dfe6497e96323p-5);
+    p = SASA_FMA_K(p, s2, -0x1.10fa77b1a6d57p-4);
+    p = SASA_FMA_K(p, s2, 0x1.3b1263064f6b9p-4);
+    p = SASA_FMA_K(p, s2, -0x1.745d0b28a7e37p-4);
+    p = SASA_FMA_K(p, s2, 0x1.c71c71853d7fap-4);
+    p = SASA_FMA_K(p, s2, -0x1.2492492436201p-3);
+    p = SASA_FMA_K(p, s2, 0x1.999999999934cp-3);
+    p = SASA_FMA_K(p, s2, -0x1.5555555555555p-2);
+    double a = fma(u * s2, p, u);
+    const double pio4 = 0x1.921fb54442d18p-1, pio2 = 0x1.921fb54442d18p+0, pi = 0x1.921fb54442d18p+1;
+    a = red ? a + pio4 : a;
+    a = swap ? pio2 - a : a;
+    a = x < 0 ? pi - a : a;
+    return y < 0 ? -a : a;
+}
+
 /* ---------------------------------------------------------------- Lee & Richards */
 
 /* phase P1: beta = atan2(yd, xd) + pi for every (atom, neighbor) pair (ref: src/sasa_lr.c:337;
@@ -649,7 +693,7 @@ SASA_D void lr_phase_beta(const TileArgs &a, TileMem &m, int tid, int B)
         if (k >= m.acnt[la]) continue; /* padding slot */
         const int q = m.idx[la * a.cap_idx + k];
         const double xd = a.sx[q] - m.ax[la], yd = a.sy[q] - m.ay[la]; /* ref: src/nb.c:445-448 */
-        m.tb[gp] = atan2(yd, xd) + SASA_PI;
+        m.tb[gp] = atan2_fast(yd, xd) + SASA_PI;
     }
 }
 
@@ -1066,26 +1110,44 @@ static inline TileCfg choose_cfg(int resolution, bool lr, int pool_hint = 0)
     if (pool_hint > 0) c.pool = pool_hint;
     c.ds = lr ? 3 : 0; /* deeper arc stacks are rare: those tiles go to the second launch */
     c.lds = tile_fixed_bytes(c.TA, c.items) + tile_list_bytes(c.TA, c.cap_idx, c.pool, c.npw, c.ds, c.B);
+    if (pool_hint > 0) {
+        /* occupancy comes in steps of whole workgroups per CU (160 KB of LDS): spend the slack of
+           the current step on a larger pool instead of leaving it unused */
+        const size_t cu_lds = 160 * 1024;
+        const size_t nblk = cu_lds / c.lds;
+        if (nblk >= 1 && nblk < 32) {
+            const size_t slack = cu_lds / nblk - c.lds;
+            c.pool += (int)(slack / (8 * (size_t)c.npw + (lr ? 8 : 0))) & ~1;
+            size_t lds2 = tile_fixed_bytes(c.TA, c.items) + tile_list_bytes(c.TA, c.cap_idx, c.pool, c.npw, c.ds, c.B);
+            while (cu_lds / lds2 < nblk && c.pool > pool_hint) { /* aliasing/rounding pushed it over */
+                c.pool -= 2;
+                lds2 = tile_fixed_bytes(c.TA, c.items) + tile_list_bytes(c.TA, c.cap_idx, c.pool, c.npw, c.ds, c.B);
+            }
+            c.lds = lds2;
+        }
+    }
     return c;
 }
 
 /* Pool size for the NEXT batch on this context from the demand histogram of the last one: the
- * smallest multiple of 16 records that would have kept all but ~0.05% of the tiles out of the
- * second launch, plus one bin of headroom.  Less LDS per tile = more resident tiles. */
+ * smallest size that would have kept all but ~1.5% of the tiles out of the second launch (which
+ * re-does them at a fraction of the main launch's cost).  Less LDS per tile = more resident
+ * tiles; choose_cfg then grows the pool again up to the next occupancy step. */
 static inline int pool_from_hist(const int *hist, int TA)
 {
     long long total = 0;
     for (int k = 0; k < 64; ++k) total += hist[k];
     if (total <= 0) return 0;
-    long long allowed = total / 300, acc = 0; /* ~0.3% of tiles may spill to the second launch (1-in-32 sample) */
+    long long allowed = total / 64, acc = 0; /* (the histogram is a 1-in-32 sample of the tiles) */
     int k = 63;
     for (; k > 0; --k) {
         acc += hist[k];
         if (acc > allowed) break;
     }
     if (k >= 63) return 0; /* demand beyond the histogram: keep the default */
-    int pool = (k + 2) * 16;
-    if (pool < 64) pool = 64;
+    int pool = (k + 1) * hist_bin_width(TA);
+    pool = (pool + 1) & ~1;
+    if (pool < 32) pool = 32;
     return pool;
 }
 
@@ -1093,9 +1155,9 @@ static inline TileCfg mid_cfg(const TileCfg &main_cfg, bool lr)
 {
     TileCfg c = main_cfg;
     c.cap_idx = 256;
-    c.pool = 160 * c.TA < 512 ? 512 : 160 * c.TA;
-    if (c.pool > 2560) c.pool = 2560;
-    c.ds = lr ? 10 : 0;
+    c.pool = 2 * main_cfg.pool < 64 * c.TA ? 64 * c.TA : 2 * main_cfg.pool; /* twice the (adaptive) main pool */
+    if (c.pool > 3072) c.pool = 3072;
+    c.ds = lr ? 8 : 0;
     c.lds = tile_fixed_bytes(c.TA, c.items) + tile_list_bytes(c.TA, c.cap_idx, c.pool, c.npw, c.ds, c.B);
     return c;
 }

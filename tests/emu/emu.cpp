@@ -200,3 +200,7 @@ extern "C" void emu_sqrt_rh(const double *x, double *g, double *h, int n)
 {
     for (int i = 0; i < n; ++i) sqrt_rh(x[i], g[i], h[i]);
 }
+extern "C" void emu_atan2_fast(const double *y, const double *x, double *out, int n)
+{
+    for (int i = 0; i < n; ++i) out[i] = atan2_fast(y[i], x[i]);
+}

@@ -163,6 +163,17 @@ def test_device_math_helpers_accuracy():
     want = np.arccos(x)
     ulp = np.spacing(want)
     assert np.max(np.abs(out - want) / ulp) <= 2.0
+    lib.emu_atan2_fast.argtypes = [dp, dp, dp, C.c_int]
+    ang = np.concatenate([rng.uniform(-np.pi, np.pi, 200_000), np.pi / 8 * np.arange(-8, 9) + 1e-12,
+                          np.pi / 8 * np.arange(-8, 9) - 1e-12, np.array([0.0, 1e-300, -1e-300])])
+    rad = rng.uniform(1e-3, 30.0, ang.size)
+    yy, xx = rad * np.sin(ang), rad * np.cos(ang)
+    got = np.empty_like(yy)
+    lib.emu_atan2_fast(yy.ctypes.data_as(dp), xx.ctypes.data_as(dp), got.ctypes.data_as(dp), yy.size)
+    ref = np.arctan2(yy, xx)
+    assert np.max(np.abs(got - ref)) <= 3 * np.spacing(np.pi)        # a few ulp of pi, absolute
+    small = np.abs(ref) < 1e-3
+    assert np.all(np.abs(got[small] - ref[small]) <= 4 * np.spacing(np.abs(ref[small]) + 1e-300))
     v = np.concatenate([rng.uniform(1e-12, 1e4, 100_000), np.logspace(-30, 30, 1000)])
     g, h = np.empty_like(v), np.empty_like(v)
     lib.emu_sqrt_rh(v.ctypes.data_as(dp), g.ctypes.data_as(dp), h.ctypes.data_as(dp), v.size)
