@@ -314,7 +314,7 @@ static const char *err_text(int code)
 
 /* ------------------------------------------------------------------ one batch */
 
-static int run_batch(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, const double *d_radii,
+static int run_batch_impl(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, const double *d_radii,
                      const int64_t *offsets, int n_structs, double probe, int resolution,
                      const double *unit_points, double *d_sasa, int *d_counts, double *d_totals)
 {
@@ -465,8 +465,8 @@ static int run_batch(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, const do
     }
     hipError_t le;
     {
-        static bool attr_done = false; /* allow > 64 KB of dynamic LDS */
-        if (!attr_done) {
+        static std::once_flag attr_once; /* allow > 64 KB of dynamic LDS */
+        std::call_once(attr_once, [] {
             const void *fns[] = {(const void *)k_lr_tile<320, false, 0, 4>, (const void *)k_lr_tile<256, false, 0, 4>,
                                  (const void *)k_lr_tile<128, false, 0, 4>, (const void *)k_lr_tile<64, false, 0, 4>,
                                  (const void *)k_sr_tile<320, false, 0>, (const void *)k_sr_tile<256, false, 0>,
@@ -476,8 +476,7 @@ static int run_batch(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, const do
                                  (const void *)k_sr_tile<320, false, 1>, (const void *)k_sr_tile<256, false, 1>,
                                  (const void *)k_sr_tile<128, false, 1>, (const void *)k_sr_tile<64, false, 1>};
             for (const void *fn : fns) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_done = true;
-        }
+        });
     }
     le = lr ? launch_lr<false, 0>(cfg, ta, grid_main, cfg.lds, st) : launch_sr<false, 0>(cfg, ta, grid_main, cfg.lds, st);
     if (le != hipSuccess) return ctx_fail(c, "tile kernel launch failed: %s", hipGetErrorString(le));
@@ -541,6 +540,18 @@ static int run_batch(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, const do
     c->hint_ta[hi] = cfg.TA;
     c->hint_pool[hi] = pool_from_hist(status_h + ST_HIST, cfg.TA);
     return 0;
+}
+
+/* On failure nothing may still be running on the stream when the caller gets control back (it
+ * is entitled to free its buffers right away). */
+static int run_batch(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, const double *d_radii,
+                     const int64_t *offsets, int n_structs, double probe, int resolution,
+                     const double *unit_points, double *d_sasa, int *d_counts, double *d_totals)
+{
+    const int rc = run_batch_impl(c, lr, d_xyz, d_radii, offsets, n_structs, probe, resolution, unit_points,
+                                  d_sasa, d_counts, d_totals);
+    if (rc) (void)hipStreamSynchronize(c->stream);
+    return rc;
 }
 
 extern "C" int freesasa_gpu_lr_batch_dev(freesasa_gpu_ctx *c, const double *d_xyz, const double *d_radii,
@@ -752,6 +763,7 @@ extern "C" int freesasa_gpu_trajectory(const double *xyz_frames, const double *r
         if (ok) ret = 0;
     } while (0);
     if (ret) set_err(err_out, err_len, c->err[0] ? c->err : "trajectory run failed");
+    (void)hipStreamSynchronize(c->stream);
     if (copy) { (void)hipStreamSynchronize(copy); (void)hipStreamDestroy(copy); }
     for (int b = 0; b < 2; ++b) {
         if (ev_in[b]) (void)hipEventDestroy(ev_in[b]);
