@@ -779,7 +779,8 @@ SASA_D int lr_screen(const Quad *PQ, int lim, double A, double h2, double z, uns
 SASA_D void lr_arc(const Quad q, double beta, double A, double h2, double z, double &inf, double &sup)
 {
     const double dj = q.x - z;
-    const double c = lr_cos(A, h2, dj * dj, q.y, q.z, q.w);
+    /* same expression as lr_cos; the z-overlap test is known to hold for a screened neighbor */
+    const double c = ((A + q.z) - (q.y - dj * dj)) * (q.w * h2);
     const double alpha = acos_fast(c);
     inf = beta - alpha;
     sup = beta + alpha;
@@ -839,7 +840,7 @@ SASA_D double lr_union_exact(const TileMem &m, int o, int nn, double A, double h
                 wrap = 1;
                 W = sup > W ? sup : W;
                 V = inf < V ? inf : V;
-            } else if (inf <= beta && beta <= sup) { /* (false only for a zero-length arc at alpha == pi) */
+            } else { /* inf <= beta <= sup: alpha < pi because the screening kept only c > -1 */
                 if (depth == 0) {
                     ts = inf; te = sup; depth = 1;
                 } else if (inf <= te) {
