@@ -145,6 +145,8 @@ __global__ __launch_bounds__(B) void k_sr_tile(TileArgs a, int items)
         __syncthreads();
         sr_phase_points(a, m, tile, tid, B);
         __syncthreads();
+        sr_phase_points2(a, m, tid, B);
+        __syncthreads();
         sr_phase_store(a, m, tile, tid);
         __syncthreads();
     }

@@ -978,28 +978,74 @@ SASA_D void sr_phase_pairs(const TileArgs &a, TileMem &m, int tid, int B)
     }
 }
 
-/* phase L: work items = (atom, test point).  A point is exposed iff no neighbor covers it
+/* phase L1: work items = (atom, test point).  A point is exposed iff no neighbor covers it
  * (ref: src/sasa_sr.c:311-330; the reference's "last hit first" order does not change the
- * outcome, which is an OR over neighbors). */
+ * outcome, which is an OR over neighbors).  About 93 % of the points of a protein are covered,
+ * most of them by one of the first few neighbors, while an exposed point must be tested against
+ * all of them: with one lane per point a wave would run the full neighbor loop with a quarter
+ * of its lanes alive.  So L1 tests only the first SR_FIRST neighbors and appends the survivors
+ * (still uncovered, neighbors left) to a compact LDS list; L2 finishes them with dense lanes. */
+#ifndef SR_FIRST
+#define SR_FIRST 12
+#endif
+SASA_D bool sr_compact_ok(const TileArgs &a, int items)
+{
+    return a.TA <= 8 && a.n_res <= 8192 && items <= 2 * a.TA * a.cap_idx;
+}
+SASA_D bool sr_covered(const TileMem &m, int o, int k0, int k1, double tx, double ty, double tz)
+{
+    for (int k = k0; k < k1; ++k) {
+        const Quad q = m.pq[o + k];
+        const double dx = tx - q.x, dy = ty - q.y, dz = tz - q.z;
+        if (dx * dx + dy * dy + dz * dz <= q.w) return true; /* ref: src/sasa_sr.c:324 */
+    }
+    return false;
+}
+SASA_D void sr_point(const TileArgs &a, const TileMem &m, int la, int pt, double &tx, double &ty, double &tz)
+{
+    const double ri = m.aR[la];
+    /* test point = unit * ri, then + centre: two rounded steps (ref: src/coord.c:331-342, 314-329) */
+    tx = a.unit_pts[3 * pt] * ri; ty = a.unit_pts[3 * pt + 1] * ri; tz = a.unit_pts[3 * pt + 2] * ri;
+    tx += m.ax[la]; ty += m.ay[la]; tz += m.az[la];
+}
 SASA_D void sr_phase_points(const TileArgs &a, TileMem &m, int tile, int tid, int B)
 {
     if (m.flags[0]) return;
+#ifdef SASA_ABLATE_POINTS
+    return;
+#endif
     const int na = tile_atoms(a, tile);
     const int np = a.n_res, items = na * np;
+    const bool compact = sr_compact_ok(a, a.TA * np);
+    unsigned short *surv = (unsigned short *)m.idx; /* the index lists are dead after phase P */
     for (int it = tid; it < items; it += B) {
         const int la = it / np, pt = it - la * np;
-        const double ri = m.aR[la];
-        /* test point = unit * ri, then + centre: two rounded steps (ref: src/coord.c:331-342, 314-329) */
-        double tx = a.unit_pts[3 * pt] * ri, ty = a.unit_pts[3 * pt + 1] * ri, tz = a.unit_pts[3 * pt + 2] * ri;
-        tx += m.ax[la]; ty += m.ay[la]; tz += m.az[la];
+        double tx, ty, tz;
+        sr_point(a, m, la, pt, tx, ty, tz);
         const int o = m.aoff[la], nn = m.aoff[la + 1] - o;
-        int covered = 0;
-        for (int k = 0; k < nn; ++k) {
-            const Quad q = m.pq[o + k];
-            const double dx = tx - q.x, dy = ty - q.y, dz = tz - q.z;
-            if (dx * dx + dy * dy + dz * dz <= q.w) { covered = 1; break; } /* ref: src/sasa_sr.c:324 */
+        const int k1 = compact && nn > SR_FIRST ? SR_FIRST : nn;
+        if (sr_covered(m, o, 0, k1, tx, ty, tz)) continue;
+        if (k1 == nn) {
+            SASA_ATOMIC_ADD_LDS(&m.aexp[la], 1);
+        } else {
+            const int w = SASA_ATOMIC_ADD_LDS(&m.flags[3], 1);
+            surv[w] = (unsigned short)(la * 8192 + pt);
         }
-        if (!covered) SASA_ATOMIC_ADD_LDS(&m.aexp[la], 1);
+    }
+}
+
+/* phase L2: the survivors of L1 against the rest of their atom's neighbors */
+SASA_D void sr_phase_points2(const TileArgs &a, TileMem &m, int tid, int B)
+{
+    if (m.flags[0]) return;
+    const unsigned short *surv = (const unsigned short *)m.idx;
+    const int ns = m.flags[3];
+    for (int s = tid; s < ns; s += B) {
+        const int la = surv[s] >> 13, pt = surv[s] & 8191;
+        double tx, ty, tz;
+        sr_point(a, m, la, pt, tx, ty, tz);
+        const int o = m.aoff[la], nn = m.aoff[la + 1] - o;
+        if (!sr_covered(m, o, SR_FIRST, nn, tx, ty, tz)) SASA_ATOMIC_ADD_LDS(&m.aexp[la], 1);
     }
 }
 

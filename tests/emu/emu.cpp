@@ -39,6 +39,7 @@ static void emu_tile_kernel(bool lr, const TileCfg &cfg, TileArgs a, int grid)
             } else {
                 PHASE(tile_report<GLOBAL>(a, m, tile, tid); sr_phase_pairs(a, m, tid, B));
                 PHASE(sr_phase_points(a, m, tile, tid, B));
+                PHASE(sr_phase_points2(a, m, tid, B));
                 PHASE(sr_phase_store(a, m, tile, tid));
             }
 #undef PHASE
