@@ -96,7 +96,7 @@ __global__ __launch_bounds__(SASA_TOT_B) void k_totals(const double *sasa, const
 /* TIER only names the launch (0 main, 1 second, 2 slab) so that profiles list them separately.
  * WPE = waves per SIMD the register allocation is capped for: 4 (128 VGPRs), or 5 (96 VGPRs, no
  * spill since atan2_fast) when the tile's LDS footprint lets more than 16 one-wave tiles reside. */
-template <int B, bool GLOBAL, int TIER, int WPE>
+template <int B, bool GLOBAL, int TIER, int WPE, bool BUCKET = false>
 __global__ __launch_bounds__(B) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lr_tile(TileArgs a, int items)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -106,16 +106,27 @@ __global__ __launch_bounds__(B) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) v
     for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
         const int tile = a.work_tiles ? a.work_tiles[w] : xcd_tile(w, a.n_tiles);
         if (tile >= a.n_tiles) continue; /* uniform per workgroup */
-        tile_phase_load(a, m, tile, tid, B);
+        tile_phase_load(a, m, tile, tid, B, BUCKET);
         __syncthreads();
         tile_phase_neighbors(a, m, tile, tid, B);
         __syncthreads();
         tile_phase_offsets(a, m, tid);
         __syncthreads();
         tile_report<GLOBAL>(a, m, tile, tid);
-        lr_phase_beta(a, m, tid, B);
+        lr_phase_beta(a, m, tid, B, BUCKET);
         __syncthreads();
-        lr_phase_rank(a, m, tid, B);
+        if (BUCKET && lr_bucket_path(a, m, B)) { /* uniform per workgroup */
+            RankRegs rr;
+            lr_phase_prefix(a, m, tid);
+            __syncthreads();
+            lr_phase_scatter(a, m, tid, B);
+            __syncthreads();
+            lr_phase_rank2(a, m, tid, B, rr);
+            __syncthreads();
+            lr_phase_write(a, m, tid, B, rr);
+        } else {
+            lr_phase_rank(a, m, tid, B);
+        }
         __syncthreads();
         lr_phase_slices(a, m, tile, tid, B);
         __syncthreads();
@@ -181,6 +192,7 @@ struct freesasa_gpu_ctx {
     long long max_cells = 1LL << 30;
     /* adaptive neighbor-pool size, per algorithm: (resolution, TA) it was learnt for and the value */
     int hint_res[2] = {0, 0}, hint_ta[2] = {0, 0}, hint_pool[2] = {0, 0};
+    bool hint_bucket = false; /* L&R: the last batch had long neighbor lists */
 };
 
 static int ctx_fail(freesasa_gpu_ctx *c, const char *fmt, ...)
@@ -273,7 +285,7 @@ extern "C" const char *freesasa_gpu_ctx_last_error(const freesasa_gpu_ctx *c) { 
 
 
 template <bool GLOBAL, int TIER>
-static hipError_t launch_lr(const TileCfg &c, const TileArgs &t, int grid, size_t lds, hipStream_t s)
+static hipError_t launch_lr(const TileCfg &c, const TileArgs &t, int grid, size_t lds, hipStream_t s, bool bucket = false)
 {
     /* 160 KB of LDS per CU: more than 16 resident one-wave tiles only pay off with <= 96 VGPRs */
     const bool wpe5 = TIER == 0 && !GLOBAL && c.B == 64 && lds * 17 <= 160 * 1024;
@@ -285,6 +297,7 @@ static hipError_t launch_lr(const TileCfg &c, const TileArgs &t, int grid, size_
         hipLaunchKernelGGL((k_lr_tile<128, GLOBAL, TIER, 4>), dim3(grid), dim3(128), lds, s, t, c.items);
     else
         { if (wpe5) hipLaunchKernelGGL((k_lr_tile<64, GLOBAL, TIER, 5>), dim3(grid), dim3(64), lds, s, t, c.items);
+          else if (bucket && !GLOBAL) hipLaunchKernelGGL((k_lr_tile<64, false, TIER, 4, true>), dim3(grid), dim3(64), lds, s, t, c.items);
           else hipLaunchKernelGGL((k_lr_tile<64, GLOBAL, TIER, 4>), dim3(grid), dim3(64), lds, s, t, c.items); }
     return hipGetLastError();
 }
@@ -475,12 +488,14 @@ static int run_batch_impl(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
                                  (const void *)k_sr_tile<128, false, 0>, (const void *)k_sr_tile<64, false, 0>,
                                  (const void *)k_lr_tile<320, false, 1, 4>, (const void *)k_lr_tile<256, false, 1, 4>,
                                  (const void *)k_lr_tile<128, false, 1, 4>, (const void *)k_lr_tile<64, false, 1, 4>,
+                                 (const void *)k_lr_tile<64, false, 0, 4, true>, (const void *)k_lr_tile<64, false, 1, 4, true>,
                                  (const void *)k_sr_tile<320, false, 1>, (const void *)k_sr_tile<256, false, 1>,
                                  (const void *)k_sr_tile<128, false, 1>, (const void *)k_sr_tile<64, false, 1>};
             for (const void *fn : fns) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         });
     }
-    le = lr ? launch_lr<false, 0>(cfg, ta, grid_main, cfg.lds, st) : launch_sr<false, 0>(cfg, ta, grid_main, cfg.lds, st);
+    const bool bucket = lr && c->hint_bucket && c->hint_res[0] == resolution;
+    le = lr ? launch_lr<false, 0>(cfg, ta, grid_main, cfg.lds, st, bucket) : launch_sr<false, 0>(cfg, ta, grid_main, cfg.lds, st);
     if (le != hipSuccess) return ctx_fail(c, "tile kernel launch failed: %s", hipGetErrorString(le));
     if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[2], st));
 
@@ -495,7 +510,7 @@ static int run_batch_impl(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
         tm.ovf_tiles = (int *)c->ovf_tiles2.p;
         tm.ovf_count = (int *)c->status.p + ST_OVF2_TILES;
         const int grid_mid = n_tiles < SASA_MID_BLOCKS ? n_tiles : SASA_MID_BLOCKS;
-        le = lr ? launch_lr<false, 1>(mc, tm, grid_mid, mc.lds, st) : launch_sr<false, 1>(mc, tm, grid_mid, mc.lds, st);
+        le = lr ? launch_lr<false, 1>(mc, tm, grid_mid, mc.lds, st, bucket) : launch_sr<false, 1>(mc, tm, grid_mid, mc.lds, st);
         if (le != hipSuccess) return ctx_fail(c, "second tile launch failed: %s", hipGetErrorString(le));
     }
     /* third launch: whatever is left (pathological densities), lists in a global slab */
@@ -541,6 +556,7 @@ static int run_batch_impl(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
     c->hint_res[hi] = resolution;
     c->hint_ta[hi] = cfg.TA;
     c->hint_pool[hi] = pool_from_hist(status_h + ST_HIST, cfg.TA);
+    if (lr) c->hint_bucket = mean_from_hist(status_h + ST_HIST, cfg.TA) > 30.0 * cfg.TA;
     return 0;
 }
 

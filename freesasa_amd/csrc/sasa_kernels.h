@@ -390,6 +390,8 @@ struct TileMem {
     double *contrib;           /* [TA*n_res] slice areas (tab mode) / [B] partials */
     int *idx;                  /* [TA*cap_idx] neighbor candidates (sorted positions) */
     double *tb;                /* [pool] beta of each pair before ranking */
+    unsigned short *ki2;       /* [pool] L&R: list position of the pair behind each bucket-sorted beta */
+    int *hist;                 /* [TA*LR_NBUCKET] L&R: beta histogram -> bucket cursors */
     Quad *pq;                  /* [pool] neighbor records */
     double *pb;                /* [pool] L&R: beta, sorted */
     Arc *stack;                /* [ds][B] spilled components */
@@ -403,6 +405,7 @@ SASA_HD size_t tile_fixed_bytes(int TA, int items)
     return align16(sizeof(double) * 4 * TA) + align16(sizeof(int) * (3 * TA + 1 + 4 + 18 * TA)) +
            align16(sizeof(double) * items);
 }
+#define LR_NBUCKET 32
 SASA_HD size_t tile_union_bytes(int TA, int cap_idx, int pool, int ds, int B, bool lr)
 {
     size_t u1 = align16(sizeof(int) * (size_t)TA * cap_idx) + (lr ? align16(sizeof(double) * (size_t)pool) : 0);
@@ -446,6 +449,10 @@ SASA_D TileMem tile_carve(const TileArgs &a, char *smem, int items, int B, int b
     }
     m.pq = (Quad *)q;
     m.pb = (double *)(q + 4 * pw);
+    /* the bucket sort's scratch lives in the record array, which stays unwritten until the sort's
+     * last phase (which no longer reads it): 2*pool + 128*TA bytes of the 32*pool */
+    m.ki2 = (unsigned short *)q;
+    m.hist = (int *)(q + align16(sizeof(unsigned short) * (size_t)a.pool));
     return m;
 }
 
@@ -460,7 +467,7 @@ SASA_D int tile_atoms(const TileArgs &a, int tile)
  * cell-sorted atoms that cover its 27 surrounding cells (x-adjacent cells are contiguous).
  * Every thread has one short chain s_struct/s_cell -> grid -> cell_start, and the chains of
  * all threads run concurrently, so the whole tile pays about three memory round trips. */
-SASA_D void tile_phase_load(const TileArgs &a, TileMem &m, int tile, int tid, int B)
+SASA_D void tile_phase_load(const TileArgs &a, TileMem &m, int tile, int tid, int B, bool bucket = false)
 {
     const int na = tile_atoms(a, tile), p0 = tile_first_atom(a, tile);
     if (tid < a.TA) {
@@ -474,6 +481,8 @@ SASA_D void tile_phase_load(const TileArgs &a, TileMem &m, int tile, int tid, in
         m.aexp[tid] = 0;
     }
     if (tid < 4) m.flags[tid] = 0;
+    if (bucket)
+        for (int t = tid; t < LR_NBUCKET * a.TA; t += B) m.hist[t] = 0;
     for (int t = tid; t < 9 * a.TA; t += B) {
         const int la = t / 9, r = t - 9 * la;
         int lo = 0, cnt = 0;
@@ -677,9 +686,16 @@ SASA_D double atan2_fast(double y, double x)
 
 /* ---------------------------------------------------------------- Lee & Richards */
 
+/* Angular bucket of beta in [0, 2pi]: monotone in beta, so bucket order is beta order. */
+SASA_D int lr_bucket(double beta)
+{
+    const int b = (int)(beta * (LR_NBUCKET / SASA_TWOPI));
+    return b < 0 ? 0 : (b > LR_NBUCKET - 1 ? LR_NBUCKET - 1 : b);
+}
+
 /* phase P1: beta = atan2(yd, xd) + pi for every (atom, neighbor) pair (ref: src/sasa_lr.c:337;
  * the reference recomputes it per slice, it only depends on the pair). */
-SASA_D void lr_phase_beta(const TileArgs &a, TileMem &m, int tid, int B)
+SASA_D void lr_phase_beta(const TileArgs &a, TileMem &m, int tid, int B, bool bucket = false)
 {
     if (m.flags[0]) return;
 #ifdef SASA_ABLATE_PAIRS
@@ -693,7 +709,9 @@ SASA_D void lr_phase_beta(const TileArgs &a, TileMem &m, int tid, int B)
         if (k >= m.acnt[la]) continue; /* padding slot */
         const int q = m.idx[la * a.cap_idx + k];
         const double xd = a.sx[q] - m.ax[la], yd = a.sy[q] - m.ay[la]; /* ref: src/nb.c:445-448 */
-        m.tb[gp] = atan2_fast(yd, xd) + SASA_PI;
+        const double beta = atan2_fast(yd, xd) + SASA_PI;
+        m.tb[gp] = beta;
+        if (bucket) SASA_ATOMIC_ADD_LDS(&m.hist[la * LR_NBUCKET + lr_bucket(beta)], 1);
     }
 }
 
@@ -739,6 +757,110 @@ SASA_D void lr_phase_rank(const TileArgs &a, TileMem &m, int tid, int B)
         rec.w = D > 0 ? 2.0 * h : INFINITY; /* 1/d_ij; coincident xy: see lr_cos */
         m.pq[o + rank] = rec;
         m.pb[o + rank] = beta;
+    }
+}
+
+/* Bucketed ranking (O(nn) per atom instead of the O(nn^2) of lr_phase_rank), used when the
+ * tile's pairs fit LR_RANK_ROUNDS rounds of the workgroup:
+ *   P1  histogram of beta over LR_NBUCKET angular buckets per atom (in lr_phase_beta)
+ *   Pa  exclusive prefix per atom                       -> bucket cursors
+ *   Pb  scatter (beta, list position) by bucket         -> pb / ki2   (order inside a bucket: arrival)
+ *   Pc  exact rank inside the pair's own bucket (mean occupancy ~1)  -> final position, in registers
+ *   Pd  write the records at their final positions.
+ * The result is the same permutation as lr_phase_rank's: ascending beta, ties by list position. */
+#define LR_RANK_ROUNDS 3
+struct RankRegs { /* carried across the barrier between Pc and Pd */
+    int fin[LR_RANK_ROUNDS]; /* final position of this slot's pair */
+    int q[LR_RANK_ROUNDS];   /* its neighbor atom */
+};
+/* worth its fixed cost (three more phases) only for long lists: measured -15 % kernel time at 47
+ * neighbors/atom, +13 % at 19 when applied unconditionally */
+SASA_D bool lr_bucket_path(const TileArgs &a, const TileMem &m, int B)
+{
+    const int total = m.aoff[a.TA];
+    return total <= LR_RANK_ROUNDS * B && total > 30 * a.TA;
+}
+
+SASA_D void lr_phase_prefix(const TileArgs &a, TileMem &m, int tid)
+{
+    if (m.flags[0] || tid >= a.TA) return;
+    int run = 0;
+    for (int b = 0; b < LR_NBUCKET; ++b) {
+        const int v = m.hist[tid * LR_NBUCKET + b];
+        m.hist[tid * LR_NBUCKET + b] = run;
+        run += v;
+    }
+}
+
+SASA_D void lr_phase_scatter(const TileArgs &a, TileMem &m, int tid, int B)
+{
+    if (m.flags[0]) return;
+    const int total = m.aoff[a.TA];
+    for (int gp = tid; gp < total; gp += B) {
+        int la = 0;
+        while (m.aoff[la + 1] <= gp) ++la;
+        const int o = m.aoff[la], k = gp - o;
+        if (k >= m.acnt[la]) continue;
+        const double beta = m.tb[gp];
+        const int slot = SASA_ATOMIC_ADD_LDS(&m.hist[la * LR_NBUCKET + lr_bucket(beta)], 1);
+        m.pb[o + slot] = beta; /* pb is free until Pd */
+        m.ki2[o + slot] = (unsigned short)k;
+    }
+}
+
+SASA_D void lr_phase_rank2(const TileArgs &a, TileMem &m, int tid, int B, RankRegs &rr)
+{
+    if (m.flags[0]) return;
+    const int total = m.aoff[a.TA];
+    for (int r = 0; r < LR_RANK_ROUNDS; ++r) {
+        const int gp = tid + r * B;
+        rr.fin[r] = -1;
+        if (gp >= total) continue;
+        int la = 0;
+        while (m.aoff[la + 1] <= gp) ++la;
+        const int o = m.aoff[la], s = gp - o;
+        if (s >= m.acnt[la]) { rr.fin[r] = -2; continue; } /* padding slot */
+        const double beta = m.pb[gp];
+        const int kme = m.ki2[gp], b = lr_bucket(beta);
+        const int lo = b ? m.hist[la * LR_NBUCKET + b - 1] : 0, hi = m.hist[la * LR_NBUCKET + b]; /* cursors now = bucket ends */
+        int rank = lo;
+        for (int t = lo; t < hi; ++t) {
+            const double bt = m.pb[o + t];
+            rank += (bt < beta || (bt == beta && m.ki2[o + t] < kme)) ? 1 : 0;
+        }
+        rr.fin[r] = o + rank;
+        rr.q[r] = m.idx[la * a.cap_idx + kme];
+        m.tb[gp] = beta; /* tb is dead since Pb: park this slot's beta where Pd cannot clobber it */
+    }
+}
+
+SASA_D void lr_phase_write(const TileArgs &a, TileMem &m, int tid, int B, const RankRegs &rr)
+{
+    if (m.flags[0]) return;
+    for (int r = 0; r < LR_RANK_ROUNDS; ++r) {
+        const int gp = tid + r * B;
+        if (rr.fin[r] == -1) continue;
+        if (rr.fin[r] == -2) { /* padding slot: a record that never overlaps any slice */
+            Quad d; d.x = 0; d.y = 0; d.z = 1; d.w = 1;
+            m.pq[gp] = d;
+            m.pb[gp] = 0;
+            continue;
+        }
+        int la = 0;
+        while (m.aoff[la + 1] <= gp) ++la;
+        const int q = rr.q[r];
+        const double xd = a.sx[q] - m.ax[la], yd = a.sy[q] - m.ay[la];
+        const double rj = a.sr[q];
+        const double D = xd * xd + yd * yd; /* = d_ij^2 (ref: src/nb.c:438) */
+        double g = 0, h = 0;
+        if (D > 0) sqrt_rh(D, g, h);
+        Quad rec;
+        rec.x = a.sz[q];
+        rec.y = rj * rj;
+        rec.z = D;
+        rec.w = D > 0 ? 2.0 * h : INFINITY; /* 1/d_ij; coincident xy: see lr_cos */
+        m.pq[rr.fin[r]] = rec;
+        m.pb[rr.fin[r]] = m.tb[gp];
     }
 }
 
@@ -1196,6 +1318,16 @@ static inline int pool_from_hist(const int *hist, int TA)
     pool = (pool + 1) & ~1;
     if (pool < 32) pool = 32;
     return pool;
+}
+
+/* Mean neighbor records per tile of the last batch (same sampled histogram): long lists switch
+ * the next batch to the kernel variant with bucketed beta ranking. */
+static inline double mean_from_hist(const int *hist, int TA)
+{
+    long long total = 0;
+    double acc = 0;
+    for (int k = 0; k < 64; ++k) { total += hist[k]; acc += (double)hist[k] * (k + 0.5) * hist_bin_width(TA); }
+    return total > 0 ? acc / (double)total : 0.0;
 }
 
 static inline TileCfg mid_cfg(const TileCfg &main_cfg, bool lr)

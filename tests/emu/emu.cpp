@@ -16,6 +16,9 @@
 
 using namespace sasa;
 
+static bool emu_bucket = true; /* the BUCKET kernel variant; emu_set_bucket(0) emulates the plain one */
+extern "C" void emu_set_bucket(int on) { emu_bucket = on != 0; }
+
 template <bool GLOBAL>
 static void emu_tile_kernel(bool lr, const TileCfg &cfg, TileArgs a, int grid)
 {
@@ -28,12 +31,20 @@ static void emu_tile_kernel(bool lr, const TileCfg &cfg, TileArgs a, int grid)
             const int tile = a.work_tiles ? a.work_tiles[w] : xcd_tile(w, a.n_tiles);
             if (tile >= a.n_tiles) continue;
 #define PHASE(call) for (int tid = 0; tid < B; ++tid) { call; }
-            PHASE(tile_phase_load(a, m, tile, tid, B));
+            PHASE(tile_phase_load(a, m, tile, tid, B, lr && emu_bucket));
             PHASE(tile_phase_neighbors(a, m, tile, tid, B));
             PHASE(tile_phase_offsets(a, m, tid));
             if (lr) {
-                PHASE(tile_report<GLOBAL>(a, m, tile, tid); lr_phase_beta(a, m, tid, B));
-                PHASE(lr_phase_rank(a, m, tid, B));
+                PHASE(tile_report<GLOBAL>(a, m, tile, tid); lr_phase_beta(a, m, tid, B, emu_bucket));
+                if (emu_bucket && lr_bucket_path(a, m, B)) {
+                    std::vector<RankRegs> rrs(B);
+                    PHASE(lr_phase_prefix(a, m, tid));
+                    PHASE(lr_phase_scatter(a, m, tid, B));
+                    PHASE(lr_phase_rank2(a, m, tid, B, rrs[tid]));
+                    PHASE(lr_phase_write(a, m, tid, B, rrs[tid]));
+                } else {
+                    PHASE(lr_phase_rank(a, m, tid, B));
+                }
                 PHASE(lr_phase_slices(a, m, tile, tid, B));
                 PHASE(lr_phase_store<GLOBAL>(a, m, tile, tid, B));
             } else {

@@ -9,6 +9,7 @@ import pytest
 
 import tools
 from conftest import load_golden
+import emu
 from emu import run_batch
 
 LR_TOL = 1e-11
@@ -28,6 +29,13 @@ def test_golden_structures(oracle_lib, name):
     g = load_golden(name)
     sasa, _, tot, st = run_batch(True, g["xyz"], g["radii"], resolution=20)
     assert close(sasa, g["lr20"]) and abs(tot[0] - float(g["lr20_total"])) < 1e-9
+    # the kernel variant without bucketed beta ranking (sparse inputs) must agree bit for bit
+    emu._load().emu_set_bucket(0)
+    try:
+        plain, _, _, _ = run_batch(True, g["xyz"], g["radii"], resolution=20)
+    finally:
+        emu._load().emu_set_bucket(1)
+    assert np.array_equal(plain, sasa)
     sasa, counts, tot, _ = _sr(oracle_lib, g["xyz"], g["radii"])
     assert np.array_equal(counts, g["sr100_counts"])
     assert np.array_equal(sasa, g["sr100"]) and abs(tot[0] - float(g["sr100_total"])) < 1e-9
