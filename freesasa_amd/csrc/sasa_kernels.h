@@ -620,7 +620,8 @@ SASA_D double acos_fast(double x)
 {
     const double ax = fabs(x);
     const bool big = ax > 0.5;
-    const double z = big ? (1.0 - ax) * 0.5 : x * x;
+    const double zb = (1.0 - ax) * 0.5; /* in (0, 0.5] for |x| < 1 */
+    const double z = big ? zb : x * x;
     double p = 0x1.cd864394d2ff2p-6;
     p = SASA_FMA_K(p, z, -0x1.603991d6060e0p-7);
     p = SASA_FMA_K(p, z, 0x1.06b9d26d10838p-6);
@@ -634,7 +635,7 @@ SASA_D double acos_fast(double x)
     p = SASA_FMA_K(p, z, 0x1.3333333336da5p-4);
     p = SASA_FMA_K(p, z, 0x1.555555555554fp-3);
     double s, hh;
-    sqrt_rh(big ? z : 1.0, s, hh);
+    sqrt_rh(zb, s, hh); /* only used when big */
     const double u = big ? s : x;      /* asin argument */
     const double t = fma(u * z, p, u); /* asin(u) */
     const double pio2_hi = 0x1.921fb54442d18p+0, pio2_lo = 0x1.1a62633145c07p-54; /* pi/2 = hi + lo */
@@ -877,27 +878,29 @@ SASA_D double lr_cos(double A, double h2, double dj2, double R2, double D, doubl
     return Bq > 0 ? ((A + D) - Bq) * (ginv * h2) : 2.0; /* ref: src/sasa_lr.c:320 dj < Rj */
 }
 
-/* Screening pass over up to 64 neighbors (lim is even, lists are padded): bit k of
- * the mask is set when neighbor k cuts an arc out of circle i (|cos alpha| < 1).  Returns 1 if
- * some neighbor's circle contains circle i entirely (slice buried, ref: src/sasa_lr.c:327-330). */
-SASA_D int lr_screen(const Quad *PQ, int lim, double A, double h2, double z, unsigned long long &mask)
+/* Screening pass over up to 32 neighbors (lim is even, lists are padded): bit k of the result
+ * is set when neighbor k cuts an arc out of circle i (|cos alpha| < 1).  `buried` is raised if
+ * some neighbor's circle contains circle i entirely (ref: src/sasa_lr.c:327-330).  The loop
+ * counter is wave-uniform, so the bit masks are scalars and `buried` lives in a lane mask. */
+SASA_D unsigned lr_screen32(const Quad *PQ, int lim, double A, double h2, double z, bool &buried)
 {
-    int buried = 0;
-    mask = 0;
+    unsigned w = 0;
     for (int k = 0; k < lim; k += 2) {
         const Quad q0 = PQ[k], q1 = PQ[k + 1];
         const double d0 = q0.x - z, d1 = q1.x - z;
-        const double c0 = lr_cos(A, h2, d0 * d0, q0.y, q0.z, q0.w);
-        const double c1 = lr_cos(A, h2, d1 * d1, q1.y, q1.z, q1.w);
-        const unsigned b0 = c0 < 1.0, b1 = c1 < 1.0;
-        buried |= (b0 & !(c0 > -1.0)) | (b1 & !(c1 > -1.0));
-        mask |= (unsigned long long)(b0 | (b1 << 1)) << k;
+        const double B0 = q0.y - d0 * d0, B1 = q1.y - d1 * d1; /* Rj'^2; ref: :320 dj < Rj */
+        const double c0 = ((A + q0.z) - B0) * (q0.w * h2);     /* same expression as lr_cos */
+        const double c1 = ((A + q1.z) - B1) * (q1.w * h2);
+        const bool a0 = B0 > 0 && c0 < 1.0, a1 = B1 > 0 && c1 < 1.0;
+        buried |= (a0 && !(c0 > -1.0)) || (a1 && !(c1 > -1.0));
+        w |= (a0 ? 1u << k : 0u) | (a1 ? 2u << k : 0u);
     }
-    return buried;
+    return w;
 }
 
-/* End points of the arc neighbor record q (mid-angle beta) buries on circle i, normalised to
- * [0,2pi) exactly as the reference does (src/sasa_lr.c:335-341); sup < inf means it wraps. */
+/* Raw end points beta -+ alpha of the arc neighbor record q (mid-angle beta) buries on circle i
+ * (ref: src/sasa_lr.c:335-339).  The arc passes the origin iff inf < 0 or sup > 2pi (never
+ * both: alpha < pi), which is when the reference's normalisation (:340-341) makes sup < inf. */
 SASA_D void lr_arc(const Quad q, double beta, double A, double h2, double z, double &inf, double &sup)
 {
     const double dj = q.x - z;
@@ -906,8 +909,6 @@ SASA_D void lr_arc(const Quad q, double beta, double A, double h2, double z, dou
     const double alpha = acos_fast(c);
     inf = beta - alpha;
     sup = beta + alpha;
-    if (inf < 0) inf += SASA_TWOPI;
-    if (sup > SASA_TWOPI) sup -= SASA_TWOPI;
 }
 
 /* Sum of the exposed gaps given the disjoint components in ascending order (component c is
@@ -938,57 +939,76 @@ SASA_D void lr_arc(const Quad q, double beta, double A, double h2, double z, dou
  * through 0 only extend a covered prefix [0,W] / suffix [V,2pi].  End points are only ever
  * compared and copied, and gaps are summed in ascending order, so given the same inf/sup
  * values the result equals the reference's sort + sweep (src/sasa_lr.c:367-408) bit for bit. */
+struct UnionState {
+    double W, V;   /* covered prefix [0,W] and suffix [V,2pi] of the arcs that pass the origin */
+    double ts, te; /* top component (in registers); the ones below it are in the LDS stack */
+    int depth, wrap;
+};
+
+/* Feed the arcs of the set bits of w (neighbors PQ[k], PB[k]) to the union, ascending k = ascending beta. */
+SASA_D void lr_arcs32(unsigned w, const Quad *PQ, const double *PB, double A, double h2, double z,
+                      UnionState &u, Arc *stk, int stride, int ds, int *err)
+{
+    while (w) {
+        const int k = __builtin_ctz(w);
+        w &= w - 1;
+        double inf, sup;
+        lr_arc(PQ[k], PB[k], A, h2, z, inf, sup);
+        if (inf < 0 || sup > SASA_TWOPI) {           /* ref: :340-351 arc passes the origin */
+            const double wi = inf < 0 ? inf + SASA_TWOPI : inf;
+            const double ws = sup > SASA_TWOPI ? sup - SASA_TWOPI : sup;
+            u.wrap = 1;
+            u.W = ws > u.W ? ws : u.W;
+            u.V = wi < u.V ? wi : u.V;
+        } else { /* inf <= beta <= sup: alpha < pi because the screening kept only c > -1 */
+            if (u.depth == 0) {
+                u.ts = inf; u.te = sup; u.depth = 1;
+            } else if (inf <= u.te) {
+                u.ts = inf < u.ts ? inf : u.ts;
+                u.te = sup > u.te ? sup : u.te;
+                while (u.depth > 1) {
+                    const Arc lo = stk[(u.depth - 2) * stride];
+                    if (lo.e < u.ts) break;
+                    u.ts = lo.s < u.ts ? lo.s : u.ts;
+                    u.te = lo.e > u.te ? lo.e : u.te;
+                    --u.depth;
+                }
+            } else if (u.depth - 1 < ds) {
+                Arc t; t.s = u.ts; t.e = u.te;
+                stk[(u.depth - 1) * stride] = t;
+                u.ts = inf; u.te = sup; ++u.depth;
+            } else {
+                *err = 1;
+            }
+        }
+    }
+}
+
 SASA_D double lr_union_exact(const TileMem &m, int o, int nn, double A, double h2, double z,
                              Arc *stk, int stride, int ds, int *err)
 {
-    double W = 0, V = SASA_TWOPI, ts = 0, te = 0;
-    int depth = 0, wrap = 0;
+    UnionState u;
+    u.W = 0; u.V = SASA_TWOPI; u.ts = 0; u.te = 0; u.depth = 0; u.wrap = 0;
     for (int base = 0; base < nn; base += 64) { /* nn is even (padded) */
         const int lim = nn - base < 64 ? nn - base : 64;
         const Quad *PQ = m.pq + o + base;
         const double *PB = m.pb + o + base;
-        unsigned long long mask;
-        if (lr_screen(PQ, lim, A, h2, z, mask)) return -1;
+        bool buried = false;
+        unsigned lo = lr_screen32(PQ, lim < 32 ? lim : 32, A, h2, z, buried), hi = 0;
+        if (lim > 32) hi = lr_screen32(PQ + 32, lim - 32, A, h2, z, buried);
+        if (buried) return -1;
 #ifdef SASA_ABLATE_ARCS /* timing attribution only: tools/build_variant.sh, never in the product */
-        mask = 0;
+        lo = hi = 0;
 #endif
-        while (mask) {
-            const int k = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            const double beta = PB[k];
-            double inf, sup;
-            lr_arc(PQ[k], beta, A, h2, z, inf, sup);
-            if (sup < inf) {                         /* ref: :344-351 arc passes the origin */
-                wrap = 1;
-                W = sup > W ? sup : W;
-                V = inf < V ? inf : V;
-            } else { /* inf <= beta <= sup: alpha < pi because the screening kept only c > -1 */
-                if (depth == 0) {
-                    ts = inf; te = sup; depth = 1;
-                } else if (inf <= te) {
-                    ts = inf < ts ? inf : ts;
-                    te = sup > te ? sup : te;
-                    while (depth > 1) {
-                        const Arc lo = stk[(depth - 2) * stride];
-                        if (lo.e < ts) break;
-                        ts = lo.s < ts ? lo.s : ts;
-                        te = lo.e > te ? lo.e : te;
-                        --depth;
-                    }
-                } else if (depth - 1 < ds) {
-                    Arc t; t.s = ts; t.e = te;
-                    stk[(depth - 1) * stride] = t;
-                    ts = inf; te = sup; ++depth;
-                } else {
-                    *err = 1;
-                }
-            }
-        }
+        lr_arcs32(lo, PQ, PB, A, h2, z, u, stk, stride, ds, err);
+        if (hi) lr_arcs32(hi, PQ + 32, PB + 32, A, h2, z, u, stk, stride, ds, err);
     }
     double res;
+    const double ts = u.ts, te = u.te;
+    const int depth = u.depth;
 #define CS_(c) ((c) == depth - 1 ? ts : stk[(c) * stride].s)
 #define CE_(c) ((c) == depth - 1 ? te : stk[(c) * stride].e)
-    LR_SWEEP(depth, wrap, W, V, CS_, CE_, res);
+    LR_SWEEP(depth, u.wrap, u.W, u.V, CS_, CE_, res);
 #undef CS_
 #undef CE_
     return res;
