@@ -352,9 +352,9 @@ static int run_batch_impl(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
     /* workspace */
     if (ensure(c, c->offsets, sizeof(int64_t) * ((size_t)n_structs + 1)) || ensure(c, c->grid, sizeof(GridS) * (size_t)n_structs) ||
         ensure(c, c->ncells, sizeof(long long) * ((size_t)n_structs + 1)) || ensure(c, c->sid, 4 * nb) ||
-        ensure(c, c->cell_of, 4 * nb) || ensure(c, c->rank, 4 * nb) || ensure(c, c->sx, 8 * nb) ||
+        ensure(c, c->cell_of, 8 * nb) || ensure(c, c->rank, 4 * nb) || ensure(c, c->sx, 8 * nb) ||
         ensure(c, c->sy, 8 * nb) || ensure(c, c->sz, 8 * nb) || ensure(c, c->sr, 8 * nb) ||
-        ensure(c, c->s_orig, 4 * nb) || ensure(c, c->s_cell, 4 * nb) || ensure(c, c->s_struct, 4 * nb) ||
+        ensure(c, c->s_orig, 4 * nb) || ensure(c, c->s_cell, 8 * nb) || ensure(c, c->s_struct, 4 * nb) ||
         ensure(c, c->status, sizeof(int) * ST_WORDS))
         return -1;
 
@@ -394,9 +394,9 @@ static int run_batch_impl(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
     pa.n_chunks = c->n_chunks; pa.chunk_struct = (const int *)c->chunk_struct.p; pa.chunk_begin = (const int64_t *)c->chunk_begin.p;
     pa.chunk_len = (const int *)c->chunk_len.p; pa.struct_chunk0 = (const int *)c->struct_chunk0.p; pa.bpart = (double *)c->bpart.p;
     pa.grid = (GridS *)c->grid.p; pa.ncells = (long long *)c->ncells.p;
-    pa.sid = (int *)c->sid.p; pa.cell_of = (int *)c->cell_of.p; pa.rank = (int *)c->rank.p;
+    pa.sid = (int *)c->sid.p; pa.cell_of = (long long *)c->cell_of.p; pa.rank = (int *)c->rank.p;
     pa.sx = (double *)c->sx.p; pa.sy = (double *)c->sy.p; pa.sz = (double *)c->sz.p; pa.sr = (double *)c->sr.p;
-    pa.s_orig = (int *)c->s_orig.p; pa.s_cell = (int *)c->s_cell.p; pa.s_struct = (int *)c->s_struct.p;
+    pa.s_orig = (int *)c->s_orig.p; pa.s_cell = (long long *)c->s_cell.p; pa.s_struct = (int *)c->s_struct.p;
     pa.status = (int *)c->status.p;
 
     hipLaunchKernelGGL(k_bounds, dim3(c->n_chunks), dim3(SASA_PIPE_B), 0, st, pa);

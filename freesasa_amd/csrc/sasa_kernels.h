@@ -122,14 +122,15 @@ struct PipeArgs {
     long long *ncells; /* [n_structs] cells of each structure; [n_structs] = total after K2 */
     /* per atom, original order */
     int *sid;     /* structure of atom i */
-    int *cell_of; /* batch-wide cell index */
+    long long *cell_of; /* batch-wide cell index | grid-border flags << 32 (CELL_*) */
     int *rank;    /* arrival rank within the cell */
     /* per cell */
     int *cell_start; /* [total_cells+1]: histogram, then exclusive scan */
     int *blk_sums;   /* scan scratch */
     /* per atom, cell-sorted order */
     double *sx, *sy, *sz, *sr; /* sr = radius + probe (ref: src/sasa_lr.c:136, sasa_sr.c:144) */
-    int *s_orig, *s_cell, *s_struct;
+    int *s_orig, *s_struct;
+    long long *s_cell; /* cell_of of the sorted atom */
     int *status;
 };
 
@@ -243,6 +244,9 @@ SASA_D void cellbase_phase2(const PipeArgs &a, const long long *part, int tid, i
     }
 }
 
+/* which faces of its structure's grid an atom's cell lies on (saves the tile kernels the
+ * divisions that would recover ix, iy, iz from the cell index) */
+enum { CELL_X0 = 1, CELL_X1 = 2, CELL_Y0 = 4, CELL_Y1 = 8, CELL_Z0 = 16, CELL_Z1 = 32 };
 SASA_D int cell_coord(double v, double v0, double d) { return (int)((v - v0) / d); } /* ref: src/nb.c:137-140 */
 
 /* K3: one thread per atom (original order). */
@@ -259,7 +263,9 @@ SASA_D void count_atom(const PipeArgs &a, int i)
         ix = iy = iz = 0;
     }
     const int c = g.cell_base + ix + g.nx * (iy + g.ny * iz); /* ref: src/nb.c:74-83 */
-    a.cell_of[i] = c;
+    const int fl = (ix == 0 ? CELL_X0 : 0) | (ix == g.nx - 1 ? CELL_X1 : 0) | (iy == 0 ? CELL_Y0 : 0) |
+                   (iy == g.ny - 1 ? CELL_Y1 : 0) | (iz == 0 ? CELL_Z0 : 0) | (iz == g.nz - 1 ? CELL_Z1 : 0);
+    a.cell_of[i] = (long long)c | ((long long)fl << 32);
     a.rank[i] = SASA_ATOMIC_ADD_GLB(&a.cell_start[c], 1);
 }
 
@@ -328,14 +334,15 @@ SASA_D void scan3_phase2(const PipeArgs &a, long long n, const int *part, int bl
 SASA_D void scatter_atom(const PipeArgs &a, int i)
 {
     if (i >= a.n_atoms) return;
-    const int c = a.cell_of[i];
+    const long long cf = a.cell_of[i];
+    const int c = (int)(cf & 0xffffffffLL);
     const int p = a.cell_start[c] + a.rank[i];
     a.sx[p] = a.xyz[3 * i];
     a.sy[p] = a.xyz[3 * i + 1];
     a.sz[p] = a.xyz[3 * i + 2];
     a.sr[p] = a.radii[i] + a.probe; /* ref: src/sasa_lr.c:136, src/sasa_sr.c:144 */
     a.s_orig[p] = i;
-    a.s_cell[p] = c;
+    a.s_cell[p] = cf;
     a.s_struct[p] = a.sid[i];
 }
 
@@ -346,7 +353,8 @@ struct Arc { double s, e; };
 
 struct TileArgs {
     const double *sx, *sy, *sz, *sr;
-    const int *s_orig, *s_cell, *s_struct;
+    const int *s_orig, *s_struct;
+    const long long *s_cell;
     const GridS *grid;
     const int *cell_start;
     int n_atoms;
@@ -489,14 +497,16 @@ SASA_D void tile_phase_load(const TileArgs &a, TileMem &m, int tile, int tid, in
         if (la < na) {
             const int p = p0 + la;
             const GridS g = a.grid[a.s_struct[p]];
-            const int lc = a.s_cell[p] - g.cell_base;
-            const int ix = lc % g.nx, iy = (lc / g.nx) % g.ny, iz = lc / (g.nx * g.ny);
-            const int cy = iy + (r % 3) - 1, cz = iz + (r / 3) - 1;
-            if (cy >= 0 && cy < g.ny && cz >= 0 && cz < g.nz) {
-                const int x_lo = ix > 0 ? ix - 1 : 0, x_hi = ix < g.nx - 1 ? ix + 1 : ix;
-                const int row = g.cell_base + g.nx * (cy + g.ny * cz);
-                lo = a.cell_start[row + x_lo];
-                cnt = a.cell_start[row + x_hi + 1] - lo;
+            const long long cf = a.s_cell[p];
+            const int c = (int)(cf & 0xffffffffLL), fl = (int)(cf >> 32);
+            const int dy = (r % 3) - 1, dz = (r / 3) - 1;
+            const bool out = (dy < 0 && (fl & CELL_Y0)) || (dy > 0 && (fl & CELL_Y1)) ||
+                             (dz < 0 && (fl & CELL_Z0)) || (dz > 0 && (fl & CELL_Z1));
+            if (!out) {
+                const int row = c + g.nx * (dy + g.ny * dz); /* same ix, neighbouring (iy, iz) */
+                const int x_lo = row - ((fl & CELL_X0) ? 0 : 1), x_hi = row + ((fl & CELL_X1) ? 0 : 1);
+                lo = a.cell_start[x_lo];
+                cnt = a.cell_start[x_hi + 1] - lo;
             }
         }
         m.rowlo[t] = lo;
@@ -881,7 +891,7 @@ SASA_D double lr_cos(double A, double h2, double dj2, double R2, double D, doubl
 /* Screening pass over up to 32 neighbors (lim is even, lists are padded): bit k of the result
  * is set when neighbor k cuts an arc out of circle i (|cos alpha| < 1).  `buried` is raised if
  * some neighbor's circle contains circle i entirely (ref: src/sasa_lr.c:327-330).  The loop
- * counter is wave-uniform, so the bit masks are scalars and `buried` lives in a lane mask. */
+ * counter is wave-uniform, so the bit masks are scalars. */
 SASA_D unsigned lr_screen32(const Quad *PQ, int lim, double A, double h2, double z, bool &buried)
 {
     unsigned w = 0;
@@ -1041,11 +1051,14 @@ SASA_D void lr_phase_slices(const TileArgs &a, TileMem &m, int tile, int tid, in
         /* slice-major items: a wave holds a few ADJACENT slices of every atom of the tile, so
            its lanes have similar arc counts (polar slices cut few arcs, equatorial many) */
         const int items = na * ns;
+        const float inv_na = 1.0f / (float)na;
         for (int it = tid; it < items; it += B) {
 #ifdef SASA_ATOM_MAJOR
             const int la = it / ns, s = it - la * ns;
 #else
-            const int s = it / na, la = it - s * na;
+            int s = (int)(((float)it + 0.5f) * inv_na), la = it - s * na; /* it / na without the */
+            if (la < 0) { --s; la += na; }                              /* integer-division sequence */
+            else if (la >= na) { ++s; la -= na; }
 #endif
             const double Ri = m.aR[la], zi = m.az[la];
             const double delta = 2 * Ri / ns;       /* ref: src/sasa_lr.c:304 */

@@ -72,7 +72,8 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
     const int PB = SASA_PIPE_B;
     std::vector<GridS> grid(n_structs);
     std::vector<long long> ncells(n_structs + 1);
-    std::vector<int> sid(n), cell_of(n), rank(n), s_orig(n), s_cell(n), s_struct(n), status(ST_WORDS, 0);
+    std::vector<int> sid(n), rank(n), s_orig(n), s_struct(n), status(ST_WORDS, 0);
+    std::vector<long long> cell_of(n), s_cell(n);
     std::vector<double> sx(n), sy(n), sz(n), sr(n);
 
     PipeArgs pa;
