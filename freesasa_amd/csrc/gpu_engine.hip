@@ -439,7 +439,7 @@ static int run_batch_impl(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
             (!lr || !cfg.tab || t * resolution <= 4096)) {
             cfg.B = b; cfg.TA = t; cfg.pool = pl; cfg.ds = lr ? d : 0;
             cfg.items = lr ? (cfg.tab ? cfg.TA * resolution : cfg.B) : 1;
-            cfg.lds = tile_fixed_bytes(cfg.TA, cfg.items) + tile_list_bytes(cfg.TA, cfg.cap_idx, cfg.pool, cfg.npw, cfg.ds, cfg.B);
+            cfg.lds = tile_fixed_bytes(cfg.TA, cfg.items) + tile_list_bytes(cfg.TA, cfg.cap_idx, cfg.pool, cfg.lr, cfg.ds, cfg.B);
         }
     }
     const int n_tiles = (n + cfg.TA - 1) / cfg.TA;
@@ -452,7 +452,7 @@ static int run_batch_impl(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
     ta.grid = pa.grid; ta.cell_start = pa.cell_start;
     ta.n_atoms = n; ta.n_tiles = n_tiles; ta.TA = cfg.TA; ta.n_res = resolution; ta.tab = cfg.tab;
     ta.sasa = d_sasa; ta.counts = d_counts;
-    ta.cap_idx = cfg.cap_idx; ta.pool = cfg.pool; ta.npw = cfg.npw; ta.ds = cfg.ds;
+    ta.cap_idx = cfg.cap_idx; ta.pool = cfg.pool; ta.lr = cfg.lr; ta.ds = cfg.ds;
     ta.ovf_count = (int *)c->status.p + ST_OVF_TILES;
     ta.ovf_tiles = (int *)c->ovf_tiles.p;
     ta.work_tiles = nullptr;
@@ -516,7 +516,7 @@ static int run_batch_impl(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
     /* third launch: whatever is left (pathological densities), lists in a global slab */
     {
         const TileCfg fb = fallback_cfg(cfg, lr);
-        const size_t stride = tile_slab_bytes(fb.TA, fb.cap_idx, fb.pool, fb.npw, fb.ds, fb.B);
+        const size_t stride = tile_slab_bytes(fb.TA, fb.cap_idx, fb.pool, fb.lr, fb.ds, fb.B);
         if (ensure(c, c->slab, stride * SASA_FB_BLOCKS)) return -1;
         TileArgs tf = ta;
         tf.cap_idx = fb.cap_idx; tf.pool = fb.pool; tf.ds = fb.ds;

@@ -368,7 +368,7 @@ struct TileArgs {
     /* capacities of the per-tile lists */
     int cap_idx; /* neighbor indices per atom */
     int pool;    /* neighbor records per tile */
-    int npw;     /* doubles per neighbor record: 5 (L&R) or 4 (S&R) */
+    int lr;      /* 1: Lee-Richards records (z, D - Rj^2, 1/dij, beta); 0: Shrake-Rupley (x, y, z, Rj^2) */
     int ds;      /* spilled stack levels per thread (L&R) */
     /* overflow hand-off: a tile that does not fit this launch's capacities is appended to the
        next launch's work list (null in the last launch: error) */
@@ -401,7 +401,7 @@ struct TileMem {
     unsigned short *ki2;       /* [pool] L&R: list position of the pair behind each bucket-sorted beta */
     int *hist;                 /* [TA*LR_NBUCKET] L&R: beta histogram -> bucket cursors */
     Quad *pq;                  /* [pool] neighbor records */
-    double *pb;                /* [pool] L&R: beta, sorted */
+    double *sb;                /* L&R bucket sort: betas in bucket order (scratch inside pq) */
     Arc *stack;                /* [ds][B] spilled components */
 };
 
@@ -420,15 +420,15 @@ SASA_HD size_t tile_union_bytes(int TA, int cap_idx, int pool, int ds, int B, bo
     size_t u2 = sizeof(Arc) * (size_t)ds * B;
     return u1 > u2 ? u1 : u2;
 }
-SASA_HD size_t tile_list_bytes(int TA, int cap_idx, int pool, int npw, int ds, int B)
+SASA_HD size_t tile_list_bytes(int TA, int cap_idx, int pool, int lr, int ds, int B)
 {
-    return tile_union_bytes(TA, cap_idx, pool, ds, B, npw == 5) + align16(sizeof(double) * (size_t)pool) * npw;
+    return tile_union_bytes(TA, cap_idx, pool, ds, B, lr != 0) + sizeof(Quad) * (size_t)pool;
 }
 /* slab of the third launch (no aliasing) */
-SASA_HD size_t tile_slab_bytes(int TA, int cap_idx, int pool, int npw, int ds, int B)
+SASA_HD size_t tile_slab_bytes(int TA, int cap_idx, int pool, int lr, int ds, int B)
 {
     return align16(sizeof(int) * (size_t)TA * cap_idx) + align16(sizeof(double) * (size_t)pool) +
-           align16(sizeof(Arc) * (size_t)ds * B) + align16(sizeof(double) * (size_t)pool) * npw;
+           align16(sizeof(Arc) * (size_t)ds * B) + sizeof(Quad) * (size_t)pool;
 }
 
 template <bool GLOBAL>
@@ -453,14 +453,14 @@ SASA_D TileMem tile_carve(const TileArgs &a, char *smem, int items, int B, int b
         m.idx = (int *)p;
         m.tb = (double *)(p + align16(sizeof(int) * (size_t)a.TA * a.cap_idx));
         m.stack = (Arc *)p;
-        q = p + tile_union_bytes(a.TA, a.cap_idx, a.pool, a.ds, B, a.npw == 5);
+        q = p + tile_union_bytes(a.TA, a.cap_idx, a.pool, a.ds, B, a.lr != 0);
     }
     m.pq = (Quad *)q;
-    m.pb = (double *)(q + 4 * pw);
     /* the bucket sort's scratch lives in the record array, which stays unwritten until the sort's
-     * last phase (which no longer reads it): 2*pool + 128*TA bytes of the 32*pool */
+     * last phase (which no longer reads it): 2*pool + 128*TA + 8*pool bytes of the 32*pool */
     m.ki2 = (unsigned short *)q;
     m.hist = (int *)(q + align16(sizeof(unsigned short) * (size_t)a.pool));
+    m.sb = (double *)((char *)m.hist + align16(sizeof(int) * (size_t)LR_NBUCKET * a.TA));
     return m;
 }
 
@@ -563,18 +563,18 @@ SASA_D void tile_phase_neighbors(const TileArgs &a, TileMem &m, int tile, int ti
 }
 
 /* phase O: offsets into the pool (each of the first TA threads sums the counts before it) */
-SASA_D int pad4(int c, int npw) { return npw == 5 ? (c + 1) & ~1 : c; } /* L&R lists: even length */
+SASA_D int pad4(int c, int lr) { return lr ? (c + 1) & ~1 : c; } /* L&R lists: even length */
 SASA_D void tile_phase_offsets(const TileArgs &a, TileMem &m, int tid)
 {
     if (tid >= a.TA) return;
     int off = 0;
-    for (int k = 0; k < tid; ++k) off += pad4(m.acnt[k], a.npw);
+    for (int k = 0; k < tid; ++k) off += pad4(m.acnt[k], a.lr);
     const int c = m.acnt[tid];
     m.aoff[tid] = off;
     if (c > a.cap_idx) m.flags[0] = 1;
     if (tid == a.TA - 1) {
-        m.aoff[a.TA] = off + pad4(c, a.npw);
-        if (off + pad4(c, a.npw) > a.pool) m.flags[0] = 1;
+        m.aoff[a.TA] = off + pad4(c, a.lr);
+        if (off + pad4(c, a.lr) > a.pool) m.flags[0] = 1;
     }
     SASA_ATOMIC_MAX_LDS(&m.flags[2], c);
 }
@@ -726,6 +726,32 @@ SASA_D void lr_phase_beta(const TileArgs &a, TileMem &m, int tid, int B, bool bu
     }
 }
 
+/* The L&R record of neighbor q of an atom at (xi, yi): what the slice loop needs of the pair,
+ * independent of the slice.  With A = Ri'^2, B = Rj'^2 = Rj^2 - (zj - z)^2, D = dij^2 the
+ * reference's three geometric tests (src/sasa_lr.c:320-331) are exactly c >= 1 (no contact, j's
+ * circle inside i's, or j does not reach the plane: B <= 0 gives c >= (A + D)/(2 Ri' dij) >= 1)
+ * and c <= -1 (i inside j: slice buried) for c = (A + D - B)/(2 Ri' dij) (ref: :335)
+ *   = ((zj - z)^2 + (A + E)) * (1/dij) * (1/(2 Ri')),  E = D - Rj^2,
+ * so neither sqrt(Rj'^2) nor a division is needed per (pair, slice).  dij == 0: 1/dij = inf makes
+ * c = +-inf, deciding inside/buried like the reference; 0*inf = NaN (the reference's acos(0/0),
+ * two coincident equal circles) compares false -> no arc. */
+SASA_D Quad lr_record(const TileArgs &a, int q, double xi, double yi, double beta)
+{
+    const double xd = a.sx[q] - xi, yd = a.sy[q] - yi; /* ref: src/nb.c:445-448 */
+    const double rj = a.sr[q];
+    const double D = xd * xd + yd * yd; /* = d_ij^2 (ref: src/nb.c:438) */
+    double g = 0, h = 0;
+    if (D > 0) sqrt_rh(D, g, h);
+    Quad rec;
+    rec.x = a.sz[q];
+    rec.y = D - rj * rj;
+    rec.z = D > 0 ? 2.0 * h : INFINITY; /* 1/d_ij */
+    rec.w = beta;
+    return rec;
+}
+/* padding slot of an odd-length list: a record whose c is huge, so it never cuts an arc */
+SASA_D Quad lr_padding() { Quad d; d.x = 0; d.y = 1e300; d.z = 1; d.w = 0; return d; }
+
 /* phase P2: rank each pair by beta inside its atom's list and write the pair record at its
  * sorted position.  Sorting by the arc mid-angle is what lets the slice loop merge arcs with
  * a stack instead of the reference's per-slice insertion sort. */
@@ -740,12 +766,7 @@ SASA_D void lr_phase_rank(const TileArgs &a, TileMem &m, int tid, int B)
         int la = 0;
         while (m.aoff[la + 1] <= gp) ++la;
         const int o = m.aoff[la], nn = m.acnt[la], k = gp - o;
-        if (k >= nn) { /* padding slot: a record that never overlaps any slice */
-            Quad d; d.x = 0; d.y = 0; d.z = 1; d.w = 1;
-            m.pq[gp] = d;
-            m.pb[gp] = 0;
-            continue;
-        }
+        if (k >= nn) { m.pq[gp] = lr_padding(); continue; }
         const double beta = m.tb[gp];
         int rank = 0;
         /* two betas per LDS read (o is even, so the pair is 16-byte aligned); the slot after an
@@ -755,19 +776,7 @@ SASA_D void lr_phase_rank(const TileArgs &a, TileMem &m, int tid, int B)
             rank += (bb.s < beta || (bb.s == beta && t < k)) ? 1 : 0;
             rank += (t + 1 < nn && (bb.e < beta || (bb.e == beta && t + 1 < k))) ? 1 : 0;
         }
-        const int q = m.idx[la * a.cap_idx + k];
-        const double xd = a.sx[q] - m.ax[la], yd = a.sy[q] - m.ay[la];
-        const double rj = a.sr[q];
-        const double D = xd * xd + yd * yd; /* = d_ij^2 (ref: src/nb.c:438) */
-        double g = 0, h = 0;
-        if (D > 0) sqrt_rh(D, g, h);
-        Quad rec;
-        rec.x = a.sz[q];
-        rec.y = rj * rj;
-        rec.z = D;
-        rec.w = D > 0 ? 2.0 * h : INFINITY; /* 1/d_ij; coincident xy: see lr_cos */
-        m.pq[o + rank] = rec;
-        m.pb[o + rank] = beta;
+        m.pq[o + rank] = lr_record(a, m.idx[la * a.cap_idx + k], m.ax[la], m.ay[la], beta);
     }
 }
 
@@ -775,7 +784,7 @@ SASA_D void lr_phase_rank(const TileArgs &a, TileMem &m, int tid, int B)
  * tile's pairs fit LR_RANK_ROUNDS rounds of the workgroup:
  *   P1  histogram of beta over LR_NBUCKET angular buckets per atom (in lr_phase_beta)
  *   Pa  exclusive prefix per atom                       -> bucket cursors
- *   Pb  scatter (beta, list position) by bucket         -> pb / ki2   (order inside a bucket: arrival)
+ *   Pb  scatter (beta, list position) by bucket         -> sb / ki2   (order inside a bucket: arrival)
  *   Pc  exact rank inside the pair's own bucket (mean occupancy ~1)  -> final position, in registers
  *   Pd  write the records at their final positions.
  * The result is the same permutation as lr_phase_rank's: ascending beta, ties by list position. */
@@ -789,7 +798,7 @@ struct RankRegs { /* carried across the barrier between Pc and Pd */
 SASA_D bool lr_bucket_path(const TileArgs &a, const TileMem &m, int B)
 {
     const int total = m.aoff[a.TA];
-    return total <= LR_RANK_ROUNDS * B && total > 30 * a.TA;
+    return total <= LR_RANK_ROUNDS * B && total > 30 * a.TA; /* (scratch fits: 10*total + 128*TA < 32*total) */
 }
 
 SASA_D void lr_phase_prefix(const TileArgs &a, TileMem &m, int tid)
@@ -814,7 +823,7 @@ SASA_D void lr_phase_scatter(const TileArgs &a, TileMem &m, int tid, int B)
         if (k >= m.acnt[la]) continue;
         const double beta = m.tb[gp];
         const int slot = SASA_ATOMIC_ADD_LDS(&m.hist[la * LR_NBUCKET + lr_bucket(beta)], 1);
-        m.pb[o + slot] = beta; /* pb is free until Pd */
+        m.sb[o + slot] = beta;
         m.ki2[o + slot] = (unsigned short)k;
     }
 }
@@ -831,12 +840,12 @@ SASA_D void lr_phase_rank2(const TileArgs &a, TileMem &m, int tid, int B, RankRe
         while (m.aoff[la + 1] <= gp) ++la;
         const int o = m.aoff[la], s = gp - o;
         if (s >= m.acnt[la]) { rr.fin[r] = -2; continue; } /* padding slot */
-        const double beta = m.pb[gp];
+        const double beta = m.sb[gp];
         const int kme = m.ki2[gp], b = lr_bucket(beta);
         const int lo = b ? m.hist[la * LR_NBUCKET + b - 1] : 0, hi = m.hist[la * LR_NBUCKET + b]; /* cursors now = bucket ends */
         int rank = lo;
         for (int t = lo; t < hi; ++t) {
-            const double bt = m.pb[o + t];
+            const double bt = m.sb[o + t];
             rank += (bt < beta || (bt == beta && m.ki2[o + t] < kme)) ? 1 : 0;
         }
         rr.fin[r] = o + rank;
@@ -851,41 +860,19 @@ SASA_D void lr_phase_write(const TileArgs &a, TileMem &m, int tid, int B, const 
     for (int r = 0; r < LR_RANK_ROUNDS; ++r) {
         const int gp = tid + r * B;
         if (rr.fin[r] == -1) continue;
-        if (rr.fin[r] == -2) { /* padding slot: a record that never overlaps any slice */
-            Quad d; d.x = 0; d.y = 0; d.z = 1; d.w = 1;
-            m.pq[gp] = d;
-            m.pb[gp] = 0;
-            continue;
-        }
+        if (rr.fin[r] == -2) { m.pq[gp] = lr_padding(); continue; }
         int la = 0;
         while (m.aoff[la + 1] <= gp) ++la;
-        const int q = rr.q[r];
-        const double xd = a.sx[q] - m.ax[la], yd = a.sy[q] - m.ay[la];
-        const double rj = a.sr[q];
-        const double D = xd * xd + yd * yd; /* = d_ij^2 (ref: src/nb.c:438) */
-        double g = 0, h = 0;
-        if (D > 0) sqrt_rh(D, g, h);
-        Quad rec;
-        rec.x = a.sz[q];
-        rec.y = rj * rj;
-        rec.z = D;
-        rec.w = D > 0 ? 2.0 * h : INFINITY; /* 1/d_ij; coincident xy: see lr_cos */
-        m.pq[rr.fin[r]] = rec;
-        m.pb[rr.fin[r]] = m.tb[gp];
+        m.pq[rr.fin[r]] = lr_record(a, rr.q[r], m.ax[la], m.ay[la], m.tb[gp]);
     }
 }
 
-/* cos(alpha) of the arc that circle j cuts out of circle i in the slice, or a value outside
- * (-1,1).  With A = Ri'^2, B = Rj'^2, D = dij^2 the reference's three geometric tests
- * (src/sasa_lr.c:324-331) are exactly c >= 1 (no contact, or j inside i: no arc) and
- * c <= -1 (i inside j: slice buried) for c = (A + D - B)/(2 Ri' dij) (ref: :335), so neither
- * sqrt(Rj'^2) nor a division is needed per (pair, slice): h2 = 1/(2 Ri') is per slice, 1/dij
- * per pair.  dij == 0: c = +-inf decides inside/buried like the reference; 0*inf = NaN (the
- * reference's acos(0/0) case, two coincident equal circles) compares false -> no arc. */
-SASA_D double lr_cos(double A, double h2, double dj2, double R2, double D, double ginv)
+/* cos(alpha) of the arc record q cuts out of circle i (A = Ri'^2, h2 = 1/(2 Ri')) at height z,
+ * or a value outside (-1, 1): see lr_record */
+SASA_D double lr_cos(const Quad q, double A, double h2, double z)
 {
-    const double Bq = R2 - dj2;
-    return Bq > 0 ? ((A + D) - Bq) * (ginv * h2) : 2.0; /* ref: src/sasa_lr.c:320 dj < Rj */
+    const double dj = q.x - z;
+    return fma(dj, dj, A + q.y) * (q.z * h2);
 }
 
 /* Screening pass over up to 32 neighbors (lim is even, lists are padded): bit k of the result
@@ -896,29 +883,22 @@ SASA_D unsigned lr_screen32(const Quad *PQ, int lim, double A, double h2, double
 {
     unsigned w = 0;
     for (int k = 0; k < lim; k += 2) {
-        const Quad q0 = PQ[k], q1 = PQ[k + 1];
-        const double d0 = q0.x - z, d1 = q1.x - z;
-        const double B0 = q0.y - d0 * d0, B1 = q1.y - d1 * d1; /* Rj'^2; ref: :320 dj < Rj */
-        const double c0 = ((A + q0.z) - B0) * (q0.w * h2);     /* same expression as lr_cos */
-        const double c1 = ((A + q1.z) - B1) * (q1.w * h2);
-        const bool a0 = B0 > 0 && c0 < 1.0, a1 = B1 > 0 && c1 < 1.0;
+        const double c0 = lr_cos(PQ[k], A, h2, z), c1 = lr_cos(PQ[k + 1], A, h2, z);
+        const bool a0 = c0 < 1.0, a1 = c1 < 1.0;
         buried |= (a0 && !(c0 > -1.0)) || (a1 && !(c1 > -1.0));
         w |= (a0 ? 1u << k : 0u) | (a1 ? 2u << k : 0u);
     }
     return w;
 }
 
-/* Raw end points beta -+ alpha of the arc neighbor record q (mid-angle beta) buries on circle i
+/* Raw end points beta -+ alpha of the arc neighbor record q buries on circle i
  * (ref: src/sasa_lr.c:335-339).  The arc passes the origin iff inf < 0 or sup > 2pi (never
  * both: alpha < pi), which is when the reference's normalisation (:340-341) makes sup < inf. */
-SASA_D void lr_arc(const Quad q, double beta, double A, double h2, double z, double &inf, double &sup)
+SASA_D void lr_arc(const Quad q, double A, double h2, double z, double &inf, double &sup)
 {
-    const double dj = q.x - z;
-    /* same expression as lr_cos; the z-overlap test is known to hold for a screened neighbor */
-    const double c = ((A + q.z) - (q.y - dj * dj)) * (q.w * h2);
-    const double alpha = acos_fast(c);
-    inf = beta - alpha;
-    sup = beta + alpha;
+    const double alpha = acos_fast(lr_cos(q, A, h2, z)); /* the screening's value, bit for bit */
+    inf = q.w - alpha;
+    sup = q.w + alpha;
 }
 
 /* Sum of the exposed gaps given the disjoint components in ascending order (component c is
@@ -955,15 +935,15 @@ struct UnionState {
     int depth, wrap;
 };
 
-/* Feed the arcs of the set bits of w (neighbors PQ[k], PB[k]) to the union, ascending k = ascending beta. */
-SASA_D void lr_arcs32(unsigned w, const Quad *PQ, const double *PB, double A, double h2, double z,
+/* Feed the arcs of the set bits of w (neighbors PQ[k]) to the union, ascending k = ascending beta. */
+SASA_D void lr_arcs32(unsigned w, const Quad *PQ, double A, double h2, double z,
                       UnionState &u, Arc *stk, int stride, int ds, int *err)
 {
     while (w) {
         const int k = __builtin_ctz(w);
         w &= w - 1;
         double inf, sup;
-        lr_arc(PQ[k], PB[k], A, h2, z, inf, sup);
+        lr_arc(PQ[k], A, h2, z, inf, sup);
         if (inf < 0 || sup > SASA_TWOPI) {           /* ref: :340-351 arc passes the origin */
             const double wi = inf < 0 ? inf + SASA_TWOPI : inf;
             const double ws = sup > SASA_TWOPI ? sup - SASA_TWOPI : sup;
@@ -1002,7 +982,6 @@ SASA_D double lr_union_exact(const TileMem &m, int o, int nn, double A, double h
     for (int base = 0; base < nn; base += 64) { /* nn is even (padded) */
         const int lim = nn - base < 64 ? nn - base : 64;
         const Quad *PQ = m.pq + o + base;
-        const double *PB = m.pb + o + base;
         bool buried = false;
         unsigned lo = lr_screen32(PQ, lim < 32 ? lim : 32, A, h2, z, buried), hi = 0;
         if (lim > 32) hi = lr_screen32(PQ + 32, lim - 32, A, h2, z, buried);
@@ -1010,8 +989,8 @@ SASA_D double lr_union_exact(const TileMem &m, int o, int nn, double A, double h
 #ifdef SASA_ABLATE_ARCS /* timing attribution only: tools/build_variant.sh, never in the product */
         lo = hi = 0;
 #endif
-        lr_arcs32(lo, PQ, PB, A, h2, z, u, stk, stride, ds, err);
-        if (hi) lr_arcs32(hi, PQ + 32, PB + 32, A, h2, z, u, stk, stride, ds, err);
+        lr_arcs32(lo, PQ, A, h2, z, u, stk, stride, ds, err);
+        if (hi) lr_arcs32(hi, PQ + 32, A, h2, z, u, stk, stride, ds, err);
     }
     double res;
     const double ts = u.ts, te = u.te;
@@ -1259,7 +1238,7 @@ SASA_D int xcd_tile(int b, int n_tiles)
  * launch configuration (host side; shared by gpu_engine.hip and the test emulation)
  * ---------------------------------------------------------------------------------- */
 struct TileCfg {
-    int B, TA, tab, items, cap_idx, pool, npw, ds;
+    int B, TA, tab, items, cap_idx, pool, lr, ds;
     size_t lds;
 };
 
@@ -1306,24 +1285,26 @@ static inline TileCfg choose_cfg(int resolution, bool lr, int pool_hint = 0)
             }
     }
     c.items = lr ? (c.tab ? c.TA * resolution : c.B) : 1;
-    c.npw = lr ? 5 : 4;
+    c.lr = lr ? 1 : 0;
     c.cap_idx = 128;
     c.pool = 64 * c.TA < 128 ? 128 : 64 * c.TA;
     if (pool_hint > 0) c.pool = pool_hint;
     c.ds = lr ? 3 : 0; /* deeper arc stacks are rare: those tiles go to the second launch */
-    c.lds = tile_fixed_bytes(c.TA, c.items) + tile_list_bytes(c.TA, c.cap_idx, c.pool, c.npw, c.ds, c.B);
+    c.lds = tile_fixed_bytes(c.TA, c.items) + tile_list_bytes(c.TA, c.cap_idx, c.pool, c.lr, c.ds, c.B);
     if (pool_hint > 0) {
         /* occupancy comes in steps of whole workgroups per CU (160 KB of LDS): spend the slack of
            the current step on a larger pool instead of leaving it unused */
         const size_t cu_lds = 160 * 1024;
-        const size_t nblk = cu_lds / c.lds;
+        size_t nblk = cu_lds / c.lds;
+        const size_t wave_cap = (size_t)(20 * 64 / c.B); /* L&R: registers allow 5 waves per SIMD at best */
+        if (lr && nblk > wave_cap) nblk = wave_cap; /* (the S&R kernel is lighter) */
         if (nblk >= 1 && nblk < 32) {
             const size_t slack = cu_lds / nblk - c.lds;
-            c.pool += (int)(slack / (8 * (size_t)c.npw + (lr ? 8 : 0))) & ~1;
-            size_t lds2 = tile_fixed_bytes(c.TA, c.items) + tile_list_bytes(c.TA, c.cap_idx, c.pool, c.npw, c.ds, c.B);
+            c.pool += (int)(slack / (sizeof(Quad) + (lr ? 8 : 0))) & ~1;
+            size_t lds2 = tile_fixed_bytes(c.TA, c.items) + tile_list_bytes(c.TA, c.cap_idx, c.pool, c.lr, c.ds, c.B);
             while (cu_lds / lds2 < nblk && c.pool > pool_hint) { /* aliasing/rounding pushed it over */
                 c.pool -= 2;
-                lds2 = tile_fixed_bytes(c.TA, c.items) + tile_list_bytes(c.TA, c.cap_idx, c.pool, c.npw, c.ds, c.B);
+                lds2 = tile_fixed_bytes(c.TA, c.items) + tile_list_bytes(c.TA, c.cap_idx, c.pool, c.lr, c.ds, c.B);
             }
             c.lds = lds2;
         }
@@ -1370,7 +1351,7 @@ static inline TileCfg mid_cfg(const TileCfg &main_cfg, bool lr)
     c.pool = 2 * main_cfg.pool < 64 * c.TA ? 64 * c.TA : 2 * main_cfg.pool; /* twice the (adaptive) main pool */
     if (c.pool > 3072) c.pool = 3072;
     c.ds = lr ? 8 : 0;
-    c.lds = tile_fixed_bytes(c.TA, c.items) + tile_list_bytes(c.TA, c.cap_idx, c.pool, c.npw, c.ds, c.B);
+    c.lds = tile_fixed_bytes(c.TA, c.items) + tile_list_bytes(c.TA, c.cap_idx, c.pool, c.lr, c.ds, c.B);
     return c;
 }
 

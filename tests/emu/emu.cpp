@@ -144,7 +144,7 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
     if (force_cap_idx > 0) cfg.cap_idx = force_cap_idx;
     if (force_pool > 0) cfg.pool = force_pool;
     if (force_ds >= 0 && lr) cfg.ds = force_ds;
-    cfg.lds = tile_fixed_bytes(cfg.TA, cfg.items) + tile_list_bytes(cfg.TA, cfg.cap_idx, cfg.pool, cfg.npw, cfg.ds, cfg.B);
+    cfg.lds = tile_fixed_bytes(cfg.TA, cfg.items) + tile_list_bytes(cfg.TA, cfg.cap_idx, cfg.pool, cfg.lr, cfg.ds, cfg.B);
     const int n_tiles = (n + cfg.TA - 1) / cfg.TA;
     std::vector<int> ovf_tiles(n_tiles + 1);
 
@@ -155,7 +155,7 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
     ta.grid = pa.grid; ta.cell_start = pa.cell_start;
     ta.n_atoms = n; ta.n_tiles = n_tiles; ta.TA = cfg.TA; ta.n_res = resolution; ta.tab = cfg.tab;
     ta.unit_pts = unit_pts; ta.sasa = sasa; ta.counts = counts;
-    ta.cap_idx = cfg.cap_idx; ta.pool = cfg.pool; ta.npw = cfg.npw; ta.ds = cfg.ds;
+    ta.cap_idx = cfg.cap_idx; ta.pool = cfg.pool; ta.lr = cfg.lr; ta.ds = cfg.ds;
     ta.ovf_count = status.data() + ST_OVF_TILES; ta.ovf_tiles = ovf_tiles.data(); ta.status = status.data();
 
     ta.work_tiles = nullptr; ta.work_count = nullptr;
@@ -167,7 +167,7 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
         if (mid_cap_idx > 0) mc.cap_idx = mid_cap_idx;
         if (mid_pool > 0) mc.pool = mid_pool;
         if (mid_ds >= 0 && lr) mc.ds = mid_ds;
-        mc.lds = tile_fixed_bytes(mc.TA, mc.items) + tile_list_bytes(mc.TA, mc.cap_idx, mc.pool, mc.npw, mc.ds, mc.B);
+        mc.lds = tile_fixed_bytes(mc.TA, mc.items) + tile_list_bytes(mc.TA, mc.cap_idx, mc.pool, mc.lr, mc.ds, mc.B);
         TileArgs tm = ta;
         tm.cap_idx = mc.cap_idx; tm.pool = mc.pool; tm.ds = mc.ds;
         tm.work_tiles = ovf_tiles.data(); tm.work_count = status.data() + ST_OVF_TILES;
@@ -179,7 +179,7 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
         if (fb_cap_idx > 0) fb.cap_idx = fb_cap_idx;
         if (fb_pool > 0) fb.pool = fb_pool;
         if (fb_ds > 0 && lr) fb.ds = fb_ds;
-        const size_t stride = tile_slab_bytes(fb.TA, fb.cap_idx, fb.pool, fb.npw, fb.ds, fb.B);
+        const size_t stride = tile_slab_bytes(fb.TA, fb.cap_idx, fb.pool, fb.lr, fb.ds, fb.B);
         const int fb_blocks = 3; /* fewer than SASA_FB_BLOCKS so that the work loop wraps */
         std::vector<char> slab(stride * fb_blocks + 64);
         TileArgs tf = ta;
