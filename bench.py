@@ -126,9 +126,10 @@ def main():
     ap.add_argument("--structs", type=int, default=1000, help="structures per GPU")
     ap.add_argument("--atoms", type=int, default=10000, help="atoms per structure")
     ap.add_argument("--slices", type=int, default=20)
-    ap.add_argument("--workload", default="coil_lr", choices=["coil_lr", "globule_sr", "traj_lr"],
+    ap.add_argument("--workload", default="coil_lr", choices=["coil_lr", "globule_sr", "traj_lr", "sweep_lr"],
                     help="coil_lr: the headline metric (default).  globule_sr: BASELINE configs[1] proxy, "
-                         "ONE 200k-atom globule per GPU, Shrake-Rupley 100 points (secondary line)")
+                         "ONE 200k-atom globule per GPU, Shrake-Rupley 100 points (secondary line).  sweep_lr: configs[3] proxy, "
+                         "structures of log-uniform size 500..50 000 atoms dealt to the ranks by LPT on atom count")
     ap.add_argument("--points", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -157,6 +158,20 @@ def main():
         args.structs, args.atoms = 1, 200_000
         xyz, r = tools.globule(args.atoms, 77 + rank)
         offs = np.array([0, args.atoms], dtype=np.int64)
+    elif args.workload == "sweep_lr":
+        # whole-PDB sweep proxy: one global list of ragged structures, dealt to the ranks by
+        # longest-processing-time-first on the atom count (freesasa_amd/shard.py); weak scaling:
+        # the list grows with the number of ranks
+        from freesasa_amd import shard
+        if args.structs == 1000:
+            args.structs = 400
+        sizes = np.exp(np.random.default_rng(2024).uniform(np.log(500), np.log(50000), args.structs * world)).astype(np.int64)
+        mine = shard.lpt(sizes, world)[rank]
+        parts = [tools.coil(int(sizes[k]), 5000 + int(k)) for k in mine]
+        xyz = np.concatenate([p[0] for p in parts])
+        r = np.concatenate([p[1] for p in parts])
+        offs = np.concatenate([[0], np.cumsum(sizes[mine])]).astype(np.int64)
+        args.structs, args.atoms = len(mine), int(np.mean(sizes[mine]))
     else:
         # this rank's shard: its own independent structures (seeds are disjoint across ranks)
         xyz, r, offs = tools.coil_batch(args.structs, args.atoms, seed0=1000 + rank * args.structs)
@@ -202,10 +217,14 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    na = torch.tensor([float(n_atoms)], dtype=torch.float64, device=dev)   # ragged shards differ per rank
+    if world > 1:
+        dist.all_reduce(na, op=dist.ReduceOp.SUM)
+    atoms_all_ranks = int(na.item())
     st = ctx.stats()
 
     if rank == 0:
-        total_atoms = n_atoms * world * args.steps
+        total_atoms = atoms_all_ranks * args.steps
         value = total_atoms / elapsed
         kern_s = float(np.mean(k_ms)) * 1e-3
         achieved = ALGO_BYTES_PER_ATOM * n_atoms / kern_s / 1e9 if kern_s > 0 else None
@@ -215,6 +234,12 @@ def main():
             metric = f"atoms/sec SASA (S&R {args.points} points)"
             wl = (f"one synthetic {args.atoms}-atom globule per GPU (BASELINE configs[1] proxy: 4V6X is not available "
                   f"offline), Shrake-Rupley {args.points} test points, probe 1.4 A, inputs resident in HBM")
+        elif args.workload == "sweep_lr":
+            traffic = None
+            metric = f"atoms/sec SASA (L&R {args.slices} slices), ragged sweep"
+            wl = (f"{args.structs} synthetic random-coil structures per GPU of log-uniform size 500..50000 atoms "
+                  f"({n_atoms} atoms on rank 0; BASELINE configs[3] proxy), dealt to the ranks by LPT on atom count, "
+                  f"Lee-Richards {args.slices} slices, probe 1.4 A, inputs resident in HBM")
         else:
             metric = "atoms/sec SASA (L&R 20 slices)" if args.slices == 20 else f"atoms/sec SASA (L&R {args.slices} slices)"
             wl = (f"{args.structs} synthetic random-coil structures x {args.atoms} atoms per GPU "
@@ -241,7 +266,7 @@ def main():
                          "note": "nominal HBM roofline per north_star (40 B/atom); the kernel is fp64-VALU bound, "
                                  "see DESIGN.md"},
         }
-        if world == 1 and not args.no_cpu_baseline and not sr:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "coil_lr":
             base, err = cpu_baseline(xyz, r, offs, d_sasa.cpu().numpy())
             out["cpu_baseline"] = base
             out["max_abs_dsasa_vs_cpu"] = err

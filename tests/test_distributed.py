@@ -1,6 +1,6 @@
-"""World-size-2 CPU (gloo) test of the only multi-process logic the path has: independent
-structure shards per rank (disjoint seeds, no data-path collective) and the max-over-ranks
-timing reduction that bench.py performs."""
+"""World-size-2 CPU (gloo) tests of the only multi-process logic the path has: independent
+structure shards per rank (disjoint seeds or an LPT partition of one ragged list, no data-path
+collective) and the max-over-ranks / sum-of-atoms reductions that bench.py performs."""
 import os
 import socket
 import subprocess
@@ -50,3 +50,68 @@ def test_two_rank_sharding_gloo(tmp_path):
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
     assert res == {"t": 2.0, "distinct": True, "n": 12}
+
+
+SWEEP_WORKER = textwrap.dedent("""
+    import os, sys, json
+    import numpy as np
+    import torch, torch.distributed as dist
+    sys.path.insert(0, sys.argv[1])
+    import tools, oracle
+    from freesasa_amd import shard
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # bench.py --workload sweep_lr: one global ragged list, LPT on atom count
+    sizes = np.exp(np.random.default_rng(2024).uniform(np.log(20), np.log(400), 14)).astype(np.int64)
+    mine = shard.lpt(sizes, world)[rank]
+    o = oracle.Oracle()
+    tot = torch.zeros(len(sizes), dtype=torch.float64)
+    for k in mine:
+        xyz, r = tools.coil(int(sizes[k]), 5000 + int(k))
+        tot[k] = o.total(o.lee_richards(xyz, r))
+    dist.all_reduce(tot)                                    # host-side gather of results only
+    na = torch.tensor([float(sizes[mine].sum())], dtype=torch.float64)
+    dist.all_reduce(na)
+    if rank == 0:
+        ref = [o.total(o.lee_richards(*tools.coil(int(n), 5000 + k))) for k, n in enumerate(sizes)]
+        print(json.dumps({"atoms": int(na.item()), "expect_atoms": int(sizes.sum()),
+                          "same": bool(np.array_equal(tot.numpy(), np.array(ref)))}))
+    dist.barrier()
+    dist.destroy_process_group()
+""")
+
+
+def _run_two_ranks(tmp_path, source):
+    script = tmp_path / "worker.py"
+    script.write_text(source)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_two_rank_lpt_sweep_gloo(tmp_path):
+    res = _run_two_ranks(tmp_path, SWEEP_WORKER)
+    assert res["same"] and res["atoms"] == res["expect_atoms"]
+
+
+def test_partitions_cover_every_item_once_and_balance():
+    import numpy as np
+    from freesasa_amd import shard
+    sizes = np.exp(np.random.default_rng(7).uniform(np.log(500), np.log(50000), 3000)).astype(np.int64)
+    for parts in (shard.lpt(sizes, 8), shard.round_robin(len(sizes), 8)):
+        assert sorted(np.concatenate(parts).tolist()) == list(range(len(sizes)))
+    loads = np.array([sizes[p].sum() for p in shard.lpt(sizes, 8)])
+    assert loads.max() - loads.mean() <= sizes.max()          # LPT bound
+    assert loads.max() / loads.mean() < 1.001
+    # degenerate inputs
+    assert [len(p) for p in shard.lpt([5], 4)] == [1, 0, 0, 0]
+    assert all(len(p) == 0 for p in shard.lpt([], 3))
+    x, r, o = shard.gather_shard(np.arange(30.).reshape(10, 3), np.arange(10.), [0, 2, 5, 10], [2, 0])
+    assert o.tolist() == [0, 5, 7] and r.tolist() == [5, 6, 7, 8, 9, 0, 1] and x.shape == (7, 3)
