@@ -32,7 +32,11 @@ $(LIBDIR)/api.o: $(CSRC)/api.c include/freesasa_amd.h
 	@mkdir -p $(LIBDIR)
 	$(CC) $(CFLAGS) -c $< -o $@
 
-$(LIBDIR)/libfreesasa_amd.so: $(LIBDIR)/gpu_engine.o $(LIBDIR)/seam.o $(LIBDIR)/testpoints.o $(LIBDIR)/api.o
+$(LIBDIR)/ingest.o: $(CSRC)/ingest.c $(CSRC)/protor_table.h include/freesasa_ingest.h
+	@mkdir -p $(LIBDIR)
+	$(CC) $(CFLAGS) -Iinclude -pthread -c $< -o $@
+
+$(LIBDIR)/libfreesasa_amd.so: $(LIBDIR)/gpu_engine.o $(LIBDIR)/seam.o $(LIBDIR)/testpoints.o $(LIBDIR)/api.o $(LIBDIR)/ingest.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
 $(LIBDIR)/libfreesasa_amd_seam.a: $(LIBDIR)/gpu_engine.o $(LIBDIR)/seam.o $(LIBDIR)/testpoints.o

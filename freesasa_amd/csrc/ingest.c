@@ -1,0 +1,529 @@
+/* ingest.c — multi-threaded PDB -> packed (xyz, radius, class, residue segments) batches.
+ * Contract and scope: include/freesasa_ingest.h.  Host code only (gcc); no GPU involved.
+ *
+ * The rules that decide which atoms a file contributes, their order, coordinates, radii and
+ * residue boundaries restate the reference's reader so that a sweep through this loader computes
+ * on exactly the arrays `freesasa_structure_from_pdb` + `freesasa_structure_radius` would give:
+ *   record / hydrogen / alt-loc / model rules   ref: src/structure.c:644-722, src/pdb.c:259-281
+ *   fixed-column fields and length checks       ref: src/pdb.c:13-24, 148-237
+ *   element guess from the atom name            ref: src/structure.c:420-446
+ *   radius: classifier, else element, else 0    ref: src/structure.c:519-550, src/classifier.c:738-796, 1002-1017
+ *   residue boundaries                          ref: src/structure.c:473-512
+ * Lines are consumed the way fgets(line, 120) does (src/structure.c:654, src/pdb.h:22): physical
+ * lines longer than 119 characters continue as a new "line".
+ */
+#include "freesasa_ingest.h"
+
+#include <ctype.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <unistd.h>
+
+#include "protor_table.h"
+
+#define CHUNK 119 /* fgets(line, PDB_MAX_LINE_STRL = 120) */
+
+/* ------------------------------------------------------------------ classifier */
+
+/* first whitespace-delimited token of a field, like sscanf("%s") (ref: src/classifier.c:126-155) */
+static int first_token(const char *s, const char **tok)
+{
+    while (*s && isspace((unsigned char)*s)) ++s;
+    *tok = s;
+    int n = 0;
+    while (s[n] && !isspace((unsigned char)s[n])) ++n;
+    return n;
+}
+
+static uint64_t name_key(const char *res, int rl, const char *atom, int al)
+{
+    if (rl < 1 || rl > 3 || al < 1 || al > 4) return 0;
+    unsigned char b[7] = {' ', ' ', ' ', ' ', ' ', ' ', ' '};
+    memcpy(b, res, (size_t)rl);
+    memcpy(b + 3, atom, (size_t)al);
+    uint64_t k = 0;
+    for (int i = 0; i < 7; ++i) k = (k << 8) | b[i];
+    return k;
+}
+
+double freesasa_ingest_protor_radius(const char *res_name, const char *atom_name, int *cls)
+{
+    const char *rt, *at;
+    const int rl = first_token(res_name, &rt), al = first_token(atom_name, &at);
+    const uint64_t k = name_key(rt, rl, at, al);
+    if (cls) *cls = FREESASA_INGEST_UNKNOWN;
+    if (!k) return -1.0;
+    int lo = 0, hi = PROTOR_N - 1;
+    while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        if (protor_table[mid].key == k) {
+            if (cls) *cls = protor_table[mid].cls;
+            return protor_table[mid].radius;
+        }
+        if (protor_table[mid].key < k) lo = mid + 1;
+        else hi = mid - 1;
+    }
+    return -1.0;
+}
+
+double freesasa_ingest_guess_radius(const char *symbol)
+{
+    char s[3];
+    snprintf(s, 3, "%2s", symbol); /* right-justified, at most 2 characters */
+    for (int i = 0; i < ELEMENT_N; ++i)
+        if (strcmp(s, element_table[i].sym) == 0) return element_table[i].radius;
+    return -1.0;
+}
+
+/* ------------------------------------------------------------------ one file */
+
+typedef struct {
+    int64_t n, cap;
+    double *xyz, *rad;
+    uint8_t *cls;
+    int64_t nres, rescap;
+    int64_t *res_first;
+    char *res_name, *res_number, *res_chain;
+    int status;
+} parsed;
+
+static void parsed_free(parsed *p)
+{
+    free(p->xyz); free(p->rad); free(p->cls);
+    free(p->res_first); free(p->res_name); free(p->res_number); free(p->res_chain);
+    memset(p, 0, sizeof *p);
+}
+
+static int grow_atoms(parsed *p)
+{
+    if (p->n < p->cap) return 0;
+    const int64_t cap = p->cap ? 2 * p->cap : 4096;
+    double *x = realloc(p->xyz, sizeof(double) * 3 * (size_t)cap);
+    if (!x) return -1;
+    p->xyz = x;
+    double *r = realloc(p->rad, sizeof(double) * (size_t)cap);
+    if (!r) return -1;
+    p->rad = r;
+    uint8_t *c = realloc(p->cls, (size_t)cap);
+    if (!c) return -1;
+    p->cls = c;
+    p->cap = cap;
+    return 0;
+}
+
+static int grow_res(parsed *p)
+{
+    if (p->nres < p->rescap) return 0;
+    const int64_t cap = p->rescap ? 2 * p->rescap : 512;
+    int64_t *f = realloc(p->res_first, sizeof(int64_t) * (size_t)cap);
+    if (!f) return -1;
+    p->res_first = f;
+    char *a = realloc(p->res_name, 4 * (size_t)cap);
+    if (!a) return -1;
+    p->res_name = a;
+    char *b = realloc(p->res_number, 6 * (size_t)cap);
+    if (!b) return -1;
+    p->res_number = b;
+    char *c = realloc(p->res_chain, (size_t)cap);
+    if (!c) return -1;
+    p->res_chain = c;
+    p->rescap = cap;
+    return 0;
+}
+
+/* ATOM or HETATM and at least len characters (the line terminator counts, as in the reference's
+ * strlen on an fgets buffer; ref: src/pdb.c:13-24) */
+static int line_check(const char *line, size_t n, size_t len)
+{
+    (void)line; /* callers only pass lines already known to start with ATOM or HETATM */
+    return len >= 6 && n >= len;
+}
+
+/* ref: src/pdb.c:259-281, including what it does with lines that lack the element columns */
+static int is_hydrogen(const char *line, size_t n)
+{
+    char symbol[3] = {0, 0, 0};
+    if (line_check(line, n, 78)) { symbol[0] = line[76]; symbol[1] = line[77]; }
+    if (!line_check(line, n, 13)) return -1;
+    if (strncmp(symbol, " H", 2) == 0) return 1;
+    if (strncmp(symbol, " D", 2) == 0) return 1;
+    if (!(strncmp(symbol, "  ", 2) == 0)) return 0;
+    if (!(line[12] == ' ' || (line[12] >= '1' && line[12] <= '9'))) return 0;
+    if (line[12] == 'H' || line[13] == 'H') return 1;
+    if (line[12] == 'D' || line[13] == 'D') return 1;
+    return 0;
+}
+
+/* ref: src/structure.c:420-446 */
+static void guess_symbol(char *symbol, const char *name)
+{
+    if (name[0] == ' ' || (name[0] >= '1' && name[0] <= '9')) {
+        symbol[0] = ' '; symbol[1] = name[1];
+    } else if (name[3] == ' ') {
+        symbol[0] = name[0]; symbol[1] = name[1];
+    } else {
+        symbol[0] = ' '; symbol[1] = name[0];
+    }
+    symbol[2] = '\0';
+}
+
+static const double pow10_tab[16] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15};
+
+/* One number of the coordinate section with sscanf("%lf") semantics.  Plain decimals with at
+ * most 15 digits are converted exactly (integer / power of ten, both exact, one correctly rounded
+ * division = what strtod returns); anything else goes to strtod. */
+static int scan_double(const char **pp, double *out)
+{
+    const char *p = *pp;
+    while (*p && isspace((unsigned char)*p)) ++p;
+    const char *q = p;
+    int neg = 0;
+    if (*q == '-' || *q == '+') { neg = *q == '-'; ++q; }
+    uint64_t m = 0;
+    int digits = 0, frac = 0;
+    while (*q >= '0' && *q <= '9') { m = m * 10 + (uint64_t)(*q - '0'); ++digits; ++q; }
+    if (*q == '.') {
+        ++q;
+        while (*q >= '0' && *q <= '9') { m = m * 10 + (uint64_t)(*q - '0'); ++digits; ++frac; ++q; }
+    }
+    const int plain = digits >= 1 && digits <= 15 &&
+                      (*q == '\0' || *q == '-' || *q == '+' || isspace((unsigned char)*q));
+    if (plain) {
+        const double v = (double)m / pow10_tab[frac];
+        *out = neg ? -v : v;
+        *pp = q;
+        return 1;
+    }
+    char *end;
+    const double v = strtod(p, &end);
+    if (end == p) return 0;
+    *out = v;
+    *pp = end;
+    return 1;
+}
+
+/* Parses into p's buffers, which are reused from call to call (only the counters are reset). */
+static void parse_pdb(const char *text, size_t len, int options, parsed *p)
+{
+    p->n = 0; p->nres = 0; p->status = 0;
+    if ((options & FREESASA_INGEST_SKIP_UNKNOWN) && (options & FREESASA_INGEST_HALT_AT_UNKNOWN))
+        options &= ~FREESASA_INGEST_SKIP_UNKNOWN; /* the stricter one wins (ref: src/structure.c:596-597) */
+    char line[CHUNK + 1];
+    char the_alt = ' ';
+    char prev_number[6] = "", prev_chain = 0;
+    size_t pos = 0;
+    while (pos < len) {
+        const char *start = text + pos;
+        const size_t room = len - pos < CHUNK ? len - pos : CHUNK;
+        const char *nl = memchr(start, '\n', room);
+        size_t n = nl ? (size_t)(nl - start) + 1 : room;
+        pos += n;
+        if (n < 4 || (start[0] != 'A' && start[0] != 'H' && start[0] != 'E')) continue; /* not ATOM, HETATM or ENDMDL */
+        memcpy(line, start, n);
+        line[n] = '\0';
+        n = strlen(line); /* an embedded NUL ends the line, as it does for the reference's strlen */
+
+        const int is_atom = strncmp("ATOM", line, 4) == 0;
+        if (is_atom || ((options & FREESASA_INGEST_INCLUDE_HETATM) && strncmp("HETATM", line, 6) == 0)) {
+            if (is_hydrogen(line, n) && !(options & FREESASA_INGEST_INCLUDE_HYDROGEN)) continue;
+
+            /* the fields atom_new_from_line takes (ref: src/structure.c:199-235) */
+            const char alt = line_check(line, n, 16) ? line[16] : '\0';
+            char aname[5] = "", rname[4] = "", rnumber[6] = "", symbol[3] = "";
+            if (line_check(line, n, 16)) { memcpy(aname, line + 12, 4); aname[4] = '\0'; }
+            if (line_check(line, n, 20)) { memcpy(rname, line + 17, 3); rname[3] = '\0'; }
+            if (line_check(line, n, 27)) { memcpy(rnumber, line + 22, 5); rnumber[5] = '\0'; }
+            const char chain = line_check(line, n, 21) ? line[21] : '\0';
+            if (line_check(line, n, 78)) { symbol[0] = line[76]; symbol[1] = line[77]; symbol[2] = '\0'; }
+            if (!line_check(line, n, 78) || (symbol[0] == ' ' && symbol[1] == ' ')) {
+                /* (a line without a name column is either skipped by the alt-loc rule or fails at
+                   the coordinates below, so its symbol never matters) */
+                if (line_check(line, n, 16)) guess_symbol(symbol, aname);
+            }
+
+            /* alternate locations: keep blank ones and the first label seen (ref: :675-681) */
+            if ((alt != ' ' && the_alt == ' ') || alt == ' ') the_alt = alt;
+            else if (alt != ' ' && alt != the_alt) continue;
+
+            /* coordinates (ref: src/pdb.c:176-197) */
+            if (!line_check(line, n, 54)) { p->status = FREESASA_INGEST_EFORMAT; return; }
+            char sec[25];
+            memcpy(sec, line + 30, 24);
+            sec[24] = '\0';
+            double v[3];
+            const char *sp = sec;
+            if (!scan_double(&sp, &v[0]) || !scan_double(&sp, &v[1]) || !scan_double(&sp, &v[2])) {
+                p->status = FREESASA_INGEST_EFORMAT;
+                return;
+            }
+
+            /* radius (ref: src/structure.c:519-550, 606-612) */
+            double r;
+            int cls;
+            const double rc = freesasa_ingest_protor_radius(rname, aname, &cls);
+            if (options & FREESASA_INGEST_RADIUS_FROM_OCCUPANCY) {
+                r = 1;
+            } else if (rc >= 0) {
+                r = rc;
+            } else if (options & FREESASA_INGEST_HALT_AT_UNKNOWN) {
+                p->status = FREESASA_INGEST_EUNKNOWN;
+                return;
+            } else if (options & FREESASA_INGEST_SKIP_UNKNOWN) {
+                continue;
+            } else {
+                r = freesasa_ingest_guess_radius(symbol);
+                if (r < 0) r = +0.;
+            }
+            if (options & FREESASA_INGEST_RADIUS_FROM_OCCUPANCY) { /* ref: :696-701, src/pdb.c:31-49, 239-247 */
+                if (!line_check(line, n, 55)) { p->status = FREESASA_INGEST_EFORMAT; return; }
+                char buf[8];
+                size_t w = strlen(line + 54) < 6 ? strlen(line + 54) : 6;
+                memcpy(buf, line + 54, w);
+                buf[w] = '\0';
+                float occ;
+                if (sscanf(buf, "%f", &occ) != 1) { p->status = FREESASA_INGEST_EFORMAT; return; }
+                r = occ;
+            }
+
+            if (grow_atoms(p)) { p->status = FREESASA_INGEST_ENOMEM; return; }
+            /* a new residue starts when the residue number or the chain changes (ref: :488-496) */
+            if (p->n == 0 || strcmp(rnumber, prev_number) != 0 || chain != prev_chain) {
+                if (grow_res(p)) { p->status = FREESASA_INGEST_ENOMEM; return; }
+                p->res_first[p->nres] = p->n;
+                memset(p->res_name + 4 * p->nres, 0, 4);
+                memcpy(p->res_name + 4 * p->nres, rname, strlen(rname));
+                memset(p->res_number + 6 * p->nres, 0, 6);
+                memcpy(p->res_number + 6 * p->nres, rnumber, strlen(rnumber));
+                p->res_chain[p->nres] = chain;
+                ++p->nres;
+                memcpy(prev_number, rnumber, 6);
+                prev_chain = chain;
+            }
+            p->xyz[3 * p->n] = v[0]; p->xyz[3 * p->n + 1] = v[1]; p->xyz[3 * p->n + 2] = v[2];
+            p->rad[p->n] = r;
+            p->cls[p->n] = (uint8_t)cls;
+            ++p->n;
+        }
+        if (!(options & FREESASA_INGEST_JOIN_MODELS) && strncmp("ENDMDL", line, 6) == 0) break; /* ref: :705-708 */
+    }
+    if (p->n == 0) p->status = FREESASA_INGEST_EEMPTY;
+}
+
+/* Whole file into a buffer that is reused from call to call.  0 on success. */
+static int read_file(const char *path, char **buf, size_t *cap, size_t *len)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return -1;
+    size_t n = 0;
+    for (;;) {
+        if (n == *cap) {
+            const size_t nc = *cap ? 2 * *cap : (size_t)1 << 20;
+            char *nb = realloc(*buf, nc);
+            if (!nb) { fclose(f); return -1; }
+            *buf = nb;
+            *cap = nc;
+        }
+        const size_t got = fread(*buf + n, 1, *cap - n, f);
+        n += got;
+        if (got == 0) break;
+    }
+    const int bad = ferror(f);
+    fclose(f);
+    *len = n;
+    return bad ? -1 : 0;
+}
+
+/* exact-size copy of a worker's scratch result (the scratch buffers stay with the worker) */
+static int compact(const parsed *s, parsed *d)
+{
+    memset(d, 0, sizeof *d);
+    d->status = s->status;
+    if (s->status || s->n == 0) return 0;
+    d->xyz = malloc(sizeof(double) * 3 * (size_t)s->n);
+    d->rad = malloc(sizeof(double) * (size_t)s->n);
+    d->cls = malloc((size_t)s->n);
+    d->res_first = malloc(sizeof(int64_t) * (size_t)s->nres);
+    d->res_name = malloc(4 * (size_t)s->nres);
+    d->res_number = malloc(6 * (size_t)s->nres);
+    d->res_chain = malloc((size_t)s->nres);
+    if (!d->xyz || !d->rad || !d->cls || !d->res_first || !d->res_name || !d->res_number || !d->res_chain) {
+        parsed_free(d);
+        d->status = FREESASA_INGEST_ENOMEM;
+        return -1;
+    }
+    memcpy(d->xyz, s->xyz, sizeof(double) * 3 * (size_t)s->n);
+    memcpy(d->rad, s->rad, sizeof(double) * (size_t)s->n);
+    memcpy(d->cls, s->cls, (size_t)s->n);
+    memcpy(d->res_first, s->res_first, sizeof(int64_t) * (size_t)s->nres);
+    memcpy(d->res_name, s->res_name, 4 * (size_t)s->nres);
+    memcpy(d->res_number, s->res_number, 6 * (size_t)s->nres);
+    memcpy(d->res_chain, s->res_chain, (size_t)s->nres);
+    d->n = d->cap = s->n;
+    d->nres = d->rescap = s->nres;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ the batch */
+
+typedef struct {
+    const char *const *paths;
+    const char *const *texts;
+    const size_t *lens;
+    int n, options;
+    parsed *res;
+    int next; /* work counter */
+    pthread_mutex_t mu;
+} job;
+
+static void *worker(void *arg)
+{
+    job *j = (job *)arg;
+    /* per-thread scratch, reused for every input this thread takes: the file text and the growing
+       parse arrays (fresh allocations per file would spend the time in page faults and mmap) */
+    parsed scratch;
+    memset(&scratch, 0, sizeof scratch);
+    char *text = NULL;
+    size_t cap = 0;
+    for (;;) {
+        pthread_mutex_lock(&j->mu);
+        const int k = j->next++;
+        pthread_mutex_unlock(&j->mu);
+        if (k >= j->n) break;
+        if (j->texts) {
+            parse_pdb(j->texts[k], j->lens[k], j->options, &scratch);
+        } else {
+            size_t len = 0;
+            if (read_file(j->paths[k], &text, &cap, &len)) {
+                scratch.n = 0; scratch.nres = 0;
+                scratch.status = FREESASA_INGEST_EIO;
+            } else {
+                parse_pdb(text, len, j->options, &scratch);
+            }
+        }
+        compact(&scratch, &j->res[k]); /* failed inputs contribute an empty structure */
+    }
+    free(text);
+    parsed_free(&scratch);
+    return NULL;
+}
+
+void freesasa_ingest_free(freesasa_ingest_batch *b)
+{
+    if (!b) return;
+    free(b->xyz); free(b->radii); free(b->atom_class); free(b->offsets); free(b->res_first);
+    free(b->res_offsets); free(b->res_name); free(b->res_number); free(b->res_chain); free(b->status);
+    memset(b, 0, sizeof *b);
+}
+
+static int run(job *j, int n_threads, freesasa_ingest_batch *out)
+{
+    memset(out, 0, sizeof *out);
+    const int supported = FREESASA_INGEST_INCLUDE_HETATM | FREESASA_INGEST_INCLUDE_HYDROGEN | FREESASA_INGEST_JOIN_MODELS |
+                          FREESASA_INGEST_HALT_AT_UNKNOWN | FREESASA_INGEST_SKIP_UNKNOWN | FREESASA_INGEST_RADIUS_FROM_OCCUPANCY;
+    if (j->options & ~supported) return FREESASA_INGEST_EOPTION;
+    if (j->n < 0) return FREESASA_INGEST_EOPTION;
+    j->res = calloc((size_t)(j->n > 0 ? j->n : 1), sizeof(parsed));
+    if (!j->res) return FREESASA_INGEST_ENOMEM;
+    j->next = 0;
+    pthread_mutex_init(&j->mu, NULL);
+    if (n_threads <= 0) { /* default: the cores, but no more threads than pay for their start-up */
+        n_threads = (int)sysconf(_SC_NPROCESSORS_ONLN);
+        if (n_threads > 64) n_threads = 64;
+        if (n_threads > j->n / 4) n_threads = j->n / 4;
+    }
+    if (n_threads > j->n) n_threads = j->n;
+    if (n_threads < 1) n_threads = 1;
+    pthread_t *th = calloc((size_t)n_threads, sizeof(pthread_t));
+    int started = 0;
+    if (th)
+        for (; started < n_threads - 1; ++started)
+            if (pthread_create(&th[started], NULL, worker, j)) break;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    worker(j); /* the calling thread works too */
+    for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (getenv("FREESASA_INGEST_TIMING"))
+        fprintf(stderr, "ingest: %d inputs, %d threads, parse %.3f ms\n", j->n, started + 1,
+                1e3 * (double)(t1.tv_sec - t0.tv_sec) + 1e-6 * (double)(t1.tv_nsec - t0.tv_nsec));
+    free(th);
+    pthread_mutex_destroy(&j->mu);
+
+    int64_t na = 0, nr = 0;
+    for (int k = 0; k < j->n; ++k) { na += j->res[k].n; nr += j->res[k].nres; }
+    out->n_structs = j->n;
+    out->n_atoms = na;
+    out->n_residues = nr;
+    out->xyz = malloc(sizeof(double) * 3 * (size_t)(na ? na : 1));
+    out->radii = malloc(sizeof(double) * (size_t)(na ? na : 1));
+    out->atom_class = malloc((size_t)(na ? na : 1));
+    out->offsets = malloc(sizeof(int64_t) * ((size_t)j->n + 1));
+    out->res_first = malloc(sizeof(int64_t) * ((size_t)nr + 1));
+    out->res_offsets = malloc(sizeof(int64_t) * ((size_t)j->n + 1));
+    out->res_name = malloc(4 * (size_t)(nr ? nr : 1));
+    out->res_number = malloc(6 * (size_t)(nr ? nr : 1));
+    out->res_chain = malloc((size_t)(nr ? nr : 1));
+    out->status = malloc(sizeof(int32_t) * (size_t)(j->n ? j->n : 1));
+    int rc = 0;
+    if (!out->xyz || !out->radii || !out->atom_class || !out->offsets || !out->res_first || !out->res_offsets ||
+        !out->res_name || !out->res_number || !out->res_chain || !out->status) {
+        rc = FREESASA_INGEST_ENOMEM;
+    } else {
+        int64_t a = 0, r = 0;
+        for (int k = 0; k < j->n; ++k) {
+            const parsed *p = &j->res[k];
+            out->offsets[k] = a;
+            out->res_offsets[k] = r;
+            out->status[k] = p->status;
+            if (p->n) {
+                memcpy(out->xyz + 3 * a, p->xyz, sizeof(double) * 3 * (size_t)p->n);
+                memcpy(out->radii + a, p->rad, sizeof(double) * (size_t)p->n);
+                memcpy(out->atom_class + a, p->cls, (size_t)p->n);
+            }
+            for (int64_t i = 0; i < p->nres; ++i) out->res_first[r + i] = a + p->res_first[i];
+            if (p->nres) {
+                memcpy(out->res_name + 4 * r, p->res_name, 4 * (size_t)p->nres);
+                memcpy(out->res_number + 6 * r, p->res_number, 6 * (size_t)p->nres);
+                memcpy(out->res_chain + r, p->res_chain, (size_t)p->nres);
+            }
+            a += p->n;
+            r += p->nres;
+        }
+        out->offsets[j->n] = a;
+        out->res_offsets[j->n] = r;
+        out->res_first[nr] = a;
+    }
+    for (int k = 0; k < j->n; ++k) parsed_free(&j->res[k]);
+    free(j->res);
+    if (getenv("FREESASA_INGEST_TIMING")) {
+        struct timespec t2;
+        clock_gettime(CLOCK_MONOTONIC, &t2);
+        fprintf(stderr, "ingest: assembly of %lld atoms %.3f ms\n", (long long)na,
+                1e3 * (double)(t2.tv_sec - t1.tv_sec) + 1e-6 * (double)(t2.tv_nsec - t1.tv_nsec));
+    }
+    if (rc) freesasa_ingest_free(out);
+    return rc;
+}
+
+int freesasa_ingest_pdb_files(const char *const *paths, int n_paths, int options, int n_threads,
+                              freesasa_ingest_batch *out)
+{
+    if (!out) return FREESASA_INGEST_EOPTION;
+    job j;
+    memset(&j, 0, sizeof j);
+    j.paths = paths; j.n = n_paths; j.options = options;
+    return run(&j, n_threads, out);
+}
+
+int freesasa_ingest_pdb_texts(const char *const *texts, const size_t *lens, int n_texts, int options,
+                              int n_threads, freesasa_ingest_batch *out)
+{
+    if (!out) return FREESASA_INGEST_EOPTION;
+    job j;
+    memset(&j, 0, sizeof j);
+    j.texts = texts; j.lens = lens; j.n = n_texts; j.options = options;
+    return run(&j, n_threads, out);
+}

@@ -1,0 +1,125 @@
+"""Python face of include/freesasa_ingest.h: multi-threaded PDB -> packed batch.
+
+    batch = ingest.load_pdb_files(paths)            # host threads, one structure per file
+    sasa, totals = freesasa_amd.calc_batch(batch.xyz, batch.radii, batch.offsets)
+    per_res = batch.residue_sums(sasa)              # or GpuContext.segment_sums on the device
+
+What a file contributes is what the reference's freesasa_structure_from_pdb() holds for it
+(ref: src/structure.c:644-722); the parsing itself is C (freesasa_amd/csrc/ingest.c)."""
+import ctypes as C
+
+import numpy as np
+
+from . import lib
+
+INCLUDE_HETATM, INCLUDE_HYDROGEN, JOIN_MODELS = 1, 1 << 2, 1 << 5     # ref: src/freesasa.h:182-191
+HALT_AT_UNKNOWN, SKIP_UNKNOWN, RADIUS_FROM_OCCUPANCY = 1 << 6, 1 << 7, 1 << 8
+OK, EIO, EFORMAT, EEMPTY, EUNKNOWN, EOPTION, ENOMEM = range(7)
+APOLAR, POLAR, UNKNOWN = 0, 1, 2
+
+
+class _CBatch(C.Structure):
+    _fields_ = [("n_structs", C.c_int32), ("n_atoms", C.c_int64), ("n_residues", C.c_int64),
+                ("xyz", C.POINTER(C.c_double)), ("radii", C.POINTER(C.c_double)),
+                ("atom_class", C.POINTER(C.c_uint8)), ("offsets", C.POINTER(C.c_int64)),
+                ("res_first", C.POINTER(C.c_int64)), ("res_offsets", C.POINTER(C.c_int64)),
+                ("res_name", C.POINTER(C.c_char)), ("res_number", C.POINTER(C.c_char)),
+                ("res_chain", C.POINTER(C.c_char)), ("status", C.POINTER(C.c_int32))]
+
+
+def _arr(ptr, n, dtype):
+    if n == 0:
+        return np.zeros(0, dtype=dtype)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+
+
+class Batch:
+    """numpy copy of a freesasa_ingest_batch (field meanings: include/freesasa_ingest.h)."""
+
+    def __init__(self, cb):
+        na, nr, ns = cb.n_atoms, cb.n_residues, cb.n_structs
+        self.n_structs, self.n_atoms, self.n_residues = ns, na, nr
+        self.xyz = _arr(cb.xyz, 3 * na, np.float64).reshape(-1, 3)
+        self.radii = _arr(cb.radii, na, np.float64)
+        self.atom_class = _arr(cb.atom_class, na, np.uint8)
+        self.offsets = _arr(cb.offsets, ns + 1, np.int64)
+        self.res_first = _arr(cb.res_first, nr + 1, np.int64)
+        self.res_offsets = _arr(cb.res_offsets, ns + 1, np.int64)
+        self.status = _arr(cb.status, ns, np.int32)
+        # residue labels stay fixed-width byte arrays until somebody asks for strings
+        self.res_name_raw = np.frombuffer(C.string_at(cb.res_name, 4 * nr) if nr else b"", dtype="S4").copy()
+        self.res_number_raw = np.frombuffer(C.string_at(cb.res_number, 6 * nr) if nr else b"", dtype="S6").copy()
+        self.res_chain_raw = np.frombuffer(C.string_at(cb.res_chain, nr) if nr else b"", dtype="S1").copy()
+
+    @property
+    def res_name(self):
+        return [v.decode() for v in self.res_name_raw.tolist()]
+
+    @property
+    def res_number(self):
+        return [v.decode() for v in self.res_number_raw.tolist()]
+
+    @property
+    def res_chain(self):
+        return [v.decode() for v in self.res_chain_raw.tolist()]
+
+    def residue_sums(self, per_atom):
+        """Host-side segmented sum over the residues (the device-side one is GpuContext.segment_sums)."""
+        per_atom = np.asarray(per_atom, dtype=np.float64)
+        if self.n_residues == 0:
+            return np.zeros(0)
+        return np.add.reduceat(np.append(per_atom, 0.0), self.res_first[:-1])
+
+
+def _proto():
+    L = lib()
+    if not getattr(L, "_ingest_ready", False):
+        L.freesasa_ingest_pdb_files.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.POINTER(_CBatch)]
+        L.freesasa_ingest_pdb_texts.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.c_int,
+                                                C.POINTER(_CBatch)]
+        L.freesasa_ingest_free.argtypes = [C.POINTER(_CBatch)]
+        L.freesasa_ingest_free.restype = None
+        L.freesasa_ingest_protor_radius.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_int)]
+        L.freesasa_ingest_protor_radius.restype = C.c_double
+        L.freesasa_ingest_guess_radius.argtypes = [C.c_char_p]
+        L.freesasa_ingest_guess_radius.restype = C.c_double
+        L._ingest_ready = True
+    return L
+
+
+def _finish(L, rc, cb):
+    if rc:
+        raise RuntimeError(f"freesasa_ingest failed with code {rc}")
+    try:
+        return Batch(cb)
+    finally:
+        L.freesasa_ingest_free(C.byref(cb))
+
+
+def load_pdb_files(paths, options=0, n_threads=0):
+    """Read PDB files into one Batch; per-file failures are in batch.status (empty structures)."""
+    L = _proto()
+    arr = (C.c_char_p * len(paths))(*[str(p).encode() for p in paths])
+    cb = _CBatch()
+    return _finish(L, L.freesasa_ingest_pdb_files(arr, len(paths), options, n_threads, C.byref(cb)), cb)
+
+
+def load_pdb_texts(texts, options=0, n_threads=0):
+    """Same for PDB texts in memory (bytes or str)."""
+    L = _proto()
+    raw = [t.encode() if isinstance(t, str) else bytes(t) for t in texts]
+    arr = (C.c_char_p * len(raw))(*raw)
+    lens = (C.c_size_t * len(raw))(*[len(t) for t in raw])
+    cb = _CBatch()
+    return _finish(L, L.freesasa_ingest_pdb_texts(arr, lens, len(raw), options, n_threads, C.byref(cb)), cb)
+
+
+def protor_radius(res_name, atom_name):
+    """(radius, class) of the ProtOr classifier; radius -1.0 and class UNKNOWN if the atom is not known."""
+    cls = C.c_int()
+    r = _proto().freesasa_ingest_protor_radius(res_name.encode(), atom_name.encode(), C.byref(cls))
+    return r, cls.value
+
+
+def guess_radius(symbol):
+    return _proto().freesasa_ingest_guess_radius(symbol.encode())

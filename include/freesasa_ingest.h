@@ -1,0 +1,95 @@
+/* freesasa_ingest.h — batched PDB -> (xyz, radius) ingestion for structure sweeps.
+ *
+ * once the SASA kernels run at 1e8-1e9 atoms/s, reading the structures is the
+ * bottleneck of a whole-PDB sweep.  This is a host-side, multi-threaded loader that produces the
+ * packed batch the GPU entry points take (include/freesasa_gpu.h: concatenated xyz / radii plus
+ * CSR offsets) and, for per-residue results, the residue segments freesasa_gpu_segment_sums_dev
+ * reduces over.  It is additive: the reference has no batch reader (its CLI reads one file at a
+ * time, src/main.cc:763-779), and the drop-in library keeps using the reference's own parser.
+ *
+ * What a file contributes is what the reference's freesasa_structure_from_pdb() would hold for it
+ * (src/structure.c:644-722 with src/pdb.c:13-283 and the default ProtOr classifier,
+ * src/classifier.c:738-796, 1002-1017): same atoms in the same order, same coordinates, same
+ * radii, same polar/apolar classes, same residue boundaries.  Pinned by tests/test_ingest.py
+ * against vectors minted from the reference library for every PDB file of its test suite.
+ */
+#ifndef FREESASA_INGEST_H
+#define FREESASA_INGEST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* The reference's freesasa_structure_options bits that apply to one-structure-per-file reading
+ * (ref: src/freesasa.h:182-191; same values).  SEPARATE_MODELS / SEPARATE_CHAINS are not
+ * supported here: FREESASA_INGEST_EOPTION. */
+enum {
+    FREESASA_INGEST_INCLUDE_HETATM = 1,
+    FREESASA_INGEST_INCLUDE_HYDROGEN = 1 << 2,
+    FREESASA_INGEST_JOIN_MODELS = 1 << 5,
+    FREESASA_INGEST_HALT_AT_UNKNOWN = 1 << 6,
+    FREESASA_INGEST_SKIP_UNKNOWN = 1 << 7,
+    FREESASA_INGEST_RADIUS_FROM_OCCUPANCY = 1 << 8
+};
+
+/* per-input status */
+enum {
+    FREESASA_INGEST_OK = 0,
+    FREESASA_INGEST_EIO = 1,      /* cannot open / read the file */
+    FREESASA_INGEST_EFORMAT = 2,  /* an ATOM line too short for coordinates, or unreadable numbers
+                                     (the reference returns NULL: src/structure.c:683-685) */
+    FREESASA_INGEST_EEMPTY = 3,   /* no valid ATOM/HETATM line (ref: src/structure.c:710-713) */
+    FREESASA_INGEST_EUNKNOWN = 4, /* HALT_AT_UNKNOWN and an atom the classifier does not know */
+    FREESASA_INGEST_EOPTION = 5,  /* unsupported option bits */
+    FREESASA_INGEST_ENOMEM = 6
+};
+
+/* atom classes (ref: src/freesasa.h:163-167) */
+enum { FREESASA_INGEST_APOLAR = 0, FREESASA_INGEST_POLAR = 1, FREESASA_INGEST_UNKNOWN = 2 };
+
+/* A packed batch.  Structure s owns atoms [offsets[s], offsets[s+1]) and residues
+ * [res_offsets[s], res_offsets[s+1]); residue r owns atoms [res_first[r], res_first[r+1]).
+ * An input that failed contributes an empty structure (status[s] != 0).  All arrays are
+ * malloc'd by the library and released by freesasa_ingest_free(). */
+typedef struct freesasa_ingest_batch {
+    int32_t n_structs;
+    int64_t n_atoms;
+    int64_t n_residues;
+    double *xyz;          /* [3 * n_atoms] x1,y1,z1,... (ref: src/coord.h:26-38 layout) */
+    double *radii;        /* [n_atoms] */
+    uint8_t *atom_class;  /* [n_atoms] FREESASA_INGEST_APOLAR / POLAR / UNKNOWN */
+    int64_t *offsets;     /* [n_structs + 1] */
+    int64_t *res_first;   /* [n_residues + 1] batch-wide atom index of each residue's first atom */
+    int64_t *res_offsets; /* [n_structs + 1] */
+    char *res_name;       /* [4 * n_residues] residue names, NUL padded ("ALA\0") */
+    char *res_number;     /* [6 * n_residues] residue number incl. insertion code (" 123A\0") */
+    char *res_chain;      /* [n_residues] chain label */
+    int32_t *status;      /* [n_structs] */
+} freesasa_ingest_batch;
+
+/* Read n_paths PDB files with n_threads host threads (<= 0: one per online core, at most 64 and
+ * at most one per four inputs) into one batch.
+ * Returns 0 if the batch could be built (individual failures are in status[]), a
+ * FREESASA_INGEST_E* code otherwise (out is zeroed). */
+int freesasa_ingest_pdb_files(const char *const *paths, int n_paths, int options, int n_threads,
+                              freesasa_ingest_batch *out);
+
+/* Same for PDB texts already in memory (texts[k] has lens[k] bytes, no terminator needed). */
+int freesasa_ingest_pdb_texts(const char *const *texts, const size_t *lens, int n_texts, int options,
+                              int n_threads, freesasa_ingest_batch *out);
+
+void freesasa_ingest_free(freesasa_ingest_batch *batch);
+
+/* The classifier on its own (ref: freesasa_classifier_radius / _class with the ProtOr classifier,
+ * src/classifier.c:781-813): radius in A or -1.0 if unknown; *cls (may be NULL) receives the class. */
+double freesasa_ingest_protor_radius(const char *res_name, const char *atom_name, int *cls);
+/* ref: freesasa_guess_radius, src/classifier.c:1002-1017 */
+double freesasa_ingest_guess_radius(const char *symbol);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

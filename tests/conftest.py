@@ -46,3 +46,16 @@ def read_bfactor_pdb(path):
                 rad.append(float(line[54:60]))
                 sasa.append(float(line[60:66]))
     return np.array(xyz), np.array(rad), np.array(sasa)
+
+
+def read_seq_reference():
+    """(chain, residue number, residue name, area) per line of the reference's per-residue S&R
+    output for 1UBQ (tests/data/seq.reference, tests/test-cli.in:298-299)."""
+    rows = []
+    with open(os.path.join(GOLDEN, "seq.reference")) as fh:
+        for line in fh:
+            if line.startswith("SEQ"):
+                head, area = line.split(":")
+                _, chain, number, name = head.split()
+                rows.append((chain, number, name, float(area)))
+    return rows

@@ -31,11 +31,12 @@ def _declared_symbols(header):
 def test_exports_every_declared_symbol(L):
     out = subprocess.run(["nm", "-D", "--defined-only", fa.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = {line.split()[-1] for line in out.splitlines() if line.strip()}
-    declared = _declared_symbols("freesasa_amd.h") | _declared_symbols("freesasa_gpu.h")
+    declared = _declared_symbols("freesasa_amd.h") | _declared_symbols("freesasa_gpu.h") | _declared_symbols("freesasa_ingest.h")
     assert {"freesasa_calc_coord", "freesasa_calc_structure", "freesasa_result_free",
             "freesasa_default_parameters", "FREESASA_DEF_NUMBER_THREADS", "freesasa_lee_richards",
             "freesasa_shrake_rupley", "freesasa_gpu_lr_batch_dev", "freesasa_gpu_calc_batch",
-            "freesasa_gpu_trajectory", "freesasa_gpu_segment_sums_dev"} <= declared
+            "freesasa_gpu_trajectory", "freesasa_gpu_segment_sums_dev", "freesasa_ingest_pdb_files",
+            "freesasa_ingest_pdb_texts", "freesasa_ingest_free"} <= declared
     missing = declared - exported
     assert not missing, f"declared in include/ but not exported: {sorted(missing)}"
 

@@ -1,0 +1,147 @@
+"""Batched PDB ingestion (include/freesasa_ingest.h) against vectors minted from
+the reference library (tests/golden/make_ingest_golden.py): for every PDB file of the reference's
+test suite and a set of corner-case inputs, under ten option sets, the loader must hold exactly
+what freesasa_structure_from_pdb() holds — same atoms, bit-identical coordinates and radii, same
+classes, same residue boundaries and labels — and fail where the reference fails."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+from freesasa_amd import ingest
+
+PDB = os.path.join(ROOT, "tests", "golden", "pdb")
+with open(os.path.join(ROOT, "tests", "golden", "ingest.json")) as fh:
+    GOLD = json.load(fh)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def labels_digest(b, lo=0, hi=None):
+    hi = b.n_residues if hi is None else hi
+    return hashlib.sha256("\n".join(f"{b.res_name[k]}|{b.res_number[k]}|{b.res_chain[k]}" for k in range(lo, hi)).encode()).hexdigest()
+
+
+@pytest.mark.parametrize("name", sorted(GOLD))
+def test_matches_the_reference_reader(name):
+    checked = 0
+    for opt, exp in GOLD[name].items():
+        if exp.get("crash"):        # the reference itself aborts on this input (double free)
+            continue
+        b = ingest.load_pdb_files([os.path.join(PDB, name)], options=int(opt))
+        if exp.get("fail"):
+            assert b.status[0] != ingest.OK and b.n_atoms == 0 and b.offsets.tolist() == [0, 0], (name, opt)
+        else:
+            assert b.status[0] == ingest.OK, (name, opt)
+            assert (b.n_atoms, b.n_residues) == (exp["n_atoms"], exp["n_residues"]), (name, opt)
+            assert sha(b.xyz) == exp["xyz"] and sha(b.radii) == exp["radii"], (name, opt)
+            assert sha(b.atom_class) == exp["classes"] and sha(b.res_first) == exp["res_first"], (name, opt)
+            assert labels_digest(b) == exp["labels"], (name, opt)
+        checked += 1
+    assert checked >= 9
+
+
+def test_reference_atom_counts_of_its_cli_tests():
+    """ref: tests/test-cli.in:143,156,159 (602 / 660 with HETATM / 1231 with hydrogens)."""
+    f = [os.path.join(PDB, "1ubq.pdb")]
+    assert ingest.load_pdb_files(f).n_atoms == 602
+    assert ingest.load_pdb_files(f, options=ingest.INCLUDE_HETATM).n_atoms == 660
+    assert ingest.load_pdb_files([os.path.join(PDB, "1d3z.pdb")], options=ingest.INCLUDE_HYDROGEN).n_atoms == 1231
+
+
+def test_batch_layout_failures_and_thread_count_independence():
+    names = ["1ubq.pdb", "empty.pdb", "3bkr.pdb", "does_not_exist.pdb", "syn_short_line.pdb", "icode.pdb", "1a0q.pdb"]
+    paths = [os.path.join(PDB, n) for n in names]
+    one = ingest.load_pdb_files(paths, n_threads=1)
+    many = ingest.load_pdb_files(paths, n_threads=5)
+    assert one.status.tolist() == [ingest.OK, ingest.EEMPTY, ingest.OK, ingest.EIO, ingest.EFORMAT, ingest.OK, ingest.OK]
+    for f in ("xyz", "radii", "atom_class", "offsets", "res_first", "res_offsets", "status"):
+        assert np.array_equal(getattr(one, f), getattr(many, f)), f
+    assert one.res_name == many.res_name and one.res_number == many.res_number and one.res_chain == many.res_chain
+    # every structure's slice is what the file gives alone; failed inputs are empty structures
+    for k, n in enumerate(names):
+        lo, hi = one.offsets[k], one.offsets[k + 1]
+        rl, rh = one.res_offsets[k], one.res_offsets[k + 1]
+        if one.status[k] != ingest.OK:
+            assert lo == hi and rl == rh
+            continue
+        exp = GOLD[n]["0"]
+        assert hi - lo == exp["n_atoms"] and rh - rl == exp["n_residues"]
+        assert sha(one.xyz[lo:hi]) == exp["xyz"] and sha(one.radii[lo:hi]) == exp["radii"]
+        assert sha(np.append(one.res_first[rl:rh] - lo, hi - lo)) == exp["res_first"]
+        assert labels_digest(one, rl, rh) == exp["labels"]
+    assert one.offsets[-1] == one.n_atoms == len(one.radii) and one.res_first[-1] == one.n_atoms
+    # texts in memory == files on disk
+    texts = [open(p, "rb").read() if os.path.exists(p) else b"" for p in paths]
+    mem = ingest.load_pdb_texts(texts, n_threads=3)
+    assert np.array_equal(mem.xyz, one.xyz) and np.array_equal(mem.radii, one.radii)
+    assert mem.status.tolist() == [ingest.OK, ingest.EEMPTY, ingest.OK, ingest.EEMPTY, ingest.EFORMAT, ingest.OK, ingest.OK]
+    # no inputs at all
+    empty = ingest.load_pdb_files([])
+    assert empty.n_structs == 0 and empty.n_atoms == 0 and empty.offsets.tolist() == [0]
+
+
+def test_unsupported_options_are_refused():
+    for opt in (1 << 3, 1 << 4, 1 << 9):       # SEPARATE_MODELS, SEPARATE_CHAINS, unknown bit
+        with pytest.raises(RuntimeError):
+            ingest.load_pdb_files([os.path.join(PDB, "1ubq.pdb")], options=opt)
+
+
+def test_classifier_spot_values():
+    """ProtOr radii of the paper's atom types as the reference config lists them
+    (ref: share/protor.config:22-44) and the lookup rules (names are trimmed, no ANY residue)."""
+    assert ingest.protor_radius("ALA", " CA ") == (1.88, ingest.APOLAR)
+    assert ingest.protor_radius("ALA", "C") == (1.61, ingest.APOLAR)
+    assert ingest.protor_radius("ALA", " O  ") == (1.42, ingest.POLAR)
+    assert ingest.protor_radius("ALA", " N  ") == (1.64, ingest.POLAR)
+    assert ingest.protor_radius("SER", " OG ") == (1.46, ingest.POLAR)
+    assert ingest.protor_radius("CYS", " SG ") == (1.77, ingest.POLAR)
+    assert ingest.protor_radius("PHE", " CZ ") == (1.76, ingest.APOLAR)
+    assert ingest.protor_radius(" DA", " P  ") == (1.8, ingest.POLAR)
+    assert ingest.protor_radius("  A", " C1'")[0] == 1.88
+    for res, atom in (("XXX", " CA "), ("ANY", " CA "), ("ALA", " XX "), ("ALA", ""), ("", " CA "), ("ALAX", " CA ")):
+        assert ingest.protor_radius(res, atom) == (-1.0, ingest.UNKNOWN)
+    assert ingest.guess_radius(" C") == 1.7 and ingest.guess_radius("C") == 1.7     # right-justified like "%2s"
+    assert ingest.guess_radius("FE") > 0 and ingest.guess_radius("Fe") == -1.0 and ingest.guess_radius(" Q") == -1.0
+
+
+def test_residue_sums_helper():
+    b = ingest.load_pdb_files([os.path.join(PDB, "icode.pdb")])
+    v = np.arange(1.0, b.n_atoms + 1)
+    got = b.residue_sums(v)
+    assert len(got) == b.n_residues and got.sum() == v.sum()
+    assert got[0] == v[b.res_first[0]:b.res_first[1]].sum()
+
+
+@pytest.mark.gpu
+def test_pdb_to_sasa_end_to_end_matches_reference_totals():
+    """PDB file -> loader -> GPU batch -> totals, classes and per-residue sums, against the
+    reference's own published numbers for 1UBQ (ref: tests/test_freesasa.c:155-178,
+    tests/data/seq.reference)."""
+    import freesasa_amd as fa
+    from conftest import read_seq_reference
+    b = ingest.load_pdb_files([os.path.join(PDB, "1ubq.pdb"), os.path.join(PDB, "3bzd_trimmed.pdb"),
+                               os.path.join(PDB, "1d3z.pdb")])
+    lr, _, lr_tot = fa.calc_batch(b.xyz, b.radii, b.offsets, fa.LEE_RICHARDS, resolution=20)
+    sr, _, sr_tot = fa.calc_batch(b.xyz, b.radii, b.offsets, fa.SHRAKE_RUPLEY, resolution=100)
+    ubq = slice(b.offsets[0], b.offsets[1])
+    polar = b.atom_class[ubq] == ingest.POLAR
+    assert abs(lr_tot[0] - 4804.055641) < 1e-5 * 4804.055641
+    assert abs(lr[ubq][polar].sum() - 2504.217302) < 1e-5 * 2504.217302
+    assert abs(lr[ubq][~polar].sum() - 2299.838339) < 1e-5 * 2299.838339
+    assert abs(sr_tot[0] - 4834.716265) < 1e-5 * 4834.716265
+    assert abs(sr[ubq][polar].sum() - 2515.821238) < 1e-5 * 2515.821238
+    assert abs(sr_tot[1] - 16133.867124) < 1e-5 * 16133.867124          # 3BZD, tests/test_freesasa.c:305-327
+    assert abs(sr_tot[2] - 5000.340175) < 1e-5 * 5000.340175            # 1D3Z model 1, :441-451
+    per_res = b.residue_sums(sr)[b.res_offsets[0]:b.res_offsets[1]]
+    ref = read_seq_reference()
+    assert len(per_res) == len(ref) == 76
+    for k, (chain, number, name, area) in enumerate(ref):
+        assert (b.res_chain[k], b.res_number[k].strip(), b.res_name[k]) == (chain, number, name)
+        assert abs(per_res[k] - area) <= 0.005 + 1e-9                   # the file prints 2 decimals
