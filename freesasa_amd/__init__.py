@@ -112,6 +112,7 @@ def lib():
                                                 C.c_double, C.c_int, _dp, C.c_void_p, C.c_void_p,
                                                 C.c_void_p]
         L.freesasa_gpu_segment_sums_dev.argtypes = [C.c_void_p, C.c_void_p, _lp, C.c_int, C.c_void_p]
+        L.freesasa_gpu_class_sums_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, _lp, C.c_int, C.c_void_p]
         L.freesasa_gpu_test_points.argtypes = [C.c_int, _dp]
         L.freesasa_gpu_test_points.restype = None
         L.freesasa_gpu_calc_batch.argtypes = [_dp, _dp, _lp, C.c_int, C.c_int, C.c_double, C.c_int,
@@ -232,6 +233,12 @@ class GpuContext:
         seg = np.ascontiguousarray(seg_offsets, dtype=np.int64)
         if lib().freesasa_gpu_segment_sums_dev(self._h, d_sasa, seg.ctypes.data_as(_lp), seg.size - 1, d_out):
             raise RuntimeError("freesasa_gpu_segment_sums_dev: " + self.error())
+
+    def class_sums(self, d_sasa, d_class, offsets, d_out):
+        """d_out[3*s + c] <- sum of d_sasa over structure s's atoms of class c (0 apolar, 1 polar, 2 unknown)."""
+        offs = np.ascontiguousarray(offsets, dtype=np.int64)
+        if lib().freesasa_gpu_class_sums_dev(self._h, d_sasa, d_class, offs.ctypes.data_as(_lp), offs.size - 1, d_out):
+            raise RuntimeError("freesasa_gpu_class_sums_dev: " + self.error())
 
     def shrake_rupley(self, d_xyz, d_radii, offsets, d_sasa, d_counts=0, d_totals=0, probe=1.4,
                       n_points=100):

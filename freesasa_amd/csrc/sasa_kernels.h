@@ -1224,6 +1224,42 @@ SASA_D void totals_phase1(const double *part, double *totals, int s, int tid)
     totals[s] = t;
 }
 
+/* Short segments (residues: ~8 atoms): one thread per segment, strictly sequential in atom order,
+ * i.e. exactly the sum the reference's result tree forms (ref: src/node.c:150-176). */
+SASA_D void segsum_small(const double *sasa, const int64_t *seg, double *out, int k, int n_segs)
+{
+    if (k >= n_segs) return;
+    double t = 0;
+    for (int64_t i = seg[k]; i < seg[k + 1]; ++i) t += sasa[i];
+    out[k] = t;
+}
+
+/* Per-structure sums by atom class (0 apolar, 1 polar, 2 unknown; ref: freesasa_result_classes,
+ * src/classifier.c:830-866): like the totals, SASA_TOT_B threads per structure take contiguous
+ * chunks in atom order and thread 0 adds the partials in order.  out[3*s + c]. */
+SASA_D void class_phase0(const double *sasa, const unsigned char *cls, const int64_t *offsets, double *part, int s, int tid)
+{
+    const int64_t b = offsets[s], e = offsets[s + 1];
+    const int64_t per = (e - b + SASA_TOT_B - 1) / SASA_TOT_B;
+    const int64_t lo = b + tid * per, hi = lo + per < e ? lo + per : e;
+    double t0 = 0, t1 = 0, t2 = 0;
+    for (int64_t i = lo; i < hi; ++i) {
+        const double v = sasa[i];
+        const int c = cls[i];
+        if (c == 0) t0 += v;
+        else if (c == 1) t1 += v;
+        else t2 += v;
+    }
+    part[3 * tid] = t0; part[3 * tid + 1] = t1; part[3 * tid + 2] = t2;
+}
+SASA_D void class_phase1(const double *part, double *out, int s, int tid)
+{
+    if (tid >= 3) return;
+    double t = 0;
+    for (int k = 0; k < SASA_TOT_B; ++k) t += part[3 * k + tid];
+    out[3 * s + tid] = t;
+}
+
 /* Workgroup b runs on XCD b % 8 (observed dispatch order).  Give each XCD one contiguous
  * eighth of the cell-sorted tiles so that the candidate cells a tile reads were, with high
  * probability, last touched through the same XCD's L2.  Speed only; any mapping is correct.

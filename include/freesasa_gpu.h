@@ -74,6 +74,14 @@ int freesasa_gpu_sr_batch_dev(freesasa_gpu_ctx *ctx, const double *d_xyz, const 
 int freesasa_gpu_segment_sums_dev(freesasa_gpu_ctx *ctx, const double *d_sasa, const int64_t *seg,
                                   int n_segs, double *d_out);
 
+/* Per-structure sums by atom class: d_out[3*s + c] = sum of d_sasa over the atoms of structure s
+   whose d_class byte is c (0 apolar, 1 polar, 2 unknown — the reference's freesasa_atom_class,
+   src/freesasa.h:163-167; what freesasa_result_classes adds up on the host,
+   src/classifier.c:830-866, and the CLI prints as Apolar / Polar).  offsets is a HOST array
+   [n_structs+1]; d_class [n_atoms] and d_out [3*n_structs] are device pointers.  Returns 0 / -1. */
+int freesasa_gpu_class_sums_dev(freesasa_gpu_ctx *ctx, const double *d_sasa, const unsigned char *d_class,
+                                const int64_t *offsets, int n_structs, double *d_out);
+
 /* Golden-spiral unit test points on the host, host libm (src/sasa_sr.c:56-90). */
 void freesasa_gpu_test_points(int n_points, double *unit_points);
 

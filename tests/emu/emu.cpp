@@ -205,6 +205,20 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
 }
 
 /* scalar device math helpers, exposed for unit tests */
+/* the aggregation kernels' phase functions (per-residue and per-class sums) */
+extern "C" void emu_segsum_small(const double *sasa, const int64_t *seg, int n_segs, double *out)
+{
+    for (int k = 0; k < ((n_segs + 255) / 256) * 256; ++k) segsum_small(sasa, seg, out, k, n_segs);
+}
+extern "C" void emu_class_sums(const double *sasa, const unsigned char *cls, const int64_t *offsets, int n_structs, double *out)
+{
+    std::vector<double> part(3 * SASA_TOT_B);
+    for (int s = 0; s < n_structs; ++s) {
+        for (int l = 0; l < SASA_TOT_B; ++l) class_phase0(sasa, cls, offsets, part.data(), s, l);
+        for (int l = 0; l < SASA_TOT_B; ++l) class_phase1(part.data(), out, s, l);
+    }
+}
+
 extern "C" void emu_acos_fast(const double *x, double *out, int n)
 {
     for (int i = 0; i < n; ++i) out[i] = acos_fast(x[i]);

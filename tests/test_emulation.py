@@ -187,3 +187,35 @@ def test_device_math_helpers_accuracy():
     lib.emu_sqrt_rh(v.ctypes.data_as(dp), g.ctypes.data_as(dp), h.ctypes.data_as(dp), v.size)
     assert np.max(np.abs(g - np.sqrt(v)) / np.spacing(np.sqrt(v))) <= 1.0
     assert np.max(np.abs(h - 0.5 / np.sqrt(v)) / np.spacing(0.5 / np.sqrt(v))) <= 2.0
+
+
+def test_aggregation_kernels_logic():
+    """Per-residue (one thread per segment, strict atom order) and per-class sums."""
+    import ctypes as C
+    lib = emu._load()
+    rng = np.random.default_rng(3)
+    n = 5000
+    v = rng.uniform(0, 50, n)
+    cuts = np.sort(rng.choice(np.arange(1, n), 700, replace=False))
+    seg = np.concatenate([[0], cuts, [n]]).astype(np.int64)
+    out = np.full(len(seg) - 1, np.nan)
+    dp, lp = C.POINTER(C.c_double), C.POINTER(C.c_int64)
+    lib.emu_segsum_small(v.ctypes.data_as(dp), seg.ctypes.data_as(lp), len(seg) - 1, out.ctypes.data_as(dp))
+    want = []
+    for a, b in zip(seg[:-1], seg[1:]):
+        t = 0.0
+        for x in v[a:b]:
+            t += x
+        want.append(t)
+    assert np.array_equal(out, np.array(want))
+    cls = rng.integers(0, 3, n).astype(np.uint8)
+    offs = np.array([0, 0, 1, 300, 4999, n], dtype=np.int64)      # empty, single-atom and long structures
+    got = np.full(3 * (len(offs) - 1), np.nan)
+    lib.emu_class_sums(v.ctypes.data_as(dp), cls.ctypes.data_as(C.POINTER(C.c_ubyte)), offs.ctypes.data_as(lp),
+                       len(offs) - 1, got.ctypes.data_as(dp))
+    got = got.reshape(-1, 3)
+    for s in range(len(offs) - 1):
+        sl = slice(offs[s], offs[s + 1])
+        for c in range(3):
+            assert abs(got[s, c] - v[sl][cls[sl] == c].sum()) <= 1e-9 * max(1.0, got[s, c])
+    assert np.all(got[0] == 0)

@@ -139,6 +139,21 @@ def test_pdb_to_sasa_end_to_end_matches_reference_totals():
     assert abs(sr[ubq][polar].sum() - 2515.821238) < 1e-5 * 2515.821238
     assert abs(sr_tot[1] - 16133.867124) < 1e-5 * 16133.867124          # 3BZD, tests/test_freesasa.c:305-327
     assert abs(sr_tot[2] - 5000.340175) < 1e-5 * 5000.340175            # 1D3Z model 1, :441-451
+    # the same aggregates on the device (N2): per-structure class sums and per-residue sums
+    import torch
+    dev = torch.device("cuda:0")
+    d_sr = torch.from_numpy(sr).to(dev)
+    d_cls = torch.from_numpy(b.atom_class).to(dev)
+    d_cs = torch.empty(3 * b.n_structs, dtype=torch.float64, device=dev)
+    d_res = torch.empty(b.n_residues, dtype=torch.float64, device=dev)
+    ctx = fa.GpuContext(0)
+    ctx.class_sums(d_sr.data_ptr(), d_cls.data_ptr(), b.offsets, d_cs.data_ptr())
+    ctx.segment_sums(d_sr.data_ptr(), b.res_first, d_res.data_ptr())
+    cs = d_cs.cpu().numpy().reshape(-1, 3)
+    assert abs(cs[0, 1] - 2515.821238) < 1e-5 * 2515.821238 and abs(cs[0, 0] - 2318.895027) < 1e-5 * 2318.895027
+    assert np.allclose(cs.sum(1), sr_tot, rtol=1e-12) and cs[0, 2] == 0
+    assert np.allclose(d_res.cpu().numpy(), b.residue_sums(sr), rtol=1e-13, atol=1e-12)
+    ctx.close()
     per_res = b.residue_sums(sr)[b.res_offsets[0]:b.res_offsets[1]]
     ref = read_seq_reference()
     assert len(per_res) == len(ref) == 76
