@@ -88,7 +88,7 @@ def profiled_traffic(args):
     with open(os.path.join(ROOT, "profiles", best)) as fh:
         d = json.load(fh)
     # steady state = main launch (tier 0) of the tuned variant (5 waves/SIMD), else the 4-wave one
-    for tag in ("false, 0, 5>", "false, 0, 4>", "false, 0>"):
+    for tag in ("false, 0, 5, false>", "false, 0, 4, false>", "false, 0, 5>", "false, 0, 4>"):
         for k, v in d.items():
             if "k_lr_tile" in k and tag in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
                 return (v["FETCH_SIZE"]["per_launch_KB"] + v["WRITE_SIZE"]["per_launch_KB"]) * 1024.0, "profiles/" + best
