@@ -570,6 +570,7 @@ SASA_D void tile_phase_offsets(const TileArgs &a, TileMem &m, int tid)
     int off = 0;
     for (int k = 0; k < tid; ++k) off += pad4(m.acnt[k], a.lr);
     const int c = m.acnt[tid];
+    if (!a.lr) { m.rowlo[2 * tid] = 0; m.rowlo[2 * tid + 1] = 0; } /* S&R: front/back cursors of the pair phase */
     m.aoff[tid] = off;
     if (c > a.cap_idx) m.flags[0] = 1;
     if (tid == a.TA - 1) {
@@ -1103,12 +1104,25 @@ SASA_D void sr_phase_pairs(const TileArgs &a, TileMem &m, int tid, int B)
     for (int gp = tid; gp < total; gp += B) {
         int la = 0;
         while (m.aoff[la + 1] <= gp) ++la;
-        const int q = m.idx[la * a.cap_idx + (gp - m.aoff[la])];
+        const int o = m.aoff[la], nn = m.aoff[la + 1] - o;
+        const int q = m.idx[la * a.cap_idx + (gp - o)];
         const double rj = a.sr[q];
         Quad rec;
         rec.x = a.sx[q]; rec.y = a.sy[q]; rec.z = a.sz[q];
         rec.w = rj * rj; /* ref: src/sasa_sr.c:146 */
-        m.pq[gp] = rec;
+        /* Neighbors whose sphere hides a large cap of atom i go to the FRONT of its list, the others
+           to the back: the point test is an OR over neighbors (any order gives the same counts),
+           and with the big caps first almost every covered point is rejected by the first
+           SR_FIRST tests (measured at protein density: 2 % of the points survive instead of 21 %).
+           Cap of half-angle theta: cos(theta) = (Ri^2 + d^2 - Rj^2)/(2 Ri d) < 0.6, without the root. */
+        const double ri = m.aR[la];
+        const double dx = rec.x - m.ax[la], dy = rec.y - m.ay[la], dz = rec.z - m.az[la];
+        const double d2 = dx * dx + dy * dy + dz * dz;
+        const double num = ri * ri + d2 - rec.w;
+        const bool big = num < 0 || num * num < 1.44 * (ri * ri) * d2;
+        const int slot = big ? SASA_ATOMIC_ADD_LDS(&m.rowlo[2 * la], 1)
+                             : nn - 1 - SASA_ATOMIC_ADD_LDS(&m.rowlo[2 * la + 1], 1);
+        m.pq[o + slot] = rec;
     }
 }
 
@@ -1117,10 +1131,11 @@ SASA_D void sr_phase_pairs(const TileArgs &a, TileMem &m, int tid, int B)
  * outcome, which is an OR over neighbors).  About 93 % of the points of a protein are covered,
  * most of them by one of the first few neighbors, while an exposed point must be tested against
  * all of them: with one lane per point a wave would run the full neighbor loop with a quarter
- * of its lanes alive.  So L1 tests only the first SR_FIRST neighbors and appends the survivors
- * (still uncovered, neighbors left) to a compact LDS list; L2 finishes them with dense lanes. */
+ * of its lanes alive.  So L1 tests only the first SR_FIRST neighbors — the ones with the largest
+ * caps, see sr_phase_pairs — and appends the survivors (still uncovered, neighbors left) to a
+ * compact LDS list; L2 finishes them with dense lanes. */
 #ifndef SR_FIRST
-#define SR_FIRST 12
+#define SR_FIRST 8
 #endif
 SASA_D bool sr_compact_ok(const TileArgs &a, int items)
 {
