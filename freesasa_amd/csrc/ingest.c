@@ -88,6 +88,7 @@ typedef struct {
     int64_t *res_first;
     char *res_name, *res_number, *res_chain;
     int status;
+    int scratch_model; /* mmCIF: lowest model number found by the first pass */
 } parsed;
 
 static void parsed_free(parsed *p)
@@ -127,7 +128,7 @@ static int grow_res(parsed *p)
     char *b = realloc(p->res_number, 6 * (size_t)cap);
     if (!b) return -1;
     p->res_number = b;
-    char *c = realloc(p->res_chain, (size_t)cap);
+    char *c = realloc(p->res_chain, 4 * (size_t)cap);
     if (!c) return -1;
     p->res_chain = c;
     p->rescap = cap;
@@ -297,7 +298,8 @@ static void parse_pdb(const char *text, size_t len, int options, parsed *p)
                 memcpy(p->res_name + 4 * p->nres, rname, strlen(rname));
                 memset(p->res_number + 6 * p->nres, 0, 6);
                 memcpy(p->res_number + 6 * p->nres, rnumber, strlen(rnumber));
-                p->res_chain[p->nres] = chain;
+                memset(p->res_chain + 4 * p->nres, 0, 4);
+                p->res_chain[4 * p->nres] = chain;
                 ++p->nres;
                 memcpy(prev_number, rnumber, 6);
                 prev_chain = chain;
@@ -310,6 +312,247 @@ static void parse_pdb(const char *text, size_t len, int options, parsed *p)
         if (!(options & FREESASA_INGEST_JOIN_MODELS) && strncmp("ENDMDL", line, 6) == 0) break; /* ref: :705-708 */
     }
     if (p->n == 0) p->status = FREESASA_INGEST_EEMPTY;
+}
+
+/* ------------------------------------------------------------------ mmCIF */
+
+/* What the reference takes from an mmCIF file (ref: src/cif.cc:113-200, src/structure.c:724-836):
+ * the rows of the _atom_site loop of every data block, columns group_PDB, auth_asym_id,
+ * auth_seq_id, pdbx_PDB_ins_code, auth_comp_id, auth_atom_id, label_alt_id, type_symbol,
+ * Cartn_x/y/z, pdbx_PDB_model_num; only the lowest model number unless JOIN_MODELS; "ATOM" rows
+ * (HETATM with the option); type_symbol "H" skipped unless INCLUDE_HYDROGEN; first alt-loc label
+ * wins ('.' = none); double quotes stripped from the atom name; names cut to the widths of the
+ * reference's atom record (3 / 4 / 5 / 2 / 3 characters); coordinates by strtod; the element is
+ * the file's type_symbol, never guessed.  An atom the classifier does not know is guessed by
+ * element, or dropped under SKIP_UNKNOWN and HALT_AT_UNKNOWN alike (the reference ignores the
+ * failure of a single atom here, src/cif.cc:186).
+ * The tokenizer follows the CIF 1.1 lexical rules the reference's parser (gemmi) implements:
+ * whitespace-separated values, '...' and "..." strings closed by a quote followed by whitespace,
+ * ;-delimited text fields at line starts, # comments, case-insensitive data_/loop_/save_ keywords. */
+enum { T_END, T_TAG, T_VALUE, T_LOOP, T_DATA, T_SAVE };
+typedef struct { const char *p; size_t n; int type; } cif_tok;
+typedef struct { const char *cur, *end; int bol; } cif_lex; /* bol: at the beginning of a line */
+
+static int ieq_n(const char *a, const char *b, size_t n)
+{
+    for (size_t i = 0; i < n; ++i)
+        if (tolower((unsigned char)a[i]) != tolower((unsigned char)b[i])) return 0;
+    return 1;
+}
+
+/* 1 for the CIF whitespace characters */
+static const unsigned char cif_ws[256] = {['\t'] = 1, ['\n'] = 1, ['\r'] = 1, [' '] = 1};
+
+static cif_tok cif_next(cif_lex *lx)
+{
+    cif_tok t = {NULL, 0, T_END};
+    const unsigned char *p = (const unsigned char *)lx->cur, *end = (const unsigned char *)lx->end;
+    for (;;) { /* whitespace and comments */
+        while (p < end && cif_ws[*p]) {
+            lx->bol = *p == '\n';
+            ++p;
+        }
+        if (p < end && *p == '#') {
+            const unsigned char *nl = memchr(p, '\n', (size_t)(end - p));
+            p = nl ? nl : end;
+            continue;
+        }
+        break;
+    }
+    if (p >= end) { lx->cur = (const char *)p; return t; }
+    const unsigned char *start = p;
+    if (*p == ';' && lx->bol) { /* text field: up to a line that starts with ';' */
+        ++p;
+        while (p < end && !(*p == '\n' && p + 1 < end && p[1] == ';')) ++p;
+        if (p < end) p += 2;
+        t.type = T_VALUE;
+    } else if (*p == '\'' || *p == '"') {
+        const unsigned char q = *p++;
+        while (p < end && *p != '\n') {
+            if (*p == q && (p + 1 >= end || cif_ws[p[1]])) { ++p; break; }
+            ++p;
+        }
+        t.type = T_VALUE; /* raw, quotes included, like gemmi */
+    } else {
+        while (p < end && !cif_ws[*p]) ++p;
+        const size_t n = (size_t)(p - start);
+        if (*start == '_') t.type = T_TAG;
+        else if (n == 5 && ieq_n((const char *)start, "loop_", 5)) t.type = T_LOOP;
+        else if (n >= 5 && (start[4] == '_') && ieq_n((const char *)start, "data_", 5)) t.type = T_DATA;
+        else if (n >= 5 && (start[4] == '_') && ieq_n((const char *)start, "save_", 5)) t.type = T_SAVE;
+        else t.type = T_VALUE;
+    }
+    t.p = (const char *)start;
+    t.n = (size_t)(p - start);
+    lx->bol = 0;
+    lx->cur = (const char *)p;
+    return t;
+}
+
+static const char *const cif_cols[12] = {"group_PDB", "auth_asym_id", "auth_seq_id", "pdbx_PDB_ins_code", "auth_comp_id",
+                                         "auth_atom_id", "label_alt_id", "type_symbol", "Cartn_x", "Cartn_y", "Cartn_z",
+                                         "pdbx_PDB_model_num"};
+
+/* copy at most w characters of a token into a NUL-terminated field */
+static void cut(char *dst, size_t w, const char *p, size_t n)
+{
+    if (n > w) n = w;
+    memcpy(dst, p, n);
+    dst[n] = '\0';
+}
+
+typedef struct { cif_lex at; int ncol; int col[12]; } cif_loop; /* an _atom_site loop: lexer state at its first value */
+
+/* walk the document; calls visit(row tokens) for every row of every complete _atom_site loop */
+typedef int (*cif_row_fn)(const cif_tok *row, void *ctx);
+static int cif_walk(const char *text, size_t len, cif_row_fn visit, void *ctx)
+{
+    cif_lex lx = {text, text + len, 1};
+    cif_tok t = cif_next(&lx);
+    while (t.type != T_END) {
+        if (t.type != T_LOOP) { /* data_, save_, tag-value pairs, stray values */
+            t = cif_next(&lx);
+            continue;
+        }
+        int ncol = 0, col[12], is_site = 0;
+        for (int k = 0; k < 12; ++k) col[k] = -1;
+        t = cif_next(&lx);
+        while (t.type == T_TAG) {
+            if (t.n > 11 && ieq_n(t.p, "_atom_site.", 11)) {
+                is_site = 1;
+                for (int k = 0; k < 12; ++k)
+                    if (strlen(cif_cols[k]) == t.n - 11 && ieq_n(t.p + 11, cif_cols[k], t.n - 11)) col[k] = ncol;
+            }
+            ++ncol;
+            t = cif_next(&lx);
+        }
+        int complete = is_site && ncol > 0;
+        for (int k = 0; k < 12; ++k) complete = complete && col[k] >= 0;
+        cif_tok row[12];
+        int c = 0;
+        while (t.type == T_VALUE) {
+            if (complete)
+                for (int k = 0; k < 12; ++k)
+                    if (col[k] == c) row[k] = t;
+            if (++c == ncol) {
+                c = 0;
+                if (complete) {
+                    const int rc = visit(row, ctx);
+                    if (rc) return rc;
+                }
+            }
+            t = cif_next(&lx);
+        }
+    }
+    return 0;
+}
+
+static int tok_int(const cif_tok *t)
+{
+    char buf[24];
+    cut(buf, sizeof buf - 1, t->p, t->n);
+    return (int)strtol(buf, NULL, 10);
+}
+
+typedef struct {
+    parsed *p;
+    int options;
+    int have_model, model, min_model; /* model being read (the first one met) and the lowest seen */
+    char prev_alt;
+    char prev_number[6], prev_chain[4];
+} cif_atoms;
+
+static int cif_visit_atom(const cif_tok *row, void *ctx)
+{
+    cif_atoms *c = (cif_atoms *)ctx;
+    parsed *p = c->p;
+    /* (the model set is built from every row, whatever its record type) */
+    const int model = tok_int(&row[11]);
+    if (!c->have_model) { c->have_model = 1; c->model = c->min_model = model; }
+    if (model < c->min_model) c->min_model = model;
+    if (!(row[0].n == 4 && memcmp(row[0].p, "ATOM", 4) == 0) && !(c->options & FREESASA_INGEST_INCLUDE_HETATM)) return 0;
+    if (!(c->options & FREESASA_INGEST_JOIN_MODELS) && model != c->model) return 0;
+    if (!(c->options & FREESASA_INGEST_INCLUDE_HYDROGEN) && row[7].n == 1 && row[7].p[0] == 'H') return 0;
+    const char alt = row[6].p[0];
+    if ((alt != '.' && c->prev_alt == '.') || alt == '.') c->prev_alt = alt;
+    else if (alt != '.' && alt != c->prev_alt) return 0;
+
+    char aname[5], rname[4], rnumber[6], symbol[3], chain[4], seq[16], num[24];
+    if (row[5].n >= 2 && row[5].p[0] == '"') cut(aname, 4, row[5].p + 1, row[5].n - 2);
+    else cut(aname, 4, row[5].p, row[5].n);
+    cut(rname, 3, row[4].p, row[4].n);
+    cut(seq, sizeof seq - 1, row[2].p, row[2].n);
+    if (row[3].p[0] != '?') snprintf(num, sizeof num, "%s%c", seq, row[3].p[0]);
+    else snprintf(num, sizeof num, "%s", seq);
+    cut(rnumber, 5, num, strlen(num));
+    cut(symbol, 2, row[7].p, row[7].n);
+    cut(chain, 3, row[1].p, row[1].n);
+    double v[3];
+    for (int k = 0; k < 3; ++k) {
+        char buf[40];
+        cut(buf, sizeof buf - 1, row[8 + k].p, row[8 + k].n);
+        v[k] = strtod(buf, NULL); /* atof */
+    }
+
+    int cls;
+    double r = freesasa_ingest_protor_radius(rname, aname, &cls);
+    if (r < 0) {
+        if (c->options & (FREESASA_INGEST_HALT_AT_UNKNOWN | FREESASA_INGEST_SKIP_UNKNOWN)) return 0;
+        r = freesasa_ingest_guess_radius(symbol);
+        if (r < 0) r = +0.;
+    }
+    if (grow_atoms(p)) { p->status = FREESASA_INGEST_ENOMEM; return -1; }
+    if (p->n == 0 || strcmp(rnumber, c->prev_number) != 0 || strcmp(chain, c->prev_chain) != 0) {
+        if (grow_res(p)) { p->status = FREESASA_INGEST_ENOMEM; return -1; }
+        p->res_first[p->nres] = p->n;
+        memset(p->res_name + 4 * p->nres, 0, 4);
+        memcpy(p->res_name + 4 * p->nres, rname, strlen(rname));
+        memset(p->res_number + 6 * p->nres, 0, 6);
+        memcpy(p->res_number + 6 * p->nres, rnumber, strlen(rnumber));
+        memset(p->res_chain + 4 * p->nres, 0, 4);
+        memcpy(p->res_chain + 4 * p->nres, chain, strlen(chain));
+        ++p->nres;
+        memcpy(c->prev_number, rnumber, 6);
+        memcpy(c->prev_chain, chain, 4);
+    }
+    p->xyz[3 * p->n] = v[0]; p->xyz[3 * p->n + 1] = v[1]; p->xyz[3 * p->n + 2] = v[2];
+    p->rad[p->n] = r;
+    p->cls[p->n] = (uint8_t)cls;
+    ++p->n;
+    return 0;
+}
+
+static void parse_cif(const char *text, size_t len, int options, parsed *p)
+{
+    /* The reference collects the model numbers first and keeps the lowest (src/cif.cc:78-87,
+       225-234).  Files list their models in ascending order, so one pass suffices: read the atoms
+       of the first model met while tracking the minimum, and start over only if a lower number
+       shows up later. */
+    cif_atoms c;
+    for (int pass = 0; pass < 2; ++pass) {
+        p->n = 0; p->nres = 0; p->status = 0;
+        memset(&c, 0, sizeof c);
+        c.p = p; c.options = options; c.prev_alt = '.';
+        if (pass == 1) { c.have_model = 1; c.model = c.min_model = p->scratch_model; }
+        cif_walk(text, len, cif_visit_atom, &c);
+        if (!c.have_model || c.min_model == c.model || p->status) break;
+        p->scratch_model = c.min_model;
+    }
+    if (p->status == 0 && p->n == 0) p->status = FREESASA_INGEST_EEMPTY;
+}
+
+/* A file whose first token is data_... is mmCIF; anything else is read as PDB. */
+static int looks_like_cif(const char *text, size_t len)
+{
+    cif_lex lx = {text, text + (len < 4096 ? len : 4096), 1};
+    const cif_tok t = cif_next(&lx);
+    return t.type == T_DATA;
+}
+
+static void parse_any(const char *text, size_t len, int options, parsed *p)
+{
+    if (looks_like_cif(text, len)) parse_cif(text, len, options, p);
+    else parse_pdb(text, len, options, p);
 }
 
 /* Whole file into a buffer that is reused from call to call.  0 on success. */
@@ -348,7 +591,7 @@ static int compact(const parsed *s, parsed *d)
     d->res_first = malloc(sizeof(int64_t) * (size_t)s->nres);
     d->res_name = malloc(4 * (size_t)s->nres);
     d->res_number = malloc(6 * (size_t)s->nres);
-    d->res_chain = malloc((size_t)s->nres);
+    d->res_chain = malloc(4 * (size_t)s->nres);
     if (!d->xyz || !d->rad || !d->cls || !d->res_first || !d->res_name || !d->res_number || !d->res_chain) {
         parsed_free(d);
         d->status = FREESASA_INGEST_ENOMEM;
@@ -360,7 +603,7 @@ static int compact(const parsed *s, parsed *d)
     memcpy(d->res_first, s->res_first, sizeof(int64_t) * (size_t)s->nres);
     memcpy(d->res_name, s->res_name, 4 * (size_t)s->nres);
     memcpy(d->res_number, s->res_number, 6 * (size_t)s->nres);
-    memcpy(d->res_chain, s->res_chain, (size_t)s->nres);
+    memcpy(d->res_chain, s->res_chain, 4 * (size_t)s->nres);
     d->n = d->cap = s->n;
     d->nres = d->rescap = s->nres;
     return 0;
@@ -393,14 +636,14 @@ static void *worker(void *arg)
         pthread_mutex_unlock(&j->mu);
         if (k >= j->n) break;
         if (j->texts) {
-            parse_pdb(j->texts[k], j->lens[k], j->options, &scratch);
+            parse_any(j->texts[k], j->lens[k], j->options, &scratch);
         } else {
             size_t len = 0;
             if (read_file(j->paths[k], &text, &cap, &len)) {
                 scratch.n = 0; scratch.nres = 0;
                 scratch.status = FREESASA_INGEST_EIO;
             } else {
-                parse_pdb(text, len, j->options, &scratch);
+                parse_any(text, len, j->options, &scratch);
             }
         }
         compact(&scratch, &j->res[k]); /* failed inputs contribute an empty structure */
@@ -465,7 +708,7 @@ static int run(job *j, int n_threads, freesasa_ingest_batch *out)
     out->res_offsets = malloc(sizeof(int64_t) * ((size_t)j->n + 1));
     out->res_name = malloc(4 * (size_t)(nr ? nr : 1));
     out->res_number = malloc(6 * (size_t)(nr ? nr : 1));
-    out->res_chain = malloc((size_t)(nr ? nr : 1));
+    out->res_chain = malloc(4 * (size_t)(nr ? nr : 1));
     out->status = malloc(sizeof(int32_t) * (size_t)(j->n ? j->n : 1));
     int rc = 0;
     if (!out->xyz || !out->radii || !out->atom_class || !out->offsets || !out->res_first || !out->res_offsets ||
@@ -487,7 +730,7 @@ static int run(job *j, int n_threads, freesasa_ingest_batch *out)
             if (p->nres) {
                 memcpy(out->res_name + 4 * r, p->res_name, 4 * (size_t)p->nres);
                 memcpy(out->res_number + 6 * r, p->res_number, 6 * (size_t)p->nres);
-                memcpy(out->res_chain + r, p->res_chain, (size_t)p->nres);
+                memcpy(out->res_chain + 4 * r, p->res_chain, 4 * (size_t)p->nres);
             }
             a += p->n;
             r += p->nres;

@@ -49,7 +49,7 @@ class Batch:
         # residue labels stay fixed-width byte arrays until somebody asks for strings
         self.res_name_raw = np.frombuffer(C.string_at(cb.res_name, 4 * nr) if nr else b"", dtype="S4").copy()
         self.res_number_raw = np.frombuffer(C.string_at(cb.res_number, 6 * nr) if nr else b"", dtype="S6").copy()
-        self.res_chain_raw = np.frombuffer(C.string_at(cb.res_chain, nr) if nr else b"", dtype="S1").copy()
+        self.res_chain_raw = np.frombuffer(C.string_at(cb.res_chain, 4 * nr) if nr else b"", dtype="S4").copy()
 
     @property
     def res_name(self):

@@ -1,4 +1,4 @@
-/* freesasa_ingest.h — batched PDB -> (xyz, radius) ingestion for structure sweeps.
+/* freesasa_ingest.h — batched PDB / mmCIF -> (xyz, radius) ingestion for structure sweeps.
  *
  * once the SASA kernels run at 1e8-1e9 atoms/s, reading the structures is the
  * bottleneck of a whole-PDB sweep.  This is a host-side, multi-threaded loader that produces the
@@ -10,8 +10,10 @@
  * What a file contributes is what the reference's freesasa_structure_from_pdb() would hold for it
  * (src/structure.c:644-722 with src/pdb.c:13-283 and the default ProtOr classifier,
  * src/classifier.c:738-796, 1002-1017): same atoms in the same order, same coordinates, same
- * radii, same polar/apolar classes, same residue boundaries.  Pinned by tests/test_ingest.py
- * against vectors minted from the reference library for every PDB file of its test suite.
+ * radii, same polar/apolar classes, same residue boundaries.  mmCIF inputs (recognised by their
+ * leading data_ block) contribute what freesasa_structure_from_cif() would hold (src/cif.cc:113-240:
+ * the _atom_site loop, auth_* columns, lowest model number).  Pinned by tests/test_ingest.py
+ * against vectors minted from the reference library for every PDB and mmCIF file of its test suite.
  */
 #ifndef FREESASA_INGEST_H
 #define FREESASA_INGEST_H
@@ -66,18 +68,19 @@ typedef struct freesasa_ingest_batch {
     int64_t *res_offsets; /* [n_structs + 1] */
     char *res_name;       /* [4 * n_residues] residue names, NUL padded ("ALA\0") */
     char *res_number;     /* [6 * n_residues] residue number incl. insertion code (" 123A\0") */
-    char *res_chain;      /* [n_residues] chain label */
+    char *res_chain;      /* [4 * n_residues] chain label, NUL padded (one character from PDB files, up to
+                             three from mmCIF, as in the reference's structure) */
     int32_t *status;      /* [n_structs] */
 } freesasa_ingest_batch;
 
-/* Read n_paths PDB files with n_threads host threads (<= 0: one per online core, at most 64 and
+/* Read n_paths PDB or mmCIF files with n_threads host threads (<= 0: one per online core, at most 64 and
  * at most one per four inputs) into one batch.
  * Returns 0 if the batch could be built (individual failures are in status[]), a
  * FREESASA_INGEST_E* code otherwise (out is zeroed). */
 int freesasa_ingest_pdb_files(const char *const *paths, int n_paths, int options, int n_threads,
                               freesasa_ingest_batch *out);
 
-/* Same for PDB texts already in memory (texts[k] has lens[k] bytes, no terminator needed). */
+/* Same for PDB / mmCIF texts already in memory (texts[k] has lens[k] bytes, no terminator needed). */
 int freesasa_ingest_pdb_texts(const char *const *texts, const size_t *lens, int n_texts, int options,
                               int n_threads, freesasa_ingest_batch *out);
 

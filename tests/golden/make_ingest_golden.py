@@ -39,9 +39,15 @@ lib.freesasa_structure_residue_name.restype = C.c_char_p
 lib.freesasa_structure_residue_name.argtypes = [C.c_void_p, C.c_int]
 lib.freesasa_structure_residue_number.restype = C.c_char_p
 lib.freesasa_structure_residue_number.argtypes = [C.c_void_p, C.c_int]
-lib.freesasa_structure_residue_chain.restype = C.c_char
-lib.freesasa_structure_residue_chain.argtypes = [C.c_void_p, C.c_int]
+lib.freesasa_structure_residue_chain_lcl.restype = C.c_char_p
+lib.freesasa_structure_residue_chain_lcl.argtypes = [C.c_void_p, C.c_int]
 lib.freesasa_set_verbosity(2)  # FREESASA_V_SILENT
+# the reference's mmCIF reader (C++ over gemmi), built by `make -C oracle ref` next to the C library
+libcif = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libfreesasa_refcif.so"))
+from_cif = getattr(libcif, "_Z27freesasa_structure_from_cifP8_IO_FILEPK19freesasa_classifieri")
+from_cif.restype = C.c_void_p
+from_cif.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+
 
 HETATM, HYDROGEN, JOIN, HALT, SKIP, OCC = 1, 1 << 2, 1 << 5, 1 << 6, 1 << 7, 1 << 8
 OPTION_SETS = [0, HETATM, HYDROGEN, HETATM | HYDROGEN, JOIN, SKIP, HALT, HETATM | SKIP, OCC, HETATM | HYDROGEN | JOIN]
@@ -49,6 +55,68 @@ FILES = ["1ubq.pdb", "1a0q.pdb", "3bkr.pdb", "3bzd_trimmed.pdb", "5dx9.pdb", "1d
          "alt_model_twochain.pdb", "icode.pdb", "1ubq.occ.pdb", "empty.pdb", "empty_model.pdb", "model_mismatch.pdb",
          "reference_bfactors.pdb", "1ubq.B.pdb"]
 CUT_AFTER_MODELS = {"1d3z.pdb": 2, "2jo4.pdb": 2}
+CIF_FILES = ["1ubq.cif", "3bkr.cif", "5dx9.cif", "7cma-assembly1.cif"]
+CIF_OPTION_SETS = [0, HETATM, HYDROGEN, HETATM | HYDROGEN, JOIN, SKIP, HALT, HETATM | SKIP, HETATM | HYDROGEN | JOIN]
+
+
+def cif_loop(rows, columns=None, block="data_SYN"):
+    cols = columns or ["group_PDB", "id", "type_symbol", "label_atom_id", "label_alt_id", "label_comp_id", "label_asym_id",
+                       "label_entity_id", "label_seq_id", "pdbx_PDB_ins_code", "Cartn_x", "Cartn_y", "Cartn_z", "occupancy",
+                       "B_iso_or_equiv", "pdbx_formal_charge", "auth_seq_id", "auth_comp_id", "auth_asym_id", "auth_atom_id",
+                       "pdbx_PDB_model_num"]
+    return block + "\n#\nloop_\n" + "".join(f"_atom_site.{c}\n" for c in cols) + "\n".join(rows) + "\n#\n"
+
+
+def synthetic_cifs():
+    """mmCIF inputs of this project's own making; expected outcome = what the reference does."""
+    def row(i, sym, name, alt, comp, asym, seq, ins, xyz, model, group="ATOM", auth_name=None, auth_asym=None):
+        return (f"{group} {i} {sym} {name} {alt} {comp} {asym} 1 {seq} {ins} {xyz} 1.00 10.00 ? {seq} {comp} "
+                f"{auth_asym or asym} {auth_name or name} {model}")
+    files = {}
+    files["syn_basic.cif"] = cif_loop([
+        row(1, "N", "N", ".", "ALA", "A", 1, "?", "1.000 2.000 3.000", 1),
+        row(2, "C", "CA", ".", "ALA", "A", 1, "?", "2.000 2.000 3.000", 1),
+        row(3, "C", '"C1\'"', ".", "A", "B", 2, "?", "3.000 2.000 3.000", 1),          # quoted name with a prime
+        row(4, "H", "HA", ".", "ALA", "A", 1, "?", "4.000 2.000 3.000", 1),
+        row(5, "D", "D1", ".", "ALA", "A", 1, "?", "5.000 2.000 3.000", 1),                # deuterium is not "H"
+        row(6, "O", "O", ".", "HOH", "A", 101, "?", "6.000 2.000 3.000", 1, group="HETATM"),
+        row(7, "FE", "FE", ".", "HEM", "A", 102, "?", "7.0 -2.5e0 +3.", 1, group="HETATM"),
+        row(8, "C", "CA", ".", "UNK", "A", 3, "?", "8.000 2.000 3.000", 1),                # unknown residue
+        row(9, "Q", "QQ", ".", "UNK", "A", 3, "?", "9.000 2.000 3.000", 1),                # unknown element
+        row(10, "C", "CB", ".", "ALA", "A", 1, "?", "10.000 2.000 3.000", 2),              # other model
+    ])
+    files["syn_altloc_icode_chains.cif"] = cif_loop([
+        row(1, "N", "N", ".", "SER", "A", 1, "?", "1.000 2.000 3.000", 1),
+        row(2, "C", "CA", "B", "SER", "A", 1, "?", "2.000 2.000 3.000", 1),
+        row(3, "C", "CA", "A", "SER", "A", 1, "?", "2.100 2.000 3.000", 1),
+        row(4, "C", "CB", "B", "SER", "A", 1, "?", "3.000 2.000 3.000", 1),
+        row(5, "N", "N", ".", "GLY", "A", 1, "A", "5.000 2.000 3.000", 1),                 # insertion code
+        row(6, "N", "N", ".", "GLY", "AAAA", 1, "A", "6.000 2.000 3.000", 1),              # long chain id (cut to 3)
+        row(7, "C", "CA", ".", "GLY", "AAAB", 1, "A", "7.000 2.000 3.000", 1),             # same after the cut
+        row(8, "N", "N", ".", "ALANINE", "C", 123456, "?", "8.000 2.000 3.000", 1),        # long names / numbers are cut
+        row(9, "C", "CA", ".", "ALA", "C", 123457, "?", "9.000 2.000 3.000", 1),
+    ])
+    files["syn_models_out_of_order.cif"] = cif_loop([
+        row(1, "N", "N", ".", "ALA", "A", 1, "?", "1.000 2.000 3.000", 3),
+        row(2, "C", "CA", ".", "ALA", "A", 1, "?", "2.000 2.000 3.000", 2),
+        row(3, "C", "C", ".", "ALA", "A", 1, "?", "3.000 2.000 3.000", 3),
+        row(4, "O", "O", ".", "ALA", "A", 1, "?", "4.000 2.000 3.000", 2),
+    ])
+    two = cif_loop([row(1, "N", "N", ".", "ALA", "A", 1, "?", "1.000 2.000 3.000", 1)], block="data_ONE")
+    two += "_cell.length_a 10.0\n_struct.title\n;a text field with loop_ and _atom_site.id inside\n;\n"
+    two += cif_loop([row(1, "C", "CA", ".", "GLY", "B", 5, "?", "2.000 2.000 3.000", 1)], block="data_TWO")
+    files["syn_two_blocks_textfield.cif"] = two
+    # columns in another order, upper-case keywords and tags, values spread over lines, comments
+    cols = ["pdbx_PDB_model_num", "Cartn_z", "Cartn_y", "Cartn_x", "type_symbol", "label_alt_id", "auth_atom_id", "auth_comp_id",
+            "pdbx_PDB_ins_code", "auth_seq_id", "auth_asym_id", "group_PDB"]
+    files["syn_reordered_columns.cif"] = ("DATA_X\nLOOP_\n" + "".join(f"_ATOM_SITE.{c}\n" for c in cols) +
+                                          "1 3.0 2.0 1.0 N . N ALA ? 1 A ATOM # trailing comment\n1 3.0 2.0\n 2.0 C . 'CA' ALA\n ? 1 A ATOM\n")
+    files["syn_missing_column.cif"] = cif_loop([f"ATOM 1 N N . ALA A 1 ? 1.0 2.0 3.0 1"],
+                                               columns=["group_PDB", "id", "type_symbol", "auth_atom_id", "label_alt_id", "auth_comp_id",
+                                                        "auth_asym_id", "auth_seq_id", "pdbx_PDB_ins_code", "Cartn_x", "Cartn_y", "Cartn_z",
+                                                        "occupancy"])          # no pdbx_PDB_model_num
+    files["syn_no_atoms.cif"] = "data_EMPTY\n_cell.length_a 10.0\n"
+    return files
 
 
 def sha(a):
@@ -83,11 +151,16 @@ def reference_view(path, options):
 
 def reference_view_unsafe(path, options):
     fp = libc.fopen(path.encode(), b"r")
-    s = lib.freesasa_structure_from_pdb(fp, None, options)
+    if path.endswith(".cif"):
+        s = from_cif(fp, None, options)
+    else:
+        s = lib.freesasa_structure_from_pdb(fp, None, options)
     libc.fclose(fp)
     if not s:
         return {"fail": True}
     n, nr = lib.freesasa_structure_n(s), lib.freesasa_structure_n_residues(s)
+    if n == 0:      # the mmCIF reader hands back an empty structure where the PDB reader fails
+        return {"fail": True}
     xyz = np.ctypeslib.as_array(lib.freesasa_structure_coord_array(s), shape=(3 * n,)).copy()
     rad = np.ctypeslib.as_array(lib.freesasa_structure_radius(s), shape=(n,)).copy()
     cls = np.array([lib.freesasa_structure_atom_class(s, i) for i in range(n)], dtype=np.uint8)
@@ -97,7 +170,7 @@ def reference_view_unsafe(path, options):
         lib.freesasa_structure_residue_atoms(s, r, C.byref(a), C.byref(b))
         first.append(a.value)
         labels.append(lib.freesasa_structure_residue_name(s, r).decode() + "|" + lib.freesasa_structure_residue_number(s, r).decode()
-                      + "|" + lib.freesasa_structure_residue_chain(s, r).decode())
+                      + "|" + lib.freesasa_structure_residue_chain_lcl(s, r).decode())
     lib.freesasa_structure_free(s)
     return {"n_atoms": n, "n_residues": nr, "xyz": sha(xyz), "radii": sha(rad), "classes": sha(cls),
             "res_first": sha(np.array(first + [n], dtype=np.int64)), "labels": hashlib.sha256("\n".join(labels).encode()).hexdigest(),
@@ -196,6 +269,17 @@ def main():
             shutil.copyfile(src, dst)
         os.chmod(dst, 0o644)
         out[name] = {str(o): reference_view(dst, o) for o in OPTION_SETS}
+    os.makedirs(os.path.join(HERE, "cif"), exist_ok=True)
+    for name in CIF_FILES:
+        dst = os.path.join(HERE, "cif", name)
+        shutil.copyfile(os.path.join(DATA, name), dst)
+        os.chmod(dst, 0o644)
+        out[name] = {str(o): reference_view(dst, o) for o in CIF_OPTION_SETS}
+    for name, text in synthetic_cifs().items():
+        dst = os.path.join(HERE, "cif", name)
+        with open(dst, "w", newline="") as fh:
+            fh.write(text)
+        out[name] = {str(o): reference_view(dst, o) for o in CIF_OPTION_SETS}
     with open(os.path.join(HERE, "ingest.json"), "w") as fh:
         json.dump(out, fh, indent=1, sort_keys=True)
     print({k: v["0"].get("n_atoms", "fail") for k, v in out.items()})

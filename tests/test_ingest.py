@@ -15,6 +15,11 @@ from conftest import ROOT
 from freesasa_amd import ingest
 
 PDB = os.path.join(ROOT, "tests", "golden", "pdb")
+CIF = os.path.join(ROOT, "tests", "golden", "cif")
+
+
+def fixture(name):
+    return os.path.join(CIF if name.endswith(".cif") else PDB, name)
 with open(os.path.join(ROOT, "tests", "golden", "ingest.json")) as fh:
     GOLD = json.load(fh)
 
@@ -34,7 +39,7 @@ def test_matches_the_reference_reader(name):
     for opt, exp in GOLD[name].items():
         if exp.get("crash"):        # the reference itself aborts on this input (double free)
             continue
-        b = ingest.load_pdb_files([os.path.join(PDB, name)], options=int(opt))
+        b = ingest.load_pdb_files([fixture(name)], options=int(opt))
         if exp.get("fail"):
             assert b.status[0] != ingest.OK and b.n_atoms == 0 and b.offsets.tolist() == [0, 0], (name, opt)
         else:
@@ -45,6 +50,18 @@ def test_matches_the_reference_reader(name):
             assert labels_digest(b) == exp["labels"], (name, opt)
         checked += 1
     assert checked >= 9
+
+
+def test_mmcif_and_pdb_of_the_same_entry_agree():
+    """ref: tests/test-cli.in:229-236 (the CLI gives the same totals for 1ubq.pdb and 1ubq.cif)."""
+    b = ingest.load_pdb_files([fixture("1ubq.pdb"), fixture("1ubq.cif"), fixture("3bkr.pdb"), fixture("3bkr.cif")], n_threads=2)
+    assert b.status.tolist() == [0, 0, 0, 0]
+    for k in (0, 2):
+        a, c = slice(b.offsets[k], b.offsets[k + 1]), slice(b.offsets[k + 1], b.offsets[k + 2])
+        assert np.array_equal(b.xyz[a], b.xyz[c]) and np.array_equal(b.radii[a], b.radii[c])
+        assert np.array_equal(b.atom_class[a], b.atom_class[c])
+        assert np.array_equal(np.diff(b.res_first[b.res_offsets[k]:b.res_offsets[k + 1] + 1]),
+                              np.diff(b.res_first[b.res_offsets[k + 1]:b.res_offsets[k + 2] + 1]))
 
 
 def test_reference_atom_counts_of_its_cli_tests():
@@ -127,7 +144,7 @@ def test_pdb_to_sasa_end_to_end_matches_reference_totals():
     import freesasa_amd as fa
     from conftest import read_seq_reference
     b = ingest.load_pdb_files([os.path.join(PDB, "1ubq.pdb"), os.path.join(PDB, "3bzd_trimmed.pdb"),
-                               os.path.join(PDB, "1d3z.pdb")])
+                               os.path.join(PDB, "1d3z.pdb"), fixture("1ubq.cif")])
     lr, _, lr_tot = fa.calc_batch(b.xyz, b.radii, b.offsets, fa.LEE_RICHARDS, resolution=20)
     sr, _, sr_tot = fa.calc_batch(b.xyz, b.radii, b.offsets, fa.SHRAKE_RUPLEY, resolution=100)
     ubq = slice(b.offsets[0], b.offsets[1])
@@ -139,6 +156,7 @@ def test_pdb_to_sasa_end_to_end_matches_reference_totals():
     assert abs(sr[ubq][polar].sum() - 2515.821238) < 1e-5 * 2515.821238
     assert abs(sr_tot[1] - 16133.867124) < 1e-5 * 16133.867124          # 3BZD, tests/test_freesasa.c:305-327
     assert abs(sr_tot[2] - 5000.340175) < 1e-5 * 5000.340175            # 1D3Z model 1, :441-451
+    assert lr_tot[3] == lr_tot[0] and sr_tot[3] == sr_tot[0]             # 1ubq.cif == 1ubq.pdb (tests/test-cli.in:229-236)
     # the same aggregates on the device (N2): per-structure class sums and per-residue sums
     import torch
     dev = torch.device("cuda:0")
