@@ -1,4 +1,4 @@
-"""Python face of include/freesasa_ingest.h: multi-threaded PDB -> packed batch.
+"""Python face of include/freesasa_ingest.h: multi-threaded PDB / mmCIF -> packed batch.
 
     batch = ingest.load_pdb_files(paths)            # host threads, one structure per file
     sasa, totals = freesasa_amd.calc_batch(batch.xyz, batch.radii, batch.offsets)
@@ -112,6 +112,9 @@ def load_pdb_texts(texts, options=0, n_threads=0):
     lens = (C.c_size_t * len(raw))(*[len(t) for t in raw])
     cb = _CBatch()
     return _finish(L, L.freesasa_ingest_pdb_texts(arr, lens, len(raw), options, n_threads, C.byref(cb)), cb)
+
+
+load_files, load_texts = load_pdb_files, load_pdb_texts      # the format is recognised per input (PDB or mmCIF)
 
 
 def protor_radius(res_name, atom_name):
