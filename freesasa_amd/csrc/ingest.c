@@ -89,6 +89,7 @@ typedef struct {
     char *res_name, *res_number, *res_chain;
     int status;
     int scratch_model; /* mmCIF: lowest model number found by the first pass */
+    int64_t n0, nres0; /* where the input being parsed starts: a worker appends all its inputs to one arena */
 } parsed;
 
 static void parsed_free(parsed *p)
@@ -209,7 +210,7 @@ static int scan_double(const char **pp, double *out)
 /* Parses into p's buffers, which are reused from call to call (only the counters are reset). */
 static void parse_pdb(const char *text, size_t len, int options, parsed *p)
 {
-    p->n = 0; p->nres = 0; p->status = 0;
+    p->n = p->n0; p->nres = p->nres0; p->status = 0;
     if ((options & FREESASA_INGEST_SKIP_UNKNOWN) && (options & FREESASA_INGEST_HALT_AT_UNKNOWN))
         options &= ~FREESASA_INGEST_SKIP_UNKNOWN; /* the stricter one wins (ref: src/structure.c:596-597) */
     char line[CHUNK + 1];
@@ -291,9 +292,9 @@ static void parse_pdb(const char *text, size_t len, int options, parsed *p)
 
             if (grow_atoms(p)) { p->status = FREESASA_INGEST_ENOMEM; return; }
             /* a new residue starts when the residue number or the chain changes (ref: :488-496) */
-            if (p->n == 0 || strcmp(rnumber, prev_number) != 0 || chain != prev_chain) {
+            if (p->n == p->n0 || strcmp(rnumber, prev_number) != 0 || chain != prev_chain) {
                 if (grow_res(p)) { p->status = FREESASA_INGEST_ENOMEM; return; }
-                p->res_first[p->nres] = p->n;
+                p->res_first[p->nres] = p->n - p->n0;
                 memset(p->res_name + 4 * p->nres, 0, 4);
                 memcpy(p->res_name + 4 * p->nres, rname, strlen(rname));
                 memset(p->res_number + 6 * p->nres, 0, 6);
@@ -311,7 +312,7 @@ static void parse_pdb(const char *text, size_t len, int options, parsed *p)
         }
         if (!(options & FREESASA_INGEST_JOIN_MODELS) && strncmp("ENDMDL", line, 6) == 0) break; /* ref: :705-708 */
     }
-    if (p->n == 0) p->status = FREESASA_INGEST_EEMPTY;
+    if (p->n == p->n0) p->status = FREESASA_INGEST_EEMPTY;
 }
 
 /* ------------------------------------------------------------------ mmCIF */
@@ -502,9 +503,9 @@ static int cif_visit_atom(const cif_tok *row, void *ctx)
         if (r < 0) r = +0.;
     }
     if (grow_atoms(p)) { p->status = FREESASA_INGEST_ENOMEM; return -1; }
-    if (p->n == 0 || strcmp(rnumber, c->prev_number) != 0 || strcmp(chain, c->prev_chain) != 0) {
+    if (p->n == p->n0 || strcmp(rnumber, c->prev_number) != 0 || strcmp(chain, c->prev_chain) != 0) {
         if (grow_res(p)) { p->status = FREESASA_INGEST_ENOMEM; return -1; }
-        p->res_first[p->nres] = p->n;
+        p->res_first[p->nres] = p->n - p->n0;
         memset(p->res_name + 4 * p->nres, 0, 4);
         memcpy(p->res_name + 4 * p->nres, rname, strlen(rname));
         memset(p->res_number + 6 * p->nres, 0, 6);
@@ -530,7 +531,7 @@ static void parse_cif(const char *text, size_t len, int options, parsed *p)
        shows up later. */
     cif_atoms c;
     for (int pass = 0; pass < 2; ++pass) {
-        p->n = 0; p->nres = 0; p->status = 0;
+        p->n = p->n0; p->nres = p->nres0; p->status = 0;
         memset(&c, 0, sizeof c);
         c.p = p; c.options = options; c.prev_alt = '.';
         if (pass == 1) { c.have_model = 1; c.model = c.min_model = p->scratch_model; }
@@ -538,7 +539,7 @@ static void parse_cif(const char *text, size_t len, int options, parsed *p)
         if (!c.have_model || c.min_model == c.model || p->status) break;
         p->scratch_model = c.min_model;
     }
-    if (p->status == 0 && p->n == 0) p->status = FREESASA_INGEST_EEMPTY;
+    if (p->status == 0 && p->n == p->n0) p->status = FREESASA_INGEST_EEMPTY;
 }
 
 /* A file whose first token is data_... is mmCIF; anything else is read as PDB. */
@@ -579,77 +580,145 @@ static int read_file(const char *path, char **buf, size_t *cap, size_t *len)
     return bad ? -1 : 0;
 }
 
-/* exact-size copy of a worker's scratch result (the scratch buffers stay with the worker) */
-static int compact(const parsed *s, parsed *d)
-{
-    memset(d, 0, sizeof *d);
-    d->status = s->status;
-    if (s->status || s->n == 0) return 0;
-    d->xyz = malloc(sizeof(double) * 3 * (size_t)s->n);
-    d->rad = malloc(sizeof(double) * (size_t)s->n);
-    d->cls = malloc((size_t)s->n);
-    d->res_first = malloc(sizeof(int64_t) * (size_t)s->nres);
-    d->res_name = malloc(4 * (size_t)s->nres);
-    d->res_number = malloc(6 * (size_t)s->nres);
-    d->res_chain = malloc(4 * (size_t)s->nres);
-    if (!d->xyz || !d->rad || !d->cls || !d->res_first || !d->res_name || !d->res_number || !d->res_chain) {
-        parsed_free(d);
-        d->status = FREESASA_INGEST_ENOMEM;
-        return -1;
-    }
-    memcpy(d->xyz, s->xyz, sizeof(double) * 3 * (size_t)s->n);
-    memcpy(d->rad, s->rad, sizeof(double) * (size_t)s->n);
-    memcpy(d->cls, s->cls, (size_t)s->n);
-    memcpy(d->res_first, s->res_first, sizeof(int64_t) * (size_t)s->nres);
-    memcpy(d->res_name, s->res_name, 4 * (size_t)s->nres);
-    memcpy(d->res_number, s->res_number, 6 * (size_t)s->nres);
-    memcpy(d->res_chain, s->res_chain, 4 * (size_t)s->nres);
-    d->n = d->cap = s->n;
-    d->nres = d->rescap = s->nres;
-    return 0;
-}
-
 /* ------------------------------------------------------------------ the batch */
+
+/* Every worker appends the inputs it takes to its own arena (one set of growing arrays, no per-file
+ * allocation); when all inputs are parsed, one thread sizes the output and all workers copy their
+ * inputs' slices into place (parallel first touch of the output pages). */
+typedef struct { int worker; int status; int64_t a0, na, r0, nr; } slot; /* where input k lives */
 
 typedef struct {
     const char *const *paths;
     const char *const *texts;
     const size_t *lens;
-    int n, options;
-    parsed *res;
-    int next; /* work counter */
+    int n, options, n_workers;
+    slot *slots;
+    parsed *arena; /* [n_workers] */
+    int64_t *a_off, *r_off; /* [n + 1] output offsets of every input */
+    freesasa_ingest_batch *out;
+    int rc;
+    int next, next2; /* work counters of the two phases */
     pthread_mutex_t mu;
+    pthread_barrier_t bar;
 } job;
+
+/* arenas are kept between calls (a fresh one costs its page faults again) */
+#define ARENA_POOL 64
+static parsed g_pool[ARENA_POOL];
+static int g_pool_n = 0;
+static pthread_mutex_t g_pool_mu = PTHREAD_MUTEX_INITIALIZER;
+
+static void arena_get(parsed *a)
+{
+    memset(a, 0, sizeof *a);
+    pthread_mutex_lock(&g_pool_mu);
+    if (g_pool_n > 0) *a = g_pool[--g_pool_n];
+    pthread_mutex_unlock(&g_pool_mu);
+    a->n = a->nres = a->n0 = a->nres0 = 0;
+    a->status = 0;
+}
+static void arena_put(parsed *a)
+{
+    pthread_mutex_lock(&g_pool_mu);
+    if (g_pool_n < ARENA_POOL && a->cap <= ((int64_t)1 << 21)) { g_pool[g_pool_n++] = *a; memset(a, 0, sizeof *a); }
+    pthread_mutex_unlock(&g_pool_mu);
+    parsed_free(a);
+}
+
+static int take(job *j, int *counter)
+{
+    pthread_mutex_lock(&j->mu);
+    const int k = (*counter)++;
+    pthread_mutex_unlock(&j->mu);
+    return k;
+}
+
+static void assemble_sizes(job *j)
+{
+    freesasa_ingest_batch *out = j->out;
+    int64_t na = 0, nr = 0;
+    for (int k = 0; k < j->n; ++k) {
+        j->a_off[k] = na; j->r_off[k] = nr;
+        na += j->slots[k].na; nr += j->slots[k].nr;
+    }
+    j->a_off[j->n] = na; j->r_off[j->n] = nr;
+    out->n_structs = j->n;
+    out->n_atoms = na;
+    out->n_residues = nr;
+    out->xyz = malloc(sizeof(double) * 3 * (size_t)(na ? na : 1));
+    out->radii = malloc(sizeof(double) * (size_t)(na ? na : 1));
+    out->atom_class = malloc((size_t)(na ? na : 1));
+    out->offsets = malloc(sizeof(int64_t) * ((size_t)j->n + 1));
+    out->res_first = malloc(sizeof(int64_t) * ((size_t)nr + 1));
+    out->res_offsets = malloc(sizeof(int64_t) * ((size_t)j->n + 1));
+    out->res_name = malloc(4 * (size_t)(nr ? nr : 1));
+    out->res_number = malloc(6 * (size_t)(nr ? nr : 1));
+    out->res_chain = malloc(4 * (size_t)(nr ? nr : 1));
+    out->status = malloc(sizeof(int32_t) * (size_t)(j->n ? j->n : 1));
+    if (!out->xyz || !out->radii || !out->atom_class || !out->offsets || !out->res_first || !out->res_offsets ||
+        !out->res_name || !out->res_number || !out->res_chain || !out->status) {
+        j->rc = FREESASA_INGEST_ENOMEM;
+        return;
+    }
+    memcpy(out->offsets, j->a_off, sizeof(int64_t) * ((size_t)j->n + 1));
+    memcpy(out->res_offsets, j->r_off, sizeof(int64_t) * ((size_t)j->n + 1));
+    out->res_first[nr] = na;
+}
 
 static void *worker(void *arg)
 {
     job *j = (job *)arg;
-    /* per-thread scratch, reused for every input this thread takes: the file text and the growing
-       parse arrays (fresh allocations per file would spend the time in page faults and mmap) */
-    parsed scratch;
-    memset(&scratch, 0, sizeof scratch);
-    char *text = NULL;
+    /* which worker am I: the order of arrival */
+    const int w = take(j, &j->n_workers);
+    parsed *A = &j->arena[w];
+    arena_get(A);
+    char *text = NULL; /* file text, reused from input to input */
     size_t cap = 0;
     for (;;) {
-        pthread_mutex_lock(&j->mu);
-        const int k = j->next++;
-        pthread_mutex_unlock(&j->mu);
+        const int k = take(j, &j->next);
         if (k >= j->n) break;
+        A->n0 = A->n; A->nres0 = A->nres;
         if (j->texts) {
-            parse_any(j->texts[k], j->lens[k], j->options, &scratch);
+            parse_any(j->texts[k], j->lens[k], j->options, A);
         } else {
             size_t len = 0;
-            if (read_file(j->paths[k], &text, &cap, &len)) {
-                scratch.n = 0; scratch.nres = 0;
-                scratch.status = FREESASA_INGEST_EIO;
-            } else {
-                parse_any(text, len, j->options, &scratch);
-            }
+            if (read_file(j->paths[k], &text, &cap, &len)) A->status = FREESASA_INGEST_EIO;
+            else parse_any(text, len, j->options, A);
         }
-        compact(&scratch, &j->res[k]); /* failed inputs contribute an empty structure */
+        slot *s = &j->slots[k];
+        s->worker = w;
+        s->status = A->status;
+        if (A->status) { A->n = A->n0; A->nres = A->nres0; } /* failed inputs contribute an empty structure */
+        s->a0 = A->n0; s->na = A->n - A->n0;
+        s->r0 = A->nres0; s->nr = A->nres - A->nres0;
     }
     free(text);
-    parsed_free(&scratch);
+    if (pthread_barrier_wait(&j->bar) == PTHREAD_BARRIER_SERIAL_THREAD) assemble_sizes(j);
+    pthread_barrier_wait(&j->bar);
+    if (!j->rc) {
+        freesasa_ingest_batch *out = j->out;
+        for (;;) {
+            const int k = take(j, &j->next2);
+            if (k >= j->n) break;
+            const slot *s = &j->slots[k];
+            const parsed *S = &j->arena[s->worker];
+            const int64_t a = j->a_off[k], r = j->r_off[k];
+            out->status[k] = s->status;
+            if (s->na) {
+                memcpy(out->xyz + 3 * a, S->xyz + 3 * s->a0, sizeof(double) * 3 * (size_t)s->na);
+                memcpy(out->radii + a, S->rad + s->a0, sizeof(double) * (size_t)s->na);
+                memcpy(out->atom_class + a, S->cls + s->a0, (size_t)s->na);
+            }
+            for (int64_t i = 0; i < s->nr; ++i) out->res_first[r + i] = a + S->res_first[s->r0 + i];
+            if (s->nr) {
+                memcpy(out->res_name + 4 * r, S->res_name + 4 * s->r0, 4 * (size_t)s->nr);
+                memcpy(out->res_number + 6 * r, S->res_number + 6 * s->r0, 6 * (size_t)s->nr);
+                memcpy(out->res_chain + 4 * r, S->res_chain + 4 * s->r0, 4 * (size_t)s->nr);
+            }
+        }
+    }
+    pthread_barrier_wait(&j->bar); /* nobody's arena may go while others still copy from it */
+    arena_put(A);
     return NULL;
 }
 
@@ -668,10 +737,6 @@ static int run(job *j, int n_threads, freesasa_ingest_batch *out)
                           FREESASA_INGEST_HALT_AT_UNKNOWN | FREESASA_INGEST_SKIP_UNKNOWN | FREESASA_INGEST_RADIUS_FROM_OCCUPANCY;
     if (j->options & ~supported) return FREESASA_INGEST_EOPTION;
     if (j->n < 0) return FREESASA_INGEST_EOPTION;
-    j->res = calloc((size_t)(j->n > 0 ? j->n : 1), sizeof(parsed));
-    if (!j->res) return FREESASA_INGEST_ENOMEM;
-    j->next = 0;
-    pthread_mutex_init(&j->mu, NULL);
     if (n_threads <= 0) { /* default: the cores, but no more threads than pay for their start-up */
         n_threads = (int)sysconf(_SC_NPROCESSORS_ONLN);
         if (n_threads > 64) n_threads = 64;
@@ -679,74 +744,39 @@ static int run(job *j, int n_threads, freesasa_ingest_batch *out)
     }
     if (n_threads > j->n) n_threads = j->n;
     if (n_threads < 1) n_threads = 1;
+    j->out = out;
+    j->slots = calloc((size_t)(j->n > 0 ? j->n : 1), sizeof(slot));
+    j->arena = calloc((size_t)n_threads, sizeof(parsed));
+    j->a_off = malloc(sizeof(int64_t) * ((size_t)j->n + 1));
+    j->r_off = malloc(sizeof(int64_t) * ((size_t)j->n + 1));
     pthread_t *th = calloc((size_t)n_threads, sizeof(pthread_t));
-    int started = 0;
-    if (th)
-        for (; started < n_threads - 1; ++started)
-            if (pthread_create(&th[started], NULL, worker, j)) break;
+    if (!j->slots || !j->arena || !j->a_off || !j->r_off || !th) {
+        free(j->slots); free(j->arena); free(j->a_off); free(j->r_off); free(th);
+        return FREESASA_INGEST_ENOMEM;
+    }
+    pthread_mutex_init(&j->mu, NULL);
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
+    /* the barrier needs the exact number of participants: start the threads first */
+    int started = 0;
+    pthread_barrier_t *bar = &j->bar;
+    /* count how many threads can be created before anyone reaches the barrier: workers block on a
+       start gate (the mutex) until the count is known */
+    pthread_mutex_lock(&j->mu);
+    for (; started < n_threads - 1; ++started)
+        if (pthread_create(&th[started], NULL, worker, j)) break;
+    pthread_barrier_init(bar, NULL, (unsigned)started + 1);
+    pthread_mutex_unlock(&j->mu);
     worker(j); /* the calling thread works too */
     for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
     clock_gettime(CLOCK_MONOTONIC, &t1);
     if (getenv("FREESASA_INGEST_TIMING"))
-        fprintf(stderr, "ingest: %d inputs, %d threads, parse %.3f ms\n", j->n, started + 1,
+        fprintf(stderr, "ingest: %d inputs, %d threads, %lld atoms, %.3f ms\n", j->n, started + 1, (long long)out->n_atoms,
                 1e3 * (double)(t1.tv_sec - t0.tv_sec) + 1e-6 * (double)(t1.tv_nsec - t0.tv_nsec));
-    free(th);
+    pthread_barrier_destroy(bar);
     pthread_mutex_destroy(&j->mu);
-
-    int64_t na = 0, nr = 0;
-    for (int k = 0; k < j->n; ++k) { na += j->res[k].n; nr += j->res[k].nres; }
-    out->n_structs = j->n;
-    out->n_atoms = na;
-    out->n_residues = nr;
-    out->xyz = malloc(sizeof(double) * 3 * (size_t)(na ? na : 1));
-    out->radii = malloc(sizeof(double) * (size_t)(na ? na : 1));
-    out->atom_class = malloc((size_t)(na ? na : 1));
-    out->offsets = malloc(sizeof(int64_t) * ((size_t)j->n + 1));
-    out->res_first = malloc(sizeof(int64_t) * ((size_t)nr + 1));
-    out->res_offsets = malloc(sizeof(int64_t) * ((size_t)j->n + 1));
-    out->res_name = malloc(4 * (size_t)(nr ? nr : 1));
-    out->res_number = malloc(6 * (size_t)(nr ? nr : 1));
-    out->res_chain = malloc(4 * (size_t)(nr ? nr : 1));
-    out->status = malloc(sizeof(int32_t) * (size_t)(j->n ? j->n : 1));
-    int rc = 0;
-    if (!out->xyz || !out->radii || !out->atom_class || !out->offsets || !out->res_first || !out->res_offsets ||
-        !out->res_name || !out->res_number || !out->res_chain || !out->status) {
-        rc = FREESASA_INGEST_ENOMEM;
-    } else {
-        int64_t a = 0, r = 0;
-        for (int k = 0; k < j->n; ++k) {
-            const parsed *p = &j->res[k];
-            out->offsets[k] = a;
-            out->res_offsets[k] = r;
-            out->status[k] = p->status;
-            if (p->n) {
-                memcpy(out->xyz + 3 * a, p->xyz, sizeof(double) * 3 * (size_t)p->n);
-                memcpy(out->radii + a, p->rad, sizeof(double) * (size_t)p->n);
-                memcpy(out->atom_class + a, p->cls, (size_t)p->n);
-            }
-            for (int64_t i = 0; i < p->nres; ++i) out->res_first[r + i] = a + p->res_first[i];
-            if (p->nres) {
-                memcpy(out->res_name + 4 * r, p->res_name, 4 * (size_t)p->nres);
-                memcpy(out->res_number + 6 * r, p->res_number, 6 * (size_t)p->nres);
-                memcpy(out->res_chain + 4 * r, p->res_chain, 4 * (size_t)p->nres);
-            }
-            a += p->n;
-            r += p->nres;
-        }
-        out->offsets[j->n] = a;
-        out->res_offsets[j->n] = r;
-        out->res_first[nr] = a;
-    }
-    for (int k = 0; k < j->n; ++k) parsed_free(&j->res[k]);
-    free(j->res);
-    if (getenv("FREESASA_INGEST_TIMING")) {
-        struct timespec t2;
-        clock_gettime(CLOCK_MONOTONIC, &t2);
-        fprintf(stderr, "ingest: assembly of %lld atoms %.3f ms\n", (long long)na,
-                1e3 * (double)(t2.tv_sec - t1.tv_sec) + 1e-6 * (double)(t2.tv_nsec - t1.tv_nsec));
-    }
+    free(th); free(j->slots); free(j->arena); free(j->a_off); free(j->r_off);
+    const int rc = j->rc;
     if (rc) freesasa_ingest_free(out);
     return rc;
 }
