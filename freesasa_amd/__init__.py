@@ -113,6 +113,8 @@ def lib():
                                                 C.c_void_p]
         L.freesasa_gpu_segment_sums_dev.argtypes = [C.c_void_p, C.c_void_p, _lp, C.c_int, C.c_void_p]
         L.freesasa_gpu_class_sums_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, _lp, C.c_int, C.c_void_p]
+        L.freesasa_gpu_residue_areas_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _lp, C.c_int,
+                                                     C.POINTER(C.c_short), _dp, C.c_int, C.c_void_p, C.c_void_p]
         L.freesasa_gpu_test_points.argtypes = [C.c_int, _dp]
         L.freesasa_gpu_test_points.restype = None
         L.freesasa_gpu_calc_batch.argtypes = [_dp, _dp, _lp, C.c_int, C.c_int, C.c_double, C.c_int,
@@ -239,6 +241,18 @@ class GpuContext:
         offs = np.ascontiguousarray(offsets, dtype=np.int64)
         if lib().freesasa_gpu_class_sums_dev(self._h, d_sasa, d_class, offs.ctypes.data_as(_lp), offs.size - 1, d_out):
             raise RuntimeError("freesasa_gpu_class_sums_dev: " + self.error())
+
+    def residue_areas(self, d_sasa, d_class, d_backbone, res_first, d_abs, res_ref=None, ref_table=None, d_rel=0):
+        """Per-residue node areas (d_abs[6*r+..]) and, given res_ref / ref_table, relative areas (d_rel[5*r+..])."""
+        rf = np.ascontiguousarray(res_first, dtype=np.int64)
+        rr = np.ascontiguousarray(res_ref, dtype=np.int16) if res_ref is not None else None
+        rt = np.ascontiguousarray(ref_table, dtype=np.float64).reshape(-1) if ref_table is not None else None
+        ret = lib().freesasa_gpu_residue_areas_dev(
+            self._h, d_sasa, d_class, d_backbone, rf.ctypes.data_as(_lp), rf.size - 1,
+            rr.ctypes.data_as(C.POINTER(C.c_short)) if rr is not None else None,
+            rt.ctypes.data_as(_dp) if rt is not None else None, (rt.size // 5) if rt is not None else 0, d_abs, d_rel)
+        if ret:
+            raise RuntimeError("freesasa_gpu_residue_areas_dev: " + self.error())
 
     def shrake_rupley(self, d_xyz, d_radii, offsets, d_sasa, d_counts=0, d_totals=0, probe=1.4,
                       n_points=100):

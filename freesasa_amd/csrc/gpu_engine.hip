@@ -96,6 +96,13 @@ __global__ __launch_bounds__(256) void k_segsum_small(const double *sasa, const 
     segsum_small(sasa, seg, out, blockIdx.x * 256 + threadIdx.x, n_segs);
 }
 
+__global__ __launch_bounds__(256) void k_residue_areas(const double *sasa, const unsigned char *cls, const unsigned char *bb,
+                                                      const int64_t *res_first, const short *ref_row, const double *ref_table,
+                                                      double *abs_out, double *rel_out, int n_res)
+{
+    residue_areas(sasa, cls, bb, res_first, ref_row, ref_table, abs_out, rel_out, blockIdx.x * 256 + threadIdx.x, n_res);
+}
+
 __global__ __launch_bounds__(SASA_TOT_B) void k_class_sums(const double *sasa, const unsigned char *cls, const int64_t *offsets, double *out)
 {
     __shared__ double part[3 * SASA_TOT_B];
@@ -634,6 +641,39 @@ extern "C" int freesasa_gpu_class_sums_dev(freesasa_gpu_ctx *c, const double *d_
     if (ensure(c, c->seg, sizeof(int64_t) * ((size_t)n_structs + 1))) return -1;
     HIP_TRY(c, hipMemcpyAsync(c->seg.p, offsets, sizeof(int64_t) * ((size_t)n_structs + 1), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_class_sums, dim3(n_structs), dim3(SASA_TOT_B), 0, c->stream, d_sasa, d_class, (const int64_t *)c->seg.p, d_out);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int freesasa_gpu_residue_areas_dev(freesasa_gpu_ctx *c, const double *d_sasa, const unsigned char *d_class,
+                                              const unsigned char *d_backbone, const int64_t *res_first, int n_res,
+                                              const short *ref_row, const double *ref_table, int ref_rows,
+                                              double *d_abs, double *d_rel)
+{
+    if (!c) return -1;
+    c->err[0] = 0;
+    if (!d_sasa || !d_class || !d_backbone || !res_first || !d_abs || n_res <= 0) return ctx_fail(c, "bad argument");
+    if (d_rel && (!ref_row || !ref_table || ref_rows <= 0)) return ctx_fail(c, "relative areas need the reference rows and table");
+    for (int k = 0; k < n_res; ++k) {
+        if (res_first[k + 1] < res_first[k]) return ctx_fail(c, "residue offsets must be non-decreasing");
+        if (d_rel && ref_row[k] >= ref_rows) return ctx_fail(c, "reference row out of range");
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    /* one staging buffer: offsets, reference table, reference rows */
+    const size_t b_first = sizeof(int64_t) * ((size_t)n_res + 1);
+    const size_t b_table = d_rel ? sizeof(double) * 5 * (size_t)ref_rows : 0;
+    const size_t b_rows = d_rel ? sizeof(short) * (size_t)n_res : 0;
+    if (ensure(c, c->seg, b_first + b_table + b_rows)) return -1;
+    char *base = (char *)c->seg.p;
+    HIP_TRY(c, hipMemcpyAsync(base, res_first, b_first, hipMemcpyHostToDevice, c->stream));
+    if (d_rel) {
+        HIP_TRY(c, hipMemcpyAsync(base + b_first, ref_table, b_table, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(base + b_first + b_table, ref_row, b_rows, hipMemcpyHostToDevice, c->stream));
+    }
+    hipLaunchKernelGGL(k_residue_areas, dim3((n_res + 255) / 256), dim3(256), 0, c->stream, d_sasa, d_class, d_backbone,
+                       (const int64_t *)base, d_rel ? (const short *)(base + b_first + b_table) : nullptr,
+                       d_rel ? (const double *)(base + b_first) : nullptr, d_abs, d_rel, n_res);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return 0;

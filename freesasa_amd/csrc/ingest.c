@@ -69,6 +69,49 @@ double freesasa_ingest_protor_radius(const char *res_name, const char *atom_name
     return -1.0;
 }
 
+/* ref: freesasa_atom_is_backbone, src/classifier.c:1090-1109 (the name is trimmed first) */
+int freesasa_ingest_is_backbone(const char *atom_name)
+{
+    const char *t;
+    const int n = first_token(atom_name, &t);
+    if (n < 1 || n > 3) return 0;
+    for (int i = 0; i < BACKBONE_N; ++i)
+        if (backbone_names[i][0] == t[0] && (int)strlen(backbone_names[i]) == n && memcmp(backbone_names[i], t, (size_t)n) == 0) return 1;
+    return 0;
+}
+
+/* index into the reference-area table, -1 if the classifier has no such residue
+ * (ref: freesasa_classifier_residue_reference, src/classifier.c:853-861) */
+static int residue_ref_index(const char *res_name)
+{
+    const char *t;
+    const int n = first_token(res_name, &t);
+    if (n < 1 || n > 3) return -1;
+    for (int i = 0; i < RESIDUE_REF_N; ++i)
+        if ((int)strlen(residue_ref_table[i].res) == n && memcmp(residue_ref_table[i].res, t, (size_t)n) == 0) return i;
+    return -1;
+}
+
+int freesasa_ingest_residue_reference(const char *res_name, double ref[5])
+{
+    const int i = residue_ref_index(res_name);
+    if (i < 0) return -1;
+    ref[0] = residue_ref_table[i].total; ref[1] = residue_ref_table[i].main_chain; ref[2] = residue_ref_table[i].side_chain;
+    ref[3] = residue_ref_table[i].polar; ref[4] = residue_ref_table[i].apolar;
+    return i;
+}
+
+int freesasa_ingest_residue_reference_table(double *table)
+{
+    if (table)
+        for (int i = 0; i < RESIDUE_REF_N; ++i) {
+            table[5 * i] = residue_ref_table[i].total; table[5 * i + 1] = residue_ref_table[i].main_chain;
+            table[5 * i + 2] = residue_ref_table[i].side_chain; table[5 * i + 3] = residue_ref_table[i].polar;
+            table[5 * i + 4] = residue_ref_table[i].apolar;
+        }
+    return RESIDUE_REF_N;
+}
+
 double freesasa_ingest_guess_radius(const char *symbol)
 {
     char s[3];
@@ -83,9 +126,10 @@ double freesasa_ingest_guess_radius(const char *symbol)
 typedef struct {
     int64_t n, cap;
     double *xyz, *rad;
-    uint8_t *cls;
+    uint8_t *cls, *bb;
     int64_t nres, rescap;
     int64_t *res_first;
+    int16_t *res_ref;
     char *res_name, *res_number, *res_chain;
     int status;
     int scratch_model; /* mmCIF: lowest model number found by the first pass */
@@ -94,8 +138,8 @@ typedef struct {
 
 static void parsed_free(parsed *p)
 {
-    free(p->xyz); free(p->rad); free(p->cls);
-    free(p->res_first); free(p->res_name); free(p->res_number); free(p->res_chain);
+    free(p->xyz); free(p->rad); free(p->cls); free(p->bb);
+    free(p->res_first); free(p->res_ref); free(p->res_name); free(p->res_number); free(p->res_chain);
     memset(p, 0, sizeof *p);
 }
 
@@ -112,6 +156,9 @@ static int grow_atoms(parsed *p)
     uint8_t *c = realloc(p->cls, (size_t)cap);
     if (!c) return -1;
     p->cls = c;
+    uint8_t *b = realloc(p->bb, (size_t)cap);
+    if (!b) return -1;
+    p->bb = b;
     p->cap = cap;
     return 0;
 }
@@ -123,6 +170,9 @@ static int grow_res(parsed *p)
     int64_t *f = realloc(p->res_first, sizeof(int64_t) * (size_t)cap);
     if (!f) return -1;
     p->res_first = f;
+    int16_t *rr = realloc(p->res_ref, sizeof(int16_t) * (size_t)cap);
+    if (!rr) return -1;
+    p->res_ref = rr;
     char *a = realloc(p->res_name, 4 * (size_t)cap);
     if (!a) return -1;
     p->res_name = a;
@@ -295,6 +345,7 @@ static void parse_pdb(const char *text, size_t len, int options, parsed *p)
             if (p->n == p->n0 || strcmp(rnumber, prev_number) != 0 || chain != prev_chain) {
                 if (grow_res(p)) { p->status = FREESASA_INGEST_ENOMEM; return; }
                 p->res_first[p->nres] = p->n - p->n0;
+                p->res_ref[p->nres] = (int16_t)residue_ref_index(rname);
                 memset(p->res_name + 4 * p->nres, 0, 4);
                 memcpy(p->res_name + 4 * p->nres, rname, strlen(rname));
                 memset(p->res_number + 6 * p->nres, 0, 6);
@@ -308,6 +359,7 @@ static void parse_pdb(const char *text, size_t len, int options, parsed *p)
             p->xyz[3 * p->n] = v[0]; p->xyz[3 * p->n + 1] = v[1]; p->xyz[3 * p->n + 2] = v[2];
             p->rad[p->n] = r;
             p->cls[p->n] = (uint8_t)cls;
+            p->bb[p->n] = (uint8_t)freesasa_ingest_is_backbone(aname);
             ++p->n;
         }
         if (!(options & FREESASA_INGEST_JOIN_MODELS) && strncmp("ENDMDL", line, 6) == 0) break; /* ref: :705-708 */
@@ -506,6 +558,7 @@ static int cif_visit_atom(const cif_tok *row, void *ctx)
     if (p->n == p->n0 || strcmp(rnumber, c->prev_number) != 0 || strcmp(chain, c->prev_chain) != 0) {
         if (grow_res(p)) { p->status = FREESASA_INGEST_ENOMEM; return -1; }
         p->res_first[p->nres] = p->n - p->n0;
+        p->res_ref[p->nres] = (int16_t)residue_ref_index(rname);
         memset(p->res_name + 4 * p->nres, 0, 4);
         memcpy(p->res_name + 4 * p->nres, rname, strlen(rname));
         memset(p->res_number + 6 * p->nres, 0, 6);
@@ -519,6 +572,7 @@ static int cif_visit_atom(const cif_tok *row, void *ctx)
     p->xyz[3 * p->n] = v[0]; p->xyz[3 * p->n + 1] = v[1]; p->xyz[3 * p->n + 2] = v[2];
     p->rad[p->n] = r;
     p->cls[p->n] = (uint8_t)cls;
+    p->bb[p->n] = (uint8_t)freesasa_ingest_is_backbone(aname);
     ++p->n;
     return 0;
 }
@@ -648,6 +702,8 @@ static void assemble_sizes(job *j)
     out->xyz = malloc(sizeof(double) * 3 * (size_t)(na ? na : 1));
     out->radii = malloc(sizeof(double) * (size_t)(na ? na : 1));
     out->atom_class = malloc((size_t)(na ? na : 1));
+    out->atom_backbone = malloc((size_t)(na ? na : 1));
+    out->res_ref = malloc(sizeof(int16_t) * (size_t)(nr ? nr : 1));
     out->offsets = malloc(sizeof(int64_t) * ((size_t)j->n + 1));
     out->res_first = malloc(sizeof(int64_t) * ((size_t)nr + 1));
     out->res_offsets = malloc(sizeof(int64_t) * ((size_t)j->n + 1));
@@ -655,7 +711,7 @@ static void assemble_sizes(job *j)
     out->res_number = malloc(6 * (size_t)(nr ? nr : 1));
     out->res_chain = malloc(4 * (size_t)(nr ? nr : 1));
     out->status = malloc(sizeof(int32_t) * (size_t)(j->n ? j->n : 1));
-    if (!out->xyz || !out->radii || !out->atom_class || !out->offsets || !out->res_first || !out->res_offsets ||
+    if (!out->xyz || !out->radii || !out->atom_class || !out->atom_backbone || !out->res_ref || !out->offsets || !out->res_first || !out->res_offsets ||
         !out->res_name || !out->res_number || !out->res_chain || !out->status) {
         j->rc = FREESASA_INGEST_ENOMEM;
         return;
@@ -708,9 +764,11 @@ static void *worker(void *arg)
                 memcpy(out->xyz + 3 * a, S->xyz + 3 * s->a0, sizeof(double) * 3 * (size_t)s->na);
                 memcpy(out->radii + a, S->rad + s->a0, sizeof(double) * (size_t)s->na);
                 memcpy(out->atom_class + a, S->cls + s->a0, (size_t)s->na);
+                memcpy(out->atom_backbone + a, S->bb + s->a0, (size_t)s->na);
             }
             for (int64_t i = 0; i < s->nr; ++i) out->res_first[r + i] = a + S->res_first[s->r0 + i];
             if (s->nr) {
+                memcpy(out->res_ref + r, S->res_ref + s->r0, sizeof(int16_t) * (size_t)s->nr);
                 memcpy(out->res_name + 4 * r, S->res_name + 4 * s->r0, 4 * (size_t)s->nr);
                 memcpy(out->res_number + 6 * r, S->res_number + 6 * s->r0, 6 * (size_t)s->nr);
                 memcpy(out->res_chain + 4 * r, S->res_chain + 4 * s->r0, 4 * (size_t)s->nr);
@@ -725,7 +783,7 @@ static void *worker(void *arg)
 void freesasa_ingest_free(freesasa_ingest_batch *b)
 {
     if (!b) return;
-    free(b->xyz); free(b->radii); free(b->atom_class); free(b->offsets); free(b->res_first);
+    free(b->xyz); free(b->radii); free(b->atom_class); free(b->atom_backbone); free(b->res_ref); free(b->offsets); free(b->res_first);
     free(b->res_offsets); free(b->res_name); free(b->res_number); free(b->res_chain); free(b->status);
     memset(b, 0, sizeof *b);
 }

@@ -1249,6 +1249,40 @@ SASA_D void segsum_small(const double *sasa, const int64_t *seg, double *out, in
     out[k] = t;
 }
 
+/* The reference's per-residue node area (ref: freesasa_atom_nodearea + freesasa_add_nodearea,
+ * src/node.c:717-764): total, main chain, side chain, polar, apolar, unknown, each a sequential sum
+ * in atom order, and the relative values 100 * abs / reference (ref: src/rsa.c:14-25) for total,
+ * main chain, side chain, polar, apolar.  One thread per residue.  ref_row < 0: no reference
+ * values for that residue (rel = NaN, the reference prints N/A). */
+SASA_D void residue_areas(const double *sasa, const unsigned char *cls, const unsigned char *bb, const int64_t *res_first,
+                          const short *ref_row, const double *ref_table, double *abs_out, double *rel_out, int r, int n_res)
+{
+    if (r >= n_res) return;
+    double total = 0, mc = 0, sc = 0, polar = 0, apolar = 0, unknown = 0;
+    for (int64_t i = res_first[r]; i < res_first[r + 1]; ++i) {
+        const double a = sasa[i];
+        total += a;
+        if (bb[i]) mc += a; else sc += a;
+        const int c = cls[i];
+        if (c == 0) apolar += a;
+        else if (c == 1) polar += a;
+        else unknown += a;
+    }
+    double *o = abs_out + 6 * (int64_t)r;
+    o[0] = total; o[1] = mc; o[2] = sc; o[3] = polar; o[4] = apolar; o[5] = unknown;
+    if (rel_out) {
+        double *q = rel_out + 5 * (int64_t)r;
+        const int row = ref_row ? ref_row[r] : -1;
+        if (row < 0) {
+            q[0] = q[1] = q[2] = q[3] = q[4] = NAN;
+        } else {
+            const double *t = ref_table + 5 * row;
+            q[0] = 100. * total / t[0]; q[1] = 100. * mc / t[1]; q[2] = 100. * sc / t[2];
+            q[3] = 100. * polar / t[3]; q[4] = 100. * apolar / t[4];
+        }
+    }
+}
+
 /* Per-structure sums by atom class (0 apolar, 1 polar, 2 unknown; ref: freesasa_result_classes,
  * src/classifier.c:830-866): like the totals, SASA_TOT_B threads per structure take contiguous
  * chunks in atom order and thread 0 adds the partials in order.  out[3*s + c]. */

@@ -21,9 +21,10 @@ APOLAR, POLAR, UNKNOWN = 0, 1, 2
 class _CBatch(C.Structure):
     _fields_ = [("n_structs", C.c_int32), ("n_atoms", C.c_int64), ("n_residues", C.c_int64),
                 ("xyz", C.POINTER(C.c_double)), ("radii", C.POINTER(C.c_double)),
-                ("atom_class", C.POINTER(C.c_uint8)), ("offsets", C.POINTER(C.c_int64)),
+                ("atom_class", C.POINTER(C.c_uint8)), ("atom_backbone", C.POINTER(C.c_uint8)),
+                ("offsets", C.POINTER(C.c_int64)),
                 ("res_first", C.POINTER(C.c_int64)), ("res_offsets", C.POINTER(C.c_int64)),
-                ("res_name", C.POINTER(C.c_char)), ("res_number", C.POINTER(C.c_char)),
+                ("res_ref", C.POINTER(C.c_int16)), ("res_name", C.POINTER(C.c_char)), ("res_number", C.POINTER(C.c_char)),
                 ("res_chain", C.POINTER(C.c_char)), ("status", C.POINTER(C.c_int32))]
 
 
@@ -42,6 +43,8 @@ class Batch:
         self.xyz = _arr(cb.xyz, 3 * na, np.float64).reshape(-1, 3)
         self.radii = _arr(cb.radii, na, np.float64)
         self.atom_class = _arr(cb.atom_class, na, np.uint8)
+        self.atom_backbone = _arr(cb.atom_backbone, na, np.uint8)
+        self.res_ref = _arr(cb.res_ref, nr, np.int16)
         self.offsets = _arr(cb.offsets, ns + 1, np.int64)
         self.res_first = _arr(cb.res_first, nr + 1, np.int64)
         self.res_offsets = _arr(cb.res_offsets, ns + 1, np.int64)
@@ -83,6 +86,8 @@ def _proto():
         L.freesasa_ingest_protor_radius.restype = C.c_double
         L.freesasa_ingest_guess_radius.argtypes = [C.c_char_p]
         L.freesasa_ingest_guess_radius.restype = C.c_double
+        L.freesasa_ingest_residue_reference_table.argtypes = [C.POINTER(C.c_double)]
+        L.freesasa_ingest_is_backbone.argtypes = [C.c_char_p]
         L._ingest_ready = True
     return L
 
@@ -112,6 +117,15 @@ def load_pdb_texts(texts, options=0, n_threads=0):
     lens = (C.c_size_t * len(raw))(*[len(t) for t in raw])
     cb = _CBatch()
     return _finish(L, L.freesasa_ingest_pdb_texts(arr, lens, len(raw), options, n_threads, C.byref(cb)), cb)
+
+
+def residue_reference_table():
+    """[rows, 5] reference areas (total, main chain, side chain, polar, apolar) that Batch.res_ref indexes."""
+    L = _proto()
+    n = L.freesasa_ingest_residue_reference_table(None)
+    t = np.empty(5 * n)
+    L.freesasa_ingest_residue_reference_table(t.ctypes.data_as(C.POINTER(C.c_double)))
+    return t.reshape(n, 5)
 
 
 load_files, load_texts = load_pdb_files, load_pdb_texts      # the format is recognised per input (PDB or mmCIF)

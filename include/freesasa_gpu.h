@@ -82,6 +82,20 @@ int freesasa_gpu_segment_sums_dev(freesasa_gpu_ctx *ctx, const double *d_sasa, c
 int freesasa_gpu_class_sums_dev(freesasa_gpu_ctx *ctx, const double *d_sasa, const unsigned char *d_class,
                                 const int64_t *offsets, int n_structs, double *d_out);
 
+/* Per-residue areas as the reference's result tree holds them (freesasa_nodearea of a residue node,
+   src/node.c:717-764): d_abs[6*r + {0..5}] = total, main chain, side chain, polar, apolar, unknown,
+   summed in atom order over residue r = atoms [res_first[r], res_first[r+1]); and, if d_rel is not
+   NULL, the relative areas of the RSA output (src/rsa.c:14-25): d_rel[5*r + {0..4}] =
+   100 * {total, main chain, side chain, polar, apolar} / reference, NaN where the residue has no
+   reference values (ref_row[r] < 0; the reference prints N/A).  d_class / d_backbone [n_atoms] are
+   device byte arrays (freesasa_ingest_batch.atom_class / .atom_backbone); res_first [n_res+1],
+   ref_row [n_res] (freesasa_ingest_batch.res_ref) and ref_table [5*ref_rows]
+   (freesasa_ingest_residue_reference_table) are HOST arrays.  Returns 0 / -1. */
+int freesasa_gpu_residue_areas_dev(freesasa_gpu_ctx *ctx, const double *d_sasa, const unsigned char *d_class,
+                                   const unsigned char *d_backbone, const int64_t *res_first, int n_res,
+                                   const short *ref_row, const double *ref_table, int ref_rows,
+                                   double *d_abs, double *d_rel);
+
 /* Golden-spiral unit test points on the host, host libm (src/sasa_sr.c:56-90). */
 void freesasa_gpu_test_points(int n_points, double *unit_points);
 

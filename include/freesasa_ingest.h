@@ -63,9 +63,12 @@ typedef struct freesasa_ingest_batch {
     double *xyz;          /* [3 * n_atoms] x1,y1,z1,... (ref: src/coord.h:26-38 layout) */
     double *radii;        /* [n_atoms] */
     uint8_t *atom_class;  /* [n_atoms] FREESASA_INGEST_APOLAR / POLAR / UNKNOWN */
+    uint8_t *atom_backbone; /* [n_atoms] 1 for main-chain atoms (ref: freesasa_atom_is_backbone, src/classifier.c:1090-1109) */
     int64_t *offsets;     /* [n_structs + 1] */
     int64_t *res_first;   /* [n_residues + 1] batch-wide atom index of each residue's first atom */
     int64_t *res_offsets; /* [n_structs + 1] */
+    int16_t *res_ref;     /* [n_residues] row of the reference-area table for relative SASA, -1: the classifier
+                             does not know the residue (ref: src/classifier.c:853-861) */
     char *res_name;       /* [4 * n_residues] residue names, NUL padded ("ALA\0") */
     char *res_number;     /* [6 * n_residues] residue number incl. insertion code (" 123A\0") */
     char *res_chain;      /* [4 * n_residues] chain label, NUL padded (one character from PDB files, up to
@@ -91,6 +94,14 @@ void freesasa_ingest_free(freesasa_ingest_batch *batch);
 double freesasa_ingest_protor_radius(const char *res_name, const char *atom_name, int *cls);
 /* ref: freesasa_guess_radius, src/classifier.c:1002-1017 */
 double freesasa_ingest_guess_radius(const char *symbol);
+/* ref: freesasa_atom_is_backbone, src/classifier.c:1090-1109 */
+int freesasa_ingest_is_backbone(const char *atom_name);
+/* Reference areas of residue res_name for relative SASA (total, main chain, side chain, polar,
+ * apolar; ref: freesasa_classifier_residue_reference with the ProtOr classifier).  Returns the row
+ * of the table, -1 if unknown.  freesasa_ingest_residue_reference_table copies the whole table
+ * ([5 * rows], may be NULL) and returns its number of rows: res_ref indexes it. */
+int freesasa_ingest_residue_reference(const char *res_name, double ref[5]);
+int freesasa_ingest_residue_reference_table(double *table);
 
 #ifdef __cplusplus
 }

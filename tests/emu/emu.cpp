@@ -219,6 +219,12 @@ extern "C" void emu_class_sums(const double *sasa, const unsigned char *cls, con
     }
 }
 
+extern "C" void emu_residue_areas(const double *sasa, const unsigned char *cls, const unsigned char *bb, const int64_t *res_first,
+                                  const short *ref_row, const double *ref_table, int n_res, double *abs_out, double *rel_out)
+{
+    for (int r = 0; r < ((n_res + 255) / 256) * 256; ++r) residue_areas(sasa, cls, bb, res_first, ref_row, ref_table, abs_out, rel_out, r, n_res);
+}
+
 extern "C" void emu_acos_fast(const double *x, double *out, int n)
 {
     for (int i = 0; i < n; ++i) out[i] = acos_fast(x[i]);

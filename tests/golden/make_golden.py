@@ -145,3 +145,9 @@ if __name__ == "__main__":
     mint_structure("1d3z_H", "1d3z.pdb", options=1 << 2)  # FREESASA_INCLUDE_HYDROGEN
     mint_synthetic()
     shutil.copy(os.path.join(REFDATA, "1ubq.B.pdb"), os.path.join(OUT, "1ubq.B.pdb"))
+
+
+# RSA fixtures: the reference CLI's own --format=rsa output, generated here by
+#   oracle/_ref/freesasa_ref --format=rsa --shrake-rupley tests/golden/pdb/1ubq.pdb > tests/golden/1ubq.sr100.rsa
+#   oracle/_ref/freesasa_ref --format=rsa                 tests/golden/pdb/1ubq.pdb > tests/golden/1ubq.lr20.rsa
+#   oracle/_ref/freesasa_ref --format=rsa --shrake-rupley tests/golden/pdb/3bkr.pdb > tests/golden/3bkr.sr100.rsa

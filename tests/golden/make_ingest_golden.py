@@ -41,6 +41,11 @@ lib.freesasa_structure_residue_number.restype = C.c_char_p
 lib.freesasa_structure_residue_number.argtypes = [C.c_void_p, C.c_int]
 lib.freesasa_structure_residue_chain_lcl.restype = C.c_char_p
 lib.freesasa_structure_residue_chain_lcl.argtypes = [C.c_void_p, C.c_int]
+lib.freesasa_structure_atom_name.restype = C.c_char_p
+lib.freesasa_structure_atom_name.argtypes = [C.c_void_p, C.c_int]
+lib.freesasa_atom_is_backbone.argtypes = [C.c_char_p]
+lib.freesasa_structure_residue_reference.restype = C.c_void_p
+lib.freesasa_structure_residue_reference.argtypes = [C.c_void_p, C.c_int]
 lib.freesasa_set_verbosity(2)  # FREESASA_V_SILENT
 # the reference's mmCIF reader (C++ over gemmi), built by `make -C oracle ref` next to the C library
 libcif = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libfreesasa_refcif.so"))
@@ -164,6 +169,8 @@ def reference_view_unsafe(path, options):
     xyz = np.ctypeslib.as_array(lib.freesasa_structure_coord_array(s), shape=(3 * n,)).copy()
     rad = np.ctypeslib.as_array(lib.freesasa_structure_radius(s), shape=(n,)).copy()
     cls = np.array([lib.freesasa_structure_atom_class(s, i) for i in range(n)], dtype=np.uint8)
+    bb = np.array([lib.freesasa_atom_is_backbone(lib.freesasa_structure_atom_name(s, i)) for i in range(n)], dtype=np.uint8)
+    has_ref = np.array([1 if lib.freesasa_structure_residue_reference(s, r) else 0 for r in range(nr)], dtype=np.uint8)
     first, labels = [], []
     a, b = C.c_int(), C.c_int()
     for r in range(nr):
@@ -174,7 +181,7 @@ def reference_view_unsafe(path, options):
     lib.freesasa_structure_free(s)
     return {"n_atoms": n, "n_residues": nr, "xyz": sha(xyz), "radii": sha(rad), "classes": sha(cls),
             "res_first": sha(np.array(first + [n], dtype=np.int64)), "labels": hashlib.sha256("\n".join(labels).encode()).hexdigest(),
-            "radius_sum": float(rad.sum()), "polar": int((cls == 1).sum()), "unknown": int((cls == 2).sum())}
+            "backbone": sha(bb), "has_reference": sha(has_ref), "radius_sum": float(rad.sum()), "polar": int((cls == 1).sum()), "unknown": int((cls == 2).sum())}
 
 
 def atom_line(serial, name, res, chain, resnum, coords, tail="  1.00  0.00           C  ", alt=" ", rec="ATOM  ", icode=" "):

@@ -219,3 +219,38 @@ def test_aggregation_kernels_logic():
         for c in range(3):
             assert abs(got[s, c] - v[sl][cls[sl] == c].sum()) <= 1e-9 * max(1.0, got[s, c])
     assert np.all(got[0] == 0)
+
+
+def test_residue_area_kernel_logic():
+    """Per-residue node areas and relative areas: sequential sums in atom order, 100*abs/ref, NaN without reference."""
+    import ctypes as C
+    lib = emu._load()
+    rng = np.random.default_rng(5)
+    n, nres = 3000, 400
+    v = rng.uniform(0, 40, n)
+    cls = rng.integers(0, 3, n).astype(np.uint8)
+    bb = rng.integers(0, 2, n).astype(np.uint8)
+    first = np.concatenate([[0], np.sort(rng.choice(np.arange(1, n), nres - 1, replace=False)), [n]]).astype(np.int64)
+    table = rng.uniform(50, 250, (7, 5))
+    table[3, 2] = 0.0                                                   # a zero reference (GLY side chain)
+    rows = rng.integers(-1, 7, nres).astype(np.int16)
+    A = np.full(6 * nres, np.nan); R = np.full(5 * nres, np.nan)
+    dp = C.POINTER(C.c_double)
+    lib.emu_residue_areas(v.ctypes.data_as(dp), cls.ctypes.data_as(C.POINTER(C.c_ubyte)), bb.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                          first.ctypes.data_as(C.POINTER(C.c_int64)), rows.ctypes.data_as(C.POINTER(C.c_short)),
+                          table.ctypes.data_as(dp), nres, A.ctypes.data_as(dp), R.ctypes.data_as(dp))
+    A, R = A.reshape(-1, 6), R.reshape(-1, 5)
+    with np.errstate(all="ignore"):
+        for r in range(nres):
+            sl = slice(first[r], first[r + 1])
+            want = [0.0] * 6
+            for a, c, m in zip(v[sl], cls[sl], bb[sl]):                 # strictly sequential, like the kernel
+                want[0] += a
+                want[1 if m else 2] += a
+                want[{0: 4, 1: 3, 2: 5}[int(c)]] += a
+            assert A[r].tolist() == want
+            if rows[r] < 0:
+                assert np.all(np.isnan(R[r]))
+            else:
+                expect = 100.0 * np.array(want[:5]) / table[rows[r]]
+                assert np.array_equal(R[r], expect, equal_nan=True)

@@ -48,6 +48,8 @@ def test_matches_the_reference_reader(name):
             assert sha(b.xyz) == exp["xyz"] and sha(b.radii) == exp["radii"], (name, opt)
             assert sha(b.atom_class) == exp["classes"] and sha(b.res_first) == exp["res_first"], (name, opt)
             assert labels_digest(b) == exp["labels"], (name, opt)
+            assert sha(b.atom_backbone) == exp["backbone"], (name, opt)
+            assert sha((b.res_ref >= 0).astype(np.uint8)) == exp["has_reference"], (name, opt)
         checked += 1
     assert checked >= 9
 
@@ -178,3 +180,61 @@ def test_pdb_to_sasa_end_to_end_matches_reference_totals():
     for k, (chain, number, name, area) in enumerate(ref):
         assert (b.res_chain[k], b.res_number[k].strip(), b.res_name[k]) == (chain, number, name)
         assert abs(per_res[k] - area) <= 0.005 + 1e-9                   # the file prints 2 decimals
+
+
+def read_rsa(name):
+    """Rows of a reference --format=rsa file: (residue, chain, number, [abs, rel] x (all, side, main, apolar, polar))
+    and the TOTAL line; rel is None where the file says N/A."""
+    rows, total = [], None
+    with open(os.path.join(ROOT, "tests", "golden", name)) as fh:
+        for line in fh:
+            if line.startswith("RES "):
+                res, chain, number = line[4:7], line[8:11].strip(), line[11:15].strip()
+                f = line[16:].split()
+                vals = [(float(f[2 * k]), None if f[2 * k + 1] == "N/A" else float(f[2 * k + 1])) for k in range(5)]
+                rows.append((res, chain, number, vals))
+            elif line.startswith("TOTAL"):
+                total = [float(v) for v in line.split()[1:]]
+    return rows, total
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pdb, rsa, alg", [("1ubq.pdb", "1ubq.sr100.rsa", "sr"), ("1ubq.pdb", "1ubq.lr20.rsa", "lr"),
+                                           ("3bkr.pdb", "3bkr.sr100.rsa", "sr")])
+def test_relative_sasa_matches_the_references_rsa_output(pdb, rsa, alg):
+    """SURVEY §8(f) N4 (RSA half): per-residue absolute and relative areas computed on the device
+    from a PDB file equal the reference CLI's --format=rsa output (fixtures generated by running
+    the reference, tests/golden/make_golden.py) to the precision it prints: %.2f abs, %.1f rel, N/A."""
+    import torch
+    import freesasa_amd as fa
+    b = ingest.load_pdb_files([os.path.join(PDB, pdb)])
+    if alg == "sr":
+        sasa, _, tot = fa.calc_batch(b.xyz, b.radii, b.offsets, fa.SHRAKE_RUPLEY, resolution=100)
+    else:
+        sasa, _, tot = fa.calc_batch(b.xyz, b.radii, b.offsets, fa.LEE_RICHARDS, resolution=20)
+    dev = torch.device("cuda:0")
+    d_sasa = torch.from_numpy(sasa).to(dev)
+    d_cls, d_bb = torch.from_numpy(b.atom_class).to(dev), torch.from_numpy(b.atom_backbone).to(dev)
+    d_abs = torch.empty(6 * b.n_residues, dtype=torch.float64, device=dev)
+    d_rel = torch.empty(5 * b.n_residues, dtype=torch.float64, device=dev)
+    ctx = fa.GpuContext(0)
+    ctx.residue_areas(d_sasa.data_ptr(), d_cls.data_ptr(), d_bb.data_ptr(), b.res_first, d_abs.data_ptr(),
+                      res_ref=b.res_ref, ref_table=ingest.residue_reference_table(), d_rel=d_rel.data_ptr())
+    ctx.close()
+    A, R = d_abs.cpu().numpy().reshape(-1, 6), d_rel.cpu().numpy().reshape(-1, 5)
+    rows, total = read_rsa(rsa)
+    assert len(rows) == b.n_residues
+    # file columns: all, side, main, apolar, polar  <-  device: total, main, side, polar, apolar
+    cols = [0, 2, 1, 4, 3]
+    for r, (res, chain, number, vals) in enumerate(rows):
+        assert (b.res_name[r], b.res_chain[r], b.res_number[r].strip()) == (res.strip(), chain, number)
+        for k, (a, rel) in enumerate(vals):
+            assert abs(A[r, cols[k]] - a) <= 0.005 + 1e-9, (r, k)
+            if rel is None:
+                assert not np.isfinite(R[r, cols[k]]), (r, k)
+            else:
+                assert abs(R[r, cols[k]] - rel) <= 0.05 + 1e-9, (r, k)
+    sums = A.sum(0)
+    for k, want in enumerate(total):                                   # TOTAL line, one decimal
+        assert abs(sums[cols[k]] - want) <= 0.05 + 1e-6
+    assert abs(sums[0] - tot[0]) < 1e-9 * tot[0] and np.all(A[:, 5] == 0)
