@@ -383,10 +383,10 @@ struct TileArgs {
 };
 
 /* One neighbor record, 32 B, read with two ds_read_b128:
- *   L&R: x = z_j, y = R_j^2, z = D = xd^2+yd^2, w = 1/sqrt(D)   (+ beta in a separate array)
- *   S&R: x = x_j, y = y_j,   z = z_j,           w = R_j^2
- * In the L&R pool every atom's list is padded to an even number of records with a dummy
- * (R_j^2 = 0: never overlaps a slice) so the screening loop runs 2 neighbors per trip. */
+ *   L&R: x = z_j, y = D - R_j^2 (D = xd^2+yd^2), z = 1/sqrt(D), w = beta     (lr_record)
+ *   S&R: x = x_j, y = y_j,                       z = z_j,       w = R_j^2
+ * In the L&R pool every atom's list is padded to an even number of records with a dummy whose
+ * cos(alpha) is huge (lr_padding: it never cuts an arc) so the screening loop runs 2 neighbors per trip. */
 struct __attribute__((aligned(16))) Quad { double x, y, z, w; };
 struct TileMem {
     double *ax, *ay, *az, *aR; /* [TA] tile atoms */
@@ -949,28 +949,31 @@ SASA_D void lr_arcs32(unsigned w, const Quad *PQ, double A, double h2, double z,
             const double wi = inf < 0 ? inf + SASA_TWOPI : inf;
             const double ws = sup > SASA_TWOPI ? sup - SASA_TWOPI : sup;
             u.wrap = 1;
-            u.W = ws > u.W ? ws : u.W;
-            u.V = wi < u.V ? wi : u.V;
+            u.W = fmax(u.W, ws);
+            u.V = fmin(u.V, wi);
         } else { /* inf <= beta <= sup: alpha < pi because the screening kept only c > -1 */
-            if (u.depth == 0) {
-                u.ts = inf; u.te = sup; u.depth = 1;
-            } else if (inf <= u.te) {
-                u.ts = inf < u.ts ? inf : u.ts;
-                u.te = sup > u.te ? sup : u.te;
-                while (u.depth > 1) {
+            /* written with selects and min/max rather than one branch per case: the cases differ
+               from lane to lane, so every branch would be executed anyway */
+            const bool fresh = u.depth == 0 || inf > u.te; /* the arc starts a new top component */
+            if (fresh && u.depth > 0) {
+                if (u.depth - 1 < ds) {
+                    Arc t; t.s = u.ts; t.e = u.te;
+                    stk[(u.depth - 1) * stride] = t;
+                } else {
+                    *err = 1;
+                }
+            }
+            u.ts = fresh ? inf : fmin(u.ts, inf);
+            u.te = fresh ? sup : fmax(u.te, sup);
+            u.depth += fresh ? 1 : 0;
+            if (!fresh)
+                while (u.depth > 1) { /* the merged component may now reach the ones below it */
                     const Arc lo = stk[(u.depth - 2) * stride];
                     if (lo.e < u.ts) break;
-                    u.ts = lo.s < u.ts ? lo.s : u.ts;
-                    u.te = lo.e > u.te ? lo.e : u.te;
+                    u.ts = fmin(u.ts, lo.s);
+                    u.te = fmax(u.te, lo.e);
                     --u.depth;
                 }
-            } else if (u.depth - 1 < ds) {
-                Arc t; t.s = u.ts; t.e = u.te;
-                stk[(u.depth - 1) * stride] = t;
-                u.ts = inf; u.te = sup; ++u.depth;
-            } else {
-                *err = 1;
-            }
         }
     }
 }
