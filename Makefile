@@ -16,9 +16,12 @@ CFLAGS   = -O2 -std=gnu99 -fPIC -ffp-contract=off -Wall
 
 all: $(LIBDIR)/libfreesasa_amd.so $(LIBDIR)/libfreesasa_amd_seam.a
 
+# the compiler's per-kernel resource report (registers, scratch, LDS) is kept next to the object:
+# tests/test_capi.py checks that the hot kernels do not spill
 $(LIBDIR)/gpu_engine.o: $(CSRC)/gpu_engine.hip $(CSRC)/sasa_kernels.h include/freesasa_gpu.h
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(LIBDIR)/kernel_resources.txt; rc=$$?; \
+	grep -v "remark:" $(LIBDIR)/kernel_resources.txt >&2; exit $$rc
 
 $(LIBDIR)/seam.o: $(CSRC)/seam.c include/freesasa_amd.h include/freesasa_gpu.h
 	@mkdir -p $(LIBDIR)

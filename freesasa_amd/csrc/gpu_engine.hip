@@ -170,6 +170,7 @@ __global__ __launch_bounds__(B) void k_sr_tile(TileArgs a, int items)
         tile_phase_neighbors(a, m, tile, tid, B);
         __syncthreads();
         tile_phase_offsets(a, m, tid);
+        sr_phase_cursors(a, m, tid);
         __syncthreads();
         tile_report<GLOBAL>(a, m, tile, tid);
         sr_phase_pairs(a, m, tid, B);

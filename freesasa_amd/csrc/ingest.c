@@ -679,6 +679,14 @@ static void arena_put(parsed *a)
     parsed_free(a);
 }
 
+/* the library is usually dlopen'd: give the cached arenas back when it goes */
+__attribute__((destructor)) static void arena_pool_release(void)
+{
+    pthread_mutex_lock(&g_pool_mu);
+    while (g_pool_n > 0) parsed_free(&g_pool[--g_pool_n]);
+    pthread_mutex_unlock(&g_pool_mu);
+}
+
 static int take(job *j, int *counter)
 {
     pthread_mutex_lock(&j->mu);

@@ -570,7 +570,6 @@ SASA_D void tile_phase_offsets(const TileArgs &a, TileMem &m, int tid)
     int off = 0;
     for (int k = 0; k < tid; ++k) off += pad4(m.acnt[k], a.lr);
     const int c = m.acnt[tid];
-    if (!a.lr) { m.rowlo[2 * tid] = 0; m.rowlo[2 * tid + 1] = 0; } /* S&R: front/back cursors of the pair phase */
     m.aoff[tid] = off;
     if (c > a.cap_idx) m.flags[0] = 1;
     if (tid == a.TA - 1) {
@@ -1098,6 +1097,13 @@ SASA_D void lr_phase_store(const TileArgs &a, TileMem &m, int tile, int tid, int
 }
 
 /* ---------------------------------------------------------------- Shrake & Rupley */
+
+/* with phase O: zero the front/back cursors of phase P (they live in the candidate-run words,
+ * which are dead once the neighbors are found) */
+SASA_D void sr_phase_cursors(const TileArgs &a, TileMem &m, int tid)
+{
+    if (tid < a.TA) { m.rowlo[2 * tid] = 0; m.rowlo[2 * tid + 1] = 0; }
+}
 
 /* phase P: neighbor records (x, y, z, R^2) */
 SASA_D void sr_phase_pairs(const TileArgs &a, TileMem &m, int tid, int B)

@@ -33,7 +33,7 @@ static void emu_tile_kernel(bool lr, const TileCfg &cfg, TileArgs a, int grid)
 #define PHASE(call) for (int tid = 0; tid < B; ++tid) { call; }
             PHASE(tile_phase_load(a, m, tile, tid, B, lr && emu_bucket));
             PHASE(tile_phase_neighbors(a, m, tile, tid, B));
-            PHASE(tile_phase_offsets(a, m, tid));
+            PHASE(tile_phase_offsets(a, m, tid); if (!lr) sr_phase_cursors(a, m, tid));
             if (lr) {
                 PHASE(tile_report<GLOBAL>(a, m, tile, tid); lr_phase_beta(a, m, tid, B, emu_bucket));
                 if (emu_bucket && lr_bucket_path(a, m, B)) {

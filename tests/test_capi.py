@@ -149,3 +149,21 @@ def test_product_never_references_the_oracle():
     assert not bad
     syms = subprocess.run(["nm", "-D", fa.LIB_PATH], capture_output=True, text=True).stdout
     assert "oracle_" not in syms and "emu_run_batch" not in syms
+
+
+def test_hot_kernels_do_not_spill(L):
+    """The L&R tile kernel is capped at 96 VGPRs (5 waves/SIMD) and sits right at that cap: a spill
+    costs HBM traffic and time, and an innocent edit elsewhere in a shared phase can cause one.
+    The build keeps the compiler's resource report (Makefile)."""
+    path = os.path.join(ROOT, "freesasa_amd", "lib", "kernel_resources.txt")
+    if not os.path.exists(path):
+        pytest.skip("library was built without the resource report")
+    txt = open(path).read()
+    blocks = re.findall(r"Function Name: (\S+).*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+)", txt, flags=re.S)
+    seen = {name: (int(v), int(sc)) for name, v, sc in blocks}
+    main = [n for n in seen if n.startswith("_Z9k_lr_tileILi64ELb0ELi0ELi5ELb0")]
+    assert main, "steady-state L&R kernel not found in the report"
+    assert seen[main[0]] == (96, 0)
+    for n, (v, sc) in seen.items():
+        if "k_sr_tileILi256ELb0ELi0" in n or "k_lr_tileILi64ELb0ELi0ELi4ELb1" in n:
+            assert sc == 0, n
