@@ -32,6 +32,8 @@ sys.path.insert(0, ROOT)
 ALGO_BYTES_PER_ATOM = 40.0  # read x,y,z,R (32 B) + write sasa (8 B), fp64
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FP64_VECTOR_PEAK_TFLOPS = 78.6
+SIMDS, CLOCK_HZ, CYCLES_PER_VALU = 256 * 4, 2.4e9, 4   # MI355X: 256 CUs x 4 SIMD16; a wave64 VALU op issues over 4 cycles
+PROFILED_VALU = None        # wave-level VALU instructions per launch of the dominant kernel (committed PMC pass)
 
 
 def cpu_baseline(xyz, r, offs, gpu_sasa, budget_s=12.0):
@@ -91,6 +93,8 @@ def profiled_traffic(args):
     for tag in ("false, 0, 5, false>", "false, 0, 4, false>", "false, 0, 5>", "false, 0, 4>"):
         for k, v in d.items():
             if "k_lr_tile" in k and tag in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                global PROFILED_VALU
+                PROFILED_VALU = v.get("SQ_INSTS_VALU", {}).get("per_launch")
                 return (v["FETCH_SIZE"]["per_launch_KB"] + v["WRITE_SIZE"]["per_launch_KB"]) * 1024.0, "profiles/" + best
     return None, None
 
@@ -264,7 +268,13 @@ def main():
                          "kernel": "k_sr_tile" if sr else "k_lr_tile", "kernel_ms": 1e3 * kern_s, "prep_ms": float(np.mean(prep_ms)),
                          "kernel_atoms_per_s": n_atoms / kern_s if kern_s > 0 else None,
                          "note": "nominal HBM roofline per north_star (40 B/atom); the kernel is fp64-VALU bound, "
-                                 "see DESIGN.md"},
+                                 "see DESIGN.md",
+                         # the roofline that binds: share of the VALU issue slots of 1024 SIMDs the kernel fills
+                         "valu_issue": None if not (PROFILED_VALU and kern_s > 0 and not sr and args.workload == "coil_lr") else {
+                             "wave_instructions_per_launch": PROFILED_VALU,
+                             "wave_instructions_per_atom": PROFILED_VALU / n_atoms,
+                             "frac_of_issue_slots": PROFILED_VALU * CYCLES_PER_VALU / (kern_s * SIMDS * CLOCK_HZ),
+                             "source": traffic_src}},
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == "coil_lr":
             base, err = cpu_baseline(xyz, r, offs, d_sasa.cpu().numpy())

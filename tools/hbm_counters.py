@@ -21,4 +21,17 @@ for f, counter in ((d + "/pmc3_counter_collection.csv", "FETCH_SIZE"), (d + "/pm
         launches[r["Kernel_Name"]].add(r["Dispatch_Id"])
     for k, v in total.items():
         out.setdefault(k, {})[counter] = {"per_launch_KB": v / len(launches[k]), "launches": len(launches[k])}
+# wave-level VALU instructions per launch from the first SQ pass (bench.py turns it into the issue-port
+# utilisation, the roofline that actually binds this kernel)
+try:
+    total = collections.defaultdict(float)
+    launches = collections.defaultdict(set)
+    for r in csv.DictReader(open(d + "/pmc1_counter_collection.csv")):
+        if r["Counter_Name"] == "SQ_INSTS_VALU":
+            total[r["Kernel_Name"]] += float(r["Counter_Value"])
+            launches[r["Kernel_Name"]].add(r["Dispatch_Id"])
+    for k, v in total.items():
+        out.setdefault(k, {})["SQ_INSTS_VALU"] = {"per_launch": v / len(launches[k]), "launches": len(launches[k])}
+except FileNotFoundError:
+    pass
 json.dump(out, sys.stdout, indent=1)
