@@ -106,6 +106,51 @@ def test_batch_layout_failures_and_thread_count_independence():
     assert empty.n_structs == 0 and empty.n_atoms == 0 and empty.offsets.tolist() == [0]
 
 
+def test_coordinate_fast_path_equals_strtod_on_random_fields():
+    """The loader converts plain decimals exactly (integer / power of ten); anything else goes to
+    strtod.  Python's float() is correctly rounded like glibc's strtod, so both must agree bit for
+    bit on whatever fits the three 8-character coordinate fields."""
+    rng = np.random.default_rng(11)
+    fields = []
+    for _ in range(4000):
+        kind = rng.integers(0, 6)
+        if kind == 0:
+            v = f"{rng.uniform(-99, 999):7.3f}"
+        elif kind == 1:
+            v = f"{rng.uniform(-9, 99):7.4f}"[:7]
+        elif kind == 2:
+            v = f"{rng.integers(-999999, 9999999):7d}"
+        elif kind == 3:
+            v = f"{rng.uniform(0, 9):7.1e}"[:7]
+        elif kind == 4:
+            v = f"{rng.uniform(0, 1):7.5f}"[:7]
+        else:
+            v = f"{rng.integers(0, 9999)}.".rjust(7)
+        v = " " + v                       # fields that run together are one number for sscanf too
+        assert len(v) == 8
+        fields.append(v)
+    lines = []
+    for k in range(0, len(fields) - 2, 3):
+        sec = "".join(fields[k:k + 3])
+        assert len(sec) == 24
+        lines.append(f"ATOM  {k % 99999:5d}  CA  ALA A{k % 9999:4d}    {sec}  1.00  0.00           C  ")
+    b = ingest.load_pdb_texts(["\n".join(lines) + "\n"])
+    assert b.status[0] == ingest.OK and b.n_atoms == len(lines)
+    want = np.array([[float(fields[k + i]) for i in range(3)] for k in range(0, len(fields) - 2, 3)])
+    assert np.array_equal(b.xyz, want)
+
+
+def test_concurrent_loads_share_the_arena_cache_safely():
+    from concurrent.futures import ThreadPoolExecutor
+    paths = [fixture(n) for n in ("1ubq.pdb", "3bkr.pdb", "1a0q.pdb", "1ubq.cif", "5dx9.pdb")] * 6
+    ref = ingest.load_pdb_files(paths, n_threads=1)
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        outs = list(ex.map(lambda t: ingest.load_pdb_files(paths, n_threads=1 + t % 4), range(12)))
+    for o in outs:
+        assert np.array_equal(o.xyz, ref.xyz) and np.array_equal(o.radii, ref.radii)
+        assert np.array_equal(o.res_first, ref.res_first) and np.array_equal(o.offsets, ref.offsets)
+
+
 def test_unsupported_options_are_refused():
     for opt in (1 << 3, 1 << 4, 1 << 9):       # SEPARATE_MODELS, SEPARATE_CHAINS, unknown bit
         with pytest.raises(RuntimeError):
