@@ -18,7 +18,7 @@ all: $(LIBDIR)/libfreesasa_amd.so $(LIBDIR)/libfreesasa_amd_seam.a
 
 # the compiler's per-kernel resource report (registers, scratch, LDS) is kept next to the object:
 # tests/test_capi.py checks that the hot kernels do not spill
-$(LIBDIR)/gpu_engine.o: $(CSRC)/gpu_engine.hip $(CSRC)/sasa_kernels.h include/freesasa_gpu.h
+$(LIBDIR)/gpu_engine.o: $(CSRC)/gpu_engine.hip $(CSRC)/sasa_kernels.h include/freesasa_gpu.h include/freesasa_ingest.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(LIBDIR)/kernel_resources.txt; rc=$$?; \
 	grep -v "remark:" $(LIBDIR)/kernel_resources.txt >&2; exit $$rc
@@ -42,7 +42,7 @@ $(LIBDIR)/ingest.o: $(CSRC)/ingest.c $(CSRC)/protor_table.h include/freesasa_ing
 $(LIBDIR)/libfreesasa_amd.so: $(LIBDIR)/gpu_engine.o $(LIBDIR)/seam.o $(LIBDIR)/testpoints.o $(LIBDIR)/api.o $(LIBDIR)/ingest.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
-$(LIBDIR)/libfreesasa_amd_seam.a: $(LIBDIR)/gpu_engine.o $(LIBDIR)/seam.o $(LIBDIR)/testpoints.o
+$(LIBDIR)/libfreesasa_amd_seam.a: $(LIBDIR)/gpu_engine.o $(LIBDIR)/seam.o $(LIBDIR)/testpoints.o $(LIBDIR)/ingest.o
 	ar rcs $@ $^
 
 emu: tests/emu/libsasa_emu.so

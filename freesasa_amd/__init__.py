@@ -119,6 +119,8 @@ def lib():
         L.freesasa_gpu_test_points.restype = None
         L.freesasa_gpu_calc_batch.argtypes = [_dp, _dp, _lp, C.c_int, C.c_int, C.c_double, C.c_int,
                                               _dp, _ip, _dp, C.c_int, C.c_char_p, C.c_int]
+        L.freesasa_gpu_sweep_files.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
+                                               C.c_longlong, _dp, _dp, _lp, _ip, C.c_int, C.c_char_p, C.c_int]
         L.freesasa_gpu_trajectory.argtypes = [_dp, _dp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
                                               C.c_int, _dp, _dp, C.c_int, C.c_char_p, C.c_int]
         _lib = L
@@ -163,6 +165,23 @@ def calc_batch(xyz, radii, offsets, alg=LEE_RICHARDS, probe=1.4, resolution=20, 
     if ret:
         raise RuntimeError("freesasa_gpu_calc_batch: " + err.value.decode())
     return sasa, counts, totals
+
+
+def sweep_files(paths, alg=LEE_RICHARDS, probe=1.4, resolution=20, ingest_options=0, n_threads=0, batch_atoms=0,
+                class_sums=True, device=-1):
+    """freesasa_gpu_sweep_files(): PDB / mmCIF files -> (totals[n], class_sums[n,3] or None, n_atoms[n], status[n]);
+    loading of the next batch overlaps the GPU work on the current one."""
+    n = len(paths)
+    arr = (C.c_char_p * n)(*[str(p).encode() for p in paths])
+    totals, atoms, status = np.zeros(n), np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int32)
+    cls = np.zeros((n, 3)) if class_sums else None
+    err = C.create_string_buffer(512)
+    ret = lib().freesasa_gpu_sweep_files(arr, n, ingest_options, n_threads, alg, probe, resolution, batch_atoms,
+                                         totals.ctypes.data_as(_dp), cls.ctypes.data_as(_dp) if cls is not None else None,
+                                         atoms.ctypes.data_as(_lp), status.ctypes.data_as(_ip), device, err, 512)
+    if ret:
+        raise RuntimeError("freesasa_gpu_sweep_files: " + err.value.decode())
+    return totals, cls, atoms, status
 
 
 def trajectory(xyz_frames, radii, alg=LEE_RICHARDS, probe=1.4, resolution=20, frames_per_batch=0,

@@ -13,9 +13,12 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <thread>
 #include <vector>
 
 #include "../../include/freesasa_gpu.h"
+#include "../../include/freesasa_ingest.h"
 #include "sasa_kernels.h"
 
 using namespace sasa;
@@ -758,6 +761,97 @@ extern "C" int freesasa_gpu_calc_batch(const double *xyz, const double *radii, c
         ret = 0;
     } while (0);
     if (ret) set_err(err_out, err_len, c->err[0] ? c->err : "GPU batch failed");
+    pool_put(c);
+    return ret;
+}
+
+/* ------------------------------------------------------------------ structure sweep */
+
+/* Files -> per-structure totals: the loader (host threads, include/freesasa_ingest.h) reads batch
+ * k+1 while this thread has batch k on the GPU.  Inputs that fail to load get total 0 and their
+ * loader status; the call only fails for GPU errors. */
+extern "C" int freesasa_gpu_sweep_files(const char *const *paths, int n_paths, int ingest_options, int n_threads,
+                                        int alg, double probe, int resolution, long long batch_atoms,
+                                        double *totals_out, double *class_sums_out, long long *atoms_out, int *status_out,
+                                        int device, char *err_out, int err_len)
+{
+    if (err_out && err_len > 0) err_out[0] = 0;
+    if (!paths || n_paths < 0 || !totals_out || !status_out) return set_err(err_out, err_len, "null argument");
+    if (alg != 0 && alg != 1) return set_err(err_out, err_len, "unknown algorithm");
+    if (freesasa_gpu_device_count() <= 0)
+        return set_err(err_out, err_len, "no HIP device available: libfreesasa_amd has no CPU path");
+    if (n_paths == 0) return 0;
+    if (batch_atoms <= 0) batch_atoms = 2000000;
+    /* batches of roughly batch_atoms atoms, estimated from the file sizes (~81 bytes per ATOM line) */
+    std::vector<int> cut(1, 0);
+    {
+        long long bytes = 0;
+        for (int k = 0; k < n_paths; ++k) {
+            struct stat st;
+            bytes += (paths[k] && stat(paths[k], &st) == 0) ? (long long)st.st_size : 0;
+            if (bytes >= batch_atoms * 81 && k + 1 < n_paths) { cut.push_back(k + 1); bytes = 0; }
+        }
+        cut.push_back(n_paths);
+    }
+    freesasa_gpu_ctx *c = pool_get(device);
+    if (!c) return set_err(err_out, err_len, "could not create a GPU context");
+    const int n_batches = (int)cut.size() - 1;
+    freesasa_ingest_batch cur, next;
+    int cur_rc = 0, next_rc = 0;
+    memset(&cur, 0, sizeof cur);
+    memset(&next, 0, sizeof next);
+    auto load = [&](int b, freesasa_ingest_batch *out, int *rc) {
+        *rc = freesasa_ingest_pdb_files(paths + cut[b], cut[b + 1] - cut[b], ingest_options, n_threads, out);
+    };
+    std::vector<double> tp;
+    if (alg == 1) { tp.resize(3 * (size_t)(resolution > 0 ? resolution : 1)); if (resolution > 0) freesasa_gpu_test_points(resolution, tp.data()); }
+    load(0, &cur, &cur_rc);
+    int ret = 0;
+    for (int b = 0; b < n_batches && !ret; ++b) {
+        std::thread loader;
+        if (b + 1 < n_batches) loader = std::thread(load, b + 1, &next, &next_rc);
+        const int first = cut[b], ns = cut[b + 1] - cut[b];
+        do {
+            if (cur_rc) { ctx_fail(c, "loader failed with code %d", cur_rc); ret = -1; break; }
+            for (int k = 0; k < ns; ++k) {
+                status_out[first + k] = cur.status[k];
+                totals_out[first + k] = 0;
+                if (atoms_out) atoms_out[first + k] = cur.offsets[k + 1] - cur.offsets[k];
+                if (class_sums_out) class_sums_out[3 * (first + k)] = class_sums_out[3 * (first + k) + 1] = class_sums_out[3 * (first + k) + 2] = 0;
+            }
+            const size_t n = (size_t)cur.n_atoms;
+            if (n == 0) break;
+            ret = -1;
+            if (hipSetDevice(c->device) != hipSuccess) { ctx_fail(c, "hipSetDevice failed"); break; }
+            if (ensure(c, c->h_xyz, 24 * n) || ensure(c, c->h_radii, 8 * n) || ensure(c, c->h_sasa, 8 * n) ||
+                ensure(c, c->h_counts, n) || ensure(c, c->h_totals, 8 * 4 * (size_t)ns))
+                break;
+            if (hipMemcpyAsync(c->h_xyz.p, cur.xyz, 24 * n, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                hipMemcpyAsync(c->h_radii.p, cur.radii, 8 * n, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+                ctx_fail(c, "host-to-device copy failed");
+                break;
+            }
+            double *d_tot = (double *)c->h_totals.p, *d_cls = d_tot + ns;
+            if (run_batch(c, alg == 0, (double *)c->h_xyz.p, (double *)c->h_radii.p, cur.offsets, ns, probe, resolution,
+                          alg == 1 ? tp.data() : nullptr, (double *)c->h_sasa.p, nullptr, d_tot))
+                break;
+            if (class_sums_out) {
+                if (hipMemcpyAsync(c->h_counts.p, cur.atom_class, n, hipMemcpyHostToDevice, c->stream) != hipSuccess) { ctx_fail(c, "host-to-device copy failed"); break; }
+                if (freesasa_gpu_class_sums_dev(c, (double *)c->h_sasa.p, (const unsigned char *)c->h_counts.p, cur.offsets, ns, d_cls)) break;
+                if (hipMemcpyAsync(class_sums_out + 3 * (size_t)first, d_cls, 8 * 3 * (size_t)ns, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { ctx_fail(c, "device-to-host copy failed"); break; }
+            }
+            if (hipMemcpyAsync(totals_out + first, d_tot, 8 * (size_t)ns, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { ctx_fail(c, "device-to-host copy failed"); break; }
+            if (hipStreamSynchronize(c->stream) != hipSuccess) { ctx_fail(c, "stream synchronize failed"); break; }
+            ret = 0;
+        } while (0);
+        if (loader.joinable()) loader.join();
+        freesasa_ingest_free(&cur);
+        cur = next;
+        cur_rc = next_rc;
+        memset(&next, 0, sizeof next);
+    }
+    freesasa_ingest_free(&cur);
+    if (ret) set_err(err_out, err_len, c->err[0] ? c->err : "GPU sweep failed");
     pool_put(c);
     return ret;
 }

@@ -99,6 +99,18 @@ int freesasa_gpu_residue_areas_dev(freesasa_gpu_ctx *ctx, const double *d_sasa, 
 /* Golden-spiral unit test points on the host, host libm (src/sasa_sr.c:56-90). */
 void freesasa_gpu_test_points(int n_points, double *unit_points);
 
+/* Structure sweep (BASELINE configs[3]): PDB / mmCIF files -> per-structure totals.  The files are
+   read in batches of about batch_atoms atoms (<= 0: 2e6) by n_threads host threads
+   (include/freesasa_ingest.h; ingest_options are its option bits) while the previous batch is on
+   the GPU.  totals_out[n_paths]; class_sums_out[3*n_paths] (apolar, polar, unknown) and
+   atoms_out[n_paths] may be NULL; status_out[n_paths] receives the loader's per-input status
+   (non-zero: the input contributed nothing and its total is 0).  alg: 0 Lee-Richards (resolution =
+   slices), 1 Shrake-Rupley (test points).  Returns 0, or -1 on a GPU error (message in err). */
+int freesasa_gpu_sweep_files(const char *const *paths, int n_paths, int ingest_options, int n_threads,
+                             int alg, double probe_radius, int resolution, long long batch_atoms,
+                             double *totals_out, double *class_sums_out, long long *atoms_out, int *status_out,
+                             int device, char *err, int err_len);
+
 /* Host-pointer batch on a pooled per-thread context of `device` (-1: current default).
    alg/probe/resolution as in freesasa_parameters; counts_out may be NULL (S&R only);
    totals_out may be NULL.  Thread-safe.  Returns 0 / -1; message via err_out (>= len 1). */

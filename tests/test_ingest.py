@@ -283,3 +283,27 @@ def test_relative_sasa_matches_the_references_rsa_output(pdb, rsa, alg):
     for k, want in enumerate(total):                                   # TOTAL line, one decimal
         assert abs(sums[cols[k]] - want) <= 0.05 + 1e-6
     assert abs(sums[0] - tot[0]) < 1e-9 * tot[0] and np.all(A[:, 5] == 0)
+
+
+@pytest.mark.gpu
+def test_sweep_entry_point_equals_load_then_batch():
+    """freesasa_gpu_sweep_files (loader thread || GPU, several batches) gives the totals and class sums
+    of the two-step path, keeps the input order and reports failed inputs without failing the sweep."""
+    import freesasa_amd as fa
+    names = ["1ubq.pdb", "empty.pdb", "3bkr.cif", "1a0q.pdb", "does_not_exist.pdb", "5dx9.pdb", "icode.pdb", "1ubq.cif", "3bzd_trimmed.pdb"]
+    paths = [fixture(n) for n in names] * 3
+    b = ingest.load_pdb_files(paths)
+    ok = b.status == 0
+    for alg, res in ((fa.LEE_RICHARDS, 20), (fa.SHRAKE_RUPLEY, 100)):
+        keep = np.nonzero(ok)[0]
+        offs = np.concatenate([[0], np.cumsum(np.diff(b.offsets)[keep])]).astype(np.int64)
+        sasa, _, tot = fa.calc_batch(b.xyz, b.radii, offs, alg, resolution=res)
+        for batch_atoms in (0, 3000):                      # one batch / many small batches
+            totals, cls, atoms, status = fa.sweep_files(paths, alg, resolution=res, batch_atoms=batch_atoms, n_threads=3)
+            assert np.array_equal(status, b.status) and np.array_equal(atoms, np.diff(b.offsets))
+            assert np.array_equal(totals[ok], tot) and np.all(totals[~ok] == 0)
+            assert np.allclose(cls.sum(1), totals, rtol=1e-12, atol=1e-9)
+            k = names.index("1ubq.pdb")
+            polar = b.atom_class[b.offsets[k]:b.offsets[k + 1]] == ingest.POLAR
+            assert abs(cls[k, 1] - sasa[:len(polar)][polar].sum()) < 1e-9
+    assert abs(fa.sweep_files([fixture("1ubq.pdb")])[0][0] - 4804.055641) < 1e-5 * 4804.055641

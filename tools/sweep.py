@@ -30,6 +30,9 @@ def main():
     ap.add_argument("--batch-atoms", type=int, default=4_000_000)
     ap.add_argument("--slices", type=int, default=20)
     ap.add_argument("--no-gpu", action="store_true", help="time the loader only")
+    ap.add_argument("--engine", choices=["python", "c"], default="c",
+                    help="c: freesasa_gpu_sweep_files (loader thread || GPU inside the library); "
+                         "python: the same pipeline written with the two-step Python API")
     args = ap.parse_args()
     import freesasa_amd as fa
     from freesasa_amd import ingest
@@ -48,7 +51,17 @@ def main():
     out = {"files": len(paths), "batches": len(chunks), "threads": args.threads or os.cpu_count(),
            "loader_atoms_per_s": probe.n_atoms / t_load1, "loader_MB_per_s": sum(os.path.getsize(p) for p in chunks[0]) / t_load1 / 1e6}
 
-    if not args.no_gpu:
+    if not args.no_gpu and args.engine == "c":
+        fa.sweep_files(chunks[0][:20], fa.LEE_RICHARDS, resolution=args.slices)                      # warm-up
+        t0 = time.perf_counter()
+        totals, _, atoms, status = fa.sweep_files(paths, fa.LEE_RICHARDS, resolution=args.slices, n_threads=args.threads,
+                                                  batch_atoms=args.batch_atoms, class_sums=True)
+        dt = time.perf_counter() - t0
+        ok = status == 0
+        out.update({"engine": "freesasa_gpu_sweep_files", "atoms": int(atoms.sum()), "structures": int(ok.sum()),
+                    "failed_inputs": int((~ok).sum()), "seconds": dt, "end_to_end_atoms_per_s": float(atoms.sum()) / dt,
+                    "structures_per_s": float(ok.sum()) / dt, "mean_total_A2": float(totals[ok].mean())})
+    elif not args.no_gpu:
         totals, n_atoms, n_bad = [], 0, 0
         fa.calc_batch(probe.xyz[:3000], probe.radii[:3000], [0, 3000], fa.LEE_RICHARDS, resolution=args.slices)  # warm-up
         t0 = time.perf_counter()
