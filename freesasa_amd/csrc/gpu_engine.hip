@@ -844,6 +844,7 @@ extern "C" int freesasa_gpu_sweep_files(const char *const *paths, int n_paths, i
             if (hipStreamSynchronize(c->stream) != hipSuccess) { ctx_fail(c, "stream synchronize failed"); break; }
             ret = 0;
         } while (0);
+        if (ret) (void)hipStreamSynchronize(c->stream); /* no copy may still read the batch when it is freed */
         if (loader.joinable()) loader.join();
         freesasa_ingest_free(&cur);
         cur = next;
