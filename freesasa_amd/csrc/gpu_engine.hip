@@ -760,7 +760,10 @@ extern "C" int freesasa_gpu_calc_batch(const double *xyz, const double *radii, c
         if (hipStreamSynchronize(c->stream) != hipSuccess) { ctx_fail(c, "stream synchronize failed"); break; }
         ret = 0;
     } while (0);
-    if (ret) set_err(err_out, err_len, c->err[0] ? c->err : "GPU batch failed");
+    if (ret) {
+        (void)hipStreamSynchronize(c->stream); /* the caller's arrays must not be read after we return */
+        set_err(err_out, err_len, c->err[0] ? c->err : "GPU batch failed");
+    }
     pool_put(c);
     return ret;
 }
