@@ -468,25 +468,28 @@ static int cif_walk(const char *text, size_t len, cif_row_fn visit, void *ctx)
             continue;
         }
         int ncol = 0, col[12], is_site = 0;
+        signed char slot_of[256]; /* column of the loop -> wanted field, -1: not wanted */
+        memset(slot_of, -1, sizeof slot_of);
         for (int k = 0; k < 12; ++k) col[k] = -1;
         t = cif_next(&lx);
         while (t.type == T_TAG) {
             if (t.n > 11 && ieq_n(t.p, "_atom_site.", 11)) {
                 is_site = 1;
                 for (int k = 0; k < 12; ++k)
-                    if (strlen(cif_cols[k]) == t.n - 11 && ieq_n(t.p + 11, cif_cols[k], t.n - 11)) col[k] = ncol;
+                    if (strlen(cif_cols[k]) == t.n - 11 && ieq_n(t.p + 11, cif_cols[k], t.n - 11)) {
+                        col[k] = ncol;
+                        if (ncol < 256) slot_of[ncol] = (signed char)k;
+                    }
             }
             ++ncol;
             t = cif_next(&lx);
         }
-        int complete = is_site && ncol > 0;
+        int complete = is_site && ncol > 0 && ncol <= 256;
         for (int k = 0; k < 12; ++k) complete = complete && col[k] >= 0;
         cif_tok row[12];
         int c = 0;
         while (t.type == T_VALUE) {
-            if (complete)
-                for (int k = 0; k < 12; ++k)
-                    if (col[k] == c) row[k] = t;
+            if (complete && slot_of[c] >= 0) row[slot_of[c]] = t;
             if (++c == ncol) {
                 c = 0;
                 if (complete) {
@@ -500,11 +503,15 @@ static int cif_walk(const char *text, size_t len, cif_row_fn visit, void *ctx)
     return 0;
 }
 
+/* strtol(., 10) of a token, in place (the token is followed by whitespace or the end of the text) */
 static int tok_int(const cif_tok *t)
 {
-    char buf[24];
-    cut(buf, sizeof buf - 1, t->p, t->n);
-    return (int)strtol(buf, NULL, 10);
+    const char *p = t->p, *e = t->p + t->n;
+    int neg = 0;
+    if (p < e && (*p == '-' || *p == '+')) neg = *p++ == '-';
+    long v = 0;
+    while (p < e && *p >= '0' && *p <= '9' && v < 100000000L) v = v * 10 + (*p++ - '0');
+    return (int)(neg ? -v : v);
 }
 
 typedef struct {
@@ -541,10 +548,11 @@ static int cif_visit_atom(const cif_tok *row, void *ctx)
     cut(symbol, 2, row[7].p, row[7].n);
     cut(chain, 3, row[1].p, row[1].n);
     double v[3];
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < 3; ++k) { /* atof: the exact fast path of the PDB reader, else strtod */
         char buf[40];
         cut(buf, sizeof buf - 1, row[8 + k].p, row[8 + k].n);
-        v[k] = strtod(buf, NULL); /* atof */
+        const char *sp = buf;
+        if (!scan_double(&sp, &v[k])) v[k] = 0.0;
     }
 
     int cls;
