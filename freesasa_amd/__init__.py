@@ -119,6 +119,10 @@ def lib():
         L.freesasa_gpu_test_points.restype = None
         L.freesasa_gpu_calc_batch.argtypes = [_dp, _dp, _lp, C.c_int, C.c_int, C.c_double, C.c_int,
                                               _dp, _ip, _dp, C.c_int, C.c_char_p, C.c_int]
+        L.freesasa_gpu_calc_batch_devices.argtypes = [_dp, _dp, _lp, C.c_int, C.c_int, C.c_double, C.c_int, _dp, _ip, _dp,
+                                                      _ip, C.c_int, C.c_char_p, C.c_int]
+        L.freesasa_gpu_shard_cuts.argtypes = [_lp, C.c_int, C.c_int, _ip]
+        L.freesasa_gpu_shard_cuts.restype = None
         L.freesasa_gpu_sweep_files.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
                                                C.c_longlong, _dp, _dp, _lp, _ip, C.c_int, C.c_char_p, C.c_int]
         L.freesasa_gpu_trajectory.argtypes = [_dp, _dp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
@@ -165,6 +169,33 @@ def calc_batch(xyz, radii, offsets, alg=LEE_RICHARDS, probe=1.4, resolution=20, 
     if ret:
         raise RuntimeError("freesasa_gpu_calc_batch: " + err.value.decode())
     return sasa, counts, totals
+
+
+def calc_batch_devices(xyz, radii, offsets, devices, alg=LEE_RICHARDS, probe=1.4, resolution=20):
+    """freesasa_gpu_calc_batch_devices(): (sasa, counts-or-None, totals); contiguous runs of structures of
+    about equal atom count go to the listed devices (one host thread each; a device may repeat)."""
+    xyz, radii = _f64(xyz).reshape(-1), _f64(radii)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    devs = np.ascontiguousarray(devices, dtype=np.int32)
+    n, ns = radii.size, offsets.size - 1
+    sasa, totals = np.zeros(n), np.zeros(ns)
+    counts = np.zeros(n, dtype=np.int32) if alg == SHRAKE_RUPLEY else None
+    err = C.create_string_buffer(512)
+    ret = lib().freesasa_gpu_calc_batch_devices(xyz.ctypes.data_as(_dp), radii.ctypes.data_as(_dp), offsets.ctypes.data_as(_lp), ns,
+                                                alg, probe, resolution, sasa.ctypes.data_as(_dp),
+                                                counts.ctypes.data_as(_ip) if counts is not None else None,
+                                                totals.ctypes.data_as(_dp), devs.ctypes.data_as(_ip), devs.size, err, 512)
+    if ret:
+        raise RuntimeError("freesasa_gpu_calc_batch_devices: " + err.value.decode())
+    return sasa, counts, totals
+
+
+def shard_cuts(offsets, n_parts):
+    """freesasa_gpu_shard_cuts(): first structure of each of n_parts contiguous, atom-balanced runs (+ the end)."""
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    cuts = np.zeros(n_parts + 1, dtype=np.int32)
+    lib().freesasa_gpu_shard_cuts(offsets.ctypes.data_as(_lp), offsets.size - 1, n_parts, cuts.ctypes.data_as(_ip))
+    return cuts
 
 
 def sweep_files(paths, alg=LEE_RICHARDS, probe=1.4, resolution=20, ingest_options=0, n_threads=0, batch_atoms=0,

@@ -768,6 +768,76 @@ extern "C" int freesasa_gpu_calc_batch(const double *xyz, const double *radii, c
     return ret;
 }
 
+/* ------------------------------------------------------------------ several GPUs, one process */
+
+/* Independent structures shard with no exchange: the batch is cut into contiguous runs of
+ * structures with about equal atom counts, one run per device of the mask, each run handled by its
+ * own host thread through freesasa_gpu_calc_batch (its own pooled context, stream and workspace).
+ * Contiguous runs need no gather: every device reads and writes its slice of the caller's arrays. */
+/* cuts[k] = first structure of shard k (cuts[n_parts] = n_structs): where the running atom count passes
+ * k/n_parts of the total; shards may be empty when there are fewer structures than parts */
+extern "C" void freesasa_gpu_shard_cuts(const int64_t *offsets, int n_structs, int n_parts, int *cuts)
+{
+    cuts[0] = 0;
+    const int64_t base = offsets[0], total = offsets[n_structs] - base;
+    for (int k = 1, s = 0; k < n_parts; ++k) {
+        const int64_t want = base + total * k / n_parts;
+        while (s < n_structs && offsets[s] < want) ++s;
+        cuts[k] = s < cuts[k - 1] ? cuts[k - 1] : s;
+    }
+    cuts[n_parts] = n_structs;
+}
+
+extern "C" int freesasa_gpu_calc_batch_devices(const double *xyz, const double *radii, const int64_t *offsets, int n_structs,
+                                               int alg, double probe, int resolution, double *sasa_out, int *counts_out,
+                                               double *totals_out, const int *devices, int n_devices, char *err_out, int err_len)
+{
+    if (err_out && err_len > 0) err_out[0] = 0;
+    if (!xyz || !radii || !offsets || !sasa_out || n_structs <= 0 || !devices || n_devices <= 0)
+        return set_err(err_out, err_len, "bad argument");
+    const int n_dev = freesasa_gpu_device_count();
+    if (n_dev <= 0) return set_err(err_out, err_len, "no HIP device available: libfreesasa_amd has no CPU path");
+    for (int k = 0; k < n_devices; ++k)
+        if (devices[k] < 0 || devices[k] >= n_dev) return set_err(err_out, err_len, "device index out of range");
+    const int nd = n_devices;
+    std::vector<int> cut(nd + 1);
+    freesasa_gpu_shard_cuts(offsets, n_structs, nd, cut.data());
+    std::vector<int> rc(nd, 0);
+    std::vector<std::vector<char>> errs(nd, std::vector<char>(256, 0));
+    auto run = [&](int k) {
+        const int s0 = cut[k], ns = cut[k + 1] - cut[k];
+        if (ns <= 0 || offsets[s0 + ns] == offsets[s0]) return;
+        std::vector<int64_t> off(ns + 1); /* the shard's own CSR offsets start at 0 */
+        for (int i = 0; i <= ns; ++i) off[i] = offsets[s0 + i] - offsets[s0];
+        const int64_t a0 = offsets[s0];
+        rc[k] = freesasa_gpu_calc_batch(xyz + 3 * a0, radii + a0, off.data(), ns, alg, probe, resolution, sasa_out + a0,
+                                        counts_out ? counts_out + a0 : nullptr, totals_out ? totals_out + s0 : nullptr,
+                                        devices[k], errs[k].data(), (int)errs[k].size());
+    };
+    std::vector<std::thread> th;
+    for (int k = 1; k < nd; ++k) th.emplace_back(run, k);
+    run(0);
+    for (auto &t : th) t.join();
+    for (int k = 0; k < nd; ++k)
+        if (rc[k]) return set_err(err_out, err_len, errs[k].data()[0] ? errs[k].data() : "a device shard failed");
+    return 0;
+}
+
+extern "C" int freesasa_gpu_calc_batch_multi(const double *xyz, const double *radii, const int64_t *offsets, int n_structs,
+                                             int alg, double probe, int resolution, double *sasa_out, int *counts_out,
+                                             double *totals_out, unsigned device_mask, char *err_out, int err_len)
+{
+    if (err_out && err_len > 0) err_out[0] = 0;
+    const int n_dev = freesasa_gpu_device_count();
+    if (n_dev <= 0) return set_err(err_out, err_len, "no HIP device available: libfreesasa_amd has no CPU path");
+    std::vector<int> devs;
+    for (int d = 0; d < 32 && d < n_dev; ++d)
+        if (device_mask & (1u << d)) devs.push_back(d);
+    if (devs.empty()) return set_err(err_out, err_len, "device mask selects no available device");
+    return freesasa_gpu_calc_batch_devices(xyz, radii, offsets, n_structs, alg, probe, resolution, sasa_out, counts_out,
+                                           totals_out, devs.data(), (int)devs.size(), err_out, err_len);
+}
+
 /* ------------------------------------------------------------------ structure sweep */
 
 /* Files -> per-structure totals: the loader (host threads, include/freesasa_ingest.h) reads batch

@@ -99,6 +99,20 @@ int freesasa_gpu_residue_areas_dev(freesasa_gpu_ctx *ctx, const double *d_sasa, 
 /* Golden-spiral unit test points on the host, host libm (src/sasa_sr.c:56-90). */
 void freesasa_gpu_test_points(int n_points, double *unit_points);
 
+/* The same over several GPUs of the node from one process: the structures are cut into contiguous runs
+   of about equal atom count (freesasa_gpu_shard_cuts), one per entry of devices[] — a device may
+   appear more than once, its runs then overlap their copies and kernels — each run on its own host
+   thread, context and stream; no exchange between devices (independent structures).  Arrays as in
+   freesasa_gpu_calc_batch.  _multi takes a bit mask instead (bit d = device d).  Return 0 / -1. */
+int freesasa_gpu_calc_batch_devices(const double *xyz, const double *radii, const int64_t *offsets, int n_structs,
+                                    int alg, double probe_radius, int resolution, double *sasa_out, int *counts_out,
+                                    double *totals_out, const int *devices, int n_devices, char *err, int err_len);
+int freesasa_gpu_calc_batch_multi(const double *xyz, const double *radii, const int64_t *offsets, int n_structs,
+                                  int alg, double probe_radius, int resolution, double *sasa_out, int *counts_out,
+                                  double *totals_out, unsigned device_mask, char *err, int err_len);
+/* cuts[0..n_parts]: first structure of every run for the partition above (host-only helper) */
+void freesasa_gpu_shard_cuts(const int64_t *offsets, int n_structs, int n_parts, int *cuts);
+
 /* Structure sweep (BASELINE configs[3]): PDB / mmCIF files -> per-structure totals.  The files are
    read in batches of about batch_atoms atoms (<= 0: 2e6) by n_threads host threads
    (include/freesasa_ingest.h; ingest_options are its option bits) while the previous batch is on

@@ -115,3 +115,22 @@ def test_partitions_cover_every_item_once_and_balance():
     assert all(len(p) == 0 for p in shard.lpt([], 3))
     x, r, o = shard.gather_shard(np.arange(30.).reshape(10, 3), np.arange(10.), [0, 2, 5, 10], [2, 0])
     assert o.tolist() == [0, 5, 7] and r.tolist() == [5, 6, 7, 8, 9, 0, 1] and x.shape == (7, 3)
+
+
+def test_contiguous_atom_balanced_cuts_of_the_single_process_multi_gpu_entry():
+    """freesasa_gpu_shard_cuts (host-only part of freesasa_gpu_calc_batch_devices): contiguous runs,
+    every structure in exactly one run, atom counts within one structure of equal."""
+    import numpy as np
+    import freesasa_amd as fa
+    rng = np.random.default_rng(3)
+    sizes = np.exp(rng.uniform(np.log(500), np.log(50000), 500)).astype(np.int64)
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    for parts in (1, 2, 3, 8):
+        cuts = fa.shard_cuts(offs, parts)
+        assert cuts[0] == 0 and cuts[-1] == len(sizes) and np.all(np.diff(cuts) >= 0)
+        loads = np.array([offs[cuts[k + 1]] - offs[cuts[k]] for k in range(parts)])
+        assert loads.sum() == offs[-1] and np.all(np.abs(loads - offs[-1] / parts) <= sizes.max())
+    # fewer structures than parts: empty runs, nothing lost; empty structures are fine
+    assert fa.shard_cuts(np.array([0, 10, 30]), 5).tolist()[-1] == 2
+    cuts = fa.shard_cuts(np.array([0, 0, 5, 5, 9]), 2)
+    assert cuts[0] == 0 and cuts[-1] == 4

@@ -361,3 +361,18 @@ def test_stress_shapes(fa, oracle_lib):
     want = oracle_lib.lee_richards(xyz[near], r[near])
     assert len(inner) > 500
     assert np.max(np.abs(lr[near][inner] - want[inner])) < LR_TOL
+
+
+def test_single_process_multi_device_entry_matches_one_batch(fa, oracle_lib):
+    """Several shards on separate host threads / contexts (here all on device 0: the only one of the
+    test box; on a node the list names different GPUs) give the one-batch results bit for bit."""
+    xyz, r, offs = tools.coil_batch(17, 700, seed0=300)
+    for alg, res in ((fa.LEE_RICHARDS, 20), (fa.SHRAKE_RUPLEY, 100)):
+        want, want_c, want_t = fa.calc_batch(xyz, r, offs, alg, resolution=res)
+        for devices in ([0], [0, 0, 0], [0] * 5):
+            got, got_c, got_t = fa.calc_batch_devices(xyz, r, offs, devices, alg, resolution=res)
+            assert np.array_equal(got, want) and np.array_equal(got_t, want_t)
+            if alg == fa.SHRAKE_RUPLEY:
+                assert np.array_equal(got_c, want_c)
+    with pytest.raises(RuntimeError):
+        fa.calc_batch_devices(xyz, r, offs, [0, 99])
