@@ -422,6 +422,7 @@ static int run_batch_impl(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
     pa.sx = (double *)c->sx.p; pa.sy = (double *)c->sy.p; pa.sz = (double *)c->sz.p; pa.sr = (double *)c->sr.p;
     pa.s_orig = (int *)c->s_orig.p; pa.s_cell = (long long *)c->s_cell.p; pa.s_struct = (int *)c->s_struct.p;
     pa.status = (int *)c->status.p;
+    pa.occ_stride = c->hint_res[lr ? 0 : 1] == resolution ? 0 : (n / 256 > 0 ? n / 256 : 1);
 
     hipLaunchKernelGGL(k_bounds, dim3(c->n_chunks), dim3(SASA_PIPE_B), 0, st, pa);
     hipLaunchKernelGGL(k_grid, dim3((n_structs + 63) / 64), dim3(64), 0, st, pa);
@@ -456,6 +457,26 @@ static int run_batch_impl(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
 
     /* fused tile kernel */
     const int hi = lr ? 0 : 1;
+    if (c->hint_res[hi] != resolution) {
+        /* no demand history for this resolution on this context: estimate the neighbor count from the
+           local density (atoms in an atom's own cell; ~3.1 neighbors per such atom on coils, globules
+           and proteins alike) so that the very first launch already has a fitting neighbor pool and,
+           for dense inputs, the bucket-sort variant.  One 8-byte readback, first call only. */
+        HIP_TRY(c, hipMemcpyAsync(status_h, (int *)c->status.p + ST_OCC_SUM, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        if (status_h[1] > 0) {
+            const double nn_est = 3.1 * (double)status_h[0] / (double)status_h[1];
+            const TileCfg probe_cfg = choose_cfg(resolution, lr, 0);
+            int pool = (int)(1.35 * nn_est * probe_cfg.TA + 16.0);
+            pool = (pool + 1) & ~1;
+            if (pool < 32) pool = 32;
+            if (pool > 4096) pool = 4096;
+            c->hint_res[hi] = resolution;
+            c->hint_ta[hi] = probe_cfg.TA;
+            c->hint_pool[hi] = pool;
+            if (lr) c->hint_bucket = nn_est > 30.0;
+        }
+    }
     TileCfg cfg = choose_cfg(resolution, lr, c->hint_res[hi] == resolution ? c->hint_pool[hi] : 0);
     if (const char *e = getenv("FREESASA_AMD_CFG")) { /* tuning aid: "B,TA,pool,ds" */
         int b = 0, t = 0, pl = 0, d = 0;

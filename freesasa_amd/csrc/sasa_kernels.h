@@ -80,6 +80,8 @@ enum {
     ST_OVF_TILES = 1,  /* tiles handed to the second (large-LDS) launch */
     ST_MAX_NN = 2,     /* max neighbors/atom seen */
     ST_OVF2_TILES = 3, /* tiles handed on to the third (slab) launch */
+    ST_OCC_SUM = 4,    /* sum over sampled atoms of the number of atoms in their own cell ... */
+    ST_OCC_N = 5,      /* ... and how many atoms were sampled: local density -> first launch shape */
     ST_HIST = 8,       /* [64] tiles by neighbor records needed, bins of hist_bin_width(TA) */
     ST_WORDS = 72
 };
@@ -123,6 +125,7 @@ struct PipeArgs {
     /* per atom, original order */
     int *sid;     /* structure of atom i */
     long long *cell_of; /* batch-wide cell index | grid-border flags << 32 (CELL_*) */
+    int occ_stride;     /* > 0: every occ_stride-th atom reports its cell's occupancy (ST_OCC_*) */
     int *rank;    /* arrival rank within the cell */
     /* per cell */
     int *cell_start; /* [total_cells+1]: histogram, then exclusive scan */
@@ -342,6 +345,10 @@ SASA_D void scatter_atom(const PipeArgs &a, int i)
     a.sz[p] = a.xyz[3 * i + 2];
     a.sr[p] = a.radii[i] + a.probe; /* ref: src/sasa_lr.c:136, src/sasa_sr.c:144 */
     a.s_orig[p] = i;
+    if (a.occ_stride > 0 && i % a.occ_stride == 0) { /* ~256 density samples, only while the context has no demand history */
+        SASA_ATOMIC_ADD_GLB(&a.status[ST_OCC_SUM], a.cell_start[c + 1] - a.cell_start[c]);
+        SASA_ATOMIC_ADD_GLB(&a.status[ST_OCC_N], 1);
+    }
     a.s_cell[p] = cf;
     a.s_struct[p] = a.sid[i];
 }

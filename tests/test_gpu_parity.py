@@ -161,7 +161,8 @@ def test_device_resident_batch_full_size_properties(fa, oracle_lib):
     ctx.lee_richards(d_xyz.data_ptr(), d_r.data_ptr(), offs, d_out.data_ptr(), d_tot.data_ptr())
     a = d_out.cpu().numpy()
     tot = d_tot.cpu().numpy()
-    assert ctx.stats()["fallback_tiles"] < 0.01 * (len(r) / 16)
+    st = ctx.stats()
+    assert st["fallback_tiles"] < 0.02 * (len(r) / st["tile_atoms"])      # first call: pool sized from the density sample
     # 1. bounds: 0 <= sasa <= area of the free sphere
     R = r + 1.4
     assert np.all(a >= 0) and np.all(a <= 4 * np.pi * R * R * (1 + 1e-12))
