@@ -1155,7 +1155,7 @@ SASA_D void sr_phase_pairs(const TileArgs &a, TileMem &m, int tid, int B)
 #endif
 SASA_D bool sr_compact_ok(const TileArgs &a, int items)
 {
-    return a.TA <= 8 && a.n_res <= 8192 && items <= 2 * a.TA * a.cap_idx;
+    return a.TA <= 64 && a.n_res <= 65536 && items <= a.TA * a.cap_idx; /* one 32-bit entry per survivor in the idx lists */
 }
 SASA_D bool sr_covered(const TileMem &m, int o, int k0, int k1, double tx, double ty, double tz)
 {
@@ -1182,7 +1182,7 @@ SASA_D void sr_phase_points(const TileArgs &a, TileMem &m, int tile, int tid, in
     const int na = tile_atoms(a, tile);
     const int np = a.n_res, items = na * np;
     const bool compact = sr_compact_ok(a, a.TA * np);
-    unsigned short *surv = (unsigned short *)m.idx; /* the index lists are dead after phase P */
+    unsigned *surv = (unsigned *)m.idx; /* the index lists are dead after phase P */
     for (int it = tid; it < items; it += B) {
         const int la = it / np, pt = it - la * np;
         double tx, ty, tz;
@@ -1194,7 +1194,7 @@ SASA_D void sr_phase_points(const TileArgs &a, TileMem &m, int tile, int tid, in
             SASA_ATOMIC_ADD_LDS(&m.aexp[la], 1);
         } else {
             const int w = SASA_ATOMIC_ADD_LDS(&m.flags[3], 1);
-            surv[w] = (unsigned short)(la * 8192 + pt);
+            surv[w] = ((unsigned)la << 16) | (unsigned)pt;
         }
     }
 }
@@ -1203,10 +1203,10 @@ SASA_D void sr_phase_points(const TileArgs &a, TileMem &m, int tile, int tid, in
 SASA_D void sr_phase_points2(const TileArgs &a, TileMem &m, int tid, int B)
 {
     if (m.flags[0]) return;
-    const unsigned short *surv = (const unsigned short *)m.idx;
+    const unsigned *surv = (const unsigned *)m.idx;
     const int ns = m.flags[3];
     for (int s = tid; s < ns; s += B) {
-        const int la = surv[s] >> 13, pt = surv[s] & 8191;
+        const int la = (int)(surv[s] >> 16), pt = (int)(surv[s] & 0xffffu);
         double tx, ty, tz;
         sr_point(a, m, la, pt, tx, ty, tz);
         const int o = m.aoff[la], nn = m.aoff[la + 1] - o;
@@ -1365,7 +1365,7 @@ static inline TileCfg choose_cfg(int resolution, bool lr, int pool_hint = 0)
        arithmetic.  TA*resolution work items should fill whole rounds of B threads
        (resolution 20 -> 6 atoms x 20 slices = 120 of 128 threads). */
     const int items_cap = lr ? SASA_ITEMS_CAP : 4096;
-    const int ta_max = lr ? SASA_TA_MAX : 8;
+    const int ta_max = lr ? SASA_TA_MAX : 16;
     if (resolution > items_cap) {
         c.B = 256;
         c.TA = 1;
@@ -1384,6 +1384,14 @@ static inline TileCfg choose_cfg(int resolution, bool lr, int pool_hint = 0)
                 const double score = eff - 0.05 * (rounds - 1) - (B == 256 ? 0.04 : 0.0) - (B == 128 ? 0.02 : 0.0);
                 if (score > best + 1e-9) { best = score; c.B = B; c.TA = ta; }
             }
+    }
+    if (!lr && resolution >= 50 && resolution <= items_cap) {
+        /* S&R: the per-tile overhead and the neighbor search amortise over more atoms; measured at 100
+           points (profiles/r01_secondary.md): 256 threads x 8 atoms 0.33 ms per 2e5 atoms, x 5 atoms
+           0.40, x 12 atoms 0.39, 128 threads x 5 atoms 0.36 */
+        int ta = 1024 / resolution;
+        c.B = 256;
+        c.TA = ta < 1 ? 1 : (ta > 8 ? 8 : ta);
     }
     c.items = lr ? (c.tab ? c.TA * resolution : c.B) : 1;
     c.lr = lr ? 1 : 0;
