@@ -420,7 +420,9 @@ SASA_HD size_t tile_fixed_bytes(int TA, int items)
     return align16(sizeof(double) * 4 * TA) + align16(sizeof(int) * (3 * TA + 1 + 4 + 18 * TA)) +
            align16(sizeof(double) * items);
 }
+#ifndef LR_NBUCKET
 #define LR_NBUCKET 32
+#endif
 SASA_HD size_t tile_union_bytes(int TA, int cap_idx, int pool, int ds, int B, bool lr)
 {
     size_t u1 = align16(sizeof(int) * (size_t)TA * cap_idx) + (lr ? align16(sizeof(double) * (size_t)pool) : 0);
