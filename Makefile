@@ -39,7 +39,11 @@ $(LIBDIR)/ingest.o: $(CSRC)/ingest.c $(CSRC)/protor_table.h include/freesasa_ing
 	@mkdir -p $(LIBDIR)
 	$(CC) $(CFLAGS) -Iinclude -pthread -c $< -o $@
 
-$(LIBDIR)/libfreesasa_amd.so: $(LIBDIR)/gpu_engine.o $(LIBDIR)/seam.o $(LIBDIR)/testpoints.o $(LIBDIR)/api.o $(LIBDIR)/ingest.o
+$(LIBDIR)/select.o: $(CSRC)/select.c include/freesasa_ingest.h
+	@mkdir -p $(LIBDIR)
+	$(CC) $(CFLAGS) -Iinclude -c $< -o $@
+
+$(LIBDIR)/libfreesasa_amd.so: $(LIBDIR)/gpu_engine.o $(LIBDIR)/seam.o $(LIBDIR)/testpoints.o $(LIBDIR)/api.o $(LIBDIR)/ingest.o $(LIBDIR)/select.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
 $(LIBDIR)/libfreesasa_amd_seam.a: $(LIBDIR)/gpu_engine.o $(LIBDIR)/seam.o $(LIBDIR)/testpoints.o $(LIBDIR)/ingest.o

@@ -121,12 +121,23 @@ double freesasa_ingest_guess_radius(const char *symbol)
     return -1.0;
 }
 
+/* first token of a field, NUL padded to w bytes (no terminator when the token fills the field) */
+static void store_token(char *dst, int w, const char *field)
+{
+    const char *t;
+    int n = first_token(field, &t);
+    if (n > w) n = w;
+    memset(dst, 0, (size_t)w);
+    memcpy(dst, t, (size_t)n);
+}
+
 /* ------------------------------------------------------------------ one file */
 
 typedef struct {
     int64_t n, cap;
     double *xyz, *rad;
     uint8_t *cls, *bb;
+    char *aname, *asym; /* [4n] trimmed atom names, [2n] trimmed element symbols, NUL padded */
     int64_t nres, rescap;
     int64_t *res_first;
     int16_t *res_ref;
@@ -138,7 +149,7 @@ typedef struct {
 
 static void parsed_free(parsed *p)
 {
-    free(p->xyz); free(p->rad); free(p->cls); free(p->bb);
+    free(p->xyz); free(p->rad); free(p->cls); free(p->bb); free(p->aname); free(p->asym);
     free(p->res_first); free(p->res_ref); free(p->res_name); free(p->res_number); free(p->res_chain);
     memset(p, 0, sizeof *p);
 }
@@ -159,6 +170,12 @@ static int grow_atoms(parsed *p)
     uint8_t *b = realloc(p->bb, (size_t)cap);
     if (!b) return -1;
     p->bb = b;
+    char *an = realloc(p->aname, 4 * (size_t)cap);
+    if (!an) return -1;
+    p->aname = an;
+    char *as = realloc(p->asym, 2 * (size_t)cap);
+    if (!as) return -1;
+    p->asym = as;
     p->cap = cap;
     return 0;
 }
@@ -360,6 +377,8 @@ static void parse_pdb(const char *text, size_t len, int options, parsed *p)
             p->rad[p->n] = r;
             p->cls[p->n] = (uint8_t)cls;
             p->bb[p->n] = (uint8_t)freesasa_ingest_is_backbone(aname);
+            store_token(p->aname + 4 * p->n, 4, aname);
+            store_token(p->asym + 2 * p->n, 2, symbol);
             ++p->n;
         }
         if (!(options & FREESASA_INGEST_JOIN_MODELS) && strncmp("ENDMDL", line, 6) == 0) break; /* ref: :705-708 */
@@ -581,6 +600,8 @@ static int cif_visit_atom(const cif_tok *row, void *ctx)
     p->rad[p->n] = r;
     p->cls[p->n] = (uint8_t)cls;
     p->bb[p->n] = (uint8_t)freesasa_ingest_is_backbone(aname);
+    store_token(p->aname + 4 * p->n, 4, aname);
+    store_token(p->asym + 2 * p->n, 2, symbol);
     ++p->n;
     return 0;
 }
@@ -719,6 +740,8 @@ static void assemble_sizes(job *j)
     out->radii = malloc(sizeof(double) * (size_t)(na ? na : 1));
     out->atom_class = malloc((size_t)(na ? na : 1));
     out->atom_backbone = malloc((size_t)(na ? na : 1));
+    out->atom_name = malloc(4 * (size_t)(na ? na : 1));
+    out->atom_symbol = malloc(2 * (size_t)(na ? na : 1));
     out->res_ref = malloc(sizeof(int16_t) * (size_t)(nr ? nr : 1));
     out->offsets = malloc(sizeof(int64_t) * ((size_t)j->n + 1));
     out->res_first = malloc(sizeof(int64_t) * ((size_t)nr + 1));
@@ -727,7 +750,7 @@ static void assemble_sizes(job *j)
     out->res_number = malloc(6 * (size_t)(nr ? nr : 1));
     out->res_chain = malloc(4 * (size_t)(nr ? nr : 1));
     out->status = malloc(sizeof(int32_t) * (size_t)(j->n ? j->n : 1));
-    if (!out->xyz || !out->radii || !out->atom_class || !out->atom_backbone || !out->res_ref || !out->offsets || !out->res_first || !out->res_offsets ||
+    if (!out->xyz || !out->radii || !out->atom_class || !out->atom_backbone || !out->atom_name || !out->atom_symbol || !out->res_ref || !out->offsets || !out->res_first || !out->res_offsets ||
         !out->res_name || !out->res_number || !out->res_chain || !out->status) {
         j->rc = FREESASA_INGEST_ENOMEM;
         return;
@@ -781,6 +804,8 @@ static void *worker(void *arg)
                 memcpy(out->radii + a, S->rad + s->a0, sizeof(double) * (size_t)s->na);
                 memcpy(out->atom_class + a, S->cls + s->a0, (size_t)s->na);
                 memcpy(out->atom_backbone + a, S->bb + s->a0, (size_t)s->na);
+                memcpy(out->atom_name + 4 * a, S->aname + 4 * s->a0, 4 * (size_t)s->na);
+                memcpy(out->atom_symbol + 2 * a, S->asym + 2 * s->a0, 2 * (size_t)s->na);
             }
             for (int64_t i = 0; i < s->nr; ++i) out->res_first[r + i] = a + S->res_first[s->r0 + i];
             if (s->nr) {
@@ -799,7 +824,7 @@ static void *worker(void *arg)
 void freesasa_ingest_free(freesasa_ingest_batch *b)
 {
     if (!b) return;
-    free(b->xyz); free(b->radii); free(b->atom_class); free(b->atom_backbone); free(b->res_ref); free(b->offsets); free(b->res_first);
+    free(b->xyz); free(b->radii); free(b->atom_class); free(b->atom_backbone); free(b->atom_name); free(b->atom_symbol); free(b->res_ref); free(b->offsets); free(b->res_first);
     free(b->res_offsets); free(b->res_name); free(b->res_number); free(b->res_chain); free(b->status);
     memset(b, 0, sizeof *b);
 }

@@ -22,6 +22,7 @@ class _CBatch(C.Structure):
     _fields_ = [("n_structs", C.c_int32), ("n_atoms", C.c_int64), ("n_residues", C.c_int64),
                 ("xyz", C.POINTER(C.c_double)), ("radii", C.POINTER(C.c_double)),
                 ("atom_class", C.POINTER(C.c_uint8)), ("atom_backbone", C.POINTER(C.c_uint8)),
+                ("atom_name", C.POINTER(C.c_char)), ("atom_symbol", C.POINTER(C.c_char)),
                 ("offsets", C.POINTER(C.c_int64)),
                 ("res_first", C.POINTER(C.c_int64)), ("res_offsets", C.POINTER(C.c_int64)),
                 ("res_ref", C.POINTER(C.c_int16)), ("res_name", C.POINTER(C.c_char)), ("res_number", C.POINTER(C.c_char)),
@@ -45,6 +46,8 @@ class Batch:
         self.atom_class = _arr(cb.atom_class, na, np.uint8)
         self.atom_backbone = _arr(cb.atom_backbone, na, np.uint8)
         self.res_ref = _arr(cb.res_ref, nr, np.int16)
+        self.atom_name_raw = np.frombuffer(C.string_at(cb.atom_name, 4 * na) if na else b"", dtype="S4").copy()
+        self.atom_symbol_raw = np.frombuffer(C.string_at(cb.atom_symbol, 2 * na) if na else b"", dtype="S2").copy()
         self.offsets = _arr(cb.offsets, ns + 1, np.int64)
         self.res_first = _arr(cb.res_first, nr + 1, np.int64)
         self.res_offsets = _arr(cb.res_offsets, ns + 1, np.int64)
@@ -65,6 +68,29 @@ class Batch:
     @property
     def res_chain(self):
         return [v.decode() for v in self.res_chain_raw.tolist()]
+
+    def _as_c(self):
+        """A freesasa_ingest_batch view of the numpy arrays (no copies; valid while self lives)."""
+        cb = _CBatch()
+        cb.n_structs, cb.n_atoms, cb.n_residues = self.n_structs, self.n_atoms, self.n_residues
+        ptr = lambda a, t: C.cast(a.ctypes.data, C.POINTER(t))
+        cb.offsets, cb.res_first, cb.res_offsets = ptr(self.offsets, C.c_int64), ptr(self.res_first, C.c_int64), ptr(self.res_offsets, C.c_int64)
+        cb.atom_name, cb.atom_symbol = ptr(self.atom_name_raw, C.c_char), ptr(self.atom_symbol_raw, C.c_char)
+        cb.res_name, cb.res_number, cb.res_chain = ptr(self.res_name_raw, C.c_char), ptr(self.res_number_raw, C.c_char), ptr(self.res_chain_raw, C.c_char)
+        return cb
+
+    def select(self, structure, command):
+        """The reference's selection language on one structure: (name, mask[n_atoms of it], warned).
+        Raises ValueError on a syntax error (the reference returns FREESASA_FAIL)."""
+        L = _proto()
+        n = int(self.offsets[structure + 1] - self.offsets[structure])
+        mask = np.zeros(n, dtype=np.uint8)
+        name = C.create_string_buffer(64)
+        cb = self._as_c()
+        ret = L.freesasa_ingest_select(C.byref(cb), structure, command.encode(), name, mask.ctypes.data_as(C.POINTER(C.c_ubyte)))
+        if ret == -1:
+            raise ValueError(f"cannot parse selection {command!r}")
+        return name.value.decode(), mask, ret == -2
 
     def residue_sums(self, per_atom):
         """Host-side segmented sum over the residues (the device-side one is GpuContext.segment_sums)."""
@@ -88,6 +114,7 @@ def _proto():
         L.freesasa_ingest_guess_radius.restype = C.c_double
         L.freesasa_ingest_residue_reference_table.argtypes = [C.POINTER(C.c_double)]
         L.freesasa_ingest_is_backbone.argtypes = [C.c_char_p]
+        L.freesasa_ingest_select.argtypes = [C.POINTER(_CBatch), C.c_int, C.c_char_p, C.c_char_p, C.POINTER(C.c_ubyte)]
         L._ingest_ready = True
     return L
 

@@ -64,6 +64,8 @@ typedef struct freesasa_ingest_batch {
     double *radii;        /* [n_atoms] */
     uint8_t *atom_class;  /* [n_atoms] FREESASA_INGEST_APOLAR / POLAR / UNKNOWN */
     uint8_t *atom_backbone; /* [n_atoms] 1 for main-chain atoms (ref: freesasa_atom_is_backbone, src/classifier.c:1090-1109) */
+    char *atom_name;      /* [4 * n_atoms] atom names without padding, NUL padded (no terminator when 4 long) */
+    char *atom_symbol;    /* [2 * n_atoms] element symbols without padding, NUL padded */
     int64_t *offsets;     /* [n_structs + 1] */
     int64_t *res_first;   /* [n_residues + 1] batch-wide atom index of each residue's first atom */
     int64_t *res_offsets; /* [n_structs + 1] */
@@ -88,6 +90,18 @@ int freesasa_ingest_pdb_texts(const char *const *texts, const size_t *lens, int 
                               int n_threads, freesasa_ingest_batch *out);
 
 void freesasa_ingest_free(freesasa_ingest_batch *batch);
+
+/* The reference's selection language ("name, resn ala+arg and not chain B", src/selection.c,
+ * src/parser.y, src/lexer.l) on structure `structure` of a batch: mask_out[i] = 1 for the selected
+ * atoms ([offsets[s+1] - offsets[s]] bytes), name_out = the selection's name.  Returns the number of
+ * atoms of the structure like freesasa_select_area (src/selection.c:683-742), FREESASA_INGEST_SELECT_WARN
+ * when parts of the command were ignored (mask still valid), FREESASA_INGEST_SELECT_FAIL on a syntax
+ * error.  The area of the selection is the masked sum of the per-atom SASA. */
+#define FREESASA_INGEST_MAX_SELECTION_NAME 50 /* ref: src/freesasa.h:226 */
+#define FREESASA_INGEST_SELECT_FAIL (-1)
+#define FREESASA_INGEST_SELECT_WARN (-2)
+int freesasa_ingest_select(const freesasa_ingest_batch *batch, int structure, const char *command,
+                           char name_out[FREESASA_INGEST_MAX_SELECTION_NAME + 1], unsigned char *mask_out);
 
 /* The classifier on its own (ref: freesasa_classifier_radius / _class with the ProtOr classifier,
  * src/classifier.c:781-813): radius in A or -1.0 if unknown; *cls (may be NULL) receives the class. */

@@ -36,7 +36,7 @@ def test_exports_every_declared_symbol(L):
             "freesasa_default_parameters", "FREESASA_DEF_NUMBER_THREADS", "freesasa_lee_richards",
             "freesasa_shrake_rupley", "freesasa_gpu_lr_batch_dev", "freesasa_gpu_calc_batch",
             "freesasa_gpu_trajectory", "freesasa_gpu_segment_sums_dev", "freesasa_ingest_pdb_files",
-            "freesasa_ingest_pdb_texts", "freesasa_ingest_free", "freesasa_gpu_sweep_files",
+            "freesasa_ingest_pdb_texts", "freesasa_ingest_free", "freesasa_ingest_select", "freesasa_gpu_sweep_files",
             "freesasa_gpu_residue_areas_dev", "freesasa_gpu_class_sums_dev"} <= declared
     missing = declared - exported
     assert not missing, f"declared in include/ but not exported: {sorted(missing)}"
