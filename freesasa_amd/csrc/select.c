@@ -372,7 +372,12 @@ int freesasa_ingest_select(const freesasa_ingest_batch *b, int structure, const 
 
     ctx_t c;
     c.b = b; c.a0 = b->offsets[structure]; c.n = b->offsets[structure + 1] - c.a0; c.warn = 0;
-    int64_t *res = malloc(sizeof(int64_t) * (size_t)(c.n ? c.n : 1));
+    if (c.n == 0) { /* an input that failed to load: nothing to select from */
+        free_expr(e);
+        snprintf(name_out, FREESASA_INGEST_MAX_SELECTION_NAME + 1, "%.50s", name);
+        return 0;
+    }
+    int64_t *res = malloc(sizeof(int64_t) * (size_t)c.n);
     if (!res) { free_expr(e); return FREESASA_INGEST_SELECT_FAIL; }
     for (int64_t r = b->res_offsets[structure]; r < b->res_offsets[structure + 1]; ++r)
         for (int64_t a = b->res_first[r]; a < b->res_first[r + 1]; ++a) res[a - c.a0] = r;
