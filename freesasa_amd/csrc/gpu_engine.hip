@@ -94,6 +94,18 @@ __global__ __launch_bounds__(SASA_TOT_B) void k_totals(const double *sasa, const
     totals_phase1(part, totals, blockIdx.x, threadIdx.x);
 }
 
+__global__ __launch_bounds__(SASA_TOT_B) void k_totals_chunks(PipeArgs a, const double *sasa, double *chunk_tot)
+{
+    __shared__ double part[SASA_TOT_B];
+    totals_chunk_phase0(a, sasa, part, blockIdx.x, threadIdx.x);
+    __syncthreads();
+    totals_chunk_phase1(part, chunk_tot, blockIdx.x, threadIdx.x);
+}
+__global__ __launch_bounds__(256) void k_totals_structs(PipeArgs a, const double *chunk_tot, double *totals)
+{
+    totals_struct(a, chunk_tot, totals, blockIdx.x * 256 + threadIdx.x);
+}
+
 __global__ __launch_bounds__(256) void k_segsum_small(const double *sasa, const int64_t *seg, int n_segs, double *out)
 {
     segsum_small(sasa, seg, out, blockIdx.x * 256 + threadIdx.x, n_segs);
@@ -576,8 +588,9 @@ static int run_batch_impl(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
     }
 
     if (d_totals) {
-        hipLaunchKernelGGL(k_totals, dim3(n_structs), dim3(SASA_TOT_B), 0, st, (const double *)d_sasa,
-                           (const int64_t *)c->offsets.p, n_structs, d_totals);
+        /* the chunk partials reuse the bounds kernels' scratch (56 bytes per chunk, free by now) */
+        hipLaunchKernelGGL(k_totals_chunks, dim3(c->n_chunks), dim3(SASA_TOT_B), 0, st, pa, (const double *)d_sasa, (double *)c->bpart.p);
+        hipLaunchKernelGGL(k_totals_structs, dim3((n_structs + 255) / 256), dim3(256), 0, st, pa, (const double *)c->bpart.p, d_totals);
         HIP_TRY(c, hipGetLastError());
     }
     if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[3], st));

@@ -1257,6 +1257,33 @@ SASA_D void totals_phase1(const double *part, double *totals, int s, int tid)
     totals[s] = t;
 }
 
+/* Per-structure totals in two levels, so that one 200k-atom structure is not summed by a single
+ * workgroup: (1) one workgroup per chunk of the bounds chunk table (<= SASA_BOUNDS_CHUNK atoms of one
+ * structure): every thread adds a contiguous run in atom order, thread 0 adds the runs in order;
+ * (2) one thread per structure adds its chunks in order.  Deterministic. */
+SASA_D void totals_chunk_phase0(const PipeArgs &a, const double *sasa, double *part, int chunk, int tid)
+{
+    const int64_t b = a.chunk_begin[chunk];
+    const int len = a.chunk_len[chunk];
+    double t = 0;
+    for (int i = tid; i < len; i += SASA_TOT_B) t += sasa[b + i];
+    part[tid] = t;
+}
+SASA_D void totals_chunk_phase1(const double *part, double *chunk_tot, int chunk, int tid)
+{
+    if (tid != 0) return;
+    double t = 0;
+    for (int k = 0; k < SASA_TOT_B; ++k) t += part[k];
+    chunk_tot[chunk] = t;
+}
+SASA_D void totals_struct(const PipeArgs &a, const double *chunk_tot, double *totals, int s)
+{
+    if (s >= a.n_structs) return;
+    double t = 0;
+    for (int k = a.struct_chunk0[s]; k < a.struct_chunk0[s + 1]; ++k) t += chunk_tot[k];
+    totals[s] = t;
+}
+
 /* Short segments (residues: ~8 atoms): one thread per segment, strictly sequential in atom order,
  * i.e. exactly the sum the reference's result tree forms (ref: src/node.c:150-176). */
 SASA_D void segsum_small(const double *sasa, const int64_t *seg, double *out, int k, int n_segs)

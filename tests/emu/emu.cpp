@@ -191,10 +191,12 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
     }
     if (totals) {
         double part[SASA_TOT_B];
-        for (int s = 0; s < n_structs; ++s) {
-            for (int l = 0; l < SASA_TOT_B; ++l) totals_phase0(sasa, offsets, part, s, l);
-            for (int l = 0; l < SASA_TOT_B; ++l) totals_phase1(part, totals, s, l);
+        std::vector<double> chunk_tot(pa.n_chunks > 0 ? pa.n_chunks : 1);
+        for (int ch = 0; ch < pa.n_chunks; ++ch) {
+            for (int l = 0; l < SASA_TOT_B; ++l) totals_chunk_phase0(pa, sasa, part, ch, l);
+            for (int l = 0; l < SASA_TOT_B; ++l) totals_chunk_phase1(part, chunk_tot.data(), ch, l);
         }
+        for (int s = 0; s < ((n_structs + 255) / 256) * 256; ++s) totals_struct(pa, chunk_tot.data(), totals, s);
     }
 
     stats_out[0] = status[ST_ERROR]; stats_out[1] = status[ST_OVF_TILES]; stats_out[2] = status[ST_MAX_NN];
