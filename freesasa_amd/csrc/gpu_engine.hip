@@ -53,14 +53,16 @@ __global__ __launch_bounds__(SASA_PIPE_B) void k_count(PipeArgs a)
     count_atom(a, blockIdx.x * SASA_PIPE_B + threadIdx.x);
 }
 
+static_assert(SASA_PIPE_B == SASA_SCAN_GROUP * SASA_SCAN_GROUP, "two-level combine of the scan partials");
 __global__ __launch_bounds__(SASA_PIPE_B) void k_scan1(PipeArgs a, long long n)
 {
-    __shared__ int part[SASA_PIPE_B];
+    __shared__ int part[SASA_PIPE_B], part2[SASA_SCAN_GROUP];
     scan1_phase0(a, n, part, blockIdx.x, threadIdx.x, SASA_PIPE_B);
     __syncthreads();
-    scan1_phase1(a, part, blockIdx.x, threadIdx.x, SASA_PIPE_B);
+    scan_group_sums(part, part2, threadIdx.x);
+    __syncthreads();
+    scan1_phase2(a, part2, blockIdx.x, threadIdx.x);
 }
-
 __global__ __launch_bounds__(SASA_PIPE_B) void k_scan2(PipeArgs a, int nblk)
 {
     __shared__ int part[SASA_PIPE_B];
@@ -73,12 +75,15 @@ __global__ __launch_bounds__(SASA_PIPE_B) void k_scan2(PipeArgs a, int nblk)
 
 __global__ __launch_bounds__(SASA_PIPE_B) void k_scan3(PipeArgs a, long long n)
 {
-    __shared__ int part[SASA_PIPE_B];
-    scan3_phase0(a, n, part, blockIdx.x, threadIdx.x, SASA_PIPE_B);
+    __shared__ int part[SASA_PIPE_B], part2[SASA_SCAN_GROUP];
+    ScanRegs r;
+    scan3_phase0(a, n, part, blockIdx.x, threadIdx.x, SASA_PIPE_B, r);
     __syncthreads();
-    scan3_phase1(part, threadIdx.x, SASA_PIPE_B);
+    scan3_phase1(part, part2, threadIdx.x);
     __syncthreads();
-    scan3_phase2(a, n, part, blockIdx.x, threadIdx.x, SASA_PIPE_B);
+    scan3_phase2(part2, threadIdx.x);
+    __syncthreads();
+    scan3_phase3(a, n, part, part2, blockIdx.x, threadIdx.x, SASA_PIPE_B, r);
 }
 
 __global__ __launch_bounds__(SASA_PIPE_B) void k_scatter(PipeArgs a)

@@ -274,21 +274,46 @@ SASA_D void count_atom(const PipeArgs &a, int i)
 
 /* K4: exclusive scan of cell_start[0..n) in place, n = total cells; cell_start[n] = total.
  * Three launches: scan1 (block sums), scan2 (scan of block sums, one block), scan3 (apply).
- * Each thread owns SCAN_ITEMS consecutive cells. */
-#define SASA_SCAN_ITEMS 8
-SASA_D void scan1_phase0(const PipeArgs &a, long long n, int *part, int blk, int tid, int B)
+ * Each thread owns SCAN_ITEMS consecutive cells, moved as four 16-byte words and kept in
+ * registers between the phases of scan3 (a sparse batch has ~10 cells per atom, so these two
+ * kernels stream more bytes than the rest of the pipeline together).  The B partial sums of a
+ * block are combined in two levels of SASA_SCAN_GROUP. */
+#define SASA_SCAN_ITEMS 16
+#define SASA_SCAN_GROUP 16 /* B == GROUP * GROUP */
+struct __attribute__((aligned(16))) Int4 { int x, y, z, w; };
+struct ScanRegs { Int4 v[SASA_SCAN_ITEMS / 4]; };
+SASA_D int scan_load(const PipeArgs &a, long long n, int blk, int tid, int B, ScanRegs &r)
 {
     const long long base = ((long long)blk * B + tid) * SASA_SCAN_ITEMS;
+    if (base + SASA_SCAN_ITEMS <= n) {
+        const Int4 *p = (const Int4 *)(a.cell_start + base);
+        for (int k = 0; k < SASA_SCAN_ITEMS / 4; ++k) r.v[k] = p[k];
+    } else {
+        int *w = (int *)r.v;
+        for (int k = 0; k < SASA_SCAN_ITEMS; ++k) w[k] = base + k < n ? a.cell_start[base + k] : 0;
+    }
     int s = 0;
-    for (int k = 0; k < SASA_SCAN_ITEMS; ++k)
-        if (base + k < n) s += a.cell_start[base + k];
-    part[tid] = s;
+    for (int k = 0; k < SASA_SCAN_ITEMS / 4; ++k) s += (r.v[k].x + r.v[k].y) + (r.v[k].z + r.v[k].w);
+    return s;
 }
-SASA_D void scan1_phase1(const PipeArgs &a, int *part, int blk, int tid, int B)
+SASA_D void scan1_phase0(const PipeArgs &a, long long n, int *part, int blk, int tid, int B)
+{
+    ScanRegs r;
+    part[tid] = scan_load(a, n, blk, tid, B, r);
+}
+/* group sums: thread g < GROUP adds the partials of threads [g*GROUP, (g+1)*GROUP) */
+SASA_D void scan_group_sums(const int *part, int *part2, int tid)
+{
+    if (tid >= SASA_SCAN_GROUP) return;
+    int run = 0;
+    for (int t = 0; t < SASA_SCAN_GROUP; ++t) run += part[tid * SASA_SCAN_GROUP + t];
+    part2[tid] = run;
+}
+SASA_D void scan1_phase2(const PipeArgs &a, const int *part2, int blk, int tid)
 {
     if (tid != 0) return;
     int run = 0;
-    for (int t = 0; t < B; ++t) run += part[t];
+    for (int t = 0; t < SASA_SCAN_GROUP; ++t) run += part2[t];
     a.blk_sums[blk] = run;
 }
 /* one block; nblk block sums -> exclusive */
@@ -315,21 +340,47 @@ SASA_D void scan2_phase2(const PipeArgs &a, int nblk, const int *part, int tid, 
         run += v;
     }
 }
-SASA_D void scan3_phase0(const PipeArgs &a, long long n, int *part, int blk, int tid, int B)
+SASA_D void scan3_phase0(const PipeArgs &a, long long n, int *part, int blk, int tid, int B, ScanRegs &r)
 {
-    scan1_phase0(a, n, part, blk, tid, B);
+    part[tid] = scan_load(a, n, blk, tid, B, r);
 }
-SASA_D void scan3_phase1(int *part, int tid, int B) { scan2_phase1(part, tid, B); }
-SASA_D void scan3_phase2(const PipeArgs &a, long long n, const int *part, int blk, int tid, int B)
+/* exclusive scan inside each group, group totals to part2 */
+SASA_D void scan3_phase1(int *part, int *part2, int tid)
+{
+    if (tid >= SASA_SCAN_GROUP) return;
+    int run = 0;
+    for (int t = 0; t < SASA_SCAN_GROUP; ++t) {
+        const int v = part[tid * SASA_SCAN_GROUP + t];
+        part[tid * SASA_SCAN_GROUP + t] = run;
+        run += v;
+    }
+    part2[tid] = run;
+}
+SASA_D void scan3_phase2(int *part2, int tid)
+{
+    if (tid != 0) return;
+    int run = 0;
+    for (int t = 0; t < SASA_SCAN_GROUP; ++t) { const int v = part2[t]; part2[t] = run; run += v; }
+}
+SASA_D void scan3_phase3(const PipeArgs &a, long long n, const int *part, const int *part2, int blk, int tid, int B,
+                         ScanRegs &r)
 {
     const long long base = ((long long)blk * B + tid) * SASA_SCAN_ITEMS;
-    int run = a.blk_sums[blk] + part[tid];
-    for (int k = 0; k < SASA_SCAN_ITEMS; ++k)
-        if (base + k < n) {
-            int v = a.cell_start[base + k];
-            a.cell_start[base + k] = run;
-            run += v;
+    int run = a.blk_sums[blk] + part2[tid / SASA_SCAN_GROUP] + part[tid];
+    if (base + SASA_SCAN_ITEMS <= n) {
+        Int4 *p = (Int4 *)(a.cell_start + base);
+        for (int k = 0; k < SASA_SCAN_ITEMS / 4; ++k) {
+            const Int4 v = r.v[k];
+            Int4 o;
+            o.x = run; o.y = o.x + v.x; o.z = o.y + v.y; o.w = o.z + v.z;
+            run = o.w + v.w;
+            p[k] = o;
         }
+    } else {
+        const int *w = (const int *)r.v;
+        for (int k = 0; k < SASA_SCAN_ITEMS; ++k)
+            if (base + k < n) { a.cell_start[base + k] = run; run += w[k]; }
+    }
     if (base <= n && n < base + SASA_SCAN_ITEMS) a.cell_start[n] = run; /* sentinel = n_atoms */
 }
 

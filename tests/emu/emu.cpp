@@ -123,18 +123,21 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
     for (int b = 0; b < nblk_atoms; ++b)
         for (int t = 0; t < PB; ++t) count_atom(pa, b * PB + t);
     {
-        std::vector<int> part(PB);
+        std::vector<int> part(PB), part2(SASA_SCAN_GROUP);
+        std::vector<ScanRegs> regs(PB);
         for (int b = 0; b < nblk_scan; ++b) {
             for (int t = 0; t < PB; ++t) scan1_phase0(pa, total_cells, part.data(), b, t, PB);
-            for (int t = 0; t < PB; ++t) scan1_phase1(pa, part.data(), b, t, PB);
+            for (int t = 0; t < PB; ++t) scan_group_sums(part.data(), part2.data(), t);
+            for (int t = 0; t < PB; ++t) scan1_phase2(pa, part2.data(), b, t);
         }
         for (int t = 0; t < PB; ++t) scan2_phase0(pa, nblk_scan, part.data(), t, PB);
         for (int t = 0; t < PB; ++t) scan2_phase1(part.data(), t, PB);
         for (int t = 0; t < PB; ++t) scan2_phase2(pa, nblk_scan, part.data(), t, PB);
         for (int b = 0; b < nblk_scan; ++b) {
-            for (int t = 0; t < PB; ++t) scan3_phase0(pa, total_cells, part.data(), b, t, PB);
-            for (int t = 0; t < PB; ++t) scan3_phase1(part.data(), t, PB);
-            for (int t = 0; t < PB; ++t) scan3_phase2(pa, total_cells, part.data(), b, t, PB);
+            for (int t = 0; t < PB; ++t) scan3_phase0(pa, total_cells, part.data(), b, t, PB, regs[t]);
+            for (int t = 0; t < PB; ++t) scan3_phase1(part.data(), part2.data(), t);
+            for (int t = 0; t < PB; ++t) scan3_phase2(part2.data(), t);
+            for (int t = 0; t < PB; ++t) scan3_phase3(pa, total_cells, part.data(), part2.data(), b, t, PB, regs[t]);
         }
     }
     for (int b = 0; b < nblk_atoms; ++b)
