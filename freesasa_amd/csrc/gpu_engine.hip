@@ -50,7 +50,13 @@ __global__ __launch_bounds__(SASA_PIPE_B) void k_cell_base(PipeArgs a)
 
 __global__ __launch_bounds__(SASA_PIPE_B) void k_count(PipeArgs a)
 {
-    count_atom(a, blockIdx.x * SASA_PIPE_B + threadIdx.x);
+    __shared__ int cells[SASA_PIPE_B], base[SASA_PIPE_B];
+    const int i = blockIdx.x * SASA_PIPE_B + threadIdx.x;
+    count_phase0(a, cells, i, threadIdx.x);
+    __syncthreads();
+    count_phase1(a, cells, base, threadIdx.x, SASA_PIPE_B);
+    __syncthreads();
+    count_phase2(a, cells, base, i, threadIdx.x);
 }
 
 static_assert(SASA_PIPE_B == SASA_SCAN_GROUP * SASA_SCAN_GROUP, "two-level combine of the scan partials");

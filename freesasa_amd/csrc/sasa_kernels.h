@@ -252,10 +252,13 @@ SASA_D void cellbase_phase2(const PipeArgs &a, const long long *part, int tid, i
 enum { CELL_X0 = 1, CELL_X1 = 2, CELL_Y0 = 4, CELL_Y1 = 8, CELL_Z0 = 16, CELL_Z1 = 32 };
 SASA_D int cell_coord(double v, double v0, double d) { return (int)((v - v0) / d); } /* ref: src/nb.c:137-140 */
 
-/* K3: one thread per atom (original order). */
-SASA_D void count_atom(const PipeArgs &a, int i)
+/* K3: one thread per atom (original order): its cell, and its rank among the atoms of that cell.
+ * Consecutive atoms of a chain mostly share a cell, so a RUN of equal cells inside the workgroup
+ * takes one atomic (by its first thread, for the whole run) instead of one per atom.
+ * cells/base = LDS int [B]. */
+SASA_D void count_phase0(const PipeArgs &a, int *cells, int i, int tid)
 {
-    if (i >= a.n_atoms) return;
+    if (i >= a.n_atoms) { cells[tid] = -1; return; }
     const GridS g = a.grid[a.sid[i]];
     int ix = cell_coord(a.xyz[3 * i], g.x0, g.d);
     int iy = cell_coord(a.xyz[3 * i + 1], g.y0, g.d);
@@ -269,7 +272,23 @@ SASA_D void count_atom(const PipeArgs &a, int i)
     const int fl = (ix == 0 ? CELL_X0 : 0) | (ix == g.nx - 1 ? CELL_X1 : 0) | (iy == 0 ? CELL_Y0 : 0) |
                    (iy == g.ny - 1 ? CELL_Y1 : 0) | (iz == 0 ? CELL_Z0 : 0) | (iz == g.nz - 1 ? CELL_Z1 : 0);
     a.cell_of[i] = (long long)c | ((long long)fl << 32);
-    a.rank[i] = SASA_ATOMIC_ADD_GLB(&a.cell_start[c], 1);
+    cells[tid] = c;
+}
+SASA_D void count_phase1(const PipeArgs &a, const int *cells, int *base, int tid, int B)
+{
+    const int c = cells[tid];
+    if (c < 0 || (tid > 0 && cells[tid - 1] == c)) return; /* not the head of a run */
+    int len = 1;
+    while (tid + len < B && cells[tid + len] == c) ++len;
+    base[tid] = SASA_ATOMIC_ADD_GLB(&a.cell_start[c], len);
+}
+SASA_D void count_phase2(const PipeArgs &a, const int *cells, const int *base, int i, int tid)
+{
+    const int c = cells[tid];
+    if (c < 0) return;
+    int h = tid;
+    while (h > 0 && cells[h - 1] == c) --h;
+    a.rank[i] = base[h] + (tid - h);
 }
 
 /* K4: exclusive scan of cell_start[0..n) in place, n = total cells; cell_start[n] = total.

@@ -121,7 +121,12 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
 
     const int nblk_atoms = (n + PB - 1) / PB;
     for (int b = 0; b < nblk_atoms; ++b)
-        for (int t = 0; t < PB; ++t) count_atom(pa, b * PB + t);
+    {
+        std::vector<int> cells(PB), base(PB);
+        for (int t = 0; t < PB; ++t) count_phase0(pa, cells.data(), b * PB + t, t);
+        for (int t = 0; t < PB; ++t) count_phase1(pa, cells.data(), base.data(), t, PB);
+        for (int t = 0; t < PB; ++t) count_phase2(pa, cells.data(), base.data(), b * PB + t, t);
+    }
     {
         std::vector<int> part(PB), part2(SASA_SCAN_GROUP);
         std::vector<ScanRegs> regs(PB);
