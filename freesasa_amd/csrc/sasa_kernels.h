@@ -48,6 +48,9 @@ inline int atomic_max(int *p, int v) { int o = *p; if (v > o) *p = v; return o; 
 #define SASA_RSQ(x) (1.0 / sqrt(x))
 #define SASA_FMA_K(p, z, k) fma((p), (z), (k))
 #define SASA_RCP(x) (1.0 / (x))
+#define SASA_MIN(a, b) fmin((a), (b))
+#define SASA_MAX(a, b) fmax((a), (b))
+#define SASA_SHIFT_IN_LT1(w, c) (((w) << 1) | ((c) < 1.0 ? 1u : 0u))
 #else
 #define SASA_D __device__ __forceinline__
 #define SASA_HD __host__ __device__ __forceinline__
@@ -67,6 +70,31 @@ __device__ __forceinline__ double sasa_fma_k(double p, double z, double k)
 }
 #define SASA_FMA_K(p, z, k) sasa_fma_k((p), (z), (k))
 #define SASA_RCP(x) __builtin_amdgcn_rcp(x)
+/* min/max of two numbers that are never NaN: one v_min_f64 / v_max_f64.  fmin()/fmax() cost three —
+   hipcc first quiets both operands (v_max_f64 x, x, x) because it cannot rule out signalling NaNs */
+__device__ __forceinline__ double sasa_min(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double sasa_max(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+#define SASA_MIN(a, b) sasa_min((a), (b))
+#define SASA_MAX(a, b) sasa_max((a), (b))
+/* (w << 1) | (c < 1.0): the compare leaves the per-lane result in vcc and an add-with-carry of w to
+   itself shifts it in — two VALU instructions per screened neighbor instead of four */
+__device__ __forceinline__ unsigned sasa_shift_in_lt1(unsigned w, double c)
+{
+    unsigned r;
+    asm("v_cmp_gt_f64 vcc, 1.0, %1\n\tv_addc_co_u32 %0, vcc, %2, %2, vcc" : "=v"(r) : "v"(c), "v"(w) : "vcc");
+    return r;
+}
+#define SASA_SHIFT_IN_LT1(w, c) sasa_shift_in_lt1((w), (c))
 #endif
 
 namespace sasa {
@@ -955,17 +983,19 @@ SASA_D double lr_cos(const Quad q, double A, double h2, double z)
 }
 
 /* Screening pass over up to 32 neighbors (lim is even, lists are padded): bit k of the result
- * is set when neighbor k cuts an arc out of circle i (|cos alpha| < 1).  `buried` is raised if
- * some neighbor's circle contains circle i entirely (ref: src/sasa_lr.c:327-330).  The loop
- * counter is wave-uniform, so the bit masks are scalars. */
-SASA_D unsigned lr_screen32(const Quad *PQ, int lim, double A, double h2, double z, bool &buried)
+ * is set when neighbor k may cut an arc out of circle i (cos alpha < 1; NaN never does).  cmin
+ * collects the smallest cos alpha: at or below -1 some neighbor's circle contains circle i entirely
+ * (ref: src/sasa_lr.c:327-330) and the slice is buried.  The list is walked from its end so that
+ * shifting the results in from the right leaves neighbor k at bit k. */
+SASA_D unsigned lr_screen32(const Quad *PQ, int lim, double A, double h2, double z, double &cmin)
 {
     unsigned w = 0;
-    for (int k = 0; k < lim; k += 2) {
+    for (int k = lim - 2; k >= 0; k -= 2) {
         const double c0 = lr_cos(PQ[k], A, h2, z), c1 = lr_cos(PQ[k + 1], A, h2, z);
-        const bool a0 = c0 < 1.0, a1 = c1 < 1.0;
-        buried |= (a0 && !(c0 > -1.0)) || (a1 && !(c1 > -1.0));
-        w |= (a0 ? 1u << k : 0u) | (a1 ? 2u << k : 0u);
+        cmin = SASA_MIN(cmin, c0);
+        cmin = SASA_MIN(cmin, c1);
+        w = SASA_SHIFT_IN_LT1(w, c1);
+        w = SASA_SHIFT_IN_LT1(w, c0);
     }
     return w;
 }
@@ -1027,8 +1057,8 @@ SASA_D void lr_arcs32(unsigned w, const Quad *PQ, double A, double h2, double z,
             const double wi = inf < 0 ? inf + SASA_TWOPI : inf;
             const double ws = sup > SASA_TWOPI ? sup - SASA_TWOPI : sup;
             u.wrap = 1;
-            u.W = fmax(u.W, ws);
-            u.V = fmin(u.V, wi);
+            u.W = SASA_MAX(u.W, ws);
+            u.V = SASA_MIN(u.V, wi);
         } else { /* inf <= beta <= sup: alpha < pi because the screening kept only c > -1 */
             /* written with selects and min/max rather than one branch per case: the cases differ
                from lane to lane, so every branch would be executed anyway */
@@ -1041,15 +1071,15 @@ SASA_D void lr_arcs32(unsigned w, const Quad *PQ, double A, double h2, double z,
                     *err = 1;
                 }
             }
-            u.ts = fresh ? inf : fmin(u.ts, inf);
-            u.te = fresh ? sup : fmax(u.te, sup);
+            u.ts = fresh ? inf : SASA_MIN(u.ts, inf);
+            u.te = fresh ? sup : SASA_MAX(u.te, sup);
             u.depth += fresh ? 1 : 0;
             if (!fresh)
                 while (u.depth > 1) { /* the merged component may now reach the ones below it */
                     const Arc lo = stk[(u.depth - 2) * stride];
                     if (lo.e < u.ts) break;
-                    u.ts = fmin(u.ts, lo.s);
-                    u.te = fmax(u.te, lo.e);
+                    u.ts = SASA_MIN(u.ts, lo.s);
+                    u.te = SASA_MAX(u.te, lo.e);
                     --u.depth;
                 }
         }
@@ -1064,10 +1094,10 @@ SASA_D double lr_union_exact(const TileMem &m, int o, int nn, double A, double h
     for (int base = 0; base < nn; base += 64) { /* nn is even (padded) */
         const int lim = nn - base < 64 ? nn - base : 64;
         const Quad *PQ = m.pq + o + base;
-        bool buried = false;
-        unsigned lo = lr_screen32(PQ, lim < 32 ? lim : 32, A, h2, z, buried), hi = 0;
-        if (lim > 32) hi = lr_screen32(PQ + 32, lim - 32, A, h2, z, buried);
-        if (buried) return -1;
+        double cmin = 1.0;
+        unsigned lo = lr_screen32(PQ, lim < 32 ? lim : 32, A, h2, z, cmin), hi = 0;
+        if (lim > 32) hi = lr_screen32(PQ + 32, lim - 32, A, h2, z, cmin);
+        if (cmin <= -1.0) return -1;
 #ifdef SASA_ABLATE_ARCS /* timing attribution only: tools/build_variant.sh, never in the product */
         lo = hi = 0;
 #endif
