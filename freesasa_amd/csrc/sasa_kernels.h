@@ -730,14 +730,29 @@ SASA_D void sqrt_rh(double x, double &g, double &h)
     g = fma(d, h, g);
 }
 
-/* acos on (-1,1): fdlibm's range reduction (|x| <= 0.5: pi/2 - asin x; else 2 asin sqrt((1-|x|)/2)),
- * asin u = u + u z P(z), z = u^2 <= 0.25, P = degree-11 interpolant at Chebyshev nodes
- * (max relative error of asin 5.6e-17, fitted with mpmath).  Branch-free. */
+/* g ~ sqrt(x) for normal positive x to a few ulp: the seed, one coupled Goldschmidt step and ONE
+ * residual correction (sqrt_rh spends four more instructions on the last ulp and on h). */
+SASA_D double sqrt_g(double x)
+{
+    const double y = SASA_RSQ(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double d = fma(-g, g, x);
+    return fma(d, h, g);
+}
+
+/* acos on (-1,1): fdlibm's range reduction (|x| <= 0.5: pi/2 - asin x; else 2 asin sqrt((1-|x|)/2),
+ * reflected for x < 0), asin u = u + u z P(z), z = u^2 <= 0.25, P = degree-11 interpolant at
+ * Chebyshev nodes (max relative error of asin 5.6e-17, fitted with mpmath).  Branch-free; the
+ * square root carries the sign of x, so both outer cases are 2 asin(u) (+ pi).
+ * Absolute error a few 1e-16 (the low word of pi/2 is not carried). */
 SASA_D double acos_fast(double x)
 {
     const double ax = fabs(x);
     const bool big = ax > 0.5;
-    const double zb = (1.0 - ax) * 0.5; /* in (0, 0.5] for |x| < 1 */
+    const double zb = fma(ax, -0.5, 0.5); /* (1 - |x|)/2, exact; in (0, 0.25) for 0.5 < |x| < 1 */
     const double z = big ? zb : x * x;
     double p = 0x1.cd864394d2ff2p-6;
     p = SASA_FMA_K(p, z, -0x1.603991d6060e0p-7);
@@ -751,15 +766,14 @@ SASA_D double acos_fast(double x)
     p = SASA_FMA_K(p, z, 0x1.6db6db684b6a1p-5);
     p = SASA_FMA_K(p, z, 0x1.3333333336da5p-4);
     p = SASA_FMA_K(p, z, 0x1.555555555554fp-3);
-    double s, hh;
-    sqrt_rh(zb, s, hh); /* only used when big */
-    const double u = big ? s : x;      /* asin argument */
-    const double t = fma(u * z, p, u); /* asin(u) */
-    const double pio2_hi = 0x1.921fb54442d18p+0, pio2_lo = 0x1.1a62633145c07p-54; /* pi/2 = hi + lo */
-    const double small_r = pio2_hi - (t - pio2_lo);
-    const double big_pos = 2.0 * t;
-    const double big_neg = 2.0 * pio2_hi - (2.0 * t - 2.0 * pio2_lo);
-    return big ? (x > 0 ? big_pos : big_neg) : small_r;
+    const double s = copysign(sqrt_g(zb), x); /* only used when big */
+    const double u = big ? s : x;             /* asin argument */
+    const double t = fma(u * z, p, u);        /* asin(u) */
+    const double pio2 = 0x1.921fb54442d18p+0, pi = 0x1.921fb54442d18p+1;
+    const double t2 = t + t;   /* x > 0.5:  2 asin(sqrt zb) */
+    const double bn = t2 + pi; /* x < -0.5: pi - 2 asin(sqrt zb) = pi + 2 asin(-sqrt zb) */
+    const double sm = pio2 - t;
+    return big ? (x > 0 ? t2 : bn) : sm;
 }
 
 /* atan2(y, x) for finite arguments: ONE division (hardware reciprocal seed + two Newton steps + a
