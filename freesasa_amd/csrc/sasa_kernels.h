@@ -744,8 +744,9 @@ SASA_D double sqrt_g(double x)
 }
 
 /* acos on (-1,1): fdlibm's range reduction (|x| <= 0.5: pi/2 - asin x; else 2 asin sqrt((1-|x|)/2),
- * reflected for x < 0), asin u = u + u z P(z), z = u^2 <= 0.25, P = degree-11 interpolant at
- * Chebyshev nodes (max relative error of asin 5.6e-17, fitted with mpmath).  Branch-free; the
+ * reflected for x < 0), asin u = u + u z P(z), z = u^2 <= 0.25, P = degree-9 interpolant at
+ * Chebyshev nodes (max relative error of asin 1.4e-14, fitted with mpmath; degree 11 reaches 5.6e-17
+ * for two more instructions per arc, which the 1e-12-level conditioning of tangent arcs makes moot).  Branch-free; the
  * square root carries the sign of x, so both outer cases are 2 asin(u) (+ pi).
  * Absolute error a few 1e-16 (the low word of pi/2 is not carried). */
 SASA_D double acos_fast(double x)
@@ -754,18 +755,16 @@ SASA_D double acos_fast(double x)
     const bool big = ax > 0.5;
     const double zb = fma(ax, -0.5, 0.5); /* (1 - |x|)/2, exact; in (0, 0.25) for 0.5 < |x| < 1 */
     const double z = big ? zb : x * x;
-    double p = 0x1.cd864394d2ff2p-6;
-    p = SASA_FMA_K(p, z, -0x1.603991d6060e0p-7);
-    p = SASA_FMA_K(p, z, 0x1.06b9d26d10838p-6);
-    p = SASA_FMA_K(p, z, 0x1.ff5fc4d14c735p-8);
-    p = SASA_FMA_K(p, z, 0x1.8522ddffa6208p-7);
-    p = SASA_FMA_K(p, z, 0x1.c87265d47ef49p-7);
-    p = SASA_FMA_K(p, z, 0x1.1c593c7b1d958p-6);
-    p = SASA_FMA_K(p, z, 0x1.6e8b2b3b10be4p-6);
-    p = SASA_FMA_K(p, z, 0x1.f1c71f95269afp-6);
-    p = SASA_FMA_K(p, z, 0x1.6db6db684b6a1p-5);
-    p = SASA_FMA_K(p, z, 0x1.3333333336da5p-4);
-    p = SASA_FMA_K(p, z, 0x1.555555555554fp-3);
+    double p = 0x1.c93a92d53b4f1p-6;
+    p = SASA_FMA_K(p, z, -0x1.815314c864b09p-9);
+    p = SASA_FMA_K(p, z, 0x1.00d47e7966d94p-6);
+    p = SASA_FMA_K(p, z, 0x1.b02442413f6bap-7);
+    p = SASA_FMA_K(p, z, 0x1.1dc2ef640046fp-6);
+    p = SASA_FMA_K(p, z, 0x1.6e72146fda29ep-6);
+    p = SASA_FMA_K(p, z, 0x1.f1c81c59ea536p-6);
+    p = SASA_FMA_K(p, z, 0x1.6db6d8e71341bp-5);
+    p = SASA_FMA_K(p, z, 0x1.33333335a9cd6p-4);
+    p = SASA_FMA_K(p, z, 0x1.5555555554f05p-3);
     const double s = copysign(sqrt_g(zb), x); /* only used when big */
     const double u = big ? s : x;             /* asin argument */
     const double t = fma(u * z, p, u);        /* asin(u) */
