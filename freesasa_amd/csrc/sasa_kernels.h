@@ -1054,7 +1054,7 @@ SASA_D void lr_arc(const Quad q, double A, double h2, double z, double &inf, dou
 struct UnionState {
     double W, V;   /* covered prefix [0,W] and suffix [V,2pi] of the arcs that pass the origin */
     double ts, te; /* top component (in registers); the ones below it are in the LDS stack */
-    int depth, wrap;
+    int depth;
 };
 
 /* Feed the arcs of the set bits of w (neighbors PQ[k]) to the union, ascending k = ascending beta. */
@@ -1069,13 +1069,12 @@ SASA_D void lr_arcs32(unsigned w, const Quad *PQ, double A, double h2, double z,
         if (inf < 0 || sup > SASA_TWOPI) {           /* ref: :340-351 arc passes the origin */
             const double wi = inf < 0 ? inf + SASA_TWOPI : inf;
             const double ws = sup > SASA_TWOPI ? sup - SASA_TWOPI : sup;
-            u.wrap = 1;
             u.W = SASA_MAX(u.W, ws);
             u.V = SASA_MIN(u.V, wi);
         } else { /* inf <= beta <= sup: alpha < pi because the screening kept only c > -1 */
             /* written with selects and min/max rather than one branch per case: the cases differ
                from lane to lane, so every branch would be executed anyway */
-            const bool fresh = u.depth == 0 || inf > u.te; /* the arc starts a new top component */
+            const bool fresh = inf > u.te; /* the arc starts a new top component (te = -inf while there is none) */
             if (fresh && u.depth > 0) {
                 if (u.depth - 1 < ds) {
                     Arc t; t.s = u.ts; t.e = u.te;
@@ -1103,7 +1102,7 @@ SASA_D double lr_union_exact(const TileMem &m, int o, int nn, double A, double h
                              Arc *stk, int stride, int ds, int *err)
 {
     UnionState u;
-    u.W = 0; u.V = SASA_TWOPI; u.ts = 0; u.te = 0; u.depth = 0; u.wrap = 0;
+    u.W = 0; u.V = SASA_TWOPI; u.ts = 0; u.te = -INFINITY; u.depth = 0;
     for (int base = 0; base < nn; base += 64) { /* nn is even (padded) */
         const int lim = nn - base < 64 ? nn - base : 64;
         const Quad *PQ = m.pq + o + base;
@@ -1122,7 +1121,8 @@ SASA_D double lr_union_exact(const TileMem &m, int o, int nn, double A, double h
     const int depth = u.depth;
 #define CS_(c) ((c) == depth - 1 ? ts : stk[(c) * stride].s)
 #define CE_(c) ((c) == depth - 1 ? te : stk[(c) * stride].e)
-    LR_SWEEP(depth, u.wrap, u.W, u.V, CS_, CE_, res);
+    const bool wrap = u.V < SASA_TWOPI; /* every arc through the origin starts below 2pi */
+    LR_SWEEP(depth, wrap, u.W, u.V, CS_, CE_, res);
 #undef CS_
 #undef CE_
     return res;
@@ -1167,7 +1167,9 @@ SASA_D void lr_phase_slices(const TileArgs &a, TileMem &m, int tile, int tid, in
             const double Ri = m.aR[la], zi = m.az[la];
             const double delta = 2 * Ri / ns;       /* ref: src/sasa_lr.c:304 */
             double z = zi - Ri - 0.5 * delta;
-            for (int k = 0; k <= s; ++k) z += delta; /* accumulated like the reference, :307 */
+            int k = s + 1;                          /* accumulated like the reference, :307: s + 1 */
+            for (; k >= 2; k -= 2) { z += delta; z += delta; } /* separately rounded additions    */
+            if (k) z += delta;
             const int o = m.aoff[la];
             const double ex = lr_slice(m, o, m.aoff[la + 1] - o, zi, Ri, z, stk, B, a.ds, &err); /* padded count */
             m.contrib[la * ns + s] = ex < 0 ? 0.0 : delta * Ri * ex; /* ref: :360 */
