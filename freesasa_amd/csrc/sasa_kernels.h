@@ -730,17 +730,15 @@ SASA_D void sqrt_rh(double x, double &g, double &h)
     g = fma(d, h, g);
 }
 
-/* g ~ sqrt(x) for normal positive x to a few ulp: the seed, one coupled Goldschmidt step and ONE
- * residual correction (sqrt_rh spends four more instructions on the last ulp and on h). */
+/* g ~ sqrt(x) for normal positive x, relative error <= 4.1e-15: the hardware seed (v_rsq_f64 is
+ * good to 2^-24.2 on gfx950, measured by tools/dev/seed_accuracy.hip) and one coupled Goldschmidt
+ * step, which squares that error (x 1.5).  sqrt_rh spends seven more instructions on the last
+ * bits and on h. */
 SASA_D double sqrt_g(double x)
 {
     const double y = SASA_RSQ(x);
-    double g = x * y, h = 0.5 * y;
-    const double r = fma(-h, g, 0.5);
-    g = fma(g, r, g);
-    h = fma(h, r, h);
-    const double d = fma(-g, g, x);
-    return fma(d, h, g);
+    const double g = x * y, h = 0.5 * y;
+    return fma(g, fma(-h, g, 0.5), g);
 }
 
 /* acos on (-1,1): fdlibm's range reduction (|x| <= 0.5: pi/2 - asin x; else 2 asin sqrt((1-|x|)/2),
@@ -748,7 +746,8 @@ SASA_D double sqrt_g(double x)
  * Chebyshev nodes (max relative error of asin 1.4e-14, fitted with mpmath; degree 11 reaches 5.6e-17
  * for two more instructions per arc, which the 1e-12-level conditioning of tangent arcs makes moot).  Branch-free; the
  * square root carries the sign of x, so both outer cases are 2 asin(u) (+ pi).
- * Absolute error a few 1e-16 (the low word of pi/2 is not carried). */
+ * Relative error <= 2e-14 (polynomial 1.4e-14, square root 4e-15) plus 1e-16 absolute (the low
+ * word of pi/2 is not carried). */
 SASA_D double acos_fast(double x)
 {
     const double ax = fabs(x);
