@@ -635,8 +635,9 @@ SASA_D void nb_test(const TileArgs &a, TileMem &m, int la, int p, int q, double 
 }
 
 /* phase N: neighbor discovery.  SUB = B/TA lanes share one atom and stride over the
- * concatenation of its 9 candidate runs, two candidates per trip so that eight loads are in
- * flight before the first test. */
+ * concatenation of its 9 candidate runs, four candidates per trip so that sixteen loads are in
+ * flight before the first test (a coil atom's ~70 candidates then take one round trip to memory). */
+#define SASA_NB_UNROLL 3
 SASA_D void tile_phase_neighbors(const TileArgs &a, TileMem &m, int tile, int tid, int B)
 {
     const int na = tile_atoms(a, tile), p0 = tile_first_atom(a, tile);
@@ -652,20 +653,23 @@ SASA_D void tile_phase_neighbors(const TileArgs &a, TileMem &m, int tile, int ti
     int total = 0;
     for (int r = 0; r < 9; ++r) total += rc[r];
     int r = 0, base = 0, cnt = rc[0];
-    for (int f = sub; f < total; f += 2 * SUB) {
-        while (f >= base + cnt) { base += cnt; ++r; cnt = rc[r]; }
-        const int q0 = rl[r] + (f - base);
-        const int f1 = f + SUB;
-        const bool has1 = f1 < total;
-        int q1 = q0;
-        if (has1) {
-            while (f1 >= base + cnt) { base += cnt; ++r; cnt = rc[r]; }
-            q1 = rl[r] + (f1 - base);
+    for (int f = sub; f < total; f += SASA_NB_UNROLL * SUB) {
+        int q[SASA_NB_UNROLL];
+        double x[SASA_NB_UNROLL], y[SASA_NB_UNROLL], z[SASA_NB_UNROLL], rq[SASA_NB_UNROLL];
+        for (int j = 0; j < SASA_NB_UNROLL; ++j) {
+            const int fj = f + j * SUB;
+            if (fj < total) {
+                while (fj >= base + cnt) { base += cnt; ++r; cnt = rc[r]; }
+                q[j] = rl[r] + (fj - base);
+            } else {
+                q[j] = p; /* the atom itself: never a neighbor */
+            }
         }
-        const double x0 = a.sx[q0], y0 = a.sy[q0], z0 = a.sz[q0], r0 = a.sr[q0];
-        const double x1 = a.sx[q1], y1 = a.sy[q1], z1 = a.sz[q1], r1 = a.sr[q1];
-        nb_test(a, m, la, p, q0, xi, yi, zi, ri, x0, y0, z0, r0);
-        if (has1) nb_test(a, m, la, p, q1, xi, yi, zi, ri, x1, y1, z1, r1);
+        for (int j = 0; j < SASA_NB_UNROLL; ++j) {
+            const unsigned u = (unsigned)q[j]; /* 32-bit offset from a uniform base: no 64-bit address per load */
+            x[j] = a.sx[u]; y[j] = a.sy[u]; z[j] = a.sz[u]; rq[j] = a.sr[u];
+        }
+        for (int j = 0; j < SASA_NB_UNROLL; ++j) nb_test(a, m, la, p, q[j], xi, yi, zi, ri, x[j], y[j], z[j], rq[j]);
     }
 }
 
