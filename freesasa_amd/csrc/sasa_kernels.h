@@ -602,19 +602,21 @@ SASA_D void tile_phase_load(const TileArgs &a, TileMem &m, int tile, int tid, in
         const int la = t / 9, r = t - 9 * la;
         int lo = 0, cnt = 0;
         if (la < na) {
+            /* branch-free up to the last loads, so that s_struct and s_cell are fetched together and
+               the chain is three round trips (s_struct -> grid -> cell_start), not four */
             const int p = p0 + la;
-            const GridS g = a.grid[a.s_struct[p]];
+            const int sid = a.s_struct[p];
             const long long cf = a.s_cell[p];
+            const int nx = a.grid[sid].nx, ny = a.grid[sid].ny;
             const int c = (int)(cf & 0xffffffffLL), fl = (int)(cf >> 32);
             const int dy = (r % 3) - 1, dz = (r / 3) - 1;
             const bool out = (dy < 0 && (fl & CELL_Y0)) || (dy > 0 && (fl & CELL_Y1)) ||
                              (dz < 0 && (fl & CELL_Z0)) || (dz > 0 && (fl & CELL_Z1));
-            if (!out) {
-                const int row = c + g.nx * (dy + g.ny * dz); /* same ix, neighbouring (iy, iz) */
-                const int x_lo = row - ((fl & CELL_X0) ? 0 : 1), x_hi = row + ((fl & CELL_X1) ? 0 : 1);
-                lo = a.cell_start[x_lo];
-                cnt = a.cell_start[x_hi + 1] - lo;
-            }
+            const int row = out ? c : c + nx * (dy + ny * dz); /* same ix, neighbouring (iy, iz) */
+            const int x_lo = row - ((fl & CELL_X0) ? 0 : 1), x_hi = row + ((fl & CELL_X1) ? 0 : 1);
+            const int s0 = a.cell_start[x_lo], s1 = a.cell_start[x_hi + 1];
+            lo = out ? 0 : s0;
+            cnt = out ? 0 : s1 - s0;
         }
         m.rowlo[t] = lo;
         m.rowcnt[t] = cnt;
