@@ -49,6 +49,22 @@ static uint64_t name_key(const char *res, int rl, const char *atom, int al)
     return k;
 }
 
+/* The 506 (residue, atom) keys in an open-addressing table (built once, read-only afterwards): a
+ * lookup is one or two probes instead of a nine-step binary search per atom. */
+#define PROTOR_HASH_BITS 11
+static int16_t protor_hash[1 << PROTOR_HASH_BITS];
+static pthread_once_t protor_hash_once = PTHREAD_ONCE_INIT;
+static unsigned protor_slot(uint64_t k) { return (unsigned)((k * 0x9E3779B97F4A7C15ULL) >> (64 - PROTOR_HASH_BITS)); }
+static void protor_hash_build(void)
+{
+    for (int i = 0; i < (1 << PROTOR_HASH_BITS); ++i) protor_hash[i] = -1;
+    for (int i = 0; i < PROTOR_N; ++i) {
+        unsigned h = protor_slot(protor_table[i].key);
+        while (protor_hash[h] >= 0) h = (h + 1) & ((1 << PROTOR_HASH_BITS) - 1);
+        protor_hash[h] = (int16_t)i;
+    }
+}
+
 double freesasa_ingest_protor_radius(const char *res_name, const char *atom_name, int *cls)
 {
     const char *rt, *at;
@@ -56,17 +72,15 @@ double freesasa_ingest_protor_radius(const char *res_name, const char *atom_name
     const uint64_t k = name_key(rt, rl, at, al);
     if (cls) *cls = FREESASA_INGEST_UNKNOWN;
     if (!k) return -1.0;
-    int lo = 0, hi = PROTOR_N - 1;
-    while (lo <= hi) {
-        const int mid = (lo + hi) >> 1;
-        if (protor_table[mid].key == k) {
-            if (cls) *cls = protor_table[mid].cls;
-            return protor_table[mid].radius;
+    pthread_once(&protor_hash_once, protor_hash_build);
+    for (unsigned h = protor_slot(k);; h = (h + 1) & ((1 << PROTOR_HASH_BITS) - 1)) {
+        const int i = protor_hash[h];
+        if (i < 0) return -1.0;
+        if (protor_table[i].key == k) {
+            if (cls) *cls = protor_table[i].cls;
+            return protor_table[i].radius;
         }
-        if (protor_table[mid].key < k) lo = mid + 1;
-        else hi = mid - 1;
     }
-    return -1.0;
 }
 
 /* ref: freesasa_atom_is_backbone, src/classifier.c:1090-1109 (the name is trimmed first) */
@@ -75,13 +89,17 @@ int freesasa_ingest_is_backbone(const char *atom_name)
     const char *t;
     const int n = first_token(atom_name, &t);
     if (n < 1 || n > 3) return 0;
-    for (int i = 0; i < BACKBONE_N; ++i)
-        if (backbone_names[i][0] == t[0] && (int)strlen(backbone_names[i]) == n && memcmp(backbone_names[i], t, (size_t)n) == 0) return 1;
+    const unsigned key = (unsigned)(unsigned char)t[0] | (n > 1 ? (unsigned)(unsigned char)t[1] << 8 : 0) |
+                         (n > 2 ? (unsigned)(unsigned char)t[2] << 16 : 0);
+    for (int i = 0; i < BACKBONE_N; ++i) {
+        const char *b = backbone_names[i]; /* at most 3 characters */
+        const unsigned kb = (unsigned)(unsigned char)b[0] | (b[1] ? (unsigned)(unsigned char)b[1] << 8 : 0) |
+                            (b[1] && b[2] ? (unsigned)(unsigned char)b[2] << 16 : 0);
+        if (kb == key) return 1;
+    }
     return 0;
 }
 
-/* index into the reference-area table, -1 if the classifier has no such residue
- * (ref: freesasa_classifier_residue_reference, src/classifier.c:853-861) */
 static int residue_ref_index(const char *res_name)
 {
     const char *t;
@@ -403,7 +421,7 @@ static void parse_pdb(const char *text, size_t len, int options, parsed *p)
  * ;-delimited text fields at line starts, # comments, case-insensitive data_/loop_/save_ keywords. */
 enum { T_END, T_TAG, T_VALUE, T_LOOP, T_DATA, T_SAVE };
 typedef struct { const char *p; size_t n; int type; } cif_tok;
-typedef struct { const char *cur, *end; int bol; } cif_lex; /* bol: at the beginning of a line */
+typedef struct { const char *cur, *end; int bol; } cif_lex; /* bol: cur is at the beginning of a line */
 
 static int ieq_n(const char *a, const char *b, size_t n)
 {
@@ -415,15 +433,14 @@ static int ieq_n(const char *a, const char *b, size_t n)
 /* 1 for the CIF whitespace characters */
 static const unsigned char cif_ws[256] = {['\t'] = 1, ['\n'] = 1, ['\r'] = 1, [' '] = 1};
 
-static cif_tok cif_next(cif_lex *lx)
+/* inlined into the row loop of cif_walk (21 tokens per atom: the call and the struct return cost as
+ * much as the scanning); cif_next is the out-of-line copy for everything else */
+static inline __attribute__((always_inline)) cif_tok cif_next_inl(cif_lex *lx)
 {
     cif_tok t = {NULL, 0, T_END};
     const unsigned char *p = (const unsigned char *)lx->cur, *end = (const unsigned char *)lx->end;
     for (;;) { /* whitespace and comments */
-        while (p < end && cif_ws[*p]) {
-            lx->bol = *p == '\n';
-            ++p;
-        }
+        while (p < end && cif_ws[*p]) ++p;
         if (p < end && *p == '#') {
             const unsigned char *nl = memchr(p, '\n', (size_t)(end - p));
             p = nl ? nl : end;
@@ -433,7 +450,8 @@ static cif_tok cif_next(cif_lex *lx)
     }
     if (p >= end) { lx->cur = (const char *)p; return t; }
     const unsigned char *start = p;
-    if (*p == ';' && lx->bol) { /* text field: up to a line that starts with ';' */
+    const int bol = (const char *)p == lx->cur ? lx->bol : p[-1] == '\n'; /* whitespace was skipped: look behind */
+    if (*p == ';' && bol) { /* text field: up to a line that starts with ';' */
         ++p;
         while (p < end && !(*p == '\n' && p + 1 < end && p[1] == ';')) ++p;
         if (p < end) p += 2;
@@ -461,15 +479,17 @@ static cif_tok cif_next(cif_lex *lx)
     return t;
 }
 
+static cif_tok cif_next(cif_lex *lx) { return cif_next_inl(lx); }
+
 static const char *const cif_cols[12] = {"group_PDB", "auth_asym_id", "auth_seq_id", "pdbx_PDB_ins_code", "auth_comp_id",
                                          "auth_atom_id", "label_alt_id", "type_symbol", "Cartn_x", "Cartn_y", "Cartn_z",
                                          "pdbx_PDB_model_num"};
 
 /* copy at most w characters of a token into a NUL-terminated field */
-static void cut(char *dst, size_t w, const char *p, size_t n)
+static inline void cut(char *dst, size_t w, const char *p, size_t n)
 {
     if (n > w) n = w;
-    memcpy(dst, p, n);
+    for (size_t i = 0; i < n; ++i) dst[i] = p[i]; /* a few bytes: cheaper than a call to memcpy */
     dst[n] = '\0';
 }
 
@@ -516,7 +536,7 @@ static int cif_walk(const char *text, size_t len, cif_row_fn visit, void *ctx)
                     if (rc) return rc;
                 }
             }
-            t = cif_next(&lx);
+            t = cif_next_inl(&lx);
         }
     }
     return 0;
@@ -531,6 +551,26 @@ static int tok_int(const cif_tok *t)
     long v = 0;
     while (p < e && *p >= '0' && *p <= '9' && v < 100000000L) v = v * 10 + (*p++ - '0');
     return (int)(neg ? -v : v);
+}
+
+/* [+-]digits[.digits] filling the whole token, at most 15 digits: integer / power of ten, both exact,
+ * one correctly rounded division = what atof returns (see scan_double) */
+static int tok_plain_double(const cif_tok *t, double *out)
+{
+    const char *q = t->p, *e = t->p + t->n;
+    int neg = 0;
+    if (q < e && (*q == '-' || *q == '+')) neg = *q++ == '-';
+    uint64_t m = 0;
+    int digits = 0, frac = 0;
+    while (q < e && *q >= '0' && *q <= '9') { m = m * 10 + (uint64_t)(*q++ - '0'); ++digits; }
+    if (q < e && *q == '.') {
+        ++q;
+        while (q < e && *q >= '0' && *q <= '9') { m = m * 10 + (uint64_t)(*q++ - '0'); ++digits; ++frac; }
+    }
+    if (q != e || digits < 1 || digits > 15) return 0;
+    const double v = (double)m / pow10_tab[frac];
+    *out = neg ? -v : v;
+    return 1;
 }
 
 typedef struct {
@@ -556,18 +596,23 @@ static int cif_visit_atom(const cif_tok *row, void *ctx)
     if ((alt != '.' && c->prev_alt == '.') || alt == '.') c->prev_alt = alt;
     else if (alt != '.' && alt != c->prev_alt) return 0;
 
-    char aname[5], rname[4], rnumber[6], symbol[3], chain[4], seq[16], num[24];
+    char aname[5], rname[4], rnumber[6], symbol[3], chain[4], num[24];
     if (row[5].n >= 2 && row[5].p[0] == '"') cut(aname, 4, row[5].p + 1, row[5].n - 2);
     else cut(aname, 4, row[5].p, row[5].n);
     cut(rname, 3, row[4].p, row[4].n);
-    cut(seq, sizeof seq - 1, row[2].p, row[2].n);
-    if (row[3].p[0] != '?') snprintf(num, sizeof num, "%s%c", seq, row[3].p[0]);
-    else snprintf(num, sizeof num, "%s", seq);
+    /* residue number = auth_seq_id (at most 15 characters of it, up to a NUL) + the insertion code
+       unless it is '?', cut to 5 characters (ref: src/cif.cc:139-147, the atom record's field width) */
+    size_t nn = row[2].n < 15 ? row[2].n : 15;
+    memcpy(num, row[2].p, nn);
+    { const char *z = memchr(num, '\0', nn); if (z) nn = (size_t)(z - num); }
+    if (row[3].p[0] != '?') num[nn++] = row[3].p[0];
+    num[nn] = '\0';
     cut(rnumber, 5, num, strlen(num));
     cut(symbol, 2, row[7].p, row[7].n);
     cut(chain, 3, row[1].p, row[1].n);
     double v[3];
-    for (int k = 0; k < 3; ++k) { /* atof: the exact fast path of the PDB reader, else strtod */
+    for (int k = 0; k < 3; ++k) { /* atof: plain decimals exactly like the PDB reader's fast path, else strtod */
+        if (tok_plain_double(&row[8 + k], &v[k])) continue;
         char buf[40];
         cut(buf, sizeof buf - 1, row[8 + k].p, row[8 + k].n);
         const char *sp = buf;
@@ -582,19 +627,22 @@ static int cif_visit_atom(const cif_tok *row, void *ctx)
         if (r < 0) r = +0.;
     }
     if (grow_atoms(p)) { p->status = FREESASA_INGEST_ENOMEM; return -1; }
-    if (p->n == p->n0 || strcmp(rnumber, c->prev_number) != 0 || strcmp(chain, c->prev_chain) != 0) {
+    /* zero-padded copies of the residue labels: compared and stored as whole words */
+    char znum[8] = {0}, zchain[4] = {0};
+    for (int i = 0; i < 5 && rnumber[i]; ++i) znum[i] = rnumber[i];
+    for (int i = 0; i < 3 && chain[i]; ++i) zchain[i] = chain[i];
+    if (p->n == p->n0 || memcmp(znum, c->prev_number, 6) != 0 || memcmp(zchain, c->prev_chain, 4) != 0) {
         if (grow_res(p)) { p->status = FREESASA_INGEST_ENOMEM; return -1; }
         p->res_first[p->nres] = p->n - p->n0;
         p->res_ref[p->nres] = (int16_t)residue_ref_index(rname);
-        memset(p->res_name + 4 * p->nres, 0, 4);
-        memcpy(p->res_name + 4 * p->nres, rname, strlen(rname));
-        memset(p->res_number + 6 * p->nres, 0, 6);
-        memcpy(p->res_number + 6 * p->nres, rnumber, strlen(rnumber));
-        memset(p->res_chain + 4 * p->nres, 0, 4);
-        memcpy(p->res_chain + 4 * p->nres, chain, strlen(chain));
+        char zname[4] = {0};
+        for (int i = 0; i < 3 && rname[i]; ++i) zname[i] = rname[i];
+        memcpy(p->res_name + 4 * p->nres, zname, 4);
+        memcpy(p->res_number + 6 * p->nres, znum, 6);
+        memcpy(p->res_chain + 4 * p->nres, zchain, 4);
         ++p->nres;
-        memcpy(c->prev_number, rnumber, 6);
-        memcpy(c->prev_chain, chain, 4);
+        memcpy(c->prev_number, znum, 6);
+        memcpy(c->prev_chain, zchain, 4);
     }
     p->xyz[3 * p->n] = v[0]; p->xyz[3 * p->n + 1] = v[1]; p->xyz[3 * p->n + 2] = v[2];
     p->rad[p->n] = r;
