@@ -49,7 +49,10 @@ $(LIBDIR)/libfreesasa_amd.so: $(LIBDIR)/gpu_engine.o $(LIBDIR)/seam.o $(LIBDIR)/
 $(LIBDIR)/libfreesasa_amd_seam.a: $(LIBDIR)/gpu_engine.o $(LIBDIR)/seam.o $(LIBDIR)/testpoints.o $(LIBDIR)/ingest.o
 	ar rcs $@ $^
 
-emu: tests/emu/libsasa_emu.so
+emu: tests/emu/libsasa_emu.so tests/emu/libingest_scalar.so
+# the loader with its byte-at-a-time mmCIF tokenizer only: the differential twin of the SSE2 row scanner
+tests/emu/libingest_scalar.so: $(CSRC)/ingest.c $(CSRC)/protor_table.h include/freesasa_ingest.h
+	$(CC) $(CFLAGS) -DFREESASA_INGEST_NO_SIMD -Iinclude -pthread -shared -o $@ $(CSRC)/ingest.c -lm
 tests/emu/libsasa_emu.so: tests/emu/emu.cpp $(CSRC)/sasa_kernels.h
 	$(CXX) -O2 -std=c++17 -fPIC -ffp-contract=off -DSASA_EMU -shared -o $@ tests/emu/emu.cpp -lm
 
@@ -59,7 +62,7 @@ tools:
 	$(MAKE) -C tools
 
 clean:
-	rm -rf $(LIBDIR) tests/emu/libsasa_emu.so
+	rm -rf $(LIBDIR) tests/emu/libsasa_emu.so tests/emu/libingest_scalar.so
 	$(MAKE) -C oracle clean
 	$(MAKE) -C tools clean
 .PHONY: all emu oracle tools clean

@@ -481,6 +481,78 @@ static inline __attribute__((always_inline)) cif_tok cif_next_inl(cif_lex *lx)
 
 static cif_tok cif_next(cif_lex *lx) { return cif_next_inl(lx); }
 
+/* The values of an _atom_site loop are almost all plain tokens (21 per atom, a few characters each,
+ * padded with blanks): scanning them a byte at a time costs a mispredicted branch at every token
+ * boundary.  cif_row_next finds the boundaries in a 64-byte whitespace bit mask (SSE2 compares +
+ * count-trailing-zeros) and hands anything that is not a plain value -- quotes, comments, text
+ * fields, tags and keywords, the last bytes of the text -- to the general tokenizer, so the token
+ * stream is the same. */
+#if defined(__SSE2__) && !defined(FREESASA_INGEST_NO_SIMD) /* NO_SIMD: the test suite's byte-at-a-time twin */
+#include <emmintrin.h>
+/* base: start of the current 64-byte block (NULL: none); starts / ends: the not yet consumed token
+ * starts (a non-blank after a blank) and token ends (a blank after a non-blank) of the block;
+ * last_ws: whether the byte before the next block is whitespace */
+typedef struct { const unsigned char *base; uint64_t starts, ends; int last_ws; } cif_fast;
+static inline uint64_t cif_ws_mask64(const unsigned char *p)
+{
+    const __m128i sp = _mm_set1_epi8(' '), nl = _mm_set1_epi8('\n'), tb = _mm_set1_epi8('\t'), cr = _mm_set1_epi8('\r');
+    uint64_t m = 0;
+    for (int k = 0; k < 4; ++k) {
+        const __m128i v = _mm_loadu_si128((const __m128i *)(p + 16 * k));
+        const __m128i w = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(v, sp), _mm_cmpeq_epi8(v, nl)),
+                                       _mm_or_si128(_mm_cmpeq_epi8(v, tb), _mm_cmpeq_epi8(v, cr)));
+        m |= (uint64_t)(unsigned)_mm_movemask_epi8(w) << (16 * k);
+    }
+    return m;
+}
+/* load the block at p; prev_ws: the byte before p is whitespace (or p is the start of the text) */
+static inline void cif_fast_load(cif_fast *f, const unsigned char *p, int prev_ws)
+{
+    const uint64_t ws = cif_ws_mask64(p);
+    f->base = p;
+    f->starts = ~ws & ((ws << 1) | (uint64_t)(prev_ws != 0));
+    f->ends = ws & ((~ws << 1) | (uint64_t)(prev_ws == 0));
+    f->last_ws = (int)(ws >> 63);
+}
+static inline __attribute__((always_inline)) cif_tok cif_row_next(cif_lex *lx, cif_fast *f)
+{
+    const unsigned char *const end = (const unsigned char *)lx->end;
+    const unsigned char *const cur = (const unsigned char *)lx->cur;
+    if (!f->base) { /* (re)start behind the token the general tokenizer just returned */
+        if (end - cur < 64) return cif_next_inl(lx);
+        cif_fast_load(f, cur, 1); /* cur is the blank that ended that token: not an end to report again */
+    }
+    while (!f->starts) { /* next block with a token start */
+        if (end - (f->base + 64) < 64) goto slow;
+        cif_fast_load(f, f->base + 64, f->last_ws);
+    }
+    const unsigned char *const start = f->base + __builtin_ctzll(f->starts);
+    {
+        const unsigned char c = *start;
+        if (c == '#' || c == '\'' || c == '"' || c == '_' || c == ';') goto slow;
+    }
+    f->starts &= f->starts - 1;
+    while (!f->ends) { /* the token runs into the next block(s); no start can precede its end there */
+        if (end - (f->base + 64) < 64) goto slow;
+        cif_fast_load(f, f->base + 64, f->last_ws);
+    }
+    const unsigned char *const stop = f->base + __builtin_ctzll(f->ends);
+    f->ends &= f->ends - 1;
+    if (stop - start >= 5 && start[4] == '_') goto slow; /* loop_, data_..., save_... */
+    lx->cur = (const char *)stop;
+    lx->bol = 0;
+    return (cif_tok){(const char *)start, (size_t)(stop - start), T_VALUE};
+slow:
+    /* nothing has been consumed as far as the general tokenizer is concerned: it redoes this token
+       from the end of the previous one, and the bit masks are rebuilt behind whatever it returns */
+    f->base = NULL;
+    return cif_next_inl(lx);
+}
+#else
+typedef struct { int unused; } cif_fast;
+static inline cif_tok cif_row_next(cif_lex *lx, cif_fast *f) { (void)f; return cif_next_inl(lx); }
+#endif
+
 static const char *const cif_cols[12] = {"group_PDB", "auth_asym_id", "auth_seq_id", "pdbx_PDB_ins_code", "auth_comp_id",
                                          "auth_atom_id", "label_alt_id", "type_symbol", "Cartn_x", "Cartn_y", "Cartn_z",
                                          "pdbx_PDB_model_num"};
@@ -527,6 +599,7 @@ static int cif_walk(const char *text, size_t len, cif_row_fn visit, void *ctx)
         for (int k = 0; k < 12; ++k) complete = complete && col[k] >= 0;
         cif_tok row[12];
         int c = 0;
+        cif_fast fast = {0};
         while (t.type == T_VALUE) {
             if (complete && slot_of[c] >= 0) row[slot_of[c]] = t;
             if (++c == ncol) {
@@ -536,7 +609,7 @@ static int cif_walk(const char *text, size_t len, cif_row_fn visit, void *ctx)
                     if (rc) return rc;
                 }
             }
-            t = cif_next_inl(&lx);
+            t = cif_row_next(&lx, &fast);
         }
     }
     return 0;

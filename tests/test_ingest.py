@@ -307,3 +307,75 @@ def test_sweep_entry_point_equals_load_then_batch():
             polar = b.atom_class[b.offsets[k]:b.offsets[k + 1]] == ingest.POLAR
             assert abs(cls[k, 1] - sasa[:len(polar)][polar].sum()) < 1e-9
     assert abs(fa.sweep_files([fixture("1ubq.pdb")])[0][0] - 4804.055641) < 1e-5 * 4804.055641
+
+
+def test_mmcif_row_scanner_equals_the_byte_at_a_time_tokenizer():
+    """The SSE2 row scanner of the mmCIF reader (whitespace bit masks, freesasa_amd/csrc/ingest.c
+    cif_row_next) against its scalar twin (tests/emu/libingest_scalar.so, the same source built with
+    -DFREESASA_INGEST_NO_SIMD) on randomized _atom_site loops: ragged padding, tabs and CRLF, rows
+    broken over lines, comments, quoted values with blanks, text fields, keywords in value position,
+    loops that end at every offset modulo the 64-byte block."""
+    import ctypes as C
+    from freesasa_amd.ingest import _CBatch, Batch
+    path = os.path.join(ROOT, "tests", "emu", "libingest_scalar.so")
+    if not os.path.exists(path):
+        pytest.skip("scalar twin not built (make emu)")
+    S = C.CDLL(path)
+    S.freesasa_ingest_pdb_texts.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.c_int, C.POINTER(_CBatch)]
+    S.freesasa_ingest_free.argtypes = [C.POINTER(_CBatch)]
+    S.freesasa_ingest_free.restype = None
+
+    def scalar(texts, options):
+        raw = [t.encode() for t in texts]
+        arr = (C.c_char_p * len(raw))(*raw)
+        lens = (C.c_size_t * len(raw))(*[len(t) for t in raw])
+        cb = _CBatch()
+        assert S.freesasa_ingest_pdb_texts(arr, lens, len(raw), options, 1, C.byref(cb)) == 0
+        try:
+            return Batch(cb)
+        finally:
+            S.freesasa_ingest_free(C.byref(cb))
+
+    rng = np.random.default_rng(11)
+    cols = ["group_PDB", "id", "type_symbol", "label_atom_id", "label_alt_id", "label_comp_id", "label_asym_id",
+            "label_seq_id", "pdbx_PDB_ins_code", "Cartn_x", "Cartn_y", "Cartn_z", "occupancy", "B_iso_or_equiv",
+            "auth_seq_id", "auth_comp_id", "auth_asym_id", "auth_atom_id", "pdbx_PDB_model_num"]
+    res = ["ALA", "LEU", "SER", "ASP", "GLY", "DA", "HOH", "loop", "data", "XYZ"]
+    atoms = ["N", "CA", "C", "O", "CB", "\"C1'\"", "'O P'", "OXT", "\"N A\"", "H", "_x", "CG"]
+
+    def ws():
+        k = rng.integers(0, 12)
+        return [" ", "  ", "   ", "\t", " \t ", "      ", " ", "  ", "\n", "\r\n", " \n ", "  # note\n"][k]
+
+    def make_text():
+        order = list(rng.permutation(len(cols)))
+        out = ["data_fuzz\n", "#\n" if rng.random() < 0.5 else "", "_cell.length_a 10.0\n", "loop_\n"]
+        out += ["_atom_site.%s%s" % (cols[k], "\r\n" if rng.random() < 0.1 else "\n") for k in order]
+        n = int(rng.integers(1, 60))
+        for i in range(n):
+            rn, an = res[rng.integers(len(res))], atoms[rng.integers(len(atoms))]
+            sym = "H" if an == "H" else an.strip("\"'")[0].upper() if an[0] != "_" else "C"
+            seq = str(int(rng.integers(-5, 400)))
+            vals = {"group_PDB": "ATOM" if rng.random() < 0.85 else "HETATM", "id": str(i + 1), "type_symbol": sym,
+                    "label_atom_id": an, "label_alt_id": [".", ".", ".", "A", "B"][rng.integers(5)], "label_comp_id": rn,
+                    "label_asym_id": "A", "label_seq_id": seq, "pdbx_PDB_ins_code": ["?", "?", "?", "A"][rng.integers(4)],
+                    "Cartn_x": "%.3f" % rng.uniform(-99, 99), "Cartn_y": "%.*f" % (int(rng.integers(0, 6)), rng.uniform(-999, 999)),
+                    "Cartn_z": ["%.3f" % rng.uniform(-9, 9), "1.5e1", "-.25", "+3."][rng.integers(4)],
+                    "occupancy": "1.00", "B_iso_or_equiv": "%.2f" % rng.uniform(0, 99), "auth_seq_id": seq, "auth_comp_id": rn,
+                    "auth_asym_id": ["A", "B", "AA", "'C'"][rng.integers(4)], "auth_atom_id": an,
+                    "pdbx_PDB_model_num": str(1 + (i * 3 // (n + 1)) if rng.random() < 0.9 else 1)}
+            row = "".join(vals[cols[k]] + ws() for k in order)
+            out.append(row if row.endswith("\n") or rng.random() < 0.3 else row + "\n")
+        tail = ["", "#\n", "loop_\n_x.a\n_x.b\n1 2\n3 4\n", "_after.tag value\n", "\n;text\nfield\n;\n", "data_next\n"][rng.integers(6)]
+        out.append(tail)
+        out.append(" " * int(rng.integers(0, 70)))
+        return "".join(out)
+
+    texts = [make_text() for _ in range(400)]
+    for options in (0, ingest.INCLUDE_HETATM | ingest.INCLUDE_HYDROGEN, ingest.JOIN_MODELS):
+        a = ingest.load_pdb_texts(texts, options=options, n_threads=3)
+        b = scalar(texts, options)
+        assert a.n_atoms == b.n_atoms and a.n_atoms > 1000
+        for f in ("xyz", "radii", "atom_class", "atom_backbone", "atom_name_raw", "atom_symbol_raw", "offsets", "res_first",
+                  "res_offsets", "res_ref", "res_name_raw", "res_number_raw", "res_chain_raw", "status"):
+            assert np.array_equal(getattr(a, f), getattr(b, f)), (options, f)
