@@ -959,6 +959,10 @@ static int run(job *j, int n_threads, freesasa_ingest_batch *out)
     if (j->n < 0) return FREESASA_INGEST_EOPTION;
     if (n_threads <= 0) { /* default: the cores, but no more threads than pay for their start-up */
         n_threads = (int)sysconf(_SC_NPROCESSORS_ONLN);
+        /* one process per GPU (torchrun exports LOCAL_WORLD_SIZE): the ranks of a node share its cores */
+        const char *lws = getenv("LOCAL_WORLD_SIZE");
+        const int ranks = lws ? atoi(lws) : 1;
+        if (ranks > 1) n_threads /= ranks;
         if (n_threads > 64) n_threads = 64;
         if (n_threads > j->n / 4) n_threads = j->n / 4;
     }

@@ -78,8 +78,9 @@ typedef struct freesasa_ingest_batch {
     int32_t *status;      /* [n_structs] */
 } freesasa_ingest_batch;
 
-/* Read n_paths PDB or mmCIF files with n_threads host threads (<= 0: one per online core, at most 64 and
- * at most one per four inputs) into one batch.
+/* Read n_paths PDB or mmCIF files with n_threads host threads (<= 0: one per online core -- divided by
+ * LOCAL_WORLD_SIZE when a launcher exports it, so the ranks of a node share the cores --, at most 64
+ * and at most one per four inputs) into one batch.
  * Returns 0 if the batch could be built (individual failures are in status[]), a
  * FREESASA_INGEST_E* code otherwise (out is zeroed). */
 int freesasa_ingest_pdb_files(const char *const *paths, int n_paths, int options, int n_threads,
