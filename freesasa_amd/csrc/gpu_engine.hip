@@ -142,6 +142,13 @@ __global__ __launch_bounds__(SASA_TOT_B) void k_class_sums(const double *sasa, c
 /* TIER only names the launch (0 main, 1 second, 2 slab) so that profiles list them separately.
  * WPE = waves per SIMD the register allocation is capped for: 4 (128 VGPRs), or 5 (96 VGPRs, no
  * spill since atan2_fast) when the tile's LDS footprint lets more than 16 one-wave tiles reside. */
+#ifdef SASA_PHASE_TIMING /* dev only (tools/build_variant.sh X -DSASA_PHASE_TIMING): where a wave's time per tile goes */
+__device__ unsigned long long g_phase_clock[16];
+#define PHASE_MARK(k) do { if (tid == 0 && TIER == 0 && (tile & 255) == 0) { const unsigned long long now_ = wall_clock64(); \
+        atomicAdd(&g_phase_clock[k], now_ - last_); last_ = now_; } } while (0)
+#else
+#define PHASE_MARK(k) do { } while (0)
+#endif
 template <int B, bool GLOBAL, int TIER, int WPE, bool BUCKET = false>
 __global__ __launch_bounds__(B) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lr_tile(TileArgs a, int items)
 {
@@ -152,15 +159,23 @@ __global__ __launch_bounds__(B) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) v
     for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
         const int tile = a.work_tiles ? a.work_tiles[w] : xcd_tile(w, a.n_tiles);
         if (tile >= a.n_tiles) continue; /* uniform per workgroup */
+#ifdef SASA_PHASE_TIMING
+        unsigned long long last_ = wall_clock64();
+#endif
         tile_phase_load(a, m, tile, tid, B, BUCKET);
         __syncthreads();
+        PHASE_MARK(0);
         tile_phase_neighbors(a, m, tile, tid, B);
         __syncthreads();
+        PHASE_MARK(1);
         tile_phase_offsets(a, m, tid);
         __syncthreads();
+        PHASE_MARK(2);
         tile_report<GLOBAL>(a, m, tile, tid);
+        PHASE_MARK(3);
         lr_phase_beta(a, m, tid, B, BUCKET);
         __syncthreads();
+        PHASE_MARK(4);
         if (BUCKET && lr_bucket_path(a, m, B)) { /* uniform per workgroup */
             RankRegs rr;
             lr_phase_prefix(a, m, tid);
@@ -174,10 +189,16 @@ __global__ __launch_bounds__(B) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) v
             lr_phase_rank(a, m, tid, B);
         }
         __syncthreads();
+        PHASE_MARK(5);
         lr_phase_slices(a, m, tile, tid, B);
         __syncthreads();
+        PHASE_MARK(6);
         lr_phase_store<GLOBAL>(a, m, tile, tid, B);
         __syncthreads();
+        PHASE_MARK(7);
+#ifdef SASA_PHASE_TIMING
+        if (tid == 0 && TIER == 0 && (tile & 255) == 0) atomicAdd(&g_phase_clock[15], 1ULL);
+#endif
     }
 }
 
@@ -621,6 +642,19 @@ static int run_batch_impl(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
         if (hipEventElapsedTime(&ms, c->ev[0], c->ev[3]) == hipSuccess) S.ms_total = ms;
     }
     if (status_h[ST_ERROR]) return ctx_fail(c, "%s", err_text(status_h[ST_ERROR]));
+#ifdef SASA_PHASE_TIMING
+    {
+        unsigned long long h[16];
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_clock), sizeof h) == hipSuccess && h[15]) {
+            static const char *names[8] = {"load", "neighbors", "offsets", "report", "beta", "rank", "slices", "store"};
+            fprintf(stderr, "phase clocks (100 MHz ticks per sampled tile, thread 0, %llu tiles):", h[15]);
+            for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.1f", names[k], (double)h[k] / (double)h[15]);
+            fprintf(stderr, "\n");
+            memset(h, 0, sizeof h);
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_clock), h, sizeof h);
+        }
+    }
+#endif
     /* learn the pool size for the next batch of this kind (trajectory frames, sweeps) */
     c->hint_res[hi] = resolution;
     c->hint_ta[hi] = cfg.TA;
