@@ -51,6 +51,7 @@ inline int atomic_max(int *p, int v) { int o = *p; if (v > o) *p = v; return o; 
 #define SASA_MIN(a, b) fmin((a), (b))
 #define SASA_MAX(a, b) fmax((a), (b))
 #define SASA_SHIFT_IN_LT1(w, c) (((w) << 1) | ((c) < 1.0 ? 1u : 0u))
+#define SASA_OPAQUE(v) ((void)0)
 #else
 #define SASA_D __device__ __forceinline__
 #define SASA_HD __host__ __device__ __forceinline__
@@ -95,6 +96,8 @@ __device__ __forceinline__ unsigned sasa_shift_in_lt1(unsigned w, double c)
     return r;
 }
 #define SASA_SHIFT_IN_LT1(w, c) sasa_shift_in_lt1((w), (c))
+/* keeps a constant in a VGPR the optimizer cannot fold */
+#define SASA_OPAQUE(v) asm("" : "+v"(v))
 #endif
 
 namespace sasa {
@@ -842,7 +845,7 @@ SASA_D void lr_phase_beta(const TileArgs &a, TileMem &m, int tid, int B, bool bu
         int la = 0;
         while (m.aoff[la + 1] <= gp) ++la;
         const int k = gp - m.aoff[la];
-        if (k >= m.acnt[la]) continue; /* padding slot */
+        if (k >= m.acnt[la]) { m.tb[gp] = INFINITY; continue; } /* padding slot: ranks behind everything */
         const int q = m.idx[la * a.cap_idx + k];
         const double xd = a.sx[q] - m.ax[la], yd = a.sy[q] - m.ay[la]; /* ref: src/nb.c:445-448 */
         const double beta = atan2_fast(yd, xd) + SASA_PI;
@@ -860,19 +863,22 @@ SASA_D void lr_phase_beta(const TileArgs &a, TileMem &m, int tid, int B, bool bu
  * so neither sqrt(Rj'^2) nor a division is needed per (pair, slice).  dij == 0: 1/dij = inf makes
  * c = +-inf, deciding inside/buried like the reference; 0*inf = NaN (the reference's acos(0/0),
  * two coincident equal circles) compares false -> no arc. */
-SASA_D Quad lr_record(const TileArgs &a, int q, double xi, double yi, double beta)
+SASA_D Quad lr_record_of(double xq, double yq, double zq, double rj, double xi, double yi, double beta)
 {
-    const double xd = a.sx[q] - xi, yd = a.sy[q] - yi; /* ref: src/nb.c:445-448 */
-    const double rj = a.sr[q];
+    const double xd = xq - xi, yd = yq - yi; /* ref: src/nb.c:445-448 */
     const double D = xd * xd + yd * yd; /* = d_ij^2 (ref: src/nb.c:438) */
     double g = 0, h = 0;
     if (D > 0) sqrt_rh(D, g, h);
     Quad rec;
-    rec.x = a.sz[q];
+    rec.x = zq;
     rec.y = D - rj * rj;
     rec.z = D > 0 ? 2.0 * h : INFINITY; /* 1/d_ij */
     rec.w = beta;
     return rec;
+}
+SASA_D Quad lr_record(const TileArgs &a, int q, double xi, double yi, double beta)
+{
+    return lr_record_of(a.sx[q], a.sy[q], a.sz[q], a.sr[q], xi, yi, beta);
 }
 /* padding slot of an odd-length list: a record whose c is huge, so it never cuts an arc */
 SASA_D Quad lr_padding() { Quad d; d.x = 0; d.y = 1e300; d.z = 1; d.w = 0; return d; }
@@ -880,6 +886,18 @@ SASA_D Quad lr_padding() { Quad d; d.x = 0; d.y = 1e300; d.z = 1; d.w = 0; retur
 /* phase P2: rank each pair by beta inside its atom's list and write the pair record at its
  * sorted position.  Sorting by the arc mid-angle is what lets the slice loop merge arcs with
  * a stack instead of the reference's per-slice insertion sort. */
+/* beta with its low 12 mantissa bits replaced by a list position (see lr_phase_rank); only the low
+ * word changes.  `low` = 0xfff: handed in from a register the compiler cannot see through, so that
+ * (lo & ~low) | pos is one v_and_or_b32 instead of an and + or with a literal. */
+SASA_D double lr_rank_key(double beta, unsigned pos, unsigned low)
+{
+    unsigned w[2];
+    memcpy(w, &beta, 8);
+    w[0] = (w[0] & ~low) | pos; /* pos < 4096 */
+    double key;
+    memcpy(&key, w, 8);
+    return key;
+}
 SASA_D void lr_phase_rank(const TileArgs &a, TileMem &m, int tid, int B)
 {
     if (m.flags[0]) return;
@@ -892,16 +910,26 @@ SASA_D void lr_phase_rank(const TileArgs &a, TileMem &m, int tid, int B)
         while (m.aoff[la + 1] <= gp) ++la;
         const int o = m.aoff[la], nn = m.acnt[la], k = gp - o;
         if (k >= nn) { m.pq[gp] = lr_padding(); continue; }
+        /* the neighbor's coordinates are requested before the ranking loop and used after it */
+        const unsigned q = (unsigned)m.idx[la * a.cap_idx + k];
+        const double xq = a.sx[q], yq = a.sy[q], zq = a.sz[q], rq = a.sr[q];
         const double beta = m.tb[gp];
         int rank = 0;
-        /* two betas per LDS read (o is even, so the pair is 16-byte aligned); the slot after an
-           odd-length list is padding and is excluded by t + 1 < nn */
+        /* Order by (beta, list position) with ONE comparison per element: the list position replaces
+           the low 12 bits of beta's mantissa (positions < 4096 = SASA_FB_CAP), which makes the keys
+           distinct; two betas that agree in everything above (relative difference < 1e-12) belong to
+           arcs that overlap around a common midpoint (alpha > 1e-8), and such arcs commute in the
+           union.  Two betas per LDS read (o is even, so the pair is 16-byte aligned); the slot after
+           an odd-length list holds +inf, whose key is a NaN and never compares below. */
+        unsigned low = 0xfffu;
+        SASA_OPAQUE(low);
+        const double kme = lr_rank_key(beta, (unsigned)k, low);
         for (int t = 0; t < nn; t += 2) {
             const Arc bb = *(const Arc *)(m.tb + o + t);
-            rank += (bb.s < beta || (bb.s == beta && t < k)) ? 1 : 0;
-            rank += (t + 1 < nn && (bb.e < beta || (bb.e == beta && t + 1 < k))) ? 1 : 0;
+            rank += lr_rank_key(bb.s, (unsigned)t, low) < kme ? 1 : 0;
+            rank += lr_rank_key(bb.e, (unsigned)t + 1u, low) < kme ? 1 : 0;
         }
-        m.pq[o + rank] = lr_record(a, m.idx[la * a.cap_idx + k], m.ax[la], m.ay[la], beta);
+        m.pq[o + rank] = lr_record_of(xq, yq, zq, rq, m.ax[la], m.ay[la], beta);
     }
 }
 
