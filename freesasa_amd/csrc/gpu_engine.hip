@@ -156,6 +156,7 @@ __global__ __launch_bounds__(B) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) v
     const int tid = threadIdx.x;
     TileMem m = tile_carve<GLOBAL>(a, smem, items, B, blockIdx.x);
     const int n_work = a.work_tiles ? *a.work_count : ((a.n_tiles + 7) >> 3) << 3;
+    int wg_max_nn = 0;
     for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
         const int tile = a.work_tiles ? a.work_tiles[w] : xcd_tile(w, a.n_tiles);
         if (tile >= a.n_tiles) continue; /* uniform per workgroup */
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(B) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) v
         tile_phase_offsets(a, m, tid);
         __syncthreads();
         PHASE_MARK(2);
-        tile_report<GLOBAL>(a, m, tile, tid);
+        tile_report<GLOBAL>(a, m, tile, tid, wg_max_nn);
         PHASE_MARK(3);
         lr_phase_beta(a, m, tid, B, BUCKET);
         __syncthreads();
@@ -200,6 +201,7 @@ __global__ __launch_bounds__(B) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) v
         if (tid == 0 && TIER == 0 && (tile & 255) == 0) atomicAdd(&g_phase_clock[15], 1ULL);
 #endif
     }
+    tile_report_flush(a, tid, wg_max_nn);
 }
 
 template <int B, bool GLOBAL, int TIER>
@@ -209,6 +211,7 @@ __global__ __launch_bounds__(B) void k_sr_tile(TileArgs a, int items)
     const int tid = threadIdx.x;
     TileMem m = tile_carve<GLOBAL>(a, smem, items, B, blockIdx.x);
     const int n_work = a.work_tiles ? *a.work_count : ((a.n_tiles + 7) >> 3) << 3;
+    int wg_max_nn = 0;
     for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
         const int tile = a.work_tiles ? a.work_tiles[w] : xcd_tile(w, a.n_tiles);
         if (tile >= a.n_tiles) continue;
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(B) void k_sr_tile(TileArgs a, int items)
         tile_phase_offsets(a, m, tid);
         sr_phase_cursors(a, m, tid);
         __syncthreads();
-        tile_report<GLOBAL>(a, m, tile, tid);
+        tile_report<GLOBAL>(a, m, tile, tid, wg_max_nn);
         sr_phase_pairs(a, m, tid, B);
         __syncthreads();
         sr_phase_points(a, m, tile, tid, B);
@@ -229,6 +232,7 @@ __global__ __launch_bounds__(B) void k_sr_tile(TileArgs a, int items)
         sr_phase_store(a, m, tile, tid);
         __syncthreads();
     }
+    tile_report_flush(a, tid, wg_max_nn);
 }
 
 /* ------------------------------------------------------------------ context */

@@ -699,12 +699,13 @@ SASA_HD int hist_bin_width(int TA) { return 2 * TA + 2; }
 
 /* first thing after the barrier that follows phase O: overflow -> next launch's work list */
 template <bool GLOBAL>
-SASA_D void tile_report(const TileArgs &a, TileMem &m, int tile, int tid)
+SASA_D void tile_report(const TileArgs &a, TileMem &m, int tile, int tid, int &wg_max_nn)
 {
     if (tid != 0) return;
-    /* statistics must not serialise half a million tiles on one L2 atomic unit: the maximum is
-       only pushed when it beats the value already there, the demand histogram samples 1 tile in 32 */
-    if (m.flags[2] > a.status[ST_MAX_NN]) SASA_ATOMIC_MAX_GLB(&a.status[ST_MAX_NN], m.flags[2]);
+    /* statistics must not serialise half a million tiles on one L2 atomic unit, nor put a global
+       round trip into every tile: the largest neighbor count is kept in a register of thread 0 and
+       pushed once per workgroup (tile_report_flush), the demand histogram samples 1 tile in 32 */
+    if (m.flags[2] > wg_max_nn) wg_max_nn = m.flags[2];
     if (!a.work_tiles && (tile & 31) == 0) {
         const int need = m.aoff[a.TA] / hist_bin_width(a.TA);
         SASA_ATOMIC_ADD_GLB(&a.status[ST_HIST + (need < 63 ? need : 63)], 1);
@@ -717,6 +718,13 @@ SASA_D void tile_report(const TileArgs &a, TileMem &m, int tile, int tid)
             a.ovf_tiles[w] = tile;
         }
     }
+}
+
+/* after a workgroup's last tile */
+SASA_D void tile_report_flush(const TileArgs &a, int tid, int wg_max_nn)
+{
+    /* pushed only when it beats the value already there: same-address atomics serialise in L2 */
+    if (tid == 0 && wg_max_nn > a.status[ST_MAX_NN]) SASA_ATOMIC_MAX_GLB(&a.status[ST_MAX_NN], wg_max_nn);
 }
 
 /* ---------------------------------------------------------------- fp64 helpers */

@@ -27,6 +27,7 @@ static void emu_tile_kernel(bool lr, const TileCfg &cfg, TileArgs a, int grid)
     for (int blk = 0; blk < grid; ++blk) {
         TileMem m = tile_carve<GLOBAL>(a, smem.data(), cfg.items, B, blk);
         const int n_work = a.work_tiles ? *a.work_count : ((a.n_tiles + 7) >> 3) << 3;
+        std::vector<int> wg_max_nn(B, 0);
         for (int w = blk; w < n_work; w += grid) {
             const int tile = a.work_tiles ? a.work_tiles[w] : xcd_tile(w, a.n_tiles);
             if (tile >= a.n_tiles) continue;
@@ -35,7 +36,7 @@ static void emu_tile_kernel(bool lr, const TileCfg &cfg, TileArgs a, int grid)
             PHASE(tile_phase_neighbors(a, m, tile, tid, B));
             PHASE(tile_phase_offsets(a, m, tid); if (!lr) sr_phase_cursors(a, m, tid));
             if (lr) {
-                PHASE(tile_report<GLOBAL>(a, m, tile, tid); lr_phase_beta(a, m, tid, B, emu_bucket));
+                PHASE(tile_report<GLOBAL>(a, m, tile, tid, wg_max_nn[tid]); lr_phase_beta(a, m, tid, B, emu_bucket));
                 if (emu_bucket && lr_bucket_path(a, m, B)) {
                     std::vector<RankRegs> rrs(B);
                     PHASE(lr_phase_prefix(a, m, tid));
@@ -48,13 +49,14 @@ static void emu_tile_kernel(bool lr, const TileCfg &cfg, TileArgs a, int grid)
                 PHASE(lr_phase_slices(a, m, tile, tid, B));
                 PHASE(lr_phase_store<GLOBAL>(a, m, tile, tid, B));
             } else {
-                PHASE(tile_report<GLOBAL>(a, m, tile, tid); sr_phase_pairs(a, m, tid, B));
+                PHASE(tile_report<GLOBAL>(a, m, tile, tid, wg_max_nn[tid]); sr_phase_pairs(a, m, tid, B));
                 PHASE(sr_phase_points(a, m, tile, tid, B));
                 PHASE(sr_phase_points2(a, m, tid, B));
                 PHASE(sr_phase_store(a, m, tile, tid));
             }
-#undef PHASE
         }
+        PHASE(tile_report_flush(a, tid, wg_max_nn[tid]));
+#undef PHASE
     }
 }
 
