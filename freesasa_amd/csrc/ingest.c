@@ -65,6 +65,27 @@ static void protor_hash_build(void)
     }
 }
 
+/* the lookup on tokens that are already trimmed (rl, al: their lengths) */
+static inline double protor_lookup(const char *rt, int rl, const char *at, int al, int *cls)
+{
+    *cls = FREESASA_INGEST_UNKNOWN;
+    if (rl < 1 || rl > 3 || al < 1 || al > 4) return -1.0;
+    unsigned char b[7] = {' ', ' ', ' ', ' ', ' ', ' ', ' '};
+    for (int i = 0; i < rl; ++i) b[i] = (unsigned char)rt[i];
+    for (int i = 0; i < al; ++i) b[3 + i] = (unsigned char)at[i];
+    uint64_t k = 0;
+    for (int i = 0; i < 7; ++i) k = (k << 8) | b[i];
+    pthread_once(&protor_hash_once, protor_hash_build);
+    for (unsigned h = protor_slot(k);; h = (h + 1) & ((1 << PROTOR_HASH_BITS) - 1)) {
+        const int i = protor_hash[h];
+        if (i < 0) return -1.0;
+        if (protor_table[i].key == k) {
+            *cls = protor_table[i].cls;
+            return protor_table[i].radius;
+        }
+    }
+}
+
 double freesasa_ingest_protor_radius(const char *res_name, const char *atom_name, int *cls)
 {
     const char *rt, *at;
@@ -84,6 +105,20 @@ double freesasa_ingest_protor_radius(const char *res_name, const char *atom_name
 }
 
 /* ref: freesasa_atom_is_backbone, src/classifier.c:1090-1109 (the name is trimmed first) */
+static inline int backbone_tok(const char *t, int n)
+{
+    if (n < 1 || n > 3) return 0;
+    const unsigned key = (unsigned)(unsigned char)t[0] | (n > 1 ? (unsigned)(unsigned char)t[1] << 8 : 0) |
+                         (n > 2 ? (unsigned)(unsigned char)t[2] << 16 : 0);
+    for (int i = 0; i < BACKBONE_N; ++i) {
+        const char *b = backbone_names[i]; /* at most 3 characters */
+        const unsigned kb = (unsigned)(unsigned char)b[0] | (b[1] ? (unsigned)(unsigned char)b[1] << 8 : 0) |
+                            (b[1] && b[2] ? (unsigned)(unsigned char)b[2] << 16 : 0);
+        if (kb == key) return 1;
+    }
+    return 0;
+}
+
 int freesasa_ingest_is_backbone(const char *atom_name)
 {
     const char *t;
@@ -692,8 +727,16 @@ static int cif_visit_atom(const cif_tok *row, void *ctx)
         if (!scan_double(&sp, &v[k])) v[k] = 0.0;
     }
 
+    /* names without blanks or NULs (all but quoted oddities) are their own first token: classify and
+       store them without the sscanf("%s")-style rescans of the general path */
+    int al = 0, rl = 0, sl = 0, plain = 1;
+    while (aname[al]) { plain &= !isspace((unsigned char)aname[al]); ++al; }
+    while (rname[rl]) { plain &= !isspace((unsigned char)rname[rl]); ++rl; }
+    while (symbol[sl]) { plain &= !isspace((unsigned char)symbol[sl]); ++sl; }
+    plain = plain && (size_t)al == (row[5].n >= 2 && row[5].p[0] == '"' ? (row[5].n - 2 < 4 ? row[5].n - 2 : 4) : (row[5].n < 4 ? row[5].n : 4)) &&
+            (size_t)rl == (row[4].n < 3 ? row[4].n : 3) && (size_t)sl == (row[7].n < 2 ? row[7].n : 2);
     int cls;
-    double r = freesasa_ingest_protor_radius(rname, aname, &cls);
+    double r = plain ? protor_lookup(rname, rl, aname, al, &cls) : freesasa_ingest_protor_radius(rname, aname, &cls);
     if (r < 0) {
         if (c->options & (FREESASA_INGEST_HALT_AT_UNKNOWN | FREESASA_INGEST_SKIP_UNKNOWN)) return 0;
         r = freesasa_ingest_guess_radius(symbol);
@@ -720,9 +763,16 @@ static int cif_visit_atom(const cif_tok *row, void *ctx)
     p->xyz[3 * p->n] = v[0]; p->xyz[3 * p->n + 1] = v[1]; p->xyz[3 * p->n + 2] = v[2];
     p->rad[p->n] = r;
     p->cls[p->n] = (uint8_t)cls;
-    p->bb[p->n] = (uint8_t)freesasa_ingest_is_backbone(aname);
-    store_token(p->aname + 4 * p->n, 4, aname);
-    store_token(p->asym + 2 * p->n, 2, symbol);
+    if (plain) {
+        p->bb[p->n] = (uint8_t)backbone_tok(aname, al);
+        char *dn = p->aname + 4 * p->n, *ds = p->asym + 2 * p->n;
+        for (int i = 0; i < 4; ++i) dn[i] = i < al ? aname[i] : '\0';
+        for (int i = 0; i < 2; ++i) ds[i] = i < sl ? symbol[i] : '\0';
+    } else {
+        p->bb[p->n] = (uint8_t)freesasa_ingest_is_backbone(aname);
+        store_token(p->aname + 4 * p->n, 4, aname);
+        store_token(p->asym + 2 * p->n, 2, symbol);
+    }
     ++p->n;
     return 0;
 }
