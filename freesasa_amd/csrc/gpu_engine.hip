@@ -20,6 +20,7 @@
 #include "../../include/freesasa_gpu.h"
 #include "../../include/freesasa_ingest.h"
 #include "sasa_kernels.h"
+#include "lr2_kernels.h"
 
 using namespace sasa;
 
@@ -204,6 +205,27 @@ __global__ __launch_bounds__(B) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) v
     tile_report_flush(a, tid, wg_max_nn);
 }
 
+/* Second-generation L&R kernel (lr2_kernels.h): one wave per tile.  RMAX = rounds of pair records a
+ * lane keeps in registers (3: main launch, 8: second launch); WPE = waves per SIMD the register
+ * allocation is capped for. */
+template <int RMAX, int TIER, int WPE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lr2_tile(Lr2Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x;
+    Lr2Mem m = lr2_carve(a, smem);
+    const int n_work = a.work_tiles ? *a.work_count : ((a.n_tiles + 7) >> 3) << 3;
+    int wg_max_nn = 0;
+    for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
+        const int tile = a.work_tiles ? a.work_tiles[w] : xcd_tile(w, a.n_tiles);
+        if (tile >= a.n_tiles) continue; /* uniform per workgroup */
+        lr2_tile<RMAX>(a, m, tile, lane, wg_max_nn);
+    }
+    if (lane == 0 && wg_max_nn > a.status[ST_MAX_NN]) atomicMax(&a.status[ST_MAX_NN], wg_max_nn);
+}
+template __global__ void k_lr2_tile<LR2_RMAX_MAIN, 0, 4>(Lr2Args);
+template __global__ void k_lr2_tile<LR2_RMAX_MID, 1, 2>(Lr2Args);
+
 template <int B, bool GLOBAL, int TIER>
 __global__ __launch_bounds__(B) void k_sr_tile(TileArgs a, int items)
 {
@@ -265,6 +287,7 @@ struct freesasa_gpu_ctx {
     /* adaptive neighbor-pool size, per algorithm: (resolution, TA) it was learnt for and the value */
     int hint_res[2] = {0, 0}, hint_ta[2] = {0, 0}, hint_pool[2] = {0, 0};
     bool hint_bucket = false; /* L&R: the last batch had long neighbor lists */
+    double hint_nn = 0;       /* L&R (lr2): neighbor records per atom the main launch should hold */
 };
 
 static int ctx_fail(freesasa_gpu_ctx *c, const char *fmt, ...)
@@ -399,6 +422,125 @@ static const char *err_text(int code)
     }
 }
 
+/* ------------------------------------------------------------------ L&R, second generation */
+
+static int finish_batch(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs, long long total_cells, double *d_sasa,
+                        double *d_totals, int tile_atoms, int block_threads, int lds, int *status_h)
+{
+    hipStream_t st = c->stream;
+    if (d_totals) {
+        /* the chunk partials reuse the bounds kernels' scratch (56 bytes per chunk, free by now) */
+        hipLaunchKernelGGL(k_totals_chunks, dim3(c->n_chunks), dim3(SASA_TOT_B), 0, st, pa, (const double *)d_sasa, (double *)c->bpart.p);
+        hipLaunchKernelGGL(k_totals_structs, dim3((n_structs + 255) / 256), dim3(256), 0, st, pa, (const double *)c->bpart.p, d_totals);
+        HIP_TRY(c, hipGetLastError());
+    }
+    if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[3], st));
+    HIP_TRY(c, hipMemcpyAsync(status_h, c->status.p, sizeof(int) * ST_WORDS, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    freesasa_gpu_stats &S = c->stats;
+    S.n_atoms = n; S.n_cells = total_cells; S.n_structs = n_structs;
+    S.max_neighbors = status_h[ST_MAX_NN]; S.fallback_tiles = status_h[ST_OVF_TILES];
+    S.tile_atoms = tile_atoms; S.block_threads = block_threads; S.lds_bytes = lds;
+    S.ms_prep = S.ms_kernel = S.ms_total = 0;
+    if (c->timing) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) S.ms_prep = ms;
+        if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) S.ms_kernel = ms;
+        if (hipEventElapsedTime(&ms, c->ev[0], c->ev[3]) == hipSuccess) S.ms_total = ms;
+    }
+    if (status_h[ST_ERROR]) return ctx_fail(c, "%s", err_text(status_h[ST_ERROR]));
+    return 0;
+}
+
+static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs, int resolution, double *d_sasa,
+                   double *d_totals, long long total_cells)
+{
+    hipStream_t st = c->stream;
+    int *status_h = c->pinned;
+    int ta_env = 0, pool_env = 0, ds_env = -1, refill_env = 0;
+    if (const char *e = getenv("FREESASA_AMD_LR2")) (void)sscanf(e, "%d,%d,%d,%d", &ta_env, &pool_env, &ds_env, &refill_env); /* tuning aid: "TA,pool,ds,refill" */
+    if (c->hint_res[0] != resolution) {
+        /* no demand history for this resolution on this context: size the neighbor pool from the local
+           density (atoms in an atom's own cell; ~3.1 neighbors per such atom on coils, globules and
+           proteins alike).  One 8-byte readback, first call only. */
+        HIP_TRY(c, hipMemcpyAsync(status_h, (int *)c->status.p + ST_OCC_SUM, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        c->hint_nn = status_h[1] > 0 ? 1.25 * 3.1 * (double)status_h[0] / (double)status_h[1] + 2.0 : 0.0;
+        c->hint_res[0] = resolution;
+    }
+    Lr2Cfg cfg = lr2_choose_cfg(resolution, c->hint_nn, ta_env);
+    if (pool_env > 0) cfg.pool = (pool_env + 1) & ~1;
+    if (ds_env >= 0) cfg.ds = ds_env;
+    if (refill_env > 0) cfg.refill = refill_env;
+    cfg.lds = lr2_layout(cfg.TA, cfg.ns, cfg.pool, cfg.mw, cfg.ds).total;
+    const int n_tiles = (n + cfg.TA - 1) / cfg.TA;
+    if (ensure(c, c->ovf_tiles, sizeof(int) * ((size_t)n_tiles + 1)) || ensure(c, c->ovf_tiles2, sizeof(int) * ((size_t)n_tiles + 1))) return -1;
+
+    Lr2Args la;
+    memset(&la, 0, sizeof la);
+    la.sx = pa.sx; la.sy = pa.sy; la.sz = pa.sz; la.sr = pa.sr;
+    la.s_orig = pa.s_orig; la.s_struct = pa.s_struct; la.s_cell = pa.s_cell;
+    la.grid = pa.grid; la.cell_start = pa.cell_start;
+    la.n_atoms = n; la.n_tiles = n_tiles; la.TA = cfg.TA; la.ns = resolution;
+    la.pool = cfg.pool; la.mw = cfg.mw; la.ds = cfg.ds; la.refill = cfg.refill;
+    la.sasa = d_sasa; la.status = (int *)c->status.p;
+    la.ovf_count = (int *)c->status.p + ST_OVF_TILES;
+    la.ovf_tiles = (int *)c->ovf_tiles.p;
+
+    int grid_main = ((n_tiles + 7) / 8) * 8;
+    if (grid_main > 147456) grid_main = 147456;
+    if (const char *e = getenv("FREESASA_AMD_GRID")) { /* tuning aid */
+        const int g = atoi(e);
+        if (g >= 8 && g < grid_main) grid_main = (g / 8) * 8;
+    }
+    hipLaunchKernelGGL((k_lr2_tile<LR2_RMAX_MAIN, 0, 4>), dim3(grid_main), dim3(64), (size_t)cfg.lds, st, la);
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return ctx_fail(c, "tile kernel launch failed: %s", hipGetErrorString(le));
+    if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[2], st));
+
+    /* second launch: the tiles whose lists did not fit (normally a fraction of a percent) */
+    const Lr2Cfg cm = lr2_mid_cfg(cfg);
+    {
+        Lr2Args lm = la;
+        lm.pool = cm.pool; lm.mw = cm.mw; lm.ds = cm.ds;
+        lm.work_tiles = (const int *)c->ovf_tiles.p;
+        lm.work_count = (const int *)c->status.p + ST_OVF_TILES;
+        lm.ovf_tiles = (int *)c->ovf_tiles2.p;
+        lm.ovf_count = (int *)c->status.p + ST_OVF2_TILES;
+        const int grid_mid = n_tiles < SASA_MID_BLOCKS ? n_tiles : SASA_MID_BLOCKS;
+        hipLaunchKernelGGL((k_lr2_tile<LR2_RMAX_MID, 1, 2>), dim3(grid_mid), dim3(64), (size_t)cm.lds, st, lm);
+        le = hipGetLastError();
+        if (le != hipSuccess) return ctx_fail(c, "second tile launch failed: %s", hipGetErrorString(le));
+    }
+    /* third launch: whatever is left (pathological densities): the first-generation kernel over the same
+       tiling, lists in a global slab */
+    {
+        const TileCfg fb = fallback_cfg(lr_slab_cfg(cfg.TA, resolution), true);
+        const size_t stride = tile_slab_bytes(fb.TA, fb.cap_idx, fb.pool, fb.lr, fb.ds, fb.B);
+        if (ensure(c, c->slab, stride * SASA_FB_BLOCKS)) return -1;
+        TileArgs tf;
+        memset(&tf, 0, sizeof tf);
+        tf.sx = pa.sx; tf.sy = pa.sy; tf.sz = pa.sz; tf.sr = pa.sr;
+        tf.s_orig = pa.s_orig; tf.s_cell = pa.s_cell; tf.s_struct = pa.s_struct;
+        tf.grid = pa.grid; tf.cell_start = pa.cell_start;
+        tf.n_atoms = n; tf.n_tiles = n_tiles; tf.TA = fb.TA; tf.n_res = resolution; tf.tab = fb.tab;
+        tf.sasa = d_sasa; tf.lr = 1; tf.status = (int *)c->status.p;
+        tf.cap_idx = fb.cap_idx; tf.pool = fb.pool; tf.ds = fb.ds;
+        tf.work_tiles = (const int *)c->ovf_tiles2.p;
+        tf.work_count = (const int *)c->status.p + ST_OVF2_TILES;
+        tf.slab = (char *)c->slab.p;
+        tf.slab_stride = (long long)stride;
+        le = launch_lr<true, 2>(fb, tf, SASA_FB_BLOCKS, fb.lds, st);
+        if (le != hipSuccess) return ctx_fail(c, "fallback kernel launch failed: %s", hipGetErrorString(le));
+    }
+    const int rc = finish_batch(c, pa, n, n_structs, total_cells, d_sasa, d_totals, cfg.TA, 64, cfg.lds, status_h);
+    if (rc) return rc;
+    /* learn the pool size for the next batch of this kind (trajectory frames, sweeps) */
+    const int learnt = pool_from_hist(status_h + ST_HIST, cfg.TA);
+    if (learnt > 0) c->hint_nn = (double)learnt / cfg.TA;
+    return 0;
+}
+
 /* ------------------------------------------------------------------ one batch */
 
 static int run_batch_impl(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, const double *d_radii,
@@ -502,6 +644,10 @@ static int run_batch_impl(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
     hipLaunchKernelGGL(k_scatter, dim3(nblk_atoms), dim3(SASA_PIPE_B), 0, st, pa);
     HIP_TRY(c, hipGetLastError());
     if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[1], st));
+
+    /* Lee & Richards at ordinary resolutions: the second-generation kernel (lr2_kernels.h) */
+    if (lr && lr2_supported(resolution) && !getenv("FREESASA_AMD_LR1"))
+        return run_lr2(c, pa, n, n_structs, resolution, d_sasa, d_totals, total_cells);
 
     /* fused tile kernel */
     const int hi = lr ? 0 : 1;

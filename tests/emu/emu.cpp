@@ -12,9 +12,86 @@
 #include <string.h>
 #include <vector>
 
-#include "../../freesasa_amd/csrc/sasa_kernels.h"
+#include <ucontext.h>
+
+#include "../../freesasa_amd/csrc/lr2_kernels.h"
 
 using namespace sasa;
+
+/* ---------------------------------------------------------------------------------------------
+ * A wave in lock step: the second-generation L&R kernel (lr2_kernels.h) talks across its 64 lanes
+ * (ballot, shuffle, one-wave barriers).  Here every lane is a fiber (ucontext); a cross-lane
+ * operation deposits the lane's operand and yields to the scheduler, which resumes the lanes once
+ * all of them have arrived — the device's semantics for wave-uniform control flow. */
+namespace sasa_emu {
+static const int W = 64;
+static ucontext_t g_main, g_fiber[W];
+static bool g_done[W];
+static int g_lane = -1;
+static long long g_dep[W];
+static unsigned long long g_ballot;
+static void (*g_body)(int lane, void *ctx);
+static void *g_ctx;
+static std::vector<char> g_stacks;
+
+static void yield_to_scheduler() { swapcontext(&g_fiber[g_lane], &g_main); }
+unsigned long long wave_ballot(bool p)
+{
+    g_dep[g_lane] = p ? 1 : 0;
+    yield_to_scheduler(); /* the scheduler folds the deposits into g_ballot before anyone resumes */
+    return g_ballot;
+}
+void wave_sync()
+{
+    g_dep[g_lane] = 0;
+    yield_to_scheduler();
+}
+static long long g_snap[W]; /* the deposits of the last completed round */
+long long wave_exchange(long long v, int src)
+{
+    g_dep[g_lane] = v;
+    yield_to_scheduler();
+    return g_snap[src];
+}
+static void trampoline()
+{
+    g_body(g_lane, g_ctx);
+    g_done[g_lane] = true;
+    swapcontext(&g_fiber[g_lane], &g_main);
+}
+/* run body(lane, ctx) for the 64 lanes of one wave */
+static void run_wave(void (*body)(int, void *), void *ctx)
+{
+    const size_t STK = 256 * 1024;
+    if (g_stacks.empty()) g_stacks.resize(STK * W);
+    g_body = body; g_ctx = ctx;
+    for (int l = 0; l < W; ++l) {
+        getcontext(&g_fiber[l]);
+        g_fiber[l].uc_stack.ss_sp = g_stacks.data() + STK * l;
+        g_fiber[l].uc_stack.ss_size = STK;
+        g_fiber[l].uc_link = &g_main;
+        makecontext(&g_fiber[l], trampoline, 0);
+        g_done[l] = false;
+    }
+    for (;;) {
+        bool any = false;
+        for (int l = 0; l < W; ++l) {
+            if (g_done[l]) continue;
+            any = true;
+            g_lane = l;
+            swapcontext(&g_main, &g_fiber[l]);
+        }
+        if (!any) break;
+        unsigned long long b = 0;
+        for (int l = 0; l < W; ++l) {
+            if (!g_done[l] && g_dep[l]) b |= 1ull << l;
+            g_snap[l] = g_dep[l];
+        }
+        g_ballot = b;
+    }
+    g_lane = -1;
+}
+} /* namespace sasa_emu */
 
 static bool emu_bucket = true; /* the BUCKET kernel variant; emu_set_bucket(0) emulates the plain one */
 extern "C" void emu_set_bucket(int on) { emu_bucket = on != 0; }
@@ -57,6 +134,34 @@ static void emu_tile_kernel(bool lr, const TileCfg &cfg, TileArgs a, int grid)
         }
         PHASE(tile_report_flush(a, tid, wg_max_nn[tid]));
 #undef PHASE
+    }
+}
+
+/* second-generation L&R kernel: one wave (64 fibers) per tile */
+static int emu_lr2 = 1, emu_lr2_ta = 0, emu_lr2_refill = 0;
+extern "C" void emu_set_lr2(int on, int ta, int refill) { emu_lr2 = on; emu_lr2_ta = ta; emu_lr2_refill = refill; }
+
+struct Lr2Run { const Lr2Args *a; Lr2Mem *m; int tile; int rmax; int *wg_max; };
+static void lr2_lane_body(int lane, void *ctx)
+{
+    Lr2Run *r = (Lr2Run *)ctx;
+    if (r->rmax == LR2_RMAX_MAIN) lr2_tile<LR2_RMAX_MAIN>(*r->a, *r->m, r->tile, lane, r->wg_max[lane]);
+    else lr2_tile<LR2_RMAX_MID>(*r->a, *r->m, r->tile, lane, r->wg_max[lane]);
+}
+static void emu_lr2_kernel(const Lr2Cfg &cfg, Lr2Args a, int grid)
+{
+    std::vector<char> smem(cfg.lds + 64);
+    for (int blk = 0; blk < grid; ++blk) {
+        Lr2Mem m = lr2_carve(a, smem.data());
+        const int n_work = a.work_tiles ? *a.work_count : ((a.n_tiles + 7) >> 3) << 3;
+        std::vector<int> wg_max(64, 0);
+        for (int w = blk; w < n_work; w += grid) {
+            const int tile = a.work_tiles ? a.work_tiles[w] : xcd_tile(w, a.n_tiles);
+            if (tile >= a.n_tiles) continue;
+            Lr2Run run = {&a, &m, tile, cfg.rmax, wg_max.data()};
+            sasa_emu::run_wave(lr2_lane_body, &run);
+        }
+        if (wg_max[0] > a.status[ST_MAX_NN]) a.status[ST_MAX_NN] = wg_max[0];
     }
 }
 
@@ -150,6 +255,68 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
     for (int b = 0; b < nblk_atoms; ++b)
         for (int t = 0; t < PB; ++t) scatter_atom(pa, b * PB + t);
 
+    if (lr && emu_lr2 && lr2_supported(resolution)) {
+        /* main and second launch: lr2_kernels.h; third launch: the slab-backed first-generation kernel
+           over the same tiling */
+        Lr2Cfg c2 = lr2_choose_cfg(resolution, 0, emu_lr2_ta);
+        if (force_pool > 0) c2.pool = force_pool < LR2_LANES * LR2_RMAX_MAIN ? (force_pool + 1) & ~1 : LR2_LANES * LR2_RMAX_MAIN;
+        if (force_cap_idx > 0) c2.mw = (force_cap_idx + 31) / 32;
+        if (force_ds >= 0) c2.ds = force_ds;
+        if (emu_lr2_refill > 0) c2.refill = emu_lr2_refill;
+        c2.lds = lr2_layout(c2.TA, c2.ns, c2.pool, c2.mw, c2.ds).total;
+        const int n_tiles2 = (n + c2.TA - 1) / c2.TA;
+        std::vector<int> ovf1(n_tiles2 + 1), ovf2(n_tiles2 + 1);
+        Lr2Args la;
+        memset(&la, 0, sizeof la);
+        la.sx = pa.sx; la.sy = pa.sy; la.sz = pa.sz; la.sr = pa.sr; la.s_orig = pa.s_orig; la.s_struct = pa.s_struct;
+        la.s_cell = pa.s_cell; la.grid = pa.grid; la.cell_start = pa.cell_start; la.n_atoms = n; la.n_tiles = n_tiles2;
+        la.TA = c2.TA; la.ns = resolution; la.pool = c2.pool; la.mw = c2.mw; la.ds = c2.ds; la.refill = c2.refill;
+        la.sasa = sasa; la.status = status.data();
+        la.ovf_count = status.data() + ST_OVF_TILES; la.ovf_tiles = ovf1.data();
+        emu_lr2_kernel(c2, la, ((n_tiles2 + 7) / 8) * 8);
+        Lr2Cfg cm = lr2_mid_cfg(c2);
+        if (mid_cap_idx > 0) cm.mw = (mid_cap_idx + 31) / 32;
+        if (mid_pool > 0) cm.pool = mid_pool;
+        if (mid_ds >= 0) cm.ds = mid_ds;
+        cm.lds = lr2_layout(cm.TA, cm.ns, cm.pool, cm.mw, cm.ds).total;
+        Lr2Args lm = la;
+        lm.pool = cm.pool; lm.mw = cm.mw; lm.ds = cm.ds;
+        lm.work_tiles = ovf1.data(); lm.work_count = status.data() + ST_OVF_TILES;
+        lm.ovf_tiles = ovf2.data(); lm.ovf_count = status.data() + ST_OVF2_TILES;
+        emu_lr2_kernel(cm, lm, 5);
+        {
+            TileCfg fb = fallback_cfg(lr_slab_cfg(c2.TA, resolution), true);
+            if (fb_cap_idx > 0) fb.cap_idx = fb_cap_idx;
+            if (fb_pool > 0) fb.pool = fb_pool;
+            if (fb_ds > 0) fb.ds = fb_ds;
+            const size_t stride = tile_slab_bytes(fb.TA, fb.cap_idx, fb.pool, fb.lr, fb.ds, fb.B);
+            const int fb_blocks = 3;
+            std::vector<char> slab(stride * fb_blocks + 64);
+            TileArgs tf;
+            memset(&tf, 0, sizeof tf);
+            tf.sx = pa.sx; tf.sy = pa.sy; tf.sz = pa.sz; tf.sr = pa.sr; tf.s_orig = pa.s_orig; tf.s_cell = pa.s_cell; tf.s_struct = pa.s_struct;
+            tf.grid = pa.grid; tf.cell_start = pa.cell_start; tf.n_atoms = n; tf.n_tiles = n_tiles2; tf.TA = fb.TA; tf.n_res = resolution; tf.tab = fb.tab;
+            tf.sasa = sasa; tf.lr = 1; tf.status = status.data();
+            tf.cap_idx = fb.cap_idx; tf.pool = fb.pool; tf.ds = fb.ds;
+            tf.work_tiles = ovf2.data(); tf.work_count = status.data() + ST_OVF2_TILES;
+            tf.slab = slab.data(); tf.slab_stride = (long long)stride;
+            emu_tile_kernel<true>(true, fb, tf, fb_blocks);
+        }
+        if (totals) {
+            double part[SASA_TOT_B];
+            std::vector<double> chunk_tot(pa.n_chunks > 0 ? pa.n_chunks : 1);
+            for (int ch = 0; ch < pa.n_chunks; ++ch) {
+                for (int l = 0; l < SASA_TOT_B; ++l) totals_chunk_phase0(pa, sasa, part, ch, l);
+                for (int l = 0; l < SASA_TOT_B; ++l) totals_chunk_phase1(part, chunk_tot.data(), ch, l);
+            }
+            for (int s = 0; s < ((n_structs + 255) / 256) * 256; ++s) totals_struct(pa, chunk_tot.data(), totals, s);
+        }
+        stats_out[0] = status[ST_ERROR]; stats_out[1] = status[ST_OVF_TILES]; stats_out[2] = status[ST_MAX_NN];
+        stats_out[3] = c2.TA; stats_out[4] = 64; stats_out[5] = (long long)c2.lds; stats_out[6] = total_cells;
+        stats_out[7] = c2.TA * resolution;
+        stats_out[8] = status[ST_OVF2_TILES]; stats_out[9] = 0;
+        return status[ST_ERROR] ? -1 : 0;
+    }
     TileCfg cfg = choose_cfg(resolution, lr != 0);
     if (force_cap_idx > 0) cfg.cap_idx = force_cap_idx;
     if (force_pool > 0) cfg.pool = force_pool;
