@@ -18,7 +18,7 @@ all: $(LIBDIR)/libfreesasa_amd.so $(LIBDIR)/libfreesasa_amd_seam.a
 
 # the compiler's per-kernel resource report (registers, scratch, LDS) is kept next to the object:
 # tests/test_capi.py checks that the hot kernels do not spill
-$(LIBDIR)/gpu_engine.o: $(CSRC)/gpu_engine.hip $(CSRC)/sasa_kernels.h include/freesasa_gpu.h include/freesasa_ingest.h
+$(LIBDIR)/gpu_engine.o: $(CSRC)/gpu_engine.hip $(CSRC)/sasa_kernels.h $(CSRC)/lr2_kernels.h include/freesasa_gpu.h include/freesasa_ingest.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(LIBDIR)/kernel_resources.txt; rc=$$?; \
 	grep -v "remark:" $(LIBDIR)/kernel_resources.txt >&2; exit $$rc
@@ -53,7 +53,7 @@ emu: tests/emu/libsasa_emu.so tests/emu/libingest_scalar.so
 # the loader with its byte-at-a-time mmCIF tokenizer only: the differential twin of the SSE2 row scanner
 tests/emu/libingest_scalar.so: $(CSRC)/ingest.c $(CSRC)/protor_table.h include/freesasa_ingest.h
 	$(CC) $(CFLAGS) -DFREESASA_INGEST_NO_SIMD -Iinclude -pthread -shared -o $@ $(CSRC)/ingest.c -lm
-tests/emu/libsasa_emu.so: tests/emu/emu.cpp $(CSRC)/sasa_kernels.h
+tests/emu/libsasa_emu.so: tests/emu/emu.cpp $(CSRC)/sasa_kernels.h $(CSRC)/lr2_kernels.h
 	$(CXX) -O2 -std=c++17 -fPIC -ffp-contract=off -DSASA_EMU -shared -o $@ tests/emu/emu.cpp -lm
 
 oracle: $(LIBDIR)/libfreesasa_amd_seam.a

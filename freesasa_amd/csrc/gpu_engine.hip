@@ -20,6 +20,12 @@
 #include "../../include/freesasa_gpu.h"
 #include "../../include/freesasa_ingest.h"
 #include "sasa_kernels.h"
+#ifdef SASA_PHASE_TIMING /* dev only (tools/build_variant.sh X -DSASA_PHASE_TIMING): where a wave's time per tile goes */
+__device__ unsigned long long g_phase_clock[16];
+#define LR2_MARK_BEGIN unsigned long long lr2_last_ = wall_clock64(); if (lane == 0 && !a.work_tiles && (tile & 255) == 0) atomicAdd(&g_phase_clock[15], 1ULL)
+#define LR2_MARK(k) do { if (lane == 0 && !a.work_tiles && (tile & 255) == 0) { const unsigned long long now_ = wall_clock64(); \
+        atomicAdd(&g_phase_clock[(k)], now_ - lr2_last_); lr2_last_ = now_; } } while (0)
+#endif
 #include "lr2_kernels.h"
 
 using namespace sasa;
@@ -143,8 +149,7 @@ __global__ __launch_bounds__(SASA_TOT_B) void k_class_sums(const double *sasa, c
 /* TIER only names the launch (0 main, 1 second, 2 slab) so that profiles list them separately.
  * WPE = waves per SIMD the register allocation is capped for: 4 (128 VGPRs), or 5 (96 VGPRs, no
  * spill since atan2_fast) when the tile's LDS footprint lets more than 16 one-wave tiles reside. */
-#ifdef SASA_PHASE_TIMING /* dev only (tools/build_variant.sh X -DSASA_PHASE_TIMING): where a wave's time per tile goes */
-__device__ unsigned long long g_phase_clock[16];
+#ifdef SASA_PHASE_TIMING
 #define PHASE_MARK(k) do { if (tid == 0 && TIER == 0 && (tile & 255) == 0) { const unsigned long long now_ = wall_clock64(); \
         atomicAdd(&g_phase_clock[k], now_ - last_); last_ = now_; } } while (0)
 #else
@@ -223,8 +228,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     }
     if (lane == 0 && wg_max_nn > a.status[ST_MAX_NN]) atomicMax(&a.status[ST_MAX_NN], wg_max_nn);
 }
-template __global__ void k_lr2_tile<LR2_RMAX_MAIN, 0, 4>(Lr2Args);
-template __global__ void k_lr2_tile<LR2_RMAX_MID, 1, 2>(Lr2Args);
+/* main launch: the instantiation is picked by the rounds of pair records the pool needs and by the waves per
+ * SIMD the tile's LDS footprint allows */
+static hipError_t launch_lr2_main(int rmax, int wpe, int grid, size_t lds, hipStream_t st, const Lr2Args &la)
+{
+#define LR2_LAUNCH(R, W) hipLaunchKernelGGL((k_lr2_tile<R, 0, W>), dim3(grid), dim3(64), lds, st, la)
+    if (wpe >= 5) {
+        if (rmax <= 2) LR2_LAUNCH(2, 5); else if (rmax == 3) LR2_LAUNCH(3, 5); else LR2_LAUNCH(4, 5);
+    } else {
+        if (rmax <= 2) LR2_LAUNCH(2, 4); else if (rmax == 3) LR2_LAUNCH(3, 4); else LR2_LAUNCH(4, 4);
+    }
+#undef LR2_LAUNCH
+    return hipGetLastError();
+}
 
 template <int B, bool GLOBAL, int TIER>
 __global__ __launch_bounds__(B) void k_sr_tile(TileArgs a, int items)
@@ -424,6 +440,23 @@ static const char *err_text(int code)
 
 /* ------------------------------------------------------------------ L&R, second generation */
 
+static void dump_phase_clocks()
+{
+#ifdef SASA_PHASE_TIMING
+    {
+        unsigned long long h[16];
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_clock), sizeof h) == hipSuccess && h[15]) {
+            static const char *names[8] = {"P0/load", "P1/neighbors", "P2/offsets", "P3/report|pairs", "P4/beta|screen", "P5/rank|queue", "P6/slices|arcs", "P7/store"};
+            fprintf(stderr, "phase clocks (100 MHz ticks per sampled tile, thread 0, %llu tiles):", h[15]);
+            for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.1f", names[k], (double)h[k] / (double)h[15]);
+            fprintf(stderr, "\n");
+            memset(h, 0, sizeof h);
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_clock), h, sizeof h);
+        }
+    }
+#endif
+}
+
 static int finish_batch(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs, long long total_cells, double *d_sasa,
                         double *d_totals, int tile_atoms, int block_threads, int lds, int *status_h)
 {
@@ -449,6 +482,7 @@ static int finish_batch(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_st
         if (hipEventElapsedTime(&ms, c->ev[0], c->ev[3]) == hipSuccess) S.ms_total = ms;
     }
     if (status_h[ST_ERROR]) return ctx_fail(c, "%s", err_text(status_h[ST_ERROR]));
+    dump_phase_clocks();
     return 0;
 }
 
@@ -493,8 +527,9 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
         const int g = atoi(e);
         if (g >= 8 && g < grid_main) grid_main = (g / 8) * 8;
     }
-    hipLaunchKernelGGL((k_lr2_tile<LR2_RMAX_MAIN, 0, 4>), dim3(grid_main), dim3(64), (size_t)cfg.lds, st, la);
-    hipError_t le = hipGetLastError();
+    int wpe = 160 * 1024 / cfg.lds >= 20 ? 5 : 4; /* five waves per SIMD need the registers capped at 96 */
+    if (const char *e = getenv("FREESASA_AMD_WPE")) wpe = atoi(e); /* tuning aid */
+    hipError_t le = launch_lr2_main(cfg.rmax, wpe, grid_main, (size_t)cfg.lds, st, la);
     if (le != hipSuccess) return ctx_fail(c, "tile kernel launch failed: %s", hipGetErrorString(le));
     if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[2], st));
 
@@ -792,19 +827,7 @@ static int run_batch_impl(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
         if (hipEventElapsedTime(&ms, c->ev[0], c->ev[3]) == hipSuccess) S.ms_total = ms;
     }
     if (status_h[ST_ERROR]) return ctx_fail(c, "%s", err_text(status_h[ST_ERROR]));
-#ifdef SASA_PHASE_TIMING
-    {
-        unsigned long long h[16];
-        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_clock), sizeof h) == hipSuccess && h[15]) {
-            static const char *names[8] = {"load", "neighbors", "offsets", "report", "beta", "rank", "slices", "store"};
-            fprintf(stderr, "phase clocks (100 MHz ticks per sampled tile, thread 0, %llu tiles):", h[15]);
-            for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.1f", names[k], (double)h[k] / (double)h[15]);
-            fprintf(stderr, "\n");
-            memset(h, 0, sizeof h);
-            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_clock), h, sizeof h);
-        }
-    }
-#endif
+    dump_phase_clocks();
     /* learn the pool size for the next batch of this kind (trajectory frames, sweeps) */
     c->hint_res[hi] = resolution;
     c->hint_ta[hi] = cfg.TA;

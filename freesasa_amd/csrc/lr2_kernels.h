@@ -59,6 +59,15 @@ long long wave_exchange(long long v, int src);
 
 namespace sasa {
 
+#ifndef LR2_STOP_AFTER /* dev only (tools/build_variant.sh): return after phase k, for instruction attribution */
+#define LR2_STOP_AFTER 99
+#endif
+#define LR2_STOP(k) do { if (LR2_STOP_AFTER == (k)) return; } while (0)
+#ifndef LR2_MARK /* dev only (-DSASA_PHASE_TIMING in gpu_engine.hip): wall clock of lane 0 at the phase boundaries */
+#define LR2_MARK(k) do { } while (0)
+#define LR2_MARK_BEGIN do { } while (0)
+#endif
+
 #define LR2_LANES 64
 #define LR2_NONE 0xffff
 
@@ -83,72 +92,79 @@ struct Lr2Args {
     int *status;
 };
 
-struct __attribute__((aligned(16))) Pair16 { double a, b; };
+/* One neighbor record of P3..P6, 24 B: cos(alpha) of the arc the neighbor cuts at slice height t is
+ * (b + a t) * 1/(2 Ri') (see lr2_record); beta = direction of the neighbor in the slice plane. */
+struct Rec24 { double a, b, beta; };
 
 /* LDS layout of one tile (byte offsets), shared by the host (launch size) and the device */
 struct Lr2Layout {
-    int o_atoms, o_ints, o_t, o_ch, o_mask, o_queue, o_qtmp, o_r1, o_r2, total;
+    int o_atoms, o_ints, o_rec, o_ch, o_mask, o_queue, o_t, o_r2, o_tag, total;
 };
 SASA_HD int lr2_a16(int v) { return (v + 15) & ~15; }
-SASA_HD int lr2_n_ints(int TA) { return 6 * TA + 1 + 8 + 18 * TA + (9 * TA + 2) + 64; }
+SASA_HD int lr2_n_ints(int TA) { return 6 * TA + 1 + 8 + 18 * TA + (9 * TA + 2); }
 SASA_HD Lr2Layout lr2_layout(int TA, int ns, int pool, int mw, int ds)
 {
     Lr2Layout L;
     const int items = TA * ns;
     int p = 0;
-    L.o_atoms = p; p += lr2_a16(8 * 5 * TA);
+    L.o_atoms = p; p += 32 * TA + lr2_a16(8 * TA);
     L.o_ints = p;  p += lr2_a16(4 * lr2_n_ints(TA));
-    L.o_t = p;     p += lr2_a16(8 * items);
+    /* records (24 B each; P3..P6), then slice areas and masks (P4..P7).  The hits of P1 (32 B each) lie
+       over the three of them until P3 has taken every hit into registers */
+    L.o_rec = p;   p += lr2_a16(24 * pool);
     L.o_ch = p;    p += lr2_a16(8 * items);
     L.o_mask = p;  p += lr2_a16(4 * items * mw);
+    if (p - L.o_rec < 32 * pool) p = L.o_rec + 32 * pool;
     L.o_queue = p; p += lr2_a16(2 * items);
-    L.o_qtmp = p;  p += lr2_a16(2 * items);
-    /* R1: the hits of P1 (32 B each), overwritten in P3 by the records (a', b': 16 B, beta: 8 B) */
-    L.o_r1 = p;    p += 32 * pool;
-    /* R2: sort keys and hit tags of P1..P3, then the arc stack of P6 */
-    const int r2a = lr2_a16(8 * pool) + lr2_a16(4 * pool), r2b = 16 * LR2_LANES * ds;
-    L.o_r2 = p;    p += r2a > r2b ? r2a : r2b;
+    L.o_t = p;     p += lr2_a16(8 * items);
+    /* R2: sort keys and hit tags (P1..P3), then queue scratch (P4, P5), then the arc stack (P6) */
+    int r2 = lr2_a16(8 * pool) + lr2_a16(4 * pool);
+    const int r2q = lr2_a16(2 * items) + 256, r2s = 16 * LR2_LANES * (ds > 0 ? ds : 1); /* (one column level even when ds == 0: see lr2_union_step) */
+    if (r2q > r2) r2 = r2q;
+    if (r2s > r2) r2 = r2s;
+    L.o_r2 = p;
+    L.o_tag = p + lr2_a16(8 * pool);
+    p += r2;
     L.total = p;
     return L;
 }
 
 struct Lr2Mem {
-    double *ax, *ay, *az, *aR, *adel; /* [TA] tile atoms; adel = 2 Ri / ns (ref: src/sasa_lr.c:304) */
+    Quad *atom;   /* [TA] x, y, z, R + probe of the tile atoms */
+    double *adel; /* [TA] 2 Ri / ns (ref: src/sasa_lr.c:304) */
     int *acell, *lead, *gsz, *acnt, *aoff, *sorig, *flags, *rowlo, *rowcnt, *cpre, *hist;
     double *it_t;   /* [items] slice height relative to the atom centre, z - zi */
     double *it_ch;  /* [items] 1/(2 Ri') of a queued item; its slice area once it is done */
     unsigned *it_mask; /* [items*mw] neighbors that cut an arc */
-    unsigned short *queue; /* [items] items with arcs, heaviest first */
+    unsigned short *queue; /* [items] items with arcs, heaviest first: item | atom << 10 */
     unsigned short *qtmp;  /* [items] bin and arrival order of an item before the bins are laid out */
     Quad *hits;     /* [pool] (xd, yd, zd, Rj) of the neighbors found, in order of discovery */
-    Pair16 *ab;     /* [pool] records, sorted by beta inside each atom's list */
-    double *beta;   /* [pool] */
+    Rec24 *rec;     /* [pool] records, sorted by beta inside each atom's list */
     double *keys;   /* [pool] beta with the list position in its low mantissa bits */
-    unsigned *tag;  /* [pool] atom (low 8 bits) and list position of hit */
+    unsigned *tag;  /* [pool] atom (low 8 bits) and list position of a hit */
     Arc *stack;     /* [ds][64] */
 };
-/* flags: 0 tile overflow, 1 stack overflow, 2 max neighbor count, 3 hits found, 4 queue length */
+/* flags: 0 tile overflow, 1 stack overflow, 2 max neighbor count, 5 largest cell group */
 
 SASA_D Lr2Mem lr2_carve(const Lr2Args &a, char *smem)
 {
     const Lr2Layout L = lr2_layout(a.TA, a.ns, a.pool, a.mw, a.ds);
     const int TA = a.TA;
     Lr2Mem m;
-    m.ax = (double *)(smem + L.o_atoms); m.ay = m.ax + TA; m.az = m.ay + TA; m.aR = m.az + TA; m.adel = m.aR + TA;
+    m.atom = (Quad *)(smem + L.o_atoms); m.adel = (double *)(smem + L.o_atoms + 32 * TA);
     int *q = (int *)(smem + L.o_ints);
     m.acell = q; q += TA; m.lead = q; q += TA; m.gsz = q; q += TA; m.acnt = q; q += TA; m.aoff = q; q += TA + 1;
-    m.sorig = q; q += TA; m.flags = q; q += 8; m.rowlo = q; q += 9 * TA; m.rowcnt = q; q += 9 * TA; m.cpre = q; q += 9 * TA + 2;
-    m.hist = q;
+    m.sorig = q; q += TA; m.flags = q; q += 8; m.rowlo = q; q += 9 * TA; m.rowcnt = q; q += 9 * TA; m.cpre = q;
     m.it_t = (double *)(smem + L.o_t);
     m.it_ch = (double *)(smem + L.o_ch);
     m.it_mask = (unsigned *)(smem + L.o_mask);
     m.queue = (unsigned short *)(smem + L.o_queue);
-    m.qtmp = (unsigned short *)(smem + L.o_qtmp);
-    m.hits = (Quad *)(smem + L.o_r1);
-    m.ab = (Pair16 *)(smem + L.o_r1);
-    m.beta = (double *)(smem + L.o_r1 + 16 * a.pool);
+    m.hits = (Quad *)(smem + L.o_rec);
+    m.rec = (Rec24 *)(smem + L.o_rec);
     m.keys = (double *)(smem + L.o_r2);
-    m.tag = (unsigned *)(smem + L.o_r2 + lr2_a16(8 * a.pool));
+    m.tag = (unsigned *)(smem + L.o_tag);
+    m.hist = (int *)(smem + L.o_r2);
+    m.qtmp = (unsigned short *)(smem + L.o_r2 + 256);
     m.stack = (Arc *)(smem + L.o_r2);
     return m;
 }
@@ -176,53 +192,76 @@ SASA_D void lr2_record(double xd, double yd, double zd, double rj, double ri, do
     if (!(D > 0) && zd == 0 && K == 0) bp = NAN;
 }
 
-/* one step of the arc union on raw end points (inf may be negative, sup may exceed 2 pi: every arc
- * contains its beta in [0, 2 pi], so only the lowest component can start below 0 and only the
- * highest can end above 2 pi; lr2_sweep folds them back) */
-SASA_D void lr2_union_step(double inf, double sup, double &ts, double &te, int &depth, Arc *stk, int ds, int &err)
+/* Arc union on raw end points (inf may be negative, sup may exceed 2 pi: every arc contains its beta
+ * in [0, 2 pi], so only the lowest component can start below 0 and only the highest can end above
+ * 2 pi; lr2_sweep folds them back).  Arcs arrive ordered by beta, so the disjoint components form a
+ * stack (sasa_kernels.h, lr_arcs32): the two highest live in registers (ts,te above bs,be; be = -inf
+ * while there is no second one), the ones below them in the lane's LDS column. */
+struct Lr2Union {
+    double ts, te, bs, be;
+    int depth;
+};
+SASA_D void lr2_union_reset(Lr2Union &u) { u.ts = 0; u.te = -INFINITY; u.bs = 0; u.be = -INFINITY; u.depth = 0; }
+SASA_D int lr2_med3(int v, int lo, int hi)
 {
-    const bool fresh = inf > te; /* te = -inf while there is no component */
-    if (fresh && depth > 0) {
-        if (depth - 1 < ds) {
-            Arc t; t.s = ts; t.e = te;
-            stk[(depth - 1) * LR2_LANES] = t;
+#ifdef SASA_EMU
+    return v < lo ? lo : (v > hi ? hi : v);
+#else
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "s"(lo), "v"(hi));
+    return r;
+#endif
+}
+/* maxd: the largest depth the lane has seen (a tile whose stack column was too short is redone) */
+SASA_D void lr2_union_step(double inf, double sup, Lr2Union &u, Arc *stk, int ds, int &maxd)
+{
+    const bool fresh = inf > u.te; /* te = -inf while there is no component */
+    const double mts = SASA_MIN(u.ts, inf), mte = SASA_MAX(u.te, sup);
+    if (fresh) {
+        /* the second component goes to the LDS column, the top one becomes the second.  With fewer than
+           two components the store lands in level 0, which is not in use then (it is written again,
+           properly, by the push that makes a third component) */
+        Arc t; t.s = u.bs; t.e = u.be;
+        stk[lr2_med3(u.depth - 2, 0, ds > 0 ? ds - 1 : 0) * LR2_LANES] = t;
+        u.bs = u.ts; u.be = u.te;
+    }
+    u.ts = fresh ? inf : mts;
+    u.te = fresh ? sup : mte;
+    u.depth += fresh ? 1 : 0;
+    maxd = maxd > u.depth ? maxd : u.depth;
+    while (u.be >= u.ts) { /* the merged component reaches the one below it (never after a push: be = old te < inf) */
+        u.ts = SASA_MIN(u.ts, u.bs);
+        --u.depth;
+        if (u.depth >= 2) {
+            const Arc lo = stk[lr2_med3(u.depth - 2, 0, ds > 0 ? ds - 1 : 0) * LR2_LANES];
+            u.bs = lo.s; u.be = lo.e;
         } else {
-            err = 1;
+            u.be = -INFINITY;
         }
     }
-    ts = fresh ? inf : SASA_MIN(ts, inf);
-    te = fresh ? sup : SASA_MAX(te, sup);
-    depth += fresh ? 1 : 0;
-    if (!fresh)
-        while (depth > 1) { /* the merged component may now reach the ones below it */
-            const int lv = depth - 2 < ds ? depth - 2 : 0; /* (beyond ds: err is set, the tile is redone) */
-            const Arc lo = stk[lv * LR2_LANES];
-            if (lo.e < ts) break;
-            ts = SASA_MIN(ts, lo.s);
-            --depth;
-        }
 }
 
-/* exposed arc length from the final components (ascending; the top one in ts/te).
+/* exposed arc length from the final components (ascending).
  * ref: src/sasa_lr.c:340-351 (arcs through the origin) and :389-408 (sweep) */
-SASA_D double lr2_sweep(double ts, double te, int depth, const Arc *stk, int ds)
+SASA_D double lr2_sweep(const Lr2Union &u, const Arc *stk, int ds)
 {
+    const int depth = u.depth;
     if (depth == 0) return SASA_TWOPI; /* ref: :392 */
-    const double b_s = depth > 1 ? stk[0].s : ts; /* lowest component */
-    const bool wrap = b_s < 0 || te > SASA_TWOPI;
-    const double Vlo = b_s < 0 ? b_s + SASA_TWOPI : SASA_TWOPI; /* ref: :340 */
-    const double Vhi = te > SASA_TWOPI ? ts : SASA_TWOPI;        /* the piece [inf, 2pi] of an arc whose sup wraps */
-    const double V = SASA_MIN(Vlo, Vhi);
-    const double W = te > SASA_TWOPI ? te - SASA_TWOPI : 0.0;   /* ref: :341 */
+    const double b_s = depth == 1 ? u.ts : (depth == 2 ? u.bs : stk[0].s); /* lowest component */
+    const bool wrap = b_s < 0 || u.te > SASA_TWOPI;
+    const double Vlo = b_s < 0 ? b_s + SASA_TWOPI : SASA_TWOPI;   /* ref: :340 */
+    const double Vhi = u.te > SASA_TWOPI ? u.ts : SASA_TWOPI;     /* the piece [inf, 2pi] of an arc whose sup wraps */
+    const double V = Vlo < Vhi ? Vlo : Vhi;
+    const double W = u.te > SASA_TWOPI ? u.te - SASA_TWOPI : 0.0; /* ref: :341 */
     double sum = 0, sup = W;
     for (int c = 0; c < depth; ++c) {
-        const bool top = c == depth - 1;
-        const int lv = c < ds ? c : 0;
-        const Arc k = top ? Arc{ts, te} : stk[lv * LR2_LANES];
-        const double ce = top && te > SASA_TWOPI ? SASA_TWOPI : k.e;
-        if (wrap && k.s >= V) break; /* sorted behind the [V, 2pi] piece: covered */
-        if (sup < k.s) sum += k.s - sup;
-        if (ce > sup) sup = ce;
+        double ks, ke;
+        if (c == depth - 1) { ks = u.ts; ke = u.te > SASA_TWOPI ? SASA_TWOPI : u.te; }
+        else if (c == depth - 2) { ks = u.bs; ke = u.be; }
+        else { const Arc k = stk[(c < ds ? c : 0) * LR2_LANES]; ks = k.s; ke = k.e; }
+        if (wrap && ks >= V) break; /* sorted behind the [V, 2pi] piece: covered */
+        if (sup < ks) sum += ks - sup;
+        if (ke > sup) sup = ke;
     }
     if (wrap) {
         if (sup < V) sum += V - sup;
@@ -230,6 +269,8 @@ SASA_D double lr2_sweep(double ts, double te, int depth, const Arc *stk, int ds)
     }
     return sum + SASA_TWOPI - sup; /* ref: :407 */
 }
+
+#define LR2_NB_UNROLL 3
 
 /* The whole tile, executed by the 64 lanes of one wave.  RMAX = rounds of 64 pair records a lane
  * keeps in registers in P3 (pool <= 64 * RMAX). */
@@ -240,25 +281,24 @@ SASA_D void lr2_tile(const Lr2Args &a, const Lr2Mem &m, int tile, int lane, int 
     const int p0 = tile * TA;
     const int na = a.n_atoms - p0 < TA ? a.n_atoms - p0 : TA;
     const int items = na * ns;
+    LR2_MARK_BEGIN;
 
     /* ------------------------------------------------------------ P0 load */
     if (lane < TA) {
+        Quad q; q.x = q.y = q.z = 0; q.w = 1;
+        double del = 0;
+        int cell = -1 - lane, so = 0;
         if (lane < na) {
             const int p = p0 + lane;
-            const double R = a.sr[p];
-            m.ax[lane] = a.sx[p]; m.ay[lane] = a.sy[p]; m.az[lane] = a.sz[p]; m.aR[lane] = R;
-            m.adel[lane] = 2 * R / ns; /* ref: src/sasa_lr.c:304 */
-            m.acell[lane] = (int)(a.s_cell[p] & 0xffffffffLL);
-            m.sorig[lane] = a.s_orig[p];
-        } else {
-            m.ax[lane] = m.ay[lane] = m.az[lane] = 0; m.aR[lane] = 1; m.adel[lane] = 0;
-            m.acell[lane] = -1 - lane;
-            m.sorig[lane] = 0;
+            q.x = a.sx[p]; q.y = a.sy[p]; q.z = a.sz[p]; q.w = a.sr[p];
+            del = 2 * q.w / ns; /* ref: src/sasa_lr.c:304 */
+            cell = (int)(a.s_cell[p] & 0xffffffffLL);
+            so = a.s_orig[p];
         }
+        m.atom[lane] = q; m.adel[lane] = del; m.acell[lane] = cell; m.sorig[lane] = so;
         m.acnt[lane] = 0;
     }
     if (lane < 8) m.flags[lane] = 0;
-    m.hist[lane] = 0;
     int my_cnt = 0; /* candidates of row `lane` (rows of atoms that do not lead a cell group count 0) */
     if (lane < 9 * TA) {
         const int la = lane / 9, r = lane - 9 * la;
@@ -293,7 +333,7 @@ SASA_D void lr2_tile(const Lr2Args &a, const Lr2Mem &m, int tile, int lane, int 
         m.gsz[lane] = gs;
         if (gs > 0) SASA_ATOMIC_MAX_LDS(&m.flags[5], gs);
         if (lane < na) { /* slice heights, accumulated like the reference (src/sasa_lr.c:304-307) */
-            const double zi = m.az[lane], Ri = m.aR[lane], delta = m.adel[lane];
+            const double zi = m.atom[lane].z, Ri = m.atom[lane].w, delta = m.adel[lane];
             double z = zi - Ri - 0.5 * delta;
             for (int s = 0; s < ns; ++s) {
                 z += delta;
@@ -311,6 +351,8 @@ SASA_D void lr2_tile(const Lr2Args &a, const Lr2Mem &m, int tile, int lane, int 
     if (lane < 9 * TA) m.cpre[lane + 1] = incl;
     LR2_SYNC();
 
+    LR2_STOP(0);
+    LR2_MARK(0);
     /* ------------------------------------------------------------ P1 neighbors */
     const int nrows = 9 * TA;
     const int total_c = m.cpre[nrows];
@@ -318,17 +360,17 @@ SASA_D void lr2_tile(const Lr2Args &a, const Lr2Mem &m, int tile, int lane, int 
     {
         const int per = (total_c + LR2_LANES - 1) / LR2_LANES; /* consecutive candidates per lane */
         const int gmax = m.flags[5];
-        int f = lane * per;
+        const int f = lane * per;
         const int fend = f + per < total_c ? f + per : total_c;
         int t = 0;
         if (f < total_c) { /* row of the lane's first candidate: largest t with cpre[t] <= f */
             for (int step = 32; step >= 1; step >>= 1)
                 if (t + step <= nrows && m.cpre[t + step] <= f) t += step;
         }
-        for (int base = 0; base < per; base += 2) { /* (wave-uniform trip count) */
-            int q[2], la0[2], gs[2];
-            double x[2], y[2], z[2], rq[2];
-            for (int j = 0; j < 2; ++j) {
+        for (int base = 0; base < per; base += LR2_NB_UNROLL) { /* (wave-uniform trip count) */
+            int q[LR2_NB_UNROLL], la0[LR2_NB_UNROLL], gs[LR2_NB_UNROLL];
+            double x[LR2_NB_UNROLL], y[LR2_NB_UNROLL], z[LR2_NB_UNROLL], rq[LR2_NB_UNROLL];
+            for (int j = 0; j < LR2_NB_UNROLL; ++j) {
                 const int fj = f + base + j;
                 if (base + j < per && fj < fend) {
                     while (fj >= m.cpre[t + 1]) ++t;
@@ -339,29 +381,30 @@ SASA_D void lr2_tile(const Lr2Args &a, const Lr2Mem &m, int tile, int lane, int 
                     q[j] = -1; la0[j] = 0; gs[j] = 0;
                 }
             }
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < LR2_NB_UNROLL; ++j) {
                 const unsigned u = (unsigned)(q[j] < 0 ? 0 : q[j]);
                 x[j] = a.sx[u]; y[j] = a.sy[u]; z[j] = a.sz[u]; rq[j] = a.sr[u];
             }
-            for (int g = 0; g < gmax; ++g)
-                for (int j = 0; j < 2; ++j) {
-                    const int la = la0[j] + g;
-                    bool hit = false;
-                    double dx = 0, dy = 0, dz = 0;
-                    if (g < gs[j] && q[j] != p0 + la) {
-                        /* the reference's contact test, operand for operand (src/nb.c:483-492) */
-                        const double ri = m.aR[la];
-                        const double cut2 = (ri + rq[j]) * (ri + rq[j]);
-                        dx = x[j] - m.ax[la]; dy = y[j] - m.ay[la]; dz = z[j] - m.az[la];
-                        hit = dx * dx + dy * dy + dz * dz < cut2;
-                    }
-                    const unsigned long long hm = LR2_BALLOT(hit);
+            for (int g = 0; g < gmax; ++g) {
+                bool hit[LR2_NB_UNROLL];
+                double dx[LR2_NB_UNROLL], dy[LR2_NB_UNROLL], dz[LR2_NB_UNROLL];
+                Quad ai[LR2_NB_UNROLL];
+                for (int j = 0; j < LR2_NB_UNROLL; ++j) ai[j] = m.atom[g < gs[j] ? la0[j] + g : 0];
+                for (int j = 0; j < LR2_NB_UNROLL; ++j) {
+                    /* the reference's contact test, operand for operand (src/nb.c:483-492) */
+                    const double cut2 = (ai[j].w + rq[j]) * (ai[j].w + rq[j]);
+                    dx[j] = x[j] - ai[j].x; dy[j] = y[j] - ai[j].y; dz[j] = z[j] - ai[j].z;
+                    hit[j] = g < gs[j] && q[j] != p0 + la0[j] + g && dx[j] * dx[j] + dy[j] * dy[j] + dz[j] * dz[j] < cut2;
+                }
+                for (int j = 0; j < LR2_NB_UNROLL; ++j) {
+                    const unsigned long long hm = LR2_BALLOT(hit[j]);
                     if (hm) {
-                        if (hit) {
+                        if (hit[j]) {
+                            const int la = la0[j] + g;
                             const int slot = nh + LR2_RANK(hm, lane);
                             const int sa = SASA_ATOMIC_ADD_LDS(&m.acnt[la], 1);
                             if (slot < a.pool) {
-                                Quad hq; hq.x = dx; hq.y = dy; hq.z = dz; hq.w = rq[j]; /* ref: src/nb.c:445-448 */
+                                Quad hq; hq.x = dx[j]; hq.y = dy[j]; hq.z = dz[j]; hq.w = rq[j]; /* ref: src/nb.c:445-448 */
                                 m.hits[slot] = hq;
                                 m.tag[slot] = (unsigned)la | ((unsigned)sa << 8);
                             }
@@ -369,10 +412,13 @@ SASA_D void lr2_tile(const Lr2Args &a, const Lr2Mem &m, int tile, int lane, int 
                         nh += LR2_POPC64(hm);
                     }
                 }
+            }
         }
     }
     LR2_SYNC();
 
+    LR2_STOP(1);
+    LR2_MARK(1);
     /* ------------------------------------------------------------ P2 offsets */
     if (lane < TA) {
         int off = 0;
@@ -408,56 +454,80 @@ SASA_D void lr2_tile(const Lr2Args &a, const Lr2Mem &m, int tile, int lane, int 
         return;
     }
 
+    LR2_STOP(2);
+    LR2_MARK(2);
     /* ------------------------------------------------------------ P3 pair records */
     {
-        double r_a[RMAX], r_b[RMAX], r_beta[RMAX];
-        int r_la[RMAX], r_sa[RMAX];
+        double r_a[RMAX], r_b[RMAX], r_beta[RMAX], r_key[RMAX];
+        int r_pos[RMAX]; /* first record of the pair's atom | list length << 16; -1: no pair */
         unsigned low = 0xfffu;
         SASA_OPAQUE(low);
         for (int r = 0; r < RMAX; ++r) {
             const int gp = lane + LR2_LANES * r;
-            r_la[r] = -1;
+            r_pos[r] = -1;
             if (gp < nh) {
                 const Quad hq = m.hits[gp];
                 const unsigned tg = m.tag[gp];
                 const int la = (int)(tg & 0xffu), sa = (int)(tg >> 8);
-                r_la[r] = la; r_sa[r] = sa;
-                lr2_record(hq.x, hq.y, hq.z, hq.w, m.aR[la], r_a[r], r_b[r]);
+                const int o = m.aoff[la];
+                r_pos[r] = o | (m.acnt[la] << 16);
+                lr2_record(hq.x, hq.y, hq.z, hq.w, m.atom[la].w, r_a[r], r_b[r]);
                 r_beta[r] = atan2_fast(hq.y, hq.x) + SASA_PI; /* ref: src/sasa_lr.c:337 */
-                m.keys[m.aoff[la] + sa] = lr_rank_key(r_beta[r], (unsigned)sa, low);
+                r_key[r] = lr_rank_key(r_beta[r], (unsigned)sa, low);
+                m.keys[o + sa] = r_key[r];
             }
         }
         if (lane < TA && (m.acnt[lane] & 1)) m.keys[m.aoff[lane] + m.acnt[lane]] = INFINITY; /* never ranks below */
         LR2_SYNC(); /* every hit is in registers: R1 may now take the records */
-        for (int r = 0; r < RMAX; ++r) {
-            if (r_la[r] < 0) continue;
-            const int la = r_la[r], o = m.aoff[la], nn = m.acnt[la];
-            const double kme = lr_rank_key(r_beta[r], (unsigned)r_sa[r], low);
-            int rank = 0;
-            for (int t = 0; t < nn; t += 2) { /* two keys per LDS read (o is even) */
-                const Arc kk = *(const Arc *)(m.keys + o + t);
-                rank += kk.s < kme ? 1 : 0;
-                rank += kk.e < kme ? 1 : 0;
+        {
+            /* rank of every pair inside its atom's list: all rounds walk their lists together, four keys per
+               round and trip, so that the LDS reads of a trip are in flight at the same time */
+            int rank[RMAX], ro[RMAX], rn[RMAX];
+            for (int r = 0; r < RMAX; ++r) {
+                rank[r] = 0;
+                ro[r] = r_pos[r] < 0 ? 0 : r_pos[r] & 0xffff;
+                rn[r] = r_pos[r] < 0 ? 0 : r_pos[r] >> 16;
             }
-            Pair16 pr; pr.a = r_a[r]; pr.b = r_b[r];
-            m.ab[o + rank] = pr;
-            m.beta[o + rank] = r_beta[r];
+            const int nnmax = m.flags[2]; /* longest list of the tile (uniform) */
+            for (int t = 0; t < nnmax; t += 4) {
+                Arc k0[RMAX], k1[RMAX];
+                for (int r = 0; r < RMAX; ++r) { /* (o is even: 16-byte aligned pairs; reads past a list stay inside the key array) */
+                    k0[r] = *(const Arc *)(m.keys + ro[r] + (t < rn[r] ? t : 0));
+                    k1[r] = *(const Arc *)(m.keys + ro[r] + (t + 2 < rn[r] ? t + 2 : 0));
+                }
+                for (int r = 0; r < RMAX; ++r) {
+                    const double kme = r_key[r];
+                    int c = 0;
+                    c += t < rn[r] && k0[r].s < kme ? 1 : 0;
+                    c += t < rn[r] && k0[r].e < kme ? 1 : 0;
+                    c += t + 2 < rn[r] && k1[r].s < kme ? 1 : 0;
+                    c += t + 2 < rn[r] && k1[r].e < kme ? 1 : 0;
+                    rank[r] += c;
+                }
+            }
+            for (int r = 0; r < RMAX; ++r) {
+                if (r_pos[r] < 0) continue;
+                Rec24 rc; rc.a = r_a[r]; rc.b = r_b[r]; rc.beta = r_beta[r];
+                m.rec[ro[r] + rank[r]] = rc;
+            }
         }
         if (lane < TA && (m.acnt[lane] & 1)) { /* padding record: cos(alpha) huge, never an arc */
-            const int pp = m.aoff[lane] + m.acnt[lane];
-            Pair16 pr; pr.a = 0; pr.b = 1e300;
-            m.ab[pp] = pr;
-            m.beta[pp] = 0;
+            Rec24 rc; rc.a = 0; rc.b = 1e300; rc.beta = 0;
+            m.rec[m.aoff[lane] + m.acnt[lane]] = rc;
         }
     }
     LR2_SYNC();
 
+    LR2_STOP(3);
+    LR2_MARK(3);
     /* ------------------------------------------------------------ P4 screening */
     const float inv_ns = 1.0f / (float)ns; /* index arithmetic only */
+    m.hist[lane] = 0;
+    LR2_SYNC();
     for (int it = lane; it < items; it += LR2_LANES) {
         int la = (int)(((float)it + 0.5f) * inv_ns), s = it - la * ns; /* it / ns without the integer-division sequence */
         if (s < 0) { --la; s += ns; } else if (s >= ns) { ++la; s -= ns; }
-        const double Ri = m.aR[la], t = m.it_t[it];
+        const double Ri = m.atom[la].w, t = m.it_t[it];
         const double A = Ri * Ri - t * t; /* Ri'^2, ref: src/sasa_lr.c:309 */
         double area = 0;
         int cnt = 0;
@@ -469,11 +539,22 @@ SASA_D void lr2_tile(const Lr2Args &a, const Lr2Mem &m, int tile, int lane, int 
             for (int wi = 0; wi < mw; ++wi) {
                 unsigned w = 0;
                 const int k1 = nn - 32 * wi < 32 ? nn - 32 * wi : 32;
-                for (int k = k1 - 2; k >= 0; k -= 2) { /* from the end: neighbor k lands on bit k */
-                    const Pair16 q0 = m.ab[o + 32 * wi + k], q1 = m.ab[o + 32 * wi + k + 1];
-                    const double c0 = fma(t, q0.a, q0.b) * h2, c1 = fma(t, q1.a, q1.b) * h2;
+                const Rec24 *R = m.rec + o + 32 * wi;
+                int k = k1 - 2; /* from the end: neighbor k lands on bit k */
+                if (k1 > 0 && (k1 & 2)) {
+                    const double c0 = fma(t, R[k].a, R[k].b) * h2, c1 = fma(t, R[k + 1].a, R[k + 1].b) * h2;
                     cmin = SASA_MIN(cmin, c0);
                     cmin = SASA_MIN(cmin, c1);
+                    w = LR2_SHIFT_IN_LT1(w, c1);
+                    w = LR2_SHIFT_IN_LT1(w, c0);
+                    k -= 2;
+                }
+                for (; k >= 0; k -= 4) { /* four records per trip: their LDS reads are in flight together */
+                    const double c2 = fma(t, R[k].a, R[k].b) * h2, c3 = fma(t, R[k + 1].a, R[k + 1].b) * h2;
+                    const double c0 = fma(t, R[k - 2].a, R[k - 2].b) * h2, c1 = fma(t, R[k - 1].a, R[k - 1].b) * h2;
+                    cmin = SASA_MIN(SASA_MIN(cmin, c0), SASA_MIN(c1, SASA_MIN(c2, c3)));
+                    w = LR2_SHIFT_IN_LT1(w, c3);
+                    w = LR2_SHIFT_IN_LT1(w, c2);
                     w = LR2_SHIFT_IN_LT1(w, c1);
                     w = LR2_SHIFT_IN_LT1(w, c0);
                 }
@@ -495,74 +576,86 @@ SASA_D void lr2_tile(const Lr2Args &a, const Lr2Mem &m, int tile, int lane, int 
     }
     LR2_SYNC();
 
+    LR2_STOP(4);
+    LR2_MARK(4);
     /* ------------------------------------------------------------ P5 queue */
     int nq;
     {
         const int hv = m.hist[lane];
-        int incl = hv;
+        int incl2 = hv;
         for (int d = 1; d < LR2_LANES; d <<= 1) {
-            const int v = LR2_SHFL(incl, lane >= d ? lane - d : lane);
-            if (lane >= d) incl += v;
+            const int v = LR2_SHFL(incl2, lane >= d ? lane - d : lane);
+            if (lane >= d) incl2 += v;
         }
-        nq = LR2_SHFL(incl, LR2_LANES - 1);
-        m.hist[lane] = incl - hv; /* first queue position of the bin */
+        nq = LR2_SHFL(incl2, LR2_LANES - 1);
+        m.hist[lane] = incl2 - hv; /* first queue position of the bin */
         LR2_SYNC();
         for (int it = lane; it < items; it += LR2_LANES) {
             const unsigned qt = m.qtmp[it];
-            if (qt != 0xffffu) m.queue[m.hist[qt >> 10] + (qt & 1023u)] = (unsigned short)it;
+            int la = (int)(((float)it + 0.5f) * inv_ns);
+            { const int s = it - la * ns; if (s < 0) --la; else if (s >= ns) ++la; }
+            if (qt != 0xffffu) m.queue[m.hist[qt >> 10] + (qt & 1023u)] = (unsigned short)(it | (la << 10));
         }
     }
     LR2_SYNC();
 
+    LR2_STOP(5);
+    LR2_MARK(5);
     /* ------------------------------------------------------------ P6 arc pass */
-    int err = 0;
+    int maxd = 0;
     {
         Arc *stk = m.stack + lane;
         int next = LR2_LANES;
-        int my = lane < nq ? (int)m.queue[lane] : LR2_NONE;
-        int wi = 0, o = 0, la = 0;
+        int my = LR2_NONE, la = 0, wleft = 0;
         unsigned w = 0;
-        double t = 0, h2 = 0, ts = 0, te = -INFINITY;
-        int depth = 0;
-        if (my != LR2_NONE) {
-            la = (int)(((float)my + 0.5f) * inv_ns);
-            { int s = my - la * ns; if (s < 0) --la; else if (s >= ns) ++la; }
-            o = m.aoff[la]; t = m.it_t[my]; h2 = m.it_ch[my]; w = m.it_mask[my * mw];
-        }
+        const Rec24 *R = m.rec;       /* record of bit 0 of the current mask word */
+        const unsigned *mk = m.it_mask; /* current mask word */
+        double t = 0, h2 = 0;
+        Lr2Union u;
+        lr2_union_reset(u);
+#define LR2_FETCH(idx)                                                                             \
+    do {                                                                                           \
+        const int e_ = (idx) < nq ? (int)m.queue[(idx)] : LR2_NONE;                                \
+        my = e_ == LR2_NONE ? LR2_NONE : (e_ & 1023); w = 0; wleft = 0;                            \
+        if (my != LR2_NONE) {                                                                      \
+            la = e_ >> 10;                                                                         \
+            R = m.rec + m.aoff[la]; t = m.it_t[my]; h2 = m.it_ch[my];                              \
+            mk = m.it_mask + my * mw; w = *mk; wleft = mw - 1;                                     \
+            while (w == 0 && wleft > 0) { ++mk; R += 32; --wleft; w = *mk; }                       \
+        }                                                                                          \
+    } while (0)
+        LR2_FETCH(lane);
         for (;;) {
-            while (w == 0 && my != LR2_NONE && wi + 1 < mw) { ++wi; w = m.it_mask[my * mw + wi]; }
-            const bool act = w != 0;
-            const unsigned long long am = LR2_BALLOT(act);
-            const int idle = LR2_LANES - LR2_POPC64(am);
-            if (am == 0 || (next < nq && idle >= a.refill)) {
-                /* refill: lanes whose item is finished store its area and take the next items of the queue */
-                if (!act) {
-                    if (my != LR2_NONE) m.it_ch[my] = m.adel[la] * m.aR[la] * lr2_sweep(ts, te, depth, stk, a.ds); /* ref: :360 */
-                    const int idx = next + LR2_RANK(~am, lane);
-                    my = idx < nq ? (int)m.queue[idx] : LR2_NONE;
-                    wi = 0; w = 0; ts = 0; te = -INFINITY; depth = 0;
-                    if (my != LR2_NONE) {
-                        la = (int)(((float)my + 0.5f) * inv_ns);
-                        { int s = my - la * ns; if (s < 0) --la; else if (s >= ns) ++la; }
-                        o = m.aoff[la]; t = m.it_t[my]; h2 = m.it_ch[my]; w = m.it_mask[my * mw];
-                    }
+            for (;;) { /* arc steps until a refill is due */
+                const bool act = w != 0;
+                const unsigned long long am = LR2_BALLOT(act);
+                if (am == 0 || (next < nq && LR2_LANES - LR2_POPC64(am) >= a.refill)) break;
+                if (act) {
+                    const Rec24 *q = R + __builtin_ctz(w);
+                    w &= w - 1;
+                    const double bt = q->beta;
+                    const double alpha = acos_fast(fma(t, q->a, q->b) * h2); /* the screening's value, bit for bit */
+                    lr2_union_step(bt - alpha, bt + alpha, u, stk, a.ds, maxd); /* ref: :338-339 */
                 }
-                if (am == 0 && next >= nq) break;
-                next += idle;
-                continue;
             }
-            if (act) {
-                const int k = __builtin_ctz(w) + 32 * wi;
-                w &= w - 1;
-                const Pair16 q = m.ab[o + k];
-                const double bt = m.beta[o + k];
-                const double alpha = acos_fast(fma(t, q.a, q.b) * h2); /* the screening's value, bit for bit */
-                lr2_union_step(bt - alpha, bt + alpha, ts, te, depth, stk, a.ds, err); /* ref: :338-339 */
+            /* refill: a lane that has used up its mask word moves on to the item's next word or, when the item
+               is finished, stores its area and takes the next item of the queue */
+            if (w == 0 && wleft > 0)
+                do { ++mk; R += 32; --wleft; w = *mk; } while (w == 0 && wleft > 0);
+            const unsigned long long im = LR2_BALLOT(w == 0); /* finished (or without an item) */
+            if (w == 0) {
+                if (my != LR2_NONE) m.it_ch[my] = m.adel[la] * m.atom[la].w * lr2_sweep(u, stk, a.ds); /* ref: :360 */
+                lr2_union_reset(u);
+                LR2_FETCH(next + LR2_RANK(im, lane));
             }
+            next += LR2_POPC64(im);
+            if (next - LR2_POPC64(im) >= nq && LR2_BALLOT(w != 0) == 0) break;
         }
+#undef LR2_FETCH
     }
-    if (err) m.flags[1] = 1;
+    if (maxd - 2 > a.ds) m.flags[1] = 1;
     LR2_SYNC();
+    LR2_MARK(6);
 
     /* ------------------------------------------------------------ P7 store */
     if (m.flags[1]) { /* an arc stack overflowed: the tile is redone by the next launch */
@@ -580,6 +673,7 @@ SASA_D void lr2_tile(const Lr2Args &a, const Lr2Mem &m, int tile, int lane, int 
         a.sasa[m.sorig[lane]] = s;
     }
     LR2_SYNC();
+    LR2_MARK(7);
 }
 
 /* launch configuration (host side; shared by gpu_engine.hip and the test emulation) */
@@ -589,7 +683,7 @@ struct Lr2Cfg {
 };
 #define LR2_ITEMS_CAP 512   /* TA * ns of a tile */
 #define LR2_NS_MAX 256      /* finer resolutions use the first-generation kernel */
-#define LR2_RMAX_MAIN 3
+#define LR2_RMAX_MAIN 4
 #define LR2_RMAX_MID 8
 
 static inline bool lr2_supported(int ns) { return ns >= 1 && ns <= LR2_NS_MAX; }
@@ -614,8 +708,9 @@ static inline Lr2Cfg lr2_choose_cfg(int ns, double nn_hint = 0, int ta_override 
     c.pool = (c.pool + 1) & ~1;
     if (c.pool > pool_max) c.pool = pool_max;
     if (c.pool < 16) c.pool = 16;
+    c.rmax = (c.pool + LR2_LANES - 1) / LR2_LANES;
     c.mw = 2;
-    c.ds = 3;
+    c.ds = 2;
     c.refill = 16;
     c.lds = lr2_layout(c.TA, c.ns, c.pool, c.mw, c.ds).total;
     return c;
@@ -626,7 +721,7 @@ static inline Lr2Cfg lr2_mid_cfg(const Lr2Cfg &main_cfg)
     c.rmax = LR2_RMAX_MID;
     c.pool = LR2_LANES * LR2_RMAX_MID;
     c.mw = 8;
-    c.ds = 8;
+    c.ds = 12;
     c.lds = lr2_layout(c.TA, c.ns, c.pool, c.mw, c.ds).total;
     return c;
 }

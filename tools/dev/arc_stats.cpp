@@ -191,7 +191,7 @@ int main(int argc, char **argv)
                     sum_groups += groups; }
             }
             if (kc == 0 || kc == 3) {
-                const int TAs[3] = {3, 6, 12};
+                const int TAs[3] = {4, 5, 6};
                 const int Ts[4] = {8, 16, 24, 32};
                 for (int ti = 0; ti < 3; ++ti) for (int th = 0; th < 4; ++th) for (int sorted = 0; sorted < 2; ++sorted) {
                     const int TA = TAs[ti], T = Ts[th];
@@ -249,8 +249,8 @@ int main(int argc, char **argv)
     printf("gap count histogram:"); for (int k = 0; k < 8; ++k) printf(" %d:%.3f", k, ghist[k] / sum_slices);
     printf("\ntile max arcs over slices with >=1 gap: %.2f; 5th largest lane: %.2f; arcs in open slices %.2f of all\n", sum_tilemax_open / sum_tiles, sum_tilemax_top2 / sum_tiles, arcs_open / sum_arcs[0]);
     for (int c = 0; c < 2; ++c) for (int ti = 0; ti < 3; ++ti) for (int th = 0; th < 4; ++th) for (int so = 0; so < 2; ++so)
-        printf("queue sim containers=%d TA=%d T=%d sorted=%d: arc iterations per 3 atoms %.2f, refill events per 3 atoms %.2f\n", c ? 4 : 0, (int[]){3,6,12}[ti], (int[]){8,16,24,32}[th], so,
-               qsim_iters[c][ti][th][so] / qsim_tiles[c][ti][th][so] * 3 / (int[]){3,6,12}[ti], qsim_events[c][ti][th][so] / qsim_tiles[c][ti][th][so] * 3 / (int[]){3,6,12}[ti]);
+        printf("queue sim containers=%d TA=%d T=%d sorted=%d: arc iterations per 3 atoms %.2f, refill events per 3 atoms %.2f\n", c ? 4 : 0, (int[]){4,5,6}[ti], (int[]){8,16,24,32}[th], so,
+               qsim_iters[c][ti][th][so] / qsim_tiles[c][ti][th][so] * 3 / (int[]){4,5,6}[ti], qsim_events[c][ti][th][so] / qsim_tiles[c][ti][th][so] * 3 / (int[]){4,5,6}[ti]);
     printf("arc count histogram:");
     for (int k = 0; k < 40; ++k) printf(" %d:%.3f", k, hist[k] / sum_slices);
     printf("\n");

@@ -15,8 +15,12 @@ tot = torch.empty(structs, dtype=torch.float64, device=dev)
 ref = None
 for spec in specs:
     os.environ.pop("FREESASA_AMD_LR1", None); os.environ.pop("FREESASA_AMD_LR2", None)
+    os.environ.pop("FREESASA_AMD_WPE", None)
     if spec == "LR1": os.environ["FREESASA_AMD_LR1"] = "1"
-    else: os.environ["FREESASA_AMD_LR2"] = spec
+    else:
+        f = spec.split(",")
+        os.environ["FREESASA_AMD_LR2"] = ",".join(f[:4])
+        if len(f) > 4: os.environ["FREESASA_AMD_WPE"] = f[4]
     ctx = fa.GpuContext(0, timing=True)
     ks = []
     for i in range(5):
