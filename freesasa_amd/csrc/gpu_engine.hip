@@ -542,8 +542,8 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
         lm.work_count = (const int *)c->status.p + ST_OVF_TILES;
         lm.ovf_tiles = (int *)c->ovf_tiles2.p;
         lm.ovf_count = (int *)c->status.p + ST_OVF2_TILES;
-        const int grid_mid = n_tiles < SASA_MID_BLOCKS ? n_tiles : SASA_MID_BLOCKS;
-        hipLaunchKernelGGL((k_lr2_tile<LR2_RMAX_MID, 1, 2>), dim3(grid_mid), dim3(64), (size_t)cm.lds, st, lm);
+        const int grid_mid = n_tiles < 8 * SASA_MID_BLOCKS ? n_tiles : 8 * SASA_MID_BLOCKS;
+        hipLaunchKernelGGL((k_lr2_tile<LR2_RMAX_MID, 1, 3>), dim3(grid_mid), dim3(64), (size_t)cm.lds, st, lm);
         le = hipGetLastError();
         if (le != hipSuccess) return ctx_fail(c, "second tile launch failed: %s", hipGetErrorString(le));
     }
@@ -571,8 +571,8 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
     const int rc = finish_batch(c, pa, n, n_structs, total_cells, d_sasa, d_totals, cfg.TA, 64, cfg.lds, status_h);
     if (rc) return rc;
     /* learn the pool size for the next batch of this kind (trajectory frames, sweeps) */
-    const int learnt = pool_from_hist(status_h + ST_HIST, cfg.TA);
-    if (learnt > 0) c->hint_nn = (double)learnt / cfg.TA;
+    const int learnt = lr2_pool_from_hist(status_h + ST_HIST, cfg.TA);
+    if (learnt > 0) c->hint_nn = (double)(learnt - 8) / cfg.TA;
     return 0;
 }
 

@@ -47,7 +47,10 @@ long long wave_exchange(long long v, int src);
 #define LR2_POPC32(m) __builtin_popcount(m)
 #define LR2_RANK(m, lane) __builtin_popcountll((m) & ((1ull << (lane)) - 1ull))
 #define LR2_SHIFT_IN_LT1(w, c) (((w) << 1) | ((c) < 1.0 ? 1u : 0u))
+namespace sasa_emu { extern long long lr2_count[16]; } /* wave-level trip counts (lane 0 counts): 0 tiles, 1 arc iterations, 2 refills, 3 P1 test rounds, 4 rank trips, 5 screening trips, 6 P3 rounds */
+#define LR2_COUNT(k, n) do { if (lane == 0) sasa_emu::lr2_count[(k)] += (n); } while (0)
 #else
+#define LR2_COUNT(k, n) do { } while (0)
 #define LR2_BALLOT(p) __builtin_amdgcn_ballot_w64(p)
 #define LR2_SYNC() __syncthreads() /* one wave per workgroup: no s_barrier is emitted, only the LDS fence */
 #define LR2_SHFL(v, src) __shfl((v), (src), 64)
@@ -98,7 +101,7 @@ struct Rec24 { double a, b, beta; };
 
 /* LDS layout of one tile (byte offsets), shared by the host (launch size) and the device */
 struct Lr2Layout {
-    int o_atoms, o_ints, o_rec, o_ch, o_mask, o_queue, o_t, o_r2, o_tag, total;
+    int o_atoms, o_ints, o_rec, o_mask, o_queue, o_tc, o_r2, o_tag, total;
 };
 SASA_HD int lr2_a16(int v) { return (v + 15) & ~15; }
 SASA_HD int lr2_n_ints(int TA) { return 6 * TA + 1 + 8 + 18 * TA + (9 * TA + 2); }
@@ -109,16 +112,15 @@ SASA_HD Lr2Layout lr2_layout(int TA, int ns, int pool, int mw, int ds)
     int p = 0;
     L.o_atoms = p; p += 32 * TA + lr2_a16(8 * TA);
     L.o_ints = p;  p += lr2_a16(4 * lr2_n_ints(TA));
-    /* records (24 B each; P3..P6), then slice areas and masks (P4..P7).  The hits of P1 (32 B each) lie
-       over the three of them until P3 has taken every hit into registers */
+    /* records (24 B each; P3..P6), masks and queue (P4..P6), slice heights / areas (P4..P7).  The hits of P1
+       (32 B each) lie over all of them until P3 has taken every hit into registers */
     L.o_rec = p;   p += lr2_a16(24 * pool);
-    L.o_ch = p;    p += lr2_a16(8 * items);
     L.o_mask = p;  p += lr2_a16(4 * items * mw);
-    if (p - L.o_rec < 32 * pool) p = L.o_rec + 32 * pool;
     L.o_queue = p; p += lr2_a16(2 * items);
-    L.o_t = p;     p += lr2_a16(8 * items);
+    L.o_tc = p;    p += lr2_a16(8 * items);
+    if (p - L.o_rec < 32 * pool) p = L.o_rec + 32 * pool;
     /* R2: sort keys and hit tags (P1..P3), then queue scratch (P4, P5), then the arc stack (P6) */
-    int r2 = lr2_a16(8 * pool) + lr2_a16(4 * pool);
+    int r2 = lr2_a16(8 * pool) + lr2_a16(2 * pool);
     const int r2q = lr2_a16(2 * items) + 256, r2s = 16 * LR2_LANES * (ds > 0 ? ds : 1); /* (one column level even when ds == 0: see lr2_union_step) */
     if (r2q > r2) r2 = r2q;
     if (r2s > r2) r2 = r2s;
@@ -133,15 +135,14 @@ struct Lr2Mem {
     Quad *atom;   /* [TA] x, y, z, R + probe of the tile atoms */
     double *adel; /* [TA] 2 Ri / ns (ref: src/sasa_lr.c:304) */
     int *acell, *lead, *gsz, *acnt, *aoff, *sorig, *flags, *rowlo, *rowcnt, *cpre, *hist;
-    double *it_t;   /* [items] slice height relative to the atom centre, z - zi */
-    double *it_ch;  /* [items] 1/(2 Ri') of a queued item; its slice area once it is done */
+    double *it_tc;  /* [items] slice height relative to the atom centre (z - zi) until the item's slice is done, then its area */
     unsigned *it_mask; /* [items*mw] neighbors that cut an arc */
     unsigned short *queue; /* [items] items with arcs, heaviest first: item | atom << 10 */
     unsigned short *qtmp;  /* [items] bin and arrival order of an item before the bins are laid out */
     Quad *hits;     /* [pool] (xd, yd, zd, Rj) of the neighbors found, in order of discovery */
     Rec24 *rec;     /* [pool] records, sorted by beta inside each atom's list */
     double *keys;   /* [pool] beta with the list position in its low mantissa bits */
-    unsigned *tag;  /* [pool] atom (low 8 bits) and list position of a hit */
+    unsigned short *tag; /* [pool] atom (low 3 bits) and list position of a hit */
     Arc *stack;     /* [ds][64] */
 };
 /* flags: 0 tile overflow, 1 stack overflow, 2 max neighbor count, 5 largest cell group */
@@ -155,14 +156,13 @@ SASA_D Lr2Mem lr2_carve(const Lr2Args &a, char *smem)
     int *q = (int *)(smem + L.o_ints);
     m.acell = q; q += TA; m.lead = q; q += TA; m.gsz = q; q += TA; m.acnt = q; q += TA; m.aoff = q; q += TA + 1;
     m.sorig = q; q += TA; m.flags = q; q += 8; m.rowlo = q; q += 9 * TA; m.rowcnt = q; q += 9 * TA; m.cpre = q;
-    m.it_t = (double *)(smem + L.o_t);
-    m.it_ch = (double *)(smem + L.o_ch);
+    m.it_tc = (double *)(smem + L.o_tc);
     m.it_mask = (unsigned *)(smem + L.o_mask);
     m.queue = (unsigned short *)(smem + L.o_queue);
     m.hits = (Quad *)(smem + L.o_rec);
     m.rec = (Rec24 *)(smem + L.o_rec);
     m.keys = (double *)(smem + L.o_r2);
-    m.tag = (unsigned *)(smem + L.o_tag);
+    m.tag = (unsigned short *)(smem + L.o_tag);
     m.hist = (int *)(smem + L.o_r2);
     m.qtmp = (unsigned short *)(smem + L.o_r2 + 256);
     m.stack = (Arc *)(smem + L.o_r2);
@@ -270,7 +270,7 @@ SASA_D double lr2_sweep(const Lr2Union &u, const Arc *stk, int ds)
     return sum + SASA_TWOPI - sup; /* ref: :407 */
 }
 
-#define LR2_NB_UNROLL 3
+#define LR2_NB_UNROLL 2
 
 /* The whole tile, executed by the 64 lanes of one wave.  RMAX = rounds of 64 pair records a lane
  * keeps in registers in P3 (pool <= 64 * RMAX). */
@@ -282,6 +282,7 @@ SASA_D void lr2_tile(const Lr2Args &a, const Lr2Mem &m, int tile, int lane, int 
     const int na = a.n_atoms - p0 < TA ? a.n_atoms - p0 : TA;
     const int items = na * ns;
     LR2_MARK_BEGIN;
+    LR2_COUNT(0, 1);
 
     /* ------------------------------------------------------------ P0 load */
     if (lane < TA) {
@@ -332,16 +333,15 @@ SASA_D void lr2_tile(const Lr2Args &a, const Lr2Mem &m, int tile, int lane, int 
         m.lead[lane] = lead ? 1 : 0;
         m.gsz[lane] = gs;
         if (gs > 0) SASA_ATOMIC_MAX_LDS(&m.flags[5], gs);
-        if (lane < na) { /* slice heights, accumulated like the reference (src/sasa_lr.c:304-307) */
-            const double zi = m.atom[lane].z, Ri = m.atom[lane].w, delta = m.adel[lane];
-            double z = zi - Ri - 0.5 * delta;
-            for (int s = 0; s < ns; ++s) {
-                z += delta;
-                m.it_t[lane * ns + s] = z - zi; /* exact; |z - zi| is the reference's di (:308) */
-            }
-        }
     }
-    /* inclusive prefix of the candidate counts over the rows */
+    /* P1's work items: (candidate, two atoms of the cell group the candidate belongs to); inclusive prefix of
+       the item counts over the rows */
+    if (my_cnt > 0) {
+        const int la = lane / 9;
+        int gs = 1;
+        while (la + gs < na && m.acell[la + gs] == m.acell[la]) ++gs;
+        my_cnt *= (gs + 1) >> 1;
+    }
     int incl = my_cnt;
     for (int d = 1; d < LR2_LANES; d <<= 1) {
         const int v = LR2_SHFL(incl, lane >= d ? lane - d : lane);
@@ -358,43 +358,47 @@ SASA_D void lr2_tile(const Lr2Args &a, const Lr2Mem &m, int tile, int lane, int 
     const int total_c = m.cpre[nrows];
     int nh = 0; /* hits so far (wave-uniform) */
     {
-        const int per = (total_c + LR2_LANES - 1) / LR2_LANES; /* consecutive candidates per lane */
-        const int gmax = m.flags[5];
+        const int per = (total_c + LR2_LANES - 1) / LR2_LANES; /* consecutive work items per lane */
         const int f = lane * per;
         const int fend = f + per < total_c ? f + per : total_c;
         int t = 0;
-        if (f < total_c) { /* row of the lane's first candidate: largest t with cpre[t] <= f */
+        if (f < total_c) { /* row of the lane's first item: largest t with cpre[t] <= f */
             for (int step = 32; step >= 1; step >>= 1)
                 if (t + step <= nrows && m.cpre[t + step] <= f) t += step;
         }
+        LR2_COUNT(3, (per + LR2_NB_UNROLL - 1) / LR2_NB_UNROLL * LR2_NB_UNROLL * 2);
         for (int base = 0; base < per; base += LR2_NB_UNROLL) { /* (wave-uniform trip count) */
-            int q[LR2_NB_UNROLL], la0[LR2_NB_UNROLL], gs[LR2_NB_UNROLL];
+            int q[LR2_NB_UNROLL], la0[LR2_NB_UNROLL], two[LR2_NB_UNROLL];
             double x[LR2_NB_UNROLL], y[LR2_NB_UNROLL], z[LR2_NB_UNROLL], rq[LR2_NB_UNROLL];
             for (int j = 0; j < LR2_NB_UNROLL; ++j) {
                 const int fj = f + base + j;
+                q[j] = -1; la0[j] = 0; two[j] = 0;
                 if (base + j < per && fj < fend) {
                     while (fj >= m.cpre[t + 1]) ++t;
-                    q[j] = m.rowlo[t] + (fj - m.cpre[t]);
-                    la0[j] = t / 9;
-                    gs[j] = m.gsz[la0[j]];
-                } else {
-                    q[j] = -1; la0[j] = 0; gs[j] = 0;
+                    const int lead = t / 9, gs = m.gsz[lead], hc = (gs + 1) >> 1;
+                    const unsigned i = (unsigned)(fj - m.cpre[t]);
+                    const unsigned c = hc == 1 ? i : (hc == 2 ? i >> 1 : (hc == 3 ? (i * 0xaaabu) >> 17 : i >> 2)); /* i / hc, hc <= 4 */
+                    const int h = (int)(i - c * (unsigned)hc);
+                    q[j] = m.rowlo[t] + (int)c;
+                    la0[j] = lead + 2 * h;
+                    two[j] = 2 * h + 1 < gs ? 1 : 0;
                 }
             }
             for (int j = 0; j < LR2_NB_UNROLL; ++j) {
                 const unsigned u = (unsigned)(q[j] < 0 ? 0 : q[j]);
                 x[j] = a.sx[u]; y[j] = a.sy[u]; z[j] = a.sz[u]; rq[j] = a.sr[u];
             }
-            for (int g = 0; g < gmax; ++g) {
+            for (int g = 0; g < 2; ++g) {
                 bool hit[LR2_NB_UNROLL];
                 double dx[LR2_NB_UNROLL], dy[LR2_NB_UNROLL], dz[LR2_NB_UNROLL];
                 Quad ai[LR2_NB_UNROLL];
-                for (int j = 0; j < LR2_NB_UNROLL; ++j) ai[j] = m.atom[g < gs[j] ? la0[j] + g : 0];
+                for (int j = 0; j < LR2_NB_UNROLL; ++j) ai[j] = m.atom[la0[j] + (g <= two[j] ? g : 0)];
                 for (int j = 0; j < LR2_NB_UNROLL; ++j) {
                     /* the reference's contact test, operand for operand (src/nb.c:483-492) */
                     const double cut2 = (ai[j].w + rq[j]) * (ai[j].w + rq[j]);
                     dx[j] = x[j] - ai[j].x; dy[j] = y[j] - ai[j].y; dz[j] = z[j] - ai[j].z;
-                    hit[j] = g < gs[j] && q[j] != p0 + la0[j] + g && dx[j] * dx[j] + dy[j] * dy[j] + dz[j] * dz[j] < cut2;
+                    hit[j] = q[j] >= 0 && g <= two[j] && q[j] != p0 + la0[j] + g &&
+                             dx[j] * dx[j] + dy[j] * dy[j] + dz[j] * dz[j] < cut2;
                 }
                 for (int j = 0; j < LR2_NB_UNROLL; ++j) {
                     const unsigned long long hm = LR2_BALLOT(hit[j]);
@@ -406,7 +410,7 @@ SASA_D void lr2_tile(const Lr2Args &a, const Lr2Mem &m, int tile, int lane, int 
                             if (slot < a.pool) {
                                 Quad hq; hq.x = dx[j]; hq.y = dy[j]; hq.z = dz[j]; hq.w = rq[j]; /* ref: src/nb.c:445-448 */
                                 m.hits[slot] = hq;
-                                m.tag[slot] = (unsigned)la | ((unsigned)sa << 8);
+                                m.tag[slot] = (unsigned short)((unsigned)la | ((unsigned)sa << 3)); /* la < 8, sa < 2^13 */
                             }
                         }
                         nh += LR2_POPC64(hm);
@@ -468,7 +472,7 @@ SASA_D void lr2_tile(const Lr2Args &a, const Lr2Mem &m, int tile, int lane, int 
             if (gp < nh) {
                 const Quad hq = m.hits[gp];
                 const unsigned tg = m.tag[gp];
-                const int la = (int)(tg & 0xffu), sa = (int)(tg >> 8);
+                const int la = (int)(tg & 7u), sa = (int)(tg >> 3);
                 const int o = m.aoff[la];
                 r_pos[r] = o | (m.acnt[la] << 16);
                 lr2_record(hq.x, hq.y, hq.z, hq.w, m.atom[la].w, r_a[r], r_b[r]);
@@ -479,37 +483,18 @@ SASA_D void lr2_tile(const Lr2Args &a, const Lr2Mem &m, int tile, int lane, int 
         }
         if (lane < TA && (m.acnt[lane] & 1)) m.keys[m.aoff[lane] + m.acnt[lane]] = INFINITY; /* never ranks below */
         LR2_SYNC(); /* every hit is in registers: R1 may now take the records */
-        {
-            /* rank of every pair inside its atom's list: all rounds walk their lists together, four keys per
-               round and trip, so that the LDS reads of a trip are in flight at the same time */
-            int rank[RMAX], ro[RMAX], rn[RMAX];
-            for (int r = 0; r < RMAX; ++r) {
-                rank[r] = 0;
-                ro[r] = r_pos[r] < 0 ? 0 : r_pos[r] & 0xffff;
-                rn[r] = r_pos[r] < 0 ? 0 : r_pos[r] >> 16;
+        for (int r = 0; r < RMAX; ++r) {
+            if (r_pos[r] < 0) continue;
+            const int o = r_pos[r] & 0xffff, nn = r_pos[r] >> 16;
+            const double kme = r_key[r];
+            int rank = 0;
+            for (int t = 0; t < nn; t += 2) { /* two keys per LDS read (o is even) */
+                const Arc kk = *(const Arc *)(m.keys + o + t);
+                rank += kk.s < kme ? 1 : 0;
+                rank += kk.e < kme ? 1 : 0;
             }
-            const int nnmax = m.flags[2]; /* longest list of the tile (uniform) */
-            for (int t = 0; t < nnmax; t += 4) {
-                Arc k0[RMAX], k1[RMAX];
-                for (int r = 0; r < RMAX; ++r) { /* (o is even: 16-byte aligned pairs; reads past a list stay inside the key array) */
-                    k0[r] = *(const Arc *)(m.keys + ro[r] + (t < rn[r] ? t : 0));
-                    k1[r] = *(const Arc *)(m.keys + ro[r] + (t + 2 < rn[r] ? t + 2 : 0));
-                }
-                for (int r = 0; r < RMAX; ++r) {
-                    const double kme = r_key[r];
-                    int c = 0;
-                    c += t < rn[r] && k0[r].s < kme ? 1 : 0;
-                    c += t < rn[r] && k0[r].e < kme ? 1 : 0;
-                    c += t + 2 < rn[r] && k1[r].s < kme ? 1 : 0;
-                    c += t + 2 < rn[r] && k1[r].e < kme ? 1 : 0;
-                    rank[r] += c;
-                }
-            }
-            for (int r = 0; r < RMAX; ++r) {
-                if (r_pos[r] < 0) continue;
-                Rec24 rc; rc.a = r_a[r]; rc.b = r_b[r]; rc.beta = r_beta[r];
-                m.rec[ro[r] + rank[r]] = rc;
-            }
+            Rec24 rc; rc.a = r_a[r]; rc.b = r_b[r]; rc.beta = r_beta[r];
+            m.rec[o + rank] = rc;
         }
         if (lane < TA && (m.acnt[lane] & 1)) { /* padding record: cos(alpha) huge, never an arc */
             Rec24 rc; rc.a = 0; rc.b = 1e300; rc.beta = 0;
@@ -523,11 +508,19 @@ SASA_D void lr2_tile(const Lr2Args &a, const Lr2Mem &m, int tile, int lane, int 
     /* ------------------------------------------------------------ P4 screening */
     const float inv_ns = 1.0f / (float)ns; /* index arithmetic only */
     m.hist[lane] = 0;
+    if (lane < na) { /* slice heights, accumulated like the reference (src/sasa_lr.c:304-307) */
+        const double zi = m.atom[lane].z, Ri = m.atom[lane].w, delta = m.adel[lane];
+        double z = zi - Ri - 0.5 * delta;
+        for (int s = 0; s < ns; ++s) {
+            z += delta;
+            m.it_tc[lane * ns + s] = z - zi; /* exact; |z - zi| is the reference's di (:308) */
+        }
+    }
     LR2_SYNC();
     for (int it = lane; it < items; it += LR2_LANES) {
         int la = (int)(((float)it + 0.5f) * inv_ns), s = it - la * ns; /* it / ns without the integer-division sequence */
         if (s < 0) { --la; s += ns; } else if (s >= ns) { ++la; s -= ns; }
-        const double Ri = m.atom[la].w, t = m.it_t[it];
+        const double Ri = m.atom[la].w, t = m.it_tc[it];
         const double A = Ri * Ri - t * t; /* Ri'^2, ref: src/sasa_lr.c:309 */
         double area = 0;
         int cnt = 0;
@@ -563,9 +556,8 @@ SASA_D void lr2_tile(const Lr2Args &a, const Lr2Mem &m, int tile, int lane, int 
             }
             if (cmin <= -1.0) cnt = 0; /* circle i inside a neighbor's: buried (ref: :327-330) */
             else if (cnt == 0) area = m.adel[la] * Ri * SASA_TWOPI; /* ref: :360 with exposed_arc_length(n = 0) */
-            else area = h2; /* parked for the arc pass */
         }
-        m.it_ch[it] = area;
+        if (cnt == 0) m.it_tc[it] = area; /* (an item with arcs keeps its slice height for the arc pass) */
         unsigned short qt = 0xffff;
         if (cnt > 0) { /* queue: heaviest first (bin 0 = 63 arcs or more); inside a bin in order of arrival */
             const int bin = 63 - (cnt < 63 ? cnt : 63);
@@ -619,7 +611,8 @@ SASA_D void lr2_tile(const Lr2Args &a, const Lr2Mem &m, int tile, int lane, int 
         my = e_ == LR2_NONE ? LR2_NONE : (e_ & 1023); w = 0; wleft = 0;                            \
         if (my != LR2_NONE) {                                                                      \
             la = e_ >> 10;                                                                         \
-            R = m.rec + m.aoff[la]; t = m.it_t[my]; h2 = m.it_ch[my];                              \
+            R = m.rec + m.aoff[la]; t = m.it_tc[my];                                               \
+            { const double Ri_ = m.atom[la].w; double g_; sqrt_rh(Ri_ * Ri_ - t * t, g_, h2); } /* as P4: bit for bit */ \
             mk = m.it_mask + my * mw; w = *mk; wleft = mw - 1;                                     \
             while (w == 0 && wleft > 0) { ++mk; R += 32; --wleft; w = *mk; }                       \
         }                                                                                          \
@@ -630,6 +623,7 @@ SASA_D void lr2_tile(const Lr2Args &a, const Lr2Mem &m, int tile, int lane, int 
                 const bool act = w != 0;
                 const unsigned long long am = LR2_BALLOT(act);
                 if (am == 0 || (next < nq && LR2_LANES - LR2_POPC64(am) >= a.refill)) break;
+                LR2_COUNT(1, 1);
                 if (act) {
                     const Rec24 *q = R + __builtin_ctz(w);
                     w &= w - 1;
@@ -643,8 +637,9 @@ SASA_D void lr2_tile(const Lr2Args &a, const Lr2Mem &m, int tile, int lane, int 
             if (w == 0 && wleft > 0)
                 do { ++mk; R += 32; --wleft; w = *mk; } while (w == 0 && wleft > 0);
             const unsigned long long im = LR2_BALLOT(w == 0); /* finished (or without an item) */
+            LR2_COUNT(2, 1);
             if (w == 0) {
-                if (my != LR2_NONE) m.it_ch[my] = m.adel[la] * m.atom[la].w * lr2_sweep(u, stk, a.ds); /* ref: :360 */
+                if (my != LR2_NONE) m.it_tc[my] = m.adel[la] * m.atom[la].w * lr2_sweep(u, stk, a.ds); /* ref: :360 */
                 lr2_union_reset(u);
                 LR2_FETCH(next + LR2_RANK(im, lane));
             }
@@ -669,7 +664,7 @@ SASA_D void lr2_tile(const Lr2Args &a, const Lr2Mem &m, int tile, int lane, int 
         }
     } else if (lane < na) {
         double s = 0;
-        for (int k = 0; k < ns; ++k) s += m.it_ch[lane * ns + k]; /* slice order, ref: :305-361 */
+        for (int k = 0; k < ns; ++k) s += m.it_tc[lane * ns + k]; /* slice order, ref: :305-361 */
         a.sasa[m.sorig[lane]] = s;
     }
     LR2_SYNC();
@@ -684,7 +679,7 @@ struct Lr2Cfg {
 #define LR2_ITEMS_CAP 512   /* TA * ns of a tile */
 #define LR2_NS_MAX 256      /* finer resolutions use the first-generation kernel */
 #define LR2_RMAX_MAIN 4
-#define LR2_RMAX_MID 8
+#define LR2_RMAX_MID 6
 
 static inline bool lr2_supported(int ns) { return ns >= 1 && ns <= LR2_NS_MAX; }
 
@@ -708,20 +703,47 @@ static inline Lr2Cfg lr2_choose_cfg(int ns, double nn_hint = 0, int ta_override 
     c.pool = (c.pool + 1) & ~1;
     if (c.pool > pool_max) c.pool = pool_max;
     if (c.pool < 16) c.pool = 16;
-    c.rmax = (c.pool + LR2_LANES - 1) / LR2_LANES;
     c.mw = 2;
     c.ds = 2;
     c.refill = 16;
     c.lds = lr2_layout(c.TA, c.ns, c.pool, c.mw, c.ds).total;
+    /* occupancy comes in steps of whole tiles per CU (160 KB of LDS, at most 16 one-wave tiles with the
+       registers of the 4-waves-per-SIMD build): spend the slack of the current step on a larger pool */
+    {
+        const int cu_lds = 160 * 1024;
+        int nblk = cu_lds / c.lds;
+        if (nblk > 16) nblk = 16;
+        if (nblk >= 1)
+            while (c.pool + 2 <= pool_max && lr2_layout(c.TA, c.ns, c.pool + 2, c.mw, c.ds).total * nblk <= cu_lds) c.pool += 2;
+        c.lds = lr2_layout(c.TA, c.ns, c.pool, c.mw, c.ds).total;
+    }
+    c.rmax = (c.pool + LR2_LANES - 1) / LR2_LANES;
     return c;
+}
+
+/* neighbor records per tile that all but ~4 % of the tiles of the last batch needed (sampled demand
+ * histogram of P2): the tiles above it are redone by the second launch */
+static inline int lr2_pool_from_hist(const int *hist, int TA)
+{
+    long long total = 0;
+    for (int k = 0; k < 64; ++k) total += hist[k];
+    if (total <= 0) return 0;
+    long long allowed = total / 25, acc = 0;
+    int k = 63;
+    for (; k > 0; --k) {
+        acc += hist[k];
+        if (acc > allowed) break;
+    }
+    if (k >= 63) return 0;
+    return ((k + 1) * hist_bin_width(TA) + 1) & ~1;
 }
 static inline Lr2Cfg lr2_mid_cfg(const Lr2Cfg &main_cfg)
 {
     Lr2Cfg c = main_cfg;
     c.rmax = LR2_RMAX_MID;
     c.pool = LR2_LANES * LR2_RMAX_MID;
-    c.mw = 8;
-    c.ds = 12;
+    c.mw = 4;
+    c.ds = 6;
     c.lds = lr2_layout(c.TA, c.ns, c.pool, c.mw, c.ds).total;
     return c;
 }

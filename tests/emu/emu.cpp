@@ -24,6 +24,7 @@ using namespace sasa;
  * operation deposits the lane's operand and yields to the scheduler, which resumes the lanes once
  * all of them have arrived — the device's semantics for wave-uniform control flow. */
 namespace sasa_emu {
+long long lr2_count[16];
 static const int W = 64;
 static ucontext_t g_main, g_fiber[W];
 static bool g_done[W];
@@ -139,6 +140,7 @@ static void emu_tile_kernel(bool lr, const TileCfg &cfg, TileArgs a, int grid)
 
 /* second-generation L&R kernel: one wave (64 fibers) per tile */
 static int emu_lr2 = 1, emu_lr2_ta = 0, emu_lr2_refill = 0;
+extern "C" void emu_lr2_counts(long long *out, int reset) { for (int k = 0; k < 16; ++k) { out[k] = sasa_emu::lr2_count[k]; if (reset) sasa_emu::lr2_count[k] = 0; } }
 extern "C" void emu_set_lr2(int on, int ta, int refill) { emu_lr2 = on; emu_lr2_ta = ta; emu_lr2_refill = refill; }
 
 struct Lr2Run { const Lr2Args *a; Lr2Mem *m; int tile; int rmax; int *wg_max; };
