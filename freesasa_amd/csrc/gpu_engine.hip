@@ -219,15 +219,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     Lr2Mem m = lr2_carve(a, smem);
-    const int n_work = a.work_tiles ? *a.work_count : ((a.n_tiles + 7) >> 3) << 3;
+    /* work items: all tiles (main launch), both halves of every tile of split_src, or the items of a work list */
+    const int n_work = a.work_count ? (a.work_tiles ? *a.work_count : 2 * *a.work_count) : ((a.n_tiles + 7) >> 3) << 3;
     int wg_max_nn = 0;
     for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
-        const int tile = a.work_tiles ? a.work_tiles[w] : xcd_tile(w, a.n_tiles);
-        if (tile >= a.n_tiles) continue; /* uniform per workgroup */
+        const int tile = a.work_tiles ? a.work_tiles[w] : (a.work_count ? w : xcd_tile(w, a.n_tiles));
+        if (!a.work_count && tile >= a.n_tiles) continue; /* uniform per workgroup */
         lr2_tile<RMAX>(a, m, tile, lane, wg_max_nn);
     }
     if (lane == 0 && wg_max_nn > a.status[ST_MAX_NN]) atomicMax(&a.status[ST_MAX_NN], wg_max_nn);
 }
+__global__ __launch_bounds__(256) void k_lr2_compact(const unsigned char *flag, int n_tiles, int *ovf_count, int *ovf_tiles)
+{
+    __shared__ int cnt[257];
+    cnt[threadIdx.x] = lr2_compact_count(flag, n_tiles, blockIdx.x, threadIdx.x, 256);
+    __syncthreads();
+    lr2_compact_base(cnt, ovf_count, threadIdx.x, 256);
+    __syncthreads();
+    lr2_compact_write(flag, n_tiles, cnt, ovf_tiles, blockIdx.x, threadIdx.x, 256);
+}
+
 /* main launch: the instantiation is picked by the rounds of pair records the pool needs and by the waves per
  * SIMD the tile's LDS footprint allows */
 static hipError_t launch_lr2_main(int rmax, int wpe, int grid, size_t lds, hipStream_t st, const Lr2Args &la)
@@ -293,7 +304,7 @@ struct freesasa_gpu_ctx {
     DevBuf chunk_struct, chunk_begin, chunk_len, struct_chunk0, bpart;
     int n_chunks = 0;
     DevBuf sx, sy, sz, sr, s_orig, s_cell, s_struct;
-    DevBuf status, ovf_tiles, ovf_tiles2, unit_pts, slab, seg;
+    DevBuf status, ovf_tiles, ovf_tiles2, ovf_atoms, ovf_flags, unit_pts, slab, seg;
     std::vector<int64_t> offsets_host; /* last uploaded offsets */
     std::vector<double> unit_host;     /* last uploaded S&R unit points */
     /* host staging for freesasa_gpu_calc_batch */
@@ -377,7 +388,7 @@ extern "C" void freesasa_gpu_ctx_destroy(freesasa_gpu_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->chunk_struct, &c->chunk_begin, &c->chunk_len, &c->struct_chunk0, &c->bpart, &c->offsets, &c->grid, &c->ncells, &c->sid, &c->cell_of, &c->rank, &c->cell_start,
                      &c->blk_sums, &c->sx, &c->sy, &c->sz, &c->sr, &c->s_orig, &c->s_cell, &c->s_struct,
-                     &c->status, &c->ovf_tiles, &c->ovf_tiles2, &c->unit_pts, &c->slab, &c->seg,
+                     &c->status, &c->ovf_tiles, &c->ovf_tiles2, &c->ovf_atoms, &c->ovf_flags, &c->unit_pts, &c->slab, &c->seg,
                      &c->h_xyz, &c->h_radii, &c->h_sasa, &c->h_counts, &c->h_totals};
     for (DevBuf *b : all)
         if (b->p) (void)hipFree(b->p);
@@ -508,7 +519,9 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
     if (refill_env > 0) cfg.refill = refill_env;
     cfg.lds = lr2_layout(cfg.TA, cfg.ns, cfg.pool, cfg.mw, cfg.ds).total;
     const int n_tiles = (n + cfg.TA - 1) / cfg.TA;
-    if (ensure(c, c->ovf_tiles, sizeof(int) * ((size_t)n_tiles + 1)) || ensure(c, c->ovf_tiles2, sizeof(int) * ((size_t)n_tiles + 1))) return -1;
+    if (ensure(c, c->ovf_tiles, sizeof(int) * ((size_t)n_tiles + 1)) || ensure(c, c->ovf_tiles2, sizeof(int) * (2 * (size_t)n_tiles + 2)) ||
+        ensure(c, c->ovf_atoms, sizeof(int) * ((size_t)n + 8)))
+        return -1;
 
     Lr2Args la;
     memset(&la, 0, sizeof la);
@@ -518,8 +531,10 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
     la.n_atoms = n; la.n_tiles = n_tiles; la.TA = cfg.TA; la.ns = resolution;
     la.pool = cfg.pool; la.mw = cfg.mw; la.ds = cfg.ds; la.refill = cfg.refill;
     la.sasa = d_sasa; la.status = (int *)c->status.p;
-    la.ovf_count = (int *)c->status.p + ST_OVF_TILES;
-    la.ovf_tiles = (int *)c->ovf_tiles.p;
+    /* overflow flags of the main launch: one byte per tile, behind the second work list */
+    if (ensure(c, c->ovf_flags, (size_t)n_tiles + 16)) return -1;
+    HIP_TRY(c, hipMemsetAsync(c->ovf_flags.p, 0, (size_t)n_tiles, st));
+    la.ovf_flag = (unsigned char *)c->ovf_flags.p;
 
     int grid_main = ((n_tiles + 7) / 8) * 8;
     if (grid_main > 147456) grid_main = 147456;
@@ -532,25 +547,46 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
     hipError_t le = launch_lr2_main(cfg.rmax, wpe, grid_main, (size_t)cfg.lds, st, la);
     if (le != hipSuccess) return ctx_fail(c, "tile kernel launch failed: %s", hipGetErrorString(le));
     if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[2], st));
+    hipLaunchKernelGGL(k_lr2_compact, dim3((n_tiles + 256 * LR2_COMPACT_PER - 1) / (256 * LR2_COMPACT_PER)), dim3(256), 0, st,
+                       (const unsigned char *)c->ovf_flags.p, n_tiles, (int *)c->status.p + ST_OVF_TILES, (int *)c->ovf_tiles.p);
 
-    /* second launch: the tiles whose lists did not fit (normally a fraction of a percent) */
+    /* second launch: the tiles whose lists did not fit (a few percent), as two halves each, through the same
+       kernel with the same capacities */
+    {
+        Lr2Args ls = la;
+        ls.ovf_flag = nullptr;
+        ls.split_ta = (cfg.TA + 1) / 2;
+        ls.split_src = (const int *)c->ovf_tiles.p;
+        ls.work_tiles = nullptr;
+        ls.work_count = (const int *)c->status.p + ST_OVF_TILES;
+        ls.ovf_tiles = (int *)c->ovf_tiles2.p;
+        ls.ovf_count = (int *)c->status.p + ST_OVF2_TILES;
+        const int grid_split = 2 * n_tiles < 8 * SASA_MID_BLOCKS ? 2 * n_tiles : 8 * SASA_MID_BLOCKS;
+        le = launch_lr2_main(cfg.rmax, wpe, grid_split, (size_t)cfg.lds, st, ls);
+        if (le != hipSuccess) return ctx_fail(c, "second tile launch failed: %s", hipGetErrorString(le));
+    }
+    /* third launch: halves that still do not fit: larger LDS lists, more registers */
     const Lr2Cfg cm = lr2_mid_cfg(cfg);
     {
         Lr2Args lm = la;
+        lm.ovf_flag = nullptr;
+        lm.split_ta = (cfg.TA + 1) / 2;
+        lm.split_src = (const int *)c->ovf_tiles.p;
         lm.pool = cm.pool; lm.mw = cm.mw; lm.ds = cm.ds;
-        lm.work_tiles = (const int *)c->ovf_tiles.p;
-        lm.work_count = (const int *)c->status.p + ST_OVF_TILES;
-        lm.ovf_tiles = (int *)c->ovf_tiles2.p;
-        lm.ovf_count = (int *)c->status.p + ST_OVF2_TILES;
-        const int grid_mid = n_tiles < 8 * SASA_MID_BLOCKS ? n_tiles : 8 * SASA_MID_BLOCKS;
+        lm.work_tiles = (const int *)c->ovf_tiles2.p;
+        lm.work_count = (const int *)c->status.p + ST_OVF2_TILES;
+        lm.ovf_tiles = (int *)c->ovf_atoms.p;
+        lm.ovf_count = (int *)c->status.p + ST_OVF3_ATOMS;
+        lm.ovf_atoms = 1;
+        const int grid_mid = n_tiles < SASA_MID_BLOCKS ? n_tiles : SASA_MID_BLOCKS;
         hipLaunchKernelGGL((k_lr2_tile<LR2_RMAX_MID, 1, 3>), dim3(grid_mid), dim3(64), (size_t)cm.lds, st, lm);
         le = hipGetLastError();
-        if (le != hipSuccess) return ctx_fail(c, "second tile launch failed: %s", hipGetErrorString(le));
+        if (le != hipSuccess) return ctx_fail(c, "third tile launch failed: %s", hipGetErrorString(le));
     }
-    /* third launch: whatever is left (pathological densities): the first-generation kernel over the same
-       tiling, lists in a global slab */
+    /* last launch: whatever is left (pathological densities), atom by atom: the first-generation kernel with its
+       lists in a global slab */
     {
-        const TileCfg fb = fallback_cfg(lr_slab_cfg(cfg.TA, resolution), true);
+        const TileCfg fb = fallback_cfg(lr_slab_cfg(1, resolution), true);
         const size_t stride = tile_slab_bytes(fb.TA, fb.cap_idx, fb.pool, fb.lr, fb.ds, fb.B);
         if (ensure(c, c->slab, stride * SASA_FB_BLOCKS)) return -1;
         TileArgs tf;
@@ -558,11 +594,11 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
         tf.sx = pa.sx; tf.sy = pa.sy; tf.sz = pa.sz; tf.sr = pa.sr;
         tf.s_orig = pa.s_orig; tf.s_cell = pa.s_cell; tf.s_struct = pa.s_struct;
         tf.grid = pa.grid; tf.cell_start = pa.cell_start;
-        tf.n_atoms = n; tf.n_tiles = n_tiles; tf.TA = fb.TA; tf.n_res = resolution; tf.tab = fb.tab;
+        tf.n_atoms = n; tf.n_tiles = n; tf.TA = 1; tf.n_res = resolution; tf.tab = fb.tab;
         tf.sasa = d_sasa; tf.lr = 1; tf.status = (int *)c->status.p;
         tf.cap_idx = fb.cap_idx; tf.pool = fb.pool; tf.ds = fb.ds;
-        tf.work_tiles = (const int *)c->ovf_tiles2.p;
-        tf.work_count = (const int *)c->status.p + ST_OVF2_TILES;
+        tf.work_tiles = (const int *)c->ovf_atoms.p;
+        tf.work_count = (const int *)c->status.p + ST_OVF3_ATOMS;
         tf.slab = (char *)c->slab.p;
         tf.slab_stride = (long long)stride;
         le = launch_lr<true, 2>(fb, tf, SASA_FB_BLOCKS, fb.lds, st);

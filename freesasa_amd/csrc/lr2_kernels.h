@@ -88,8 +88,15 @@ struct Lr2Args {
     int ds;     /* spilled levels of the arc stack */
     int refill; /* waiting lanes that trigger a refill of the arc pass */
     double *sasa;
-    int *ovf_count; /* tiles that do not fit are appended to the next launch's work list */
+    /* tiles that do not fit this launch's capacities go to the next launch: the main launch marks them in a
+       byte per tile (compacted into a work list by lr2_compact: no same-address atomics among half a million
+       tiles), the later launches append to a list */
+    unsigned char *ovf_flag;
+    int *ovf_count;
     int *ovf_tiles;
+    int ovf_atoms;         /* 1: append the atoms of the work item (the next launch works on single atoms) */
+    int split_ta;          /* > 0: work items are the two halves of the tiles in split_src (first half: split_ta atoms) */
+    const int *split_src;
     const int *work_tiles; /* tile ids to (re)do; null in the main launch (all tiles) */
     const int *work_count;
     int *status;
@@ -272,14 +279,71 @@ SASA_D double lr2_sweep(const Lr2Union &u, const Arc *stk, int ds)
 
 #define LR2_NB_UNROLL 2
 
+/* work item -> first atom and number of atoms */
+SASA_D void lr2_decode(const Lr2Args &a, int item, int &p0, int &na)
+{
+    if (a.split_ta <= 0) {
+        p0 = item * a.TA;
+        na = a.n_atoms - p0 < a.TA ? a.n_atoms - p0 : a.TA;
+    } else { /* a half of a tile that did not fit the main launch */
+        const int t0 = a.split_src[item >> 1] * a.TA;
+        const int full = a.n_atoms - t0 < a.TA ? a.n_atoms - t0 : a.TA;
+        const int first = full < a.split_ta ? full : a.split_ta;
+        p0 = (item & 1) ? t0 + first : t0;
+        na = (item & 1) ? full - first : first;
+    }
+}
+
+SASA_D void lr2_overflow(const Lr2Args &a, int item, int p0, int na, int err_code)
+{
+    if (a.ovf_flag) {
+        a.ovf_flag[item] = 1;
+    } else if (a.ovf_tiles && a.ovf_atoms) {
+        const int w = SASA_ATOMIC_ADD_GLB(a.ovf_count, na);
+        for (int k = 0; k < na; ++k) a.ovf_tiles[w + k] = p0 + k;
+    } else if (a.ovf_tiles) {
+        const int w = SASA_ATOMIC_ADD_GLB(a.ovf_count, 1);
+        a.ovf_tiles[w] = item;
+    } else {
+        SASA_ATOMIC_MAX_GLB(&a.status[ST_ERROR], err_code); /* the last launch: nothing left to hand the tile to */
+    }
+}
+
+/* flags -> work list.  One workgroup of B threads per LR2_COMPACT_PER * B tiles: every thread collects the
+ * marked ones among its LR2_COMPACT_PER consecutive tiles, the workgroup reserves its run of the list with ONE
+ * atomic.  cnt = LDS int [B + 1]. */
+#define LR2_COMPACT_PER 8
+SASA_D int lr2_compact_count(const unsigned char *flag, int n_tiles, int blk, int tid, int B)
+{
+    const int t0 = (blk * B + tid) * LR2_COMPACT_PER;
+    int c = 0;
+    for (int k = 0; k < LR2_COMPACT_PER; ++k) c += t0 + k < n_tiles && flag[t0 + k] ? 1 : 0;
+    return c;
+}
+SASA_D void lr2_compact_base(int *cnt, int *ovf_count, int tid, int B)
+{
+    if (tid != 0) return;
+    int run = 0;
+    for (int t = 0; t < B; ++t) { const int v = cnt[t]; cnt[t] = run; run += v; }
+    cnt[B] = run > 0 ? SASA_ATOMIC_ADD_GLB(ovf_count, run) : 0;
+}
+SASA_D void lr2_compact_write(const unsigned char *flag, int n_tiles, const int *cnt, int *ovf_tiles, int blk, int tid, int B)
+{
+    const int t0 = (blk * B + tid) * LR2_COMPACT_PER;
+    int w = cnt[B] + cnt[tid];
+    for (int k = 0; k < LR2_COMPACT_PER; ++k)
+        if (t0 + k < n_tiles && flag[t0 + k]) ovf_tiles[w++] = t0 + k;
+}
+
 /* The whole tile, executed by the 64 lanes of one wave.  RMAX = rounds of 64 pair records a lane
  * keeps in registers in P3 (pool <= 64 * RMAX). */
 template <int RMAX>
 SASA_D void lr2_tile(const Lr2Args &a, const Lr2Mem &m, int tile, int lane, int &wg_max_nn)
 {
     const int TA = a.TA, ns = a.ns, mw = a.mw;
-    const int p0 = tile * TA;
-    const int na = a.n_atoms - p0 < TA ? a.n_atoms - p0 : TA;
+    int p0, na; /* `tile` is the work item: a tile of the main launch, later a half of one */
+    lr2_decode(a, tile, p0, na);
+    if (na <= 0) return;
     const int items = na * ns;
     LR2_MARK_BEGIN;
     LR2_COUNT(0, 1);
@@ -446,14 +510,7 @@ SASA_D void lr2_tile(const Lr2Args &a, const Lr2Mem &m, int tile, int lane, int 
         }
     }
     if (m.flags[0]) { /* uniform: the tile goes to the next launch */
-        if (lane == 0) {
-            if (!a.ovf_tiles) {
-                SASA_ATOMIC_MAX_GLB(&a.status[ST_ERROR], (int)ERR_NEIGHBOR_CAP);
-            } else {
-                const int w = SASA_ATOMIC_ADD_GLB(a.ovf_count, 1);
-                a.ovf_tiles[w] = tile;
-            }
-        }
+        if (lane == 0) lr2_overflow(a, tile, p0, na, ERR_NEIGHBOR_CAP);
         LR2_SYNC();
         return;
     }
@@ -654,14 +711,7 @@ SASA_D void lr2_tile(const Lr2Args &a, const Lr2Mem &m, int tile, int lane, int 
 
     /* ------------------------------------------------------------ P7 store */
     if (m.flags[1]) { /* an arc stack overflowed: the tile is redone by the next launch */
-        if (lane == 0) {
-            if (!a.ovf_tiles) {
-                SASA_ATOMIC_MAX_GLB(&a.status[ST_ERROR], (int)ERR_STACK_CAP);
-            } else {
-                const int w = SASA_ATOMIC_ADD_GLB(a.ovf_count, 1);
-                a.ovf_tiles[w] = tile;
-            }
-        }
+        if (lane == 0) lr2_overflow(a, tile, p0, na, ERR_STACK_CAP);
     } else if (lane < na) {
         double s = 0;
         for (int k = 0; k < ns; ++k) s += m.it_tc[lane * ns + k]; /* slice order, ref: :305-361 */

@@ -113,6 +113,7 @@ enum {
     ST_OVF2_TILES = 3, /* tiles handed on to the third (slab) launch */
     ST_OCC_SUM = 4,    /* sum over sampled atoms of the number of atoms in their own cell ... */
     ST_OCC_N = 5,      /* ... and how many atoms were sampled: local density -> first launch shape */
+    ST_OVF3_ATOMS = 6, /* L&R (lr2_kernels.h): atoms handed to the last (slab) launch */
     ST_HIST = 8,       /* [64] tiles by neighbor records needed, bins of hist_bin_width(TA) */
     ST_WORDS = 72
 };

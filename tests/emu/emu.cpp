@@ -155,11 +155,11 @@ static void emu_lr2_kernel(const Lr2Cfg &cfg, Lr2Args a, int grid)
     std::vector<char> smem(cfg.lds + 64);
     for (int blk = 0; blk < grid; ++blk) {
         Lr2Mem m = lr2_carve(a, smem.data());
-        const int n_work = a.work_tiles ? *a.work_count : ((a.n_tiles + 7) >> 3) << 3;
+        const int n_work = a.work_count ? (a.work_tiles ? *a.work_count : 2 * *a.work_count) : ((a.n_tiles + 7) >> 3) << 3;
         std::vector<int> wg_max(64, 0);
         for (int w = blk; w < n_work; w += grid) {
-            const int tile = a.work_tiles ? a.work_tiles[w] : xcd_tile(w, a.n_tiles);
-            if (tile >= a.n_tiles) continue;
+            const int tile = a.work_tiles ? a.work_tiles[w] : (a.work_count ? w : xcd_tile(w, a.n_tiles));
+            if (!a.work_count && tile >= a.n_tiles) continue;
             Lr2Run run = {&a, &m, tile, cfg.rmax, wg_max.data()};
             sasa_emu::run_wave(lr2_lane_body, &run);
         }
@@ -274,20 +274,43 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
         la.s_cell = pa.s_cell; la.grid = pa.grid; la.cell_start = pa.cell_start; la.n_atoms = n; la.n_tiles = n_tiles2;
         la.TA = c2.TA; la.ns = resolution; la.pool = c2.pool; la.mw = c2.mw; la.ds = c2.ds; la.refill = c2.refill;
         la.sasa = sasa; la.status = status.data();
-        la.ovf_count = status.data() + ST_OVF_TILES; la.ovf_tiles = ovf1.data();
+        std::vector<unsigned char> flags(n_tiles2 + 16, 0);
+        la.ovf_flag = flags.data();
         emu_lr2_kernel(c2, la, ((n_tiles2 + 7) / 8) * 8);
+        { /* k_lr2_compact */
+            const int B = 256;
+            std::vector<int> cnt(B + 1);
+            for (int blk = 0; blk < (n_tiles2 + B * LR2_COMPACT_PER - 1) / (B * LR2_COMPACT_PER); ++blk) {
+                for (int t = 0; t < B; ++t) cnt[t] = lr2_compact_count(flags.data(), n_tiles2, blk, t, B);
+                for (int t = 0; t < B; ++t) lr2_compact_base(cnt.data(), status.data() + ST_OVF_TILES, t, B);
+                for (int t = 0; t < B; ++t) lr2_compact_write(flags.data(), n_tiles2, cnt.data(), ovf1.data(), blk, t, B);
+            }
+        }
+        std::vector<int> ovf2x(2 * n_tiles2 + 2), ovf3(n + 8);
+        { /* the halves of the tiles that did not fit, same kernel, same capacities */
+            Lr2Args ls = la;
+            ls.ovf_flag = nullptr;
+            ls.split_ta = (c2.TA + 1) / 2; ls.split_src = ovf1.data();
+            ls.work_tiles = nullptr; ls.work_count = status.data() + ST_OVF_TILES;
+            ls.ovf_tiles = ovf2x.data(); ls.ovf_count = status.data() + ST_OVF2_TILES;
+            emu_lr2_kernel(c2, ls, 7);
+        }
         Lr2Cfg cm = lr2_mid_cfg(c2);
         if (mid_cap_idx > 0) cm.mw = (mid_cap_idx + 31) / 32;
         if (mid_pool > 0) cm.pool = mid_pool;
         if (mid_ds >= 0) cm.ds = mid_ds;
         cm.lds = lr2_layout(cm.TA, cm.ns, cm.pool, cm.mw, cm.ds).total;
-        Lr2Args lm = la;
-        lm.pool = cm.pool; lm.mw = cm.mw; lm.ds = cm.ds;
-        lm.work_tiles = ovf1.data(); lm.work_count = status.data() + ST_OVF_TILES;
-        lm.ovf_tiles = ovf2.data(); lm.ovf_count = status.data() + ST_OVF2_TILES;
-        emu_lr2_kernel(cm, lm, 5);
         {
-            TileCfg fb = fallback_cfg(lr_slab_cfg(c2.TA, resolution), true);
+            Lr2Args lm = la;
+            lm.ovf_flag = nullptr;
+            lm.split_ta = (c2.TA + 1) / 2; lm.split_src = ovf1.data();
+            lm.pool = cm.pool; lm.mw = cm.mw; lm.ds = cm.ds;
+            lm.work_tiles = ovf2x.data(); lm.work_count = status.data() + ST_OVF2_TILES;
+            lm.ovf_tiles = ovf3.data(); lm.ovf_count = status.data() + ST_OVF3_ATOMS; lm.ovf_atoms = 1;
+            emu_lr2_kernel(cm, lm, 5);
+        }
+        {
+            TileCfg fb = fallback_cfg(lr_slab_cfg(1, resolution), true);
             if (fb_cap_idx > 0) fb.cap_idx = fb_cap_idx;
             if (fb_pool > 0) fb.pool = fb_pool;
             if (fb_ds > 0) fb.ds = fb_ds;
@@ -297,10 +320,10 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
             TileArgs tf;
             memset(&tf, 0, sizeof tf);
             tf.sx = pa.sx; tf.sy = pa.sy; tf.sz = pa.sz; tf.sr = pa.sr; tf.s_orig = pa.s_orig; tf.s_cell = pa.s_cell; tf.s_struct = pa.s_struct;
-            tf.grid = pa.grid; tf.cell_start = pa.cell_start; tf.n_atoms = n; tf.n_tiles = n_tiles2; tf.TA = fb.TA; tf.n_res = resolution; tf.tab = fb.tab;
+            tf.grid = pa.grid; tf.cell_start = pa.cell_start; tf.n_atoms = n; tf.n_tiles = n; tf.TA = 1; tf.n_res = resolution; tf.tab = fb.tab;
             tf.sasa = sasa; tf.lr = 1; tf.status = status.data();
             tf.cap_idx = fb.cap_idx; tf.pool = fb.pool; tf.ds = fb.ds;
-            tf.work_tiles = ovf2.data(); tf.work_count = status.data() + ST_OVF2_TILES;
+            tf.work_tiles = ovf3.data(); tf.work_count = status.data() + ST_OVF3_ATOMS;
             tf.slab = slab.data(); tf.slab_stride = (long long)stride;
             emu_tile_kernel<true>(true, fb, tf, fb_blocks);
         }
@@ -316,7 +339,7 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
         stats_out[0] = status[ST_ERROR]; stats_out[1] = status[ST_OVF_TILES]; stats_out[2] = status[ST_MAX_NN];
         stats_out[3] = c2.TA; stats_out[4] = 64; stats_out[5] = (long long)c2.lds; stats_out[6] = total_cells;
         stats_out[7] = c2.TA * resolution;
-        stats_out[8] = status[ST_OVF2_TILES]; stats_out[9] = 0;
+        stats_out[8] = status[ST_OVF3_ATOMS]; stats_out[9] = status[ST_OVF2_TILES];
         return status[ST_ERROR] ? -1 : 0;
     }
     TileCfg cfg = choose_cfg(resolution, lr != 0);
