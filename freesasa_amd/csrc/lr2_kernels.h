@@ -52,7 +52,15 @@ namespace sasa_emu { extern long long lr2_count[16]; } /* wave-level trip counts
 #else
 #define LR2_COUNT(k, n) do { } while (0)
 #define LR2_BALLOT(p) __builtin_amdgcn_ballot_w64(p)
-#define LR2_SYNC() __syncthreads() /* one wave per workgroup: no s_barrier is emitted, only the LDS fence */
+/* One wave per workgroup: the LDS executes a wave's instructions in the order they were issued, so a read that
+   follows a write in program order sees it, whichever lane wrote.  What is needed between phases is only that
+   the COMPILER keeps the order: no s_barrier, and no s_waitcnt for accesses that are still in flight (a full
+   workgroup fence waits for every outstanding global access, e.g. the store of the previous tile's result) */
+#ifdef LR2_FULL_FENCE
+#define LR2_SYNC() __syncthreads()
+#else
+#define LR2_SYNC() do { __atomic_signal_fence(__ATOMIC_SEQ_CST); __builtin_amdgcn_wave_barrier(); __atomic_signal_fence(__ATOMIC_SEQ_CST); } while (0)
+#endif
 #define LR2_SHFL(v, src) __shfl((v), (src), 64)
 #define LR2_POPC64(m) __popcll(m)
 #define LR2_POPC32(m) __popc(m)
