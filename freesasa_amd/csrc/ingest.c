@@ -602,36 +602,69 @@ static inline void cut(char *dst, size_t w, const char *p, size_t n)
 
 typedef struct { cif_lex at; int ncol; int col[12]; } cif_loop; /* an _atom_site loop: lexer state at its first value */
 
-/* walk the document; calls visit(row tokens) for every row of every complete _atom_site loop */
+/* Walk the document; calls visit(row tokens) for the rows of the _atom_site category of every data block, found
+ * the way the reference finds it (gemmi's block.find("_atom_site.", columns), src/cif.cc:113-126,161-200): the
+ * FIRST item of the block that carries _atom_site.group_PDB decides — a loop (it must hold all twelve columns,
+ * otherwise the block has no atoms; later _atom_site loops of the same block are not read) or a tag-value pair
+ * (then the category is one row made of the block's _atom_site.* pairs, all twelve needed). */
 typedef int (*cif_row_fn)(const cif_tok *row, void *ctx);
+static int cif_col_of(const cif_tok *t)
+{
+    if (t->n > 11 && ieq_n(t->p, "_atom_site.", 11))
+        for (int k = 0; k < 12; ++k)
+            if (strlen(cif_cols[k]) == t->n - 11 && ieq_n(t->p + 11, cif_cols[k], t->n - 11)) return k;
+    return -1;
+}
 static int cif_walk(const char *text, size_t len, cif_row_fn visit, void *ctx)
 {
     cif_lex lx = {text, text + len, 1};
     cif_tok t = cif_next(&lx);
-    while (t.type != T_END) {
-        if (t.type != T_LOOP) { /* data_, save_, tag-value pairs, stray values */
+    int decided = 0;    /* this block's _atom_site category has been located: 1 a loop (done), 2 pairs */
+    cif_tok prow[12];   /* pair form: the values collected so far */
+    int phave = 0;      /* bit k: prow[k] is set */
+    while (1) {
+        if (t.type == T_END || t.type == T_DATA) { /* a block ends: a complete row of pairs is its one atom */
+            if (decided == 2 && phave == 0xfff) {
+                const int rc = visit(prow, ctx);
+                if (rc) return rc;
+            }
+            decided = 0; phave = 0;
+            if (t.type == T_END) break;
             t = cif_next(&lx);
             continue;
         }
-        int ncol = 0, col[12], is_site = 0;
+        if (t.type == T_TAG) { /* tag-value pair */
+            const int k = cif_col_of(&t);
+            cif_tok v = cif_next(&lx);
+            if (v.type != T_VALUE) { t = v; continue; } /* (a tag without a value: malformed, skip the tag) */
+            if (k >= 0) {
+                if (k == 0 && !decided) decided = 2;
+                if (!(phave >> k & 1)) { prow[k] = v; phave |= 1 << k; } /* first occurrence, like a lookup by tag */
+            }
+            t = cif_next(&lx);
+            continue;
+        }
+        if (t.type != T_LOOP) { /* save_, stray values */
+            t = cif_next(&lx);
+            continue;
+        }
+        int ncol = 0, col[12], has_first = 0;
         signed char slot_of[256]; /* column of the loop -> wanted field, -1: not wanted */
         memset(slot_of, -1, sizeof slot_of);
         for (int k = 0; k < 12; ++k) col[k] = -1;
         t = cif_next(&lx);
         while (t.type == T_TAG) {
-            if (t.n > 11 && ieq_n(t.p, "_atom_site.", 11)) {
-                is_site = 1;
-                for (int k = 0; k < 12; ++k)
-                    if (strlen(cif_cols[k]) == t.n - 11 && ieq_n(t.p + 11, cif_cols[k], t.n - 11)) {
-                        col[k] = ncol;
-                        if (ncol < 256) slot_of[ncol] = (signed char)k;
-                    }
+            const int k = cif_col_of(&t);
+            if (k >= 0) {
+                if (k == 0) has_first = 1;
+                if (col[k] < 0) { col[k] = ncol; if (ncol < 256) slot_of[ncol] = (signed char)k; }
             }
             ++ncol;
             t = cif_next(&lx);
         }
-        int complete = is_site && ncol > 0 && ncol <= 256;
+        int complete = has_first && !decided && ncol > 0 && ncol <= 256;
         for (int k = 0; k < 12; ++k) complete = complete && col[k] >= 0;
+        if (has_first && !decided) decided = 1; /* this loop is the category, complete or not */
         cif_tok row[12];
         int c = 0;
         cif_fast fast = {0};

@@ -181,14 +181,21 @@ SASA_D void bounds_phase0(const PipeArgs &a, double *red, int chunk, int tid, in
     const int64_t b = a.chunk_begin[chunk], e = a.chunk_begin[chunk] + a.chunk_len[chunk];
     double lo0 = INFINITY, lo1 = INFINITY, lo2 = INFINITY;
     double hi0 = -INFINITY, hi1 = -INFINITY, hi2 = -INFINITY, rmax = 0; /* ref: src/nb.c:246 */
+    int bad = 0;
     for (int64_t i = b + tid; i < e; i += B) {
         const double x = a.xyz[3 * i], y = a.xyz[3 * i + 1], z = a.xyz[3 * i + 2];
         lo0 = fmin(x, lo0); hi0 = fmax(x, hi0);
         lo1 = fmin(y, lo1); hi1 = fmax(y, hi1);
         lo2 = fmin(z, lo2); hi2 = fmax(z, hi2);
-        rmax = fmax(a.radii[i] + a.probe, rmax);
+        const double rr = a.radii[i];
+        rmax = fmax(rr + a.probe, rmax);
         a.sid[i] = s;
+        /* fmin/fmax drop NaN and the float-to-int conversion of a NaN is 0 on gfx950 (INT_MIN on x86): a
+           non-finite coordinate or radius is flagged here, explicitly (v - v is NaN for NaN and +-inf) */
+        if (!(x - x == 0) || !(y - y == 0) || !(z - z == 0)) bad = ERR_BAD_COORD;
+        if (!(rr - rr == 0)) bad = bad ? bad : ERR_BAD_RADIUS;
     }
+    if (bad) SASA_ATOMIC_MAX_GLB(&a.status[ST_ERROR], bad);
     red[0 * B + tid] = lo0; red[1 * B + tid] = lo1; red[2 * B + tid] = lo2;
     red[3 * B + tid] = hi0; red[4 * B + tid] = hi1; red[5 * B + tid] = hi2;
     red[6 * B + tid] = rmax;

@@ -121,6 +121,15 @@ def synthetic_cifs():
                                                         "auth_asym_id", "auth_seq_id", "pdbx_PDB_ins_code", "Cartn_x", "Cartn_y", "Cartn_z",
                                                         "occupancy"])          # no pdbx_PDB_model_num
     files["syn_no_atoms.cif"] = "data_EMPTY\n_cell.length_a 10.0\n"
+    # the category written as tag-value pairs (a one-atom file): gemmi's block.find() takes it as a one-row table
+    pair_cols = ["group_PDB", "id", "type_symbol", "label_atom_id", "label_alt_id", "label_comp_id", "label_asym_id",
+                 "label_seq_id", "pdbx_PDB_ins_code", "Cartn_x", "Cartn_y", "Cartn_z", "auth_seq_id", "auth_comp_id", "auth_asym_id",
+                 "auth_atom_id", "pdbx_PDB_model_num"]
+    pair_vals = ["ATOM", "1", "N", "N", ".", "ALA", "A", "1", "?", "1.500", "-2.250", "3.125", "7", "ALA", "A", "N", "1"]
+    files["syn_pair_form.cif"] = "data_PAIR\n_cell.length_a 10.0\n" + "".join(f"_atom_site.{c} {v}\n" for c, v in zip(pair_cols, pair_vals))
+    files["syn_pair_form_incomplete.cif"] = "data_PAIR\n" + "".join(f"_atom_site.{c} {v}\n" for c, v in zip(pair_cols[:-1], pair_vals[:-1]))
+    # (a block with two _atom_site loops is not an input the reference defines: gemmi refuses duplicate tags with an
+    # exception that src/cif.cc does not catch; the reader here takes the first loop that carries group_PDB)
     return files
 
 

@@ -238,6 +238,18 @@ def test_errors_return_null_not_garbage(fa):
         bad[5, 2] = np.inf
         with pytest.raises(RuntimeError):
             fa.calc_coord(bad, r)
+        # NaN in one coordinate only, or in a radius: fmin/fmax drop NaN and v_cvt_i32_f64(NaN) is 0 on
+        # gfx950, so these are caught by an explicit finiteness test, for both algorithms
+        for axis in range(3):
+            nan = xyz.copy()
+            nan[7, axis] = np.nan
+            for alg in (fa.LEE_RICHARDS, fa.SHRAKE_RUPLEY):
+                with pytest.raises(RuntimeError):
+                    fa.calc_coord(nan, r, alg)
+        rn = r.copy()
+        rn[3] = np.nan
+        with pytest.raises(RuntimeError):
+            fa.calc_coord(xyz, rn)
         far = xyz.copy()
         far[0, 0] = 1e13
         with pytest.raises(RuntimeError):
