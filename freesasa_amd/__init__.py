@@ -121,6 +121,8 @@ def lib():
                                               _dp, _ip, _dp, C.c_int, C.c_char_p, C.c_int]
         L.freesasa_gpu_calc_batch_devices.argtypes = [_dp, _dp, _lp, C.c_int, C.c_int, C.c_double, C.c_int, _dp, _ip, _dp,
                                                       _ip, C.c_int, C.c_char_p, C.c_int]
+        L.freesasa_gpu_calc_batch_pipelined.argtypes = [_dp, _dp, _lp, C.c_int, C.c_int, C.c_double, C.c_int, _dp, _ip, _dp,
+                                                        C.c_int, C.c_int, C.c_longlong, C.c_char_p, C.c_int]
         L.freesasa_gpu_shard_cuts.argtypes = [_lp, C.c_int, C.c_int, _ip]
         L.freesasa_gpu_shard_cuts.restype = None
         L.freesasa_gpu_sweep_files.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
@@ -187,6 +189,30 @@ def calc_batch_devices(xyz, radii, offsets, devices, alg=LEE_RICHARDS, probe=1.4
                                                 totals.ctypes.data_as(_dp), devs.ctypes.data_as(_ip), devs.size, err, 512)
     if ret:
         raise RuntimeError("freesasa_gpu_calc_batch_devices: " + err.value.decode())
+    return sasa, counts, totals
+
+
+def calc_batch_pipelined(xyz, radii, offsets, alg=LEE_RICHARDS, probe=1.4, resolution=20, device=-1, lanes=0,
+                         chunk_atoms=0, out=None):
+    """freesasa_gpu_calc_batch_pipelined() on host arrays (numpy, or anything with .ctypes / data_ptr() such as a
+    pinned torch tensor via its numpy view): (sasa, counts-or-None, totals).  `out` = (sasa, counts, totals) arrays
+    to write into (e.g. page-locked ones); by default fresh numpy arrays."""
+    xyz, radii = _f64(xyz).reshape(-1), _f64(radii)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    n, ns = radii.size, offsets.size - 1
+    if out is None:
+        sasa, totals = np.empty(n), np.empty(ns)
+        counts = np.empty(n, dtype=np.int32) if alg == SHRAKE_RUPLEY else None
+    else:
+        sasa, counts, totals = out
+    err = C.create_string_buffer(512)
+    ret = lib().freesasa_gpu_calc_batch_pipelined(xyz.ctypes.data_as(_dp), radii.ctypes.data_as(_dp), offsets.ctypes.data_as(_lp), ns,
+                                                  alg, probe, resolution, sasa.ctypes.data_as(_dp),
+                                                  counts.ctypes.data_as(_ip) if counts is not None else None,
+                                                  totals.ctypes.data_as(_dp) if totals is not None else None,
+                                                  device, lanes, chunk_atoms, err, 512)
+    if ret:
+        raise RuntimeError("freesasa_gpu_calc_batch_pipelined: " + err.value.decode())
     return sasa, counts, totals
 
 

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <math.h>
+#include <atomic>
 #include <mutex>
 #include <stdarg.h>
 #include <stdint.h>
@@ -309,6 +310,8 @@ struct freesasa_gpu_ctx {
     std::vector<double> unit_host;     /* last uploaded S&R unit points */
     /* host staging for freesasa_gpu_calc_batch */
     DevBuf h_xyz, h_radii, h_sasa, h_counts, h_totals;
+    void *stage_in = nullptr, *stage_out = nullptr; /* page-locked host staging of freesasa_gpu_calc_batch_pipelined */
+    size_t stage_in_cap = 0, stage_out_cap = 0;
     int *pinned = nullptr; /* page-locked host words for the small device->host readbacks */
     long long max_cells = 1LL << 30;
     /* adaptive neighbor-pool size, per algorithm: (resolution, TA) it was learnt for and the value */
@@ -395,6 +398,8 @@ extern "C" void freesasa_gpu_ctx_destroy(freesasa_gpu_ctx *c)
     for (int k = 0; k < 4; ++k)
         if (c->ev[k]) (void)hipEventDestroy(c->ev[k]);
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->stage_in) (void)hipHostFree(c->stage_in);
+    if (c->stage_out) (void)hipHostFree(c->stage_out);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -751,6 +756,12 @@ static int run_batch_impl(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
             cfg.items = lr ? (cfg.tab ? cfg.TA * resolution : cfg.B) : 1;
             cfg.lds = tile_fixed_bytes(cfg.TA, cfg.items) + tile_list_bytes(cfg.TA, cfg.cap_idx, cfg.pool, cfg.lr, cfg.ds, cfg.B);
         }
+    }
+    /* whatever the estimate or the tuning aid asked for: the main launch's lists must fit the CU's LDS (dense tiles
+       then go to the later launches instead of failing the launch) */
+    while (cfg.lds > 160 * 1024 && cfg.pool > 32) {
+        cfg.pool = (cfg.pool * 3 / 4) & ~1;
+        cfg.lds = tile_fixed_bytes(cfg.TA, cfg.items) + tile_list_bytes(cfg.TA, cfg.cap_idx, cfg.pool, cfg.lr, cfg.ds, cfg.B);
     }
     const int n_tiles = (n + cfg.TA - 1) / cfg.TA;
     if (ensure(c, c->ovf_tiles, sizeof(int) * ((size_t)n_tiles + 1)) || ensure(c, c->ovf_tiles2, sizeof(int) * ((size_t)n_tiles + 1))) return -1;
@@ -1124,6 +1135,140 @@ extern "C" int freesasa_gpu_calc_batch_multi(const double *xyz, const double *ra
     if (devs.empty()) return set_err(err_out, err_len, "device mask selects no available device");
     return freesasa_gpu_calc_batch_devices(xyz, radii, offsets, n_structs, alg, probe, resolution, sasa_out, counts_out,
                                            totals_out, devs.data(), (int)devs.size(), err_out, err_len);
+}
+
+/* ------------------------------------------------------------------ host arrays in, host arrays out, pipelined */
+
+/* One host pointer: page-locked already (hipHostMalloc / hipHostRegister, e.g. a pinned tensor)? */
+static bool host_pinned(const void *p)
+{
+    hipPointerAttribute_t at;
+    if (!p || hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+
+/* Grow a context's page-locked staging buffer (for callers whose arrays are pageable). */
+static int ensure_pinned(freesasa_gpu_ctx *c, void **p, size_t *cap, size_t bytes)
+{
+    if (bytes <= *cap) return 0;
+    if (*p) (void)hipHostFree(*p);
+    *p = nullptr; *cap = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    if (hipHostMalloc(p, want, hipHostMallocDefault) != hipSuccess) return ctx_fail(c, "out of page-locked host memory (%zu bytes)", want);
+    *cap = want;
+    return 0;
+}
+
+/* The batch is cut into chunks of whole structures (about chunk_atoms atoms each) that n_lanes host threads take
+ * from a shared counter; every lane owns a pooled context (stream, workspace, staging) and runs
+ *     host -> device copy,  cell sort + tile kernels,  device -> host copy
+ * for its chunk while the other lanes are in a different stage: PCIe in, kernels and PCIe out of different
+ * chunks overlap.  Page-locked caller arrays are copied by DMA in place; pageable ones go through the lane's
+ * page-locked staging buffers (the memcpy of one lane overlaps the DMA of another). */
+extern "C" int freesasa_gpu_calc_batch_pipelined(const double *xyz, const double *radii, const int64_t *offsets, int n_structs,
+                                                 int alg, double probe, int resolution, double *sasa_out, int *counts_out,
+                                                 double *totals_out, int device, int n_lanes, long long chunk_atoms,
+                                                 char *err_out, int err_len)
+{
+    if (err_out && err_len > 0) err_out[0] = 0;
+    if (!xyz || !radii || !offsets || !sasa_out || n_structs <= 0) return set_err(err_out, err_len, "bad argument");
+    if (alg != 0 && alg != 1) return set_err(err_out, err_len, "unknown algorithm");
+    if (freesasa_gpu_device_count() <= 0)
+        return set_err(err_out, err_len, "no HIP device available: libfreesasa_amd has no CPU path");
+    const bool pin_in = host_pinned(xyz) && host_pinned(radii);
+    const bool pin_out = host_pinned(sasa_out) && (!counts_out || host_pinned(counts_out)) && (!totals_out || host_pinned(totals_out));
+    if (n_lanes <= 0) n_lanes = pin_in && pin_out ? 2 : 4; /* (measured: DMA in place needs one lane to copy while one computes; staging
+                                                              through page-locked buffers also spends host memcpy time) */
+    if (n_lanes > 8) n_lanes = 8;
+    if (chunk_atoms <= 0) chunk_atoms = 1250000;
+    std::vector<int> cut(1, 0);
+    for (int s = 0; s < n_structs; ++s)
+        if (offsets[s + 1] - offsets[cut.back()] >= chunk_atoms && s + 1 < n_structs) cut.push_back(s + 1);
+    cut.push_back(n_structs);
+    const int n_chunks = (int)cut.size() - 1;
+    if (n_lanes > n_chunks) n_lanes = n_chunks;
+    std::vector<double> tp;
+    if (alg == 1) { tp.resize(3 * (size_t)(resolution > 0 ? resolution : 1)); if (resolution > 0) freesasa_gpu_test_points(resolution, tp.data()); }
+    std::atomic<int> next(0), failed(0);
+    std::vector<std::vector<char>> errs(n_lanes, std::vector<char>(256, 0));
+    auto lane = [&](int id) {
+        freesasa_gpu_ctx *c = pool_get(device);
+        if (!c) { snprintf(errs[id].data(), 256, "could not create a GPU context"); failed = 1; return; }
+        std::vector<int64_t> off;
+        for (;;) {
+            const int k = next.fetch_add(1);
+            if (k >= n_chunks || failed.load()) break;
+            const int s0 = cut[k], ns = cut[k + 1] - cut[k];
+            const int64_t a0 = offsets[s0];
+            const size_t n = (size_t)(offsets[s0 + ns] - a0);
+            if (n == 0) { if (totals_out) for (int i = 0; i < ns; ++i) totals_out[s0 + i] = 0; continue; }
+            off.resize((size_t)ns + 1);
+            for (int i = 0; i <= ns; ++i) off[i] = offsets[s0 + i] - a0;
+            int rc = -1;
+            do {
+                if (hipSetDevice(c->device) != hipSuccess) { ctx_fail(c, "hipSetDevice failed"); break; }
+                if (ensure(c, c->h_xyz, 24 * n) || ensure(c, c->h_radii, 8 * n) || ensure(c, c->h_sasa, 8 * n) ||
+                    ensure(c, c->h_counts, 4 * n) || ensure(c, c->h_totals, 8 * (size_t)ns))
+                    break;
+                const double *src_xyz = xyz + 3 * a0, *src_r = radii + a0;
+                if (!pin_in) {
+                    if (ensure_pinned(c, &c->stage_in, &c->stage_in_cap, 32 * n)) break;
+                    memcpy(c->stage_in, src_xyz, 24 * n);
+                    memcpy((char *)c->stage_in + 24 * n, src_r, 8 * n);
+                    src_xyz = (const double *)c->stage_in;
+                    src_r = (const double *)((char *)c->stage_in + 24 * n);
+                }
+                if (hipMemcpyAsync(c->h_xyz.p, src_xyz, 24 * n, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                    hipMemcpyAsync(c->h_radii.p, src_r, 8 * n, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+                    ctx_fail(c, "host-to-device copy failed");
+                    break;
+                }
+                if (run_batch(c, alg == 0, (double *)c->h_xyz.p, (double *)c->h_radii.p, off.data(), ns, probe, resolution,
+                              alg == 1 ? tp.data() : nullptr, (double *)c->h_sasa.p, counts_out && alg == 1 ? (int *)c->h_counts.p : nullptr,
+                              totals_out ? (double *)c->h_totals.p : nullptr))
+                    break;
+                const bool want_counts = counts_out && alg == 1;
+                double *dst_sasa = sasa_out + a0, *dst_tot = totals_out ? totals_out + s0 : nullptr;
+                int *dst_cnt = want_counts ? counts_out + a0 : nullptr;
+                const size_t out_bytes = 8 * n + (want_counts ? 4 * n : 0) + (dst_tot ? 8 * (size_t)ns : 0);
+                if (!pin_out) {
+                    if (ensure_pinned(c, &c->stage_out, &c->stage_out_cap, out_bytes)) break;
+                    dst_sasa = (double *)c->stage_out;
+                    dst_cnt = want_counts ? (int *)((char *)c->stage_out + 8 * n) : nullptr;
+                    dst_tot = totals_out ? (double *)((char *)c->stage_out + 8 * n + (want_counts ? 4 * n : 0)) : nullptr;
+                }
+                bool ok = hipMemcpyAsync(dst_sasa, c->h_sasa.p, 8 * n, hipMemcpyDeviceToHost, c->stream) == hipSuccess;
+                if (ok && want_counts) ok = hipMemcpyAsync(dst_cnt, c->h_counts.p, 4 * n, hipMemcpyDeviceToHost, c->stream) == hipSuccess;
+                if (ok && dst_tot) ok = hipMemcpyAsync(dst_tot, c->h_totals.p, 8 * (size_t)ns, hipMemcpyDeviceToHost, c->stream) == hipSuccess;
+                if (!ok) { ctx_fail(c, "device-to-host copy failed"); break; }
+                if (hipStreamSynchronize(c->stream) != hipSuccess) { ctx_fail(c, "stream synchronize failed"); break; }
+                if (!pin_out) {
+                    memcpy(sasa_out + a0, dst_sasa, 8 * n);
+                    if (want_counts) memcpy(counts_out + a0, dst_cnt, 4 * n);
+                    if (totals_out) memcpy(totals_out + s0, dst_tot, 8 * (size_t)ns);
+                }
+                rc = 0;
+            } while (0);
+            if (rc) {
+                (void)hipStreamSynchronize(c->stream); /* nothing may still read the caller's arrays when we return */
+                snprintf(errs[id].data(), 256, "%s", c->err[0] ? c->err : "GPU batch failed");
+                failed = 1;
+                break;
+            }
+        }
+        pool_put(c);
+    };
+    std::vector<std::thread> th;
+    for (int k = 1; k < n_lanes; ++k) th.emplace_back(lane, k);
+    lane(0);
+    for (auto &t : th) t.join();
+    if (failed.load())
+        for (int k = 0; k < n_lanes; ++k)
+            if (errs[k][0]) return set_err(err_out, err_len, errs[k].data());
+    return failed.load() ? set_err(err_out, err_len, "GPU batch failed") : 0;
 }
 
 /* ------------------------------------------------------------------ structure sweep */

@@ -1654,8 +1654,13 @@ static inline TileCfg mid_cfg(const TileCfg &main_cfg, bool lr)
     c.cap_idx = 256;
     c.pool = 2 * main_cfg.pool < 64 * c.TA ? 64 * c.TA : 2 * main_cfg.pool; /* twice the (adaptive) main pool */
     if (c.pool > 3072) c.pool = 3072;
+    if (c.pool < main_cfg.pool) c.pool = main_cfg.pool; /* never smaller than the launch it backs up */
     c.ds = lr ? 8 : 0;
     c.lds = tile_fixed_bytes(c.TA, c.items) + tile_list_bytes(c.TA, c.cap_idx, c.pool, c.lr, c.ds, c.B);
+    while (c.lds > 160 * 1024 && c.pool > 64) { /* (the CU's LDS) */
+        c.pool = (c.pool * 3 / 4) & ~1;
+        c.lds = tile_fixed_bytes(c.TA, c.items) + tile_list_bytes(c.TA, c.cap_idx, c.pool, c.lr, c.ds, c.B);
+    }
     return c;
 }
 

@@ -110,6 +110,18 @@ int freesasa_gpu_calc_batch_devices(const double *xyz, const double *radii, cons
 int freesasa_gpu_calc_batch_multi(const double *xyz, const double *radii, const int64_t *offsets, int n_structs,
                                   int alg, double probe_radius, int resolution, double *sasa_out, int *counts_out,
                                   double *totals_out, unsigned device_mask, char *err, int err_len);
+/* Host arrays in, host arrays out, with the PCIe copies under the kernels: the batch is cut into chunks of whole
+   structures (about chunk_atoms atoms, <= 0: 1.25e6) that n_lanes host threads (<= 0: 2 for page-locked arrays, 4 for
+   pageable ones; at most 8) take from a
+   shared counter, each lane on its own pooled context and stream, so that the upload of one chunk, the kernels of
+   another and the download of a third overlap.  Page-locked caller arrays (hipHostMalloc / hipHostRegister, a
+   pinned tensor) are copied by DMA in place; pageable ones go through page-locked staging buffers of the lanes.
+   Arrays and results as in freesasa_gpu_calc_batch (bit-identical: chunks are independent structures).
+   Return 0 / -1. */
+int freesasa_gpu_calc_batch_pipelined(const double *xyz, const double *radii, const int64_t *offsets, int n_structs,
+                                      int alg, double probe_radius, int resolution, double *sasa_out, int *counts_out,
+                                      double *totals_out, int device, int n_lanes, long long chunk_atoms,
+                                      char *err, int err_len);
 /* cuts[0..n_parts]: first structure of every run for the partition above (host-only helper) */
 void freesasa_gpu_shard_cuts(const int64_t *offsets, int n_structs, int n_parts, int *cuts);
 
