@@ -123,6 +123,8 @@ def lib():
                                                       _ip, C.c_int, C.c_char_p, C.c_int]
         L.freesasa_gpu_calc_batch_pipelined.argtypes = [_dp, _dp, _lp, C.c_int, C.c_int, C.c_double, C.c_int, _dp, _ip, _dp,
                                                         C.c_int, C.c_int, C.c_longlong, C.c_char_p, C.c_int]
+        L.freesasa_gpu_lr_neighbors_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, _lp, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_int]
+        L.freesasa_gpu_arc_union_dev.argtypes = [C.c_void_p, _dp, _ip, C.c_int, _dp]
         L.freesasa_gpu_shard_cuts.argtypes = [_lp, C.c_int, C.c_int, _ip]
         L.freesasa_gpu_shard_cuts.restype = None
         L.freesasa_gpu_sweep_files.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
@@ -306,6 +308,23 @@ class GpuContext:
                                               d_totals or None)
         if ret:
             raise RuntimeError("freesasa_gpu_lr_batch_dev: " + self.error())
+
+    def lr_neighbors(self, d_xyz, d_radii, offsets, d_nn, d_nb=0, nb_cap=0, probe=1.4):
+        """Test hook: the neighbor sets the L&R kernel finds (counts, optionally the first nb_cap neighbors per atom)."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        if lib().freesasa_gpu_lr_neighbors_dev(self._h, d_xyz, d_radii, offsets.ctypes.data_as(_lp), offsets.size - 1,
+                                               probe, d_nn, d_nb or None, nb_cap):
+            raise RuntimeError("freesasa_gpu_lr_neighbors_dev: " + self.error())
+
+    def arc_union(self, sets):
+        """Test hook: exposed arc length of every set of (start, end) arcs through the kernel's arc union."""
+        first = np.concatenate([[0], np.cumsum([len(x) // 2 for x in sets])]).astype(np.int32)
+        arcs = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.float64).ravel() for x in sets]))
+        out = np.empty(len(sets))
+        if lib().freesasa_gpu_arc_union_dev(self._h, arcs.ctypes.data_as(_dp), first.ctypes.data_as(_ip), len(sets),
+                                            out.ctypes.data_as(_dp)):
+            raise RuntimeError("freesasa_gpu_arc_union_dev: " + self.error())
+        return out
 
     def segment_sums(self, d_sasa, seg_offsets, d_out):
         seg = np.ascontiguousarray(seg_offsets, dtype=np.int64)

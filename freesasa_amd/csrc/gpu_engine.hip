@@ -15,7 +15,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
+#include <algorithm>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../include/freesasa_gpu.h"
@@ -230,6 +232,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     }
     if (lane == 0 && wg_max_nn > a.status[ST_MAX_NN]) atomicMax(&a.status[ST_MAX_NN], wg_max_nn);
 }
+__global__ __launch_bounds__(64) void k_lr2_arc_kat(const double *arcs, const int *first, int n_sets, double *out)
+{
+    __shared__ Arc stack[8 * 64];
+    const int k = threadIdx.x;
+    if (k < n_sets) out[k] = lr2_arc_kat(arcs, first, k, stack + k, 8);
+}
+
 __global__ __launch_bounds__(256) void k_lr2_compact(const unsigned char *flag, int n_tiles, int *ovf_count, int *ovf_tiles)
 {
     __shared__ int cnt[257];
@@ -318,6 +327,8 @@ struct freesasa_gpu_ctx {
     int hint_res[2] = {0, 0}, hint_ta[2] = {0, 0}, hint_pool[2] = {0, 0};
     bool hint_bucket = false; /* L&R: the last batch had long neighbor lists */
     double hint_nn = 0;       /* L&R (lr2): neighbor records per atom the main launch should hold */
+    int *dbg_nn = nullptr, *dbg_nb = nullptr; /* test hook: freesasa_gpu_lr_neighbors_dev */
+    int dbg_cap = 0;
 };
 
 static int ctx_fail(freesasa_gpu_ctx *c, const char *fmt, ...)
@@ -547,11 +558,14 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
         const int g = atoi(e);
         if (g >= 8 && g < grid_main) grid_main = (g / 8) * 8;
     }
+    la.nn_out = c->dbg_nn; la.nb_out = c->dbg_nb; la.nb_cap = c->dbg_cap;
+    if (c->dbg_nn) la.ovf_flag = nullptr; /* (the hook returns before anything could overflow) */
     int wpe = 160 * 1024 / cfg.lds >= 20 ? 5 : 4; /* five waves per SIMD need the registers capped at 96 */
     if (const char *e = getenv("FREESASA_AMD_WPE")) wpe = atoi(e); /* tuning aid */
     hipError_t le = launch_lr2_main(cfg.rmax, wpe, grid_main, (size_t)cfg.lds, st, la);
     if (le != hipSuccess) return ctx_fail(c, "tile kernel launch failed: %s", hipGetErrorString(le));
     if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[2], st));
+    if (c->dbg_nn) return finish_batch(c, pa, n, n_structs, total_cells, d_sasa, nullptr, cfg.TA, 64, cfg.lds, status_h);
     hipLaunchKernelGGL(k_lr2_compact, dim3((n_tiles + 256 * LR2_COMPACT_PER - 1) / (256 * LR2_COMPACT_PER)), dim3(256), 0, st,
                        (const unsigned char *)c->ovf_flags.p, n_tiles, (int *)c->status.p + ST_OVF_TILES, (int *)c->ovf_tiles.p);
 
@@ -978,6 +992,57 @@ extern "C" int freesasa_gpu_residue_areas_dev(freesasa_gpu_ctx *c, const double 
                        (const int64_t *)base, d_rel ? (const short *)(base + b_first + b_table) : nullptr,
                        d_rel ? (const double *)(base + b_first) : nullptr, d_abs, d_rel, n_res);
     HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+/* ------------------------------------------------------------------ test hooks of the L&R kernel's integer parts */
+
+/* The neighbor sets the Lee-Richards kernel finds (ref: freesasa_nb_new with radii + probe, src/nb.c:524-557, what
+ * tests/test_nb.c checks): per atom, in original order, the number of neighbors and, if d_nb is given, the first
+ * nb_cap of them (original atom indices, in order of discovery).  Device pointers; d_nb may be NULL. */
+extern "C" int freesasa_gpu_lr_neighbors_dev(freesasa_gpu_ctx *c, const double *d_xyz, const double *d_radii, const int64_t *offsets,
+                                             int n_structs, double probe, int *d_nn, int *d_nb, int nb_cap)
+{
+    if (!c) return -1;
+    if (!d_nn || (d_nb && nb_cap <= 0)) return ctx_fail(c, "bad argument");
+    const int64_t n = offsets && n_structs > 0 ? offsets[n_structs] : 0;
+    if (n <= 0) return ctx_fail(c, "empty batch");
+    if (hipSetDevice(c->device) != hipSuccess || ensure(c, c->h_sasa, 8 * (size_t)n)) return -1;
+    c->dbg_nn = d_nn; c->dbg_nb = d_nb; c->dbg_cap = nb_cap;
+    const int rc = run_batch(c, true, d_xyz, d_radii, offsets, n_structs, probe, 20, nullptr,
+                             (double *)c->h_sasa.p, nullptr, nullptr);
+    c->dbg_nn = c->dbg_nb = nullptr; c->dbg_cap = 0;
+    return rc;
+}
+
+/* The exposed arc length of n_sets sets of arcs (start, end pairs in [0, 2 pi], set k = arcs first[k] .. first[k+1]),
+ * computed on the device by the arc union and sweep of the Lee-Richards kernel (ref: exposed_arc_length,
+ * src/sasa_lr.c:389-408, and its KATs :455-475).  Host arrays; at most 64 sets. */
+extern "C" int freesasa_gpu_arc_union_dev(freesasa_gpu_ctx *c, const double *arcs, const int *first, int n_sets, double *out)
+{
+    if (!c) return -1;
+    if (!arcs || !first || !out || n_sets <= 0 || n_sets > 64) return ctx_fail(c, "bad argument");
+    const int total = first[n_sets];
+    /* the arc pass feeds the union in the order of the arcs' mid-points (the neighbors' directions) */
+    std::vector<double> sorted(2 * (size_t)(total > 0 ? total : 1));
+    for (int k = 0; k < n_sets; ++k) {
+        std::vector<std::pair<double, double>> v;
+        for (int i = first[k]; i < first[k + 1]; ++i) v.emplace_back(arcs[2 * i], arcs[2 * i + 1]);
+        std::stable_sort(v.begin(), v.end(), [](const std::pair<double, double> &x, const std::pair<double, double> &y) {
+            return x.first + x.second < y.first + y.second; });
+        for (size_t i = 0; i < v.size(); ++i) { sorted[2 * (first[k] + i)] = v[i].first; sorted[2 * (first[k] + i) + 1] = v[i].second; }
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t b_arcs = sizeof(double) * sorted.size(), b_first = sizeof(int) * ((size_t)n_sets + 1);
+    if (ensure(c, c->seg, b_arcs + b_first + 8 * 64 + 64)) return -1;
+    char *base = (char *)c->seg.p;
+    HIP_TRY(c, hipMemcpyAsync(base, sorted.data(), b_arcs, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(base + b_arcs, first, b_first, hipMemcpyHostToDevice, c->stream));
+    double *d_out = (double *)(base + ((b_arcs + b_first + 15) & ~(size_t)15));
+    hipLaunchKernelGGL(k_lr2_arc_kat, dim3(1), dim3(64), 0, c->stream, (const double *)base, (const int *)(base + b_arcs), n_sets, d_out);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(out, d_out, sizeof(double) * (size_t)n_sets, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -105,6 +105,11 @@ struct Lr2Args {
     int ovf_atoms;         /* 1: append the atoms of the work item (the next launch works on single atoms) */
     int split_ta;          /* > 0: work items are the two halves of the tiles in split_src (first half: split_ta atoms) */
     const int *split_src;
+    /* test hook (freesasa_gpu_lr_neighbors_dev): stop after the neighbor discovery and report, in original atom
+       order, every atom's neighbor count and (optionally, nb_cap per atom) its neighbors */
+    int *nn_out;
+    int *nb_out;
+    int nb_cap;
     const int *work_tiles; /* tile ids to (re)do; null in the main launch (all tiles) */
     const int *work_count;
     int *status;
@@ -283,6 +288,17 @@ SASA_D double lr2_sweep(const Lr2Union &u, const Arc *stk, int ds)
         sup = SASA_TWOPI;
     }
     return sum + SASA_TWOPI - sup; /* ref: :407 */
+}
+
+/* test hook (freesasa_gpu_arc_union_dev): the exposed length of set `k`'s arcs, given sorted by their mid-points,
+ * through the arc union and the sweep of the arc pass (ref KATs: src/sasa_lr.c:455-475).  One lane per set. */
+SASA_D double lr2_arc_kat(const double *arcs, const int *first, int k, Arc *stk, int ds)
+{
+    Lr2Union u;
+    lr2_union_reset(u);
+    int maxd = 0;
+    for (int i = first[k]; i < first[k + 1]; ++i) lr2_union_step(arcs[2 * i], arcs[2 * i + 1], u, stk, ds, maxd);
+    return maxd - 2 > ds ? NAN : lr2_sweep(u, stk, ds);
 }
 
 #define LR2_NB_UNROLL 2
@@ -484,6 +500,7 @@ SASA_D void lr2_tile(const Lr2Args &a, const Lr2Mem &m, int tile, int lane, int 
                                 m.hits[slot] = hq;
                                 m.tag[slot] = (unsigned short)((unsigned)la | ((unsigned)sa << 3)); /* la < 8, sa < 2^13 */
                             }
+                            if (a.nb_out && sa < a.nb_cap) a.nb_out[(size_t)m.sorig[la] * a.nb_cap + sa] = a.s_orig[q[j]];
                         }
                         nh += LR2_POPC64(hm);
                     }
@@ -495,6 +512,11 @@ SASA_D void lr2_tile(const Lr2Args &a, const Lr2Mem &m, int tile, int lane, int 
 
     LR2_STOP(1);
     LR2_MARK(1);
+    if (a.nn_out) { /* (uniform) test hook: the neighbor counts are the result */
+        if (lane < na) a.nn_out[m.sorig[lane]] = m.acnt[lane];
+        LR2_SYNC();
+        return;
+    }
     /* ------------------------------------------------------------ P2 offsets */
     if (lane < TA) {
         int off = 0;

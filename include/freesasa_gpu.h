@@ -122,6 +122,16 @@ int freesasa_gpu_calc_batch_pipelined(const double *xyz, const double *radii, co
                                       int alg, double probe_radius, int resolution, double *sasa_out, int *counts_out,
                                       double *totals_out, int device, int n_lanes, long long chunk_atoms,
                                       char *err, int err_len);
+/* Test hooks: the integer / exact parts of the Lee-Richards kernel, run on the device on their own.
+   _lr_neighbors_dev: the neighbor sets it finds (what freesasa_nb_new builds, src/nb.c:524-557; the reference's
+   tests/test_nb.c): d_nn[n] = neighbors per atom, d_nb[n * nb_cap] (may be NULL) = the first nb_cap neighbors of
+   every atom (original indices); device pointers, original atom order.
+   _arc_union_dev: exposed arc length of n_sets (<= 64) sets of arcs given as (start, end) pairs in [0, 2 pi]
+   (set k = pairs first[k] .. first[k+1]), through the kernel's arc union and sweep (exposed_arc_length,
+   src/sasa_lr.c:389-408; its KATs :455-475); host arrays.  Return 0 / -1. */
+int freesasa_gpu_lr_neighbors_dev(freesasa_gpu_ctx *ctx, const double *d_xyz, const double *d_radii, const int64_t *offsets,
+                                  int n_structs, double probe_radius, int *d_nn, int *d_nb, int nb_cap);
+int freesasa_gpu_arc_union_dev(freesasa_gpu_ctx *ctx, const double *arcs, const int *first, int n_sets, double *out);
 /* cuts[0..n_parts]: first structure of every run for the partition above (host-only helper) */
 void freesasa_gpu_shard_cuts(const int64_t *offsets, int n_structs, int n_parts, int *cuts);
 

@@ -389,3 +389,99 @@ def test_single_process_multi_device_entry_matches_one_batch(fa, oracle_lib):
                 assert np.array_equal(got_c, want_c)
     with pytest.raises(RuntimeError):
         fa.calc_batch_devices(xyz, r, offs, [0, 99])
+
+
+def test_neighbor_sets_of_the_lr_kernel_are_the_reference_ones(fa, oracle_lib):
+    """Hot loop #1 on the HIP path, integers only: per-atom neighbor COUNTS (and, for the reference's own 6-atom
+    case, tests/test_nb.c:7-27, the neighbor SETS) found by the Lee-Richards kernel's discovery phase equal the
+    oracle's unique neighbor sets, bit for bit."""
+    import torch
+    dev = torch.device("cuda:0")
+    ctx = fa.GpuContext(0)
+
+    def gpu_nn(xyz, r_ext, offsets=None, cap=0):
+        n = len(r_ext)
+        offs = np.array([0, n], dtype=np.int64) if offsets is None else np.asarray(offsets, dtype=np.int64)
+        dx = torch.from_numpy(np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1)).to(dev)
+        dr = torch.from_numpy(np.ascontiguousarray(r_ext, dtype=np.float64)).to(dev)
+        nn = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        nb = torch.full((n * cap,), -1, dtype=torch.int32, device=dev) if cap else None
+        ctx.lr_neighbors(dx.data_ptr(), dr.data_ptr(), offs, nn.data_ptr(), nb.data_ptr() if cap else 0, cap, probe=0.0)
+        return nn.cpu().numpy(), (nb.cpu().numpy().reshape(n, cap) if cap else None)
+
+    # the reference's KAT: contact(0,1), contact(1,0), no contact(0,5)
+    v = np.array([0, 0, 0, 1, 1, 1, -1, 1, -1, 2, 0, -2, 2, 2, 0, -5, 5, 5], dtype=np.float64).reshape(6, 3)
+    r = np.array([4, 2, 2, 2, 2, 2], dtype=np.float64)
+    nn, nb = gpu_nn(v, r, cap=8)
+    start, idx = oracle_lib.neighbors(v, r)
+    for i in range(6):
+        assert sorted(nb[i, :nn[i]].tolist()) == sorted(set(idx[start[i]:start[i + 1]].tolist())), i
+    assert 1 in nb[0, :nn[0]] and 0 in nb[1, :nn[1]] and 5 not in nb[0, :nn[0]]
+    # counts on the golden structures and on synthetic ones (radii + probe, as the L&R set-up passes them)
+    cases = [(load_golden(k)["xyz"], load_golden(k)["radii"]) for k in ("1ubq", "3bzd_trimmed", "1a0q")]
+    cases += [tools.coil(5000, 11), tools.globule(3000, 12), tools.globule(800, 13, 2.05)]
+    for xyz, rad in cases:
+        ext = np.asarray(rad, dtype=np.float64) + 1.4
+        start, idx = oracle_lib.neighbors(xyz, ext)
+        want = np.array([len(set(idx[start[i]:start[i + 1]].tolist())) for i in range(len(ext))])
+        nn, _ = gpu_nn(xyz, ext)
+        assert np.array_equal(nn, want)
+    ctx.close()
+
+
+def test_arc_union_kats_through_the_device_union(fa, oracle_lib):
+    """The nine exposed_arc_length cases of src/sasa_lr.c:455-475 through the arc union and sweep the kernel uses
+    (device code, one lane per set), against the closed-form values the reference asserts and against the oracle."""
+    T = 2 * np.pi
+    sets = [[0, 0.1 * T, 0.9 * T, T], [0.9 * T, T, 0, 0.1 * T], [0, T, 1, 2], [1, 2, 0, T],
+            [0.1 * T, 0.2 * T, 0.5 * T, 0.6 * T], [0.1 * T, 0.2 * T, 0.5 * T, 0.6 * T],
+            [0.1 * T, 0.3 * T, 0.15 * T, 0.2 * T], [0.15 * T, 0.2 * T, 0.1 * T, 0.3 * T],
+            [0.05, 0.1, 0.5, 0.6, 0, 0.15, 0.7, 0.8, 0.75, T]]
+    want = [0.8 * T, 0.8 * T, 0, 0, 0.8 * T, 0.8 * T, 0.8 * T, 0.8 * T, 0.45]
+    ctx = fa.GpuContext(0)
+    got = ctx.arc_union(sets)
+    assert np.max(np.abs(got - np.array(want))) < 1e-10          # the reference's own tolerance
+    assert [float(g) for g in got] == [oracle_lib.exposed_arc_length(s) for s in sets]   # and bit for bit the oracle's sums
+    # random sets, many arcs, with wrapped ones given split as the reference stores them
+    rng = np.random.default_rng(5)
+    rsets = []
+    for _ in range(55):
+        arcs = []
+        for _ in range(int(rng.integers(1, 30))):
+            mid, half = rng.uniform(0, T), rng.uniform(0.01, 1.2)
+            lo, hi = mid - half, mid + half
+            if lo < 0:
+                arcs += [0, hi, lo + T, T]
+            elif hi > T:
+                arcs += [0, hi - T, lo, T]
+            else:
+                arcs += [lo, hi]
+        rsets.append(arcs)
+    got = ctx.arc_union(rsets)
+    ref = np.array([oracle_lib.exposed_arc_length(s) for s in rsets])
+    assert np.max(np.abs(got - ref)) < 1e-12
+    ctx.close()
+
+
+def test_pipelined_host_batch_is_bit_identical(fa, oracle_lib):
+    """freesasa_gpu_calc_batch_pipelined: host arrays in, host arrays out, chunks on several lanes; pageable and
+    page-locked arrays; both algorithms; equals the one-shot host batch bit for bit."""
+    import torch
+    parts = [tools.coil(int(n), 40 + k) for k, n in enumerate([900, 40, 2500, 1, 700, 3100, 1200, 60])]
+    xyz = np.concatenate([p[0] for p in parts]); r = np.concatenate([p[1] for p in parts])
+    offs = np.concatenate([[0], np.cumsum([len(p[1]) for p in parts])]).astype(np.int64)
+    for alg, res in ((fa.LEE_RICHARDS, 20), (fa.SHRAKE_RUPLEY, 100)):
+        want = fa.calc_batch(xyz, r, offs, alg=alg, resolution=res)
+        for lanes, chunk in ((1, 0), (3, 1000), (4, 2600)):
+            got = fa.calc_batch_pipelined(xyz, r, offs, alg=alg, resolution=res, lanes=lanes, chunk_atoms=chunk)
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2])
+            if alg == fa.SHRAKE_RUPLEY:
+                assert np.array_equal(got[1], want[1])
+        px, pr = torch.from_numpy(xyz).pin_memory().numpy(), torch.from_numpy(r).pin_memory().numpy()
+        out = (torch.empty(len(r), dtype=torch.float64).pin_memory().numpy(),
+               torch.empty(len(r), dtype=torch.int32).pin_memory().numpy() if alg == fa.SHRAKE_RUPLEY else None,
+               torch.empty(len(parts), dtype=torch.float64).pin_memory().numpy())
+        got = fa.calc_batch_pipelined(px, pr, offs, alg=alg, resolution=res, lanes=2, chunk_atoms=1500, out=out)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2])
+    with pytest.raises(RuntimeError):
+        fa.calc_batch_pipelined(np.full((10, 3), np.nan), np.ones(10), [0, 10])
