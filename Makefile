@@ -56,6 +56,20 @@ tests/emu/libingest_scalar.so: $(CSRC)/ingest.c $(CSRC)/protor_table.h include/f
 tests/emu/libsasa_emu.so: tests/emu/emu.cpp $(CSRC)/sasa_kernels.h $(CSRC)/lr2_kernels.h
 	$(CXX) -O2 -std=c++17 -fPIC -ffp-contract=off -DSASA_EMU -shared -o $@ tests/emu/emu.cpp -lm
 
+# Sanitizer build of the HOST sources (the reference's CI runs its C under sanitizers): the parsers,
+# the selection language, the C API shims and the test-point generator with AddressSanitizer + UBSan, linked with
+# the ordinary (uninstrumented) engine object.  `make asan-test` runs the CPU suites that exercise them.
+ASAN_SO = tests/emu/libfreesasa_amd_asan.so
+SANFLAGS = -O1 -g -std=gnu99 -fPIC -ffp-contract=off -Wall -fsanitize=address,undefined -fno-omit-frame-pointer -fno-sanitize-recover=undefined
+asan: $(ASAN_SO)
+$(ASAN_SO): $(CSRC)/api.c $(CSRC)/seam.c $(CSRC)/testpoints.c $(CSRC)/ingest.c $(CSRC)/select.c $(CSRC)/protor_table.h $(LIBDIR)/gpu_engine.o include/freesasa_amd.h include/freesasa_gpu.h include/freesasa_ingest.h
+	for f in api seam testpoints ingest select; do $(CC) $(SANFLAGS) -Iinclude -pthread -c $(CSRC)/$$f.c -o /tmp/asan_$$f.o || exit 1; done
+	$(CXX) -shared -fPIC -o $@ /tmp/asan_api.o /tmp/asan_seam.o /tmp/asan_testpoints.o /tmp/asan_ingest.o /tmp/asan_select.o $(LIBDIR)/gpu_engine.o \
+	    -fsanitize=address,undefined -L/opt/rocm/lib -Wl,-rpath,/opt/rocm/lib -lamdhip64 -lpthread -lm
+asan-test: $(ASAN_SO)
+	LD_PRELOAD="$$($(CC) -print-file-name=libasan.so) $$($(CC) -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 \
+	    FREESASA_AMD_LIB=$(CURDIR)/$(ASAN_SO) python -m pytest tests/test_ingest.py tests/test_select.py tests/test_capi.py -q -m "not gpu" -p no:cacheprovider
+
 oracle: $(LIBDIR)/libfreesasa_amd_seam.a
 	$(MAKE) -C oracle all dropin
 tools:
@@ -65,4 +79,4 @@ clean:
 	rm -rf $(LIBDIR) tests/emu/libsasa_emu.so tests/emu/libingest_scalar.so
 	$(MAKE) -C oracle clean
 	$(MAKE) -C tools clean
-.PHONY: all emu oracle tools clean
+.PHONY: all emu oracle tools clean asan asan-test

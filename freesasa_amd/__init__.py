@@ -125,6 +125,10 @@ def lib():
                                                         C.c_int, C.c_int, C.c_longlong, C.c_char_p, C.c_int]
         L.freesasa_gpu_lr_neighbors_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, _lp, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_int]
         L.freesasa_gpu_arc_union_dev.argtypes = [C.c_void_p, _dp, _ip, C.c_int, _dp]
+        L.freesasa_gpu_release_pool.argtypes = []
+        L.freesasa_gpu_release_pool.restype = None
+        L.freesasa_gpu_test_fail_after.argtypes = [C.c_int]
+        L.freesasa_gpu_test_fail_after.restype = None
         L.freesasa_gpu_shard_cuts.argtypes = [_lp, C.c_int, C.c_int, _ip]
         L.freesasa_gpu_shard_cuts.restype = None
         L.freesasa_gpu_sweep_files.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,

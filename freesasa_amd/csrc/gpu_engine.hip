@@ -347,6 +347,29 @@ static int ctx_fail(freesasa_gpu_ctx *c, const char *fmt, ...)
             return ctx_fail((c), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+/* Test hook (include/freesasa_gpu.h, freesasa_gpu_test_fail_after): the n-th device / page-locked allocation from
+ * now on fails, like the reference's interposed malloc (tests/tools.c:10-48) makes its n-th malloc fail. */
+static std::atomic<int> g_fail_after(0);
+extern "C" void freesasa_gpu_test_fail_after(int n) { g_fail_after.store(n > 0 ? n : 0); }
+static bool alloc_fails()
+{
+    int v = g_fail_after.load();
+    while (v > 0) {
+        if (g_fail_after.compare_exchange_weak(v, v - 1)) return v == 1;
+    }
+    return false;
+}
+static hipError_t dev_malloc(void **p, size_t bytes)
+{
+    if (alloc_fails()) { *p = nullptr; return hipErrorOutOfMemory; }
+    return hipMalloc(p, bytes);
+}
+static hipError_t host_malloc(void **p, size_t bytes)
+{
+    if (alloc_fails()) { *p = nullptr; return hipErrorOutOfMemory; }
+    return hipHostMalloc(p, bytes, hipHostMallocDefault);
+}
+
 static int ensure(freesasa_gpu_ctx *c, DevBuf &b, size_t bytes)
 {
     if (bytes <= b.cap) return 0;
@@ -354,7 +377,7 @@ static int ensure(freesasa_gpu_ctx *c, DevBuf &b, size_t bytes)
     b.p = nullptr;
     b.cap = 0;
     size_t want = bytes + bytes / 4 + 256; /* slack: trajectories grow/shrink a little */
-    HIP_TRY(c, hipMalloc(&b.p, want));
+    HIP_TRY(c, dev_malloc(&b.p, want));
     b.cap = want;
     return 0;
 }
@@ -366,6 +389,7 @@ extern "C" int freesasa_gpu_device_count(void)
     return n;
 }
 
+extern "C" void freesasa_gpu_ctx_destroy(freesasa_gpu_ctx *c);
 extern "C" freesasa_gpu_ctx *freesasa_gpu_ctx_create(int device, void *stream)
 {
     int n = freesasa_gpu_device_count();
@@ -378,18 +402,18 @@ extern "C" freesasa_gpu_ctx *freesasa_gpu_ctx_create(int device, void *stream)
         c->stream = (hipStream_t)stream;
     } else {
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
-            delete c;
+            freesasa_gpu_ctx_destroy(c);
             return nullptr;
         }
         c->own_stream = true;
     }
     for (int k = 0; k < 4; ++k)
         if (hipEventCreate(&c->ev[k]) != hipSuccess) {
-            delete c;
+            freesasa_gpu_ctx_destroy(c);
             return nullptr;
         }
-    if (hipHostMalloc((void **)&c->pinned, sizeof(int) * (ST_WORDS + 4), hipHostMallocDefault) != hipSuccess) {
-        delete c;
+    if (host_malloc((void **)&c->pinned, sizeof(int) * (ST_WORDS + 4)) != hipSuccess) {
+        freesasa_gpu_ctx_destroy(c);
         return nullptr;
     }
     return c;
@@ -666,7 +690,7 @@ static int run_batch_impl(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
        (trajectory frames and repeated batches reuse them) */
     if ((int)c->offsets_host.size() != n_structs + 1 ||
         memcmp(c->offsets_host.data(), offsets, sizeof(int64_t) * ((size_t)n_structs + 1)) != 0) {
-        c->offsets_host.assign(offsets, offsets + n_structs + 1);
+        c->offsets_host.clear(); /* (set again below, once the tables derived from it are on the device) */
         std::vector<int> cs, cl, sc0((size_t)n_structs + 1);
         std::vector<int64_t> cb;
         for (int s = 0; s < n_structs; ++s) {
@@ -682,11 +706,12 @@ static int run_batch_impl(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
         if (ensure(c, c->chunk_struct, 4 * nc) || ensure(c, c->chunk_begin, 8 * nc) || ensure(c, c->chunk_len, 4 * nc) ||
             ensure(c, c->struct_chunk0, 4 * ((size_t)n_structs + 1)) || ensure(c, c->bpart, 56 * nc))
             return -1;
-        HIP_TRY(c, hipMemcpy(c->offsets.p, c->offsets_host.data(), sizeof(int64_t) * ((size_t)n_structs + 1), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->offsets.p, offsets, sizeof(int64_t) * ((size_t)n_structs + 1), hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(c->chunk_struct.p, cs.data(), 4 * nc, hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(c->chunk_begin.p, cb.data(), 8 * nc, hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(c->chunk_len.p, cl.data(), 4 * nc, hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(c->struct_chunk0.p, sc0.data(), 4 * ((size_t)n_structs + 1), hipMemcpyHostToDevice));
+        c->offsets_host.assign(offsets, offsets + n_structs + 1);
     }
     HIP_TRY(c, hipMemsetAsync(c->status.p, 0, sizeof(int) * ST_WORDS, st));
     if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[0], st));
@@ -800,7 +825,10 @@ static int run_batch_impl(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
         if (c->unit_host.size() != 3 * (size_t)resolution ||
             memcmp(c->unit_host.data(), unit_points, sizeof(double) * 3 * (size_t)resolution) != 0) {
             c->unit_host.assign(unit_points, unit_points + 3 * (size_t)resolution);
-            HIP_TRY(c, hipMemcpyAsync(c->unit_pts.p, c->unit_host.data(), sizeof(double) * 3 * (size_t)resolution, hipMemcpyHostToDevice, st));
+            if (hipMemcpyAsync(c->unit_pts.p, c->unit_host.data(), sizeof(double) * 3 * (size_t)resolution, hipMemcpyHostToDevice, st) != hipSuccess) {
+                c->unit_host.clear();
+                return ctx_fail(c, "upload of the test points failed");
+            }
         }
         ta.unit_pts = (const double *)c->unit_pts.p;
     }
@@ -1073,6 +1101,18 @@ static void pool_put(freesasa_gpu_ctx *c)
     g_pool.push_back(c);
 }
 
+/* Destroy the idle contexts of the pool (their streams, workspaces and staging buffers): device memory goes back
+ * to the runtime; the next host-pointer call builds what it needs again. */
+extern "C" void freesasa_gpu_release_pool(void)
+{
+    std::vector<freesasa_gpu_ctx *> idle;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        idle.swap(g_pool);
+    }
+    for (freesasa_gpu_ctx *c : idle) freesasa_gpu_ctx_destroy(c);
+}
+
 static int set_err(char *out, int len, const char *msg)
 {
     if (out && len > 0) snprintf(out, (size_t)len, "%s", msg);
@@ -1222,7 +1262,7 @@ static int ensure_pinned(freesasa_gpu_ctx *c, void **p, size_t *cap, size_t byte
     if (*p) (void)hipHostFree(*p);
     *p = nullptr; *cap = 0;
     const size_t want = bytes + bytes / 4 + 4096;
-    if (hipHostMalloc(p, want, hipHostMallocDefault) != hipSuccess) return ctx_fail(c, "out of page-locked host memory (%zu bytes)", want);
+    if (host_malloc(p, want) != hipSuccess) return ctx_fail(c, "out of page-locked host memory (%zu bytes)", want);
     *cap = want;
     return 0;
 }
@@ -1481,9 +1521,9 @@ extern "C" int freesasa_gpu_trajectory(const double *xyz_frames, const double *r
         bool ok = true;
         for (int b = 0; b < 2 && ok; ++b)
             ok = hipEventCreateWithFlags(&ev_in[b], hipEventDisableTiming) == hipSuccess &&
-                 hipMalloc((void **)&d_xyz[b], 24 * n * FB) == hipSuccess && hipMalloc((void **)&d_sasa[b], 8 * n * FB) == hipSuccess &&
-                 hipMalloc((void **)&d_tot[b], 8 * FB) == hipSuccess;
-        ok = ok && hipMalloc((void **)&d_rad, 8 * n * FB) == hipSuccess;
+                 dev_malloc((void **)&d_xyz[b], 24 * n * FB) == hipSuccess && dev_malloc((void **)&d_sasa[b], 8 * n * FB) == hipSuccess &&
+                 dev_malloc((void **)&d_tot[b], 8 * FB) == hipSuccess;
+        ok = ok && dev_malloc((void **)&d_rad, 8 * n * FB) == hipSuccess;
         if (!ok) { ctx_fail(c, "out of device memory for the trajectory buffers"); break; }
         /* radii: one copy per frame slot of a batch (the batch API takes per-atom radii) */
         for (size_t k = 0; k < FB && ok; ++k)

@@ -122,6 +122,17 @@ int freesasa_gpu_calc_batch_pipelined(const double *xyz, const double *radii, co
                                       int alg, double probe_radius, int resolution, double *sasa_out, int *counts_out,
                                       double *totals_out, int device, int n_lanes, long long chunk_atoms,
                                       char *err, int err_len);
+/* The host-pointer entries (freesasa_calc_coord, freesasa_gpu_calc_batch*, _trajectory, _sweep_files) keep their
+   contexts — stream, device workspace, staging buffers — in a pool between calls.  This destroys the idle ones and
+   returns their device memory. */
+void freesasa_gpu_release_pool(void);
+
+/* Test hook: fault injection.  The n-th device or page-locked-host allocation made by this library from now on
+   fails (n <= 0: off), the way the reference's test suite makes its n-th malloc fail (tests/tools.c:10-48,
+   tests/test_freesasa.c:475-514): every entry point must then return its failure value with a message, leave
+   nothing running on its stream, and work again on the next call. */
+void freesasa_gpu_test_fail_after(int n);
+
 /* Test hooks: the integer / exact parts of the Lee-Richards kernel, run on the device on their own.
    _lr_neighbors_dev: the neighbor sets it finds (what freesasa_nb_new builds, src/nb.c:524-557; the reference's
    tests/test_nb.c): d_nn[n] = neighbors per atom, d_nb[n * nb_cap] (may be NULL) = the first nb_cap neighbors of

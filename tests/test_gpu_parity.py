@@ -485,3 +485,75 @@ def test_pipelined_host_batch_is_bit_identical(fa, oracle_lib):
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2])
     with pytest.raises(RuntimeError):
         fa.calc_batch_pipelined(np.full((10, 3), np.nan), np.ones(10), [0, 10])
+
+
+def test_every_allocation_failure_is_reported_and_the_next_call_works(fa):
+    """Fault injection (the reference interposes malloc and fails the n-th call at every site, tests/tools.c:10-48,
+    tests/test_freesasa.c:475-514): the n-th device / page-locked allocation fails, for n = 1, 2, ... until the call
+    gets through.  Every failing call must report failure (exception here = NULL / -1 with a message in C), the
+    next call must succeed with the right numbers, and device memory must not drain."""
+    import torch
+    L = fa.lib()
+    L.freesasa_set_verbosity(fa.V_SILENT)
+    xyz, r = tools.coil(3000, 3)
+    offs = np.array([0, 1000, 3000], dtype=np.int64)
+    want_lr = fa.calc_batch(xyz, r, offs)[0]
+    want_sr = fa.calc_batch(xyz, r, offs, alg=fa.SHRAKE_RUPLEY, resolution=100)[0]
+    dev = torch.device("cuda:0")
+    dx, dr = torch.from_numpy(xyz.reshape(-1)).to(dev), torch.from_numpy(r).to(dev)
+    out = torch.empty(len(r), dtype=torch.float64, device=dev)
+    frames = np.stack([tools.jitter(xyz, 7 + f, 0.3) for f in range(6)])
+
+    def ctx_call(alg):
+        ctx = fa.GpuContext(0)          # a fresh context: every buffer of its workspace is allocated in this call
+        try:
+            if alg == fa.LEE_RICHARDS:
+                ctx.lee_richards(dx.data_ptr(), dr.data_ptr(), offs, out.data_ptr())
+            else:
+                ctx.shrake_rupley(dx.data_ptr(), dr.data_ptr(), offs, out.data_ptr())
+            return out.cpu().numpy()
+        finally:
+            ctx.close()
+
+    entries = {
+        "context L&R": (lambda: ctx_call(fa.LEE_RICHARDS), want_lr),
+        "context S&R": (lambda: ctx_call(fa.SHRAKE_RUPLEY), want_sr),
+        "freesasa_calc_coord": (lambda: fa.calc_coord(xyz[:1000], r[:1000])[0], want_lr[:1000]),
+        "calc_batch": (lambda: fa.calc_batch(xyz, r, offs)[0], want_lr),
+        "calc_batch_pipelined": (lambda: fa.calc_batch_pipelined(xyz, r, offs, lanes=2, chunk_atoms=1000)[0], want_lr),
+        "trajectory": (lambda: fa.trajectory(frames, r, frames_per_batch=2)[1][0], None),
+    }
+    try:
+        free0 = None
+        for sweep in range(2):
+            for name, (call, want) in entries.items():
+                failures, n = 0, 1
+                while True:
+                    L.freesasa_gpu_release_pool()       # cold start: the call has to allocate everything again
+                    L.freesasa_gpu_test_fail_after(n)
+                    try:
+                        got = call()
+                        ok = True
+                    except (RuntimeError, MemoryError):
+                        ok = False
+                    L.freesasa_gpu_test_fail_after(0)
+                    if ok:
+                        break
+                    failures += 1
+                    n += 1
+                    assert n < 400, name
+                    got2 = call()                       # the library is healthy right after a failure
+                    if want is not None:
+                        assert np.array_equal(got2, want), name
+                assert failures >= 5, (name, failures)    # every entry allocates at least a handful of buffers
+                if want is not None:
+                    assert np.array_equal(got, want), name
+            L.freesasa_gpu_release_pool()
+            torch.cuda.synchronize()
+            free = torch.cuda.mem_get_info()[0]
+            if free0 is None:
+                free0 = free
+            assert free >= free0 - (64 << 20), (free0, free)   # a second sweep of failures leaks nothing
+    finally:
+        L.freesasa_gpu_test_fail_after(0)
+        L.freesasa_set_verbosity(fa.V_NORMAL)
