@@ -1271,6 +1271,41 @@ SASA_D void lr_phase_store(const TileArgs &a, TileMem &m, int tile, int tid, int
 
 /* ---------------------------------------------------------------- Shrake & Rupley */
 
+/* Wave-aggregated LDS counters (device): the lanes of a wavefront that want to bump the same counter are found
+ * with a ballot and counted with a popcount; ONE lane issues the atomic for all of them.
+ *   sasa_wave_slot(ctr, pred)       pred lanes get consecutive slots of *ctr (the order inside the wave is the lane order)
+ *   sasa_wave_count(ctrs, key, pred) ctrs[key] += number of pred lanes with that key (a wave's lanes hold one or two
+ *                                    different atoms: one atomic per atom and wave instead of one per exposed point)
+ * The CPU emulation (tests only) runs the lanes one after the other and keeps the plain atomics. */
+#ifdef SASA_EMU
+SASA_D int sasa_wave_slot(int *ctr, bool pred) { return pred ? SASA_ATOMIC_ADD_LDS(ctr, 1) : -1; }
+SASA_D void sasa_wave_count(int *ctrs, int key, bool pred) { if (pred) SASA_ATOMIC_ADD_LDS(&ctrs[key], 1); }
+#else
+SASA_D int sasa_wave_slot(int *ctr, bool pred)
+{
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(pred);
+    if (m == 0) return -1;
+    const int leader = __builtin_ctzll(m);
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    int base = 0;
+    if (lane == leader) base = atomicAdd(ctr, __popcll(m));
+    base = __builtin_amdgcn_readlane(base, leader);
+    return pred ? base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)) : -1;
+}
+SASA_D void sasa_wave_count(int *ctrs, int key, bool pred)
+{
+    unsigned long long pending = __builtin_amdgcn_ballot_w64(pred);
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    while (pending) { /* (uniform) one trip per different key among the pred lanes */
+        const int leader = __builtin_ctzll(pending);
+        const int k0 = __builtin_amdgcn_readlane(key, leader);
+        const unsigned long long same = __builtin_amdgcn_ballot_w64(pred && key == k0);
+        if (lane == leader) atomicAdd(&ctrs[k0], __popcll(same));
+        pending &= ~same;
+    }
+}
+#endif
+
 /* with phase O: zero the front/back cursors of phase P (they live in the candidate-run words,
  * which are dead once the neighbors are found) */
 SASA_D void sr_phase_cursors(const TileArgs &a, TileMem &m, int tid)
@@ -1349,19 +1384,25 @@ SASA_D void sr_phase_points(const TileArgs &a, TileMem &m, int tile, int tid, in
     const int np = a.n_res, items = na * np;
     const bool compact = sr_compact_ok(a, a.TA * np);
     unsigned *surv = (unsigned *)m.idx; /* the index lists are dead after phase P */
-    for (int it = tid; it < items; it += B) {
-        const int la = it / np, pt = it - la * np;
-        double tx, ty, tz;
-        sr_point(a, m, la, pt, tx, ty, tz);
-        const int o = m.aoff[la], nn = m.aoff[la + 1] - o;
-        const int k1 = compact && nn > SR_FIRST ? SR_FIRST : nn;
-        if (sr_covered(m, o, 0, k1, tx, ty, tz)) continue;
-        if (k1 == nn) {
-            SASA_ATOMIC_ADD_LDS(&m.aexp[la], 1);
-        } else {
-            const int w = SASA_ATOMIC_ADD_LDS(&m.flags[3], 1);
-            surv[w] = ((unsigned)la << 16) | (unsigned)pt;
+    for (int it0 = 0; it0 < items; it0 += B) { /* (trip count uniform over the workgroup: the wave operations below need every lane) */
+        const int it = it0 + tid;
+        const bool have = it < items;
+        const int la = have ? it / np : 0, pt = have ? it - la * np : 0;
+        bool exposed = false, survivor = false;
+        if (have) {
+            double tx, ty, tz;
+            sr_point(a, m, la, pt, tx, ty, tz);
+            const int o = m.aoff[la], nn = m.aoff[la + 1] - o;
+            const int k1 = compact && nn > SR_FIRST ? SR_FIRST : nn;
+            if (!sr_covered(m, o, 0, k1, tx, ty, tz)) {
+                exposed = k1 == nn;
+                survivor = !exposed;
+            }
         }
+        /* exposed points are counted per wavefront with ballot + popcount, survivors get their slots the same way */
+        sasa_wave_count(m.aexp, la, exposed);
+        const int w = sasa_wave_slot(&m.flags[3], survivor);
+        if (survivor) surv[w] = ((unsigned)la << 16) | (unsigned)pt;
     }
 }
 
@@ -1371,12 +1412,18 @@ SASA_D void sr_phase_points2(const TileArgs &a, TileMem &m, int tid, int B)
     if (m.flags[0]) return;
     const unsigned *surv = (const unsigned *)m.idx;
     const int ns = m.flags[3];
-    for (int s = tid; s < ns; s += B) {
-        const int la = (int)(surv[s] >> 16), pt = (int)(surv[s] & 0xffffu);
-        double tx, ty, tz;
-        sr_point(a, m, la, pt, tx, ty, tz);
-        const int o = m.aoff[la], nn = m.aoff[la + 1] - o;
-        if (!sr_covered(m, o, SR_FIRST, nn, tx, ty, tz)) SASA_ATOMIC_ADD_LDS(&m.aexp[la], 1);
+    for (int s0 = 0; s0 < ns; s0 += B) {
+        const int s = s0 + tid;
+        const bool have = s < ns;
+        const int la = have ? (int)(surv[s] >> 16) : 0, pt = have ? (int)(surv[s] & 0xffffu) : 0;
+        bool exposed = false;
+        if (have) {
+            double tx, ty, tz;
+            sr_point(a, m, la, pt, tx, ty, tz);
+            const int o = m.aoff[la], nn = m.aoff[la + 1] - o;
+            exposed = !sr_covered(m, o, SR_FIRST, nn, tx, ty, tz);
+        }
+        sasa_wave_count(m.aexp, la, exposed);
     }
 }
 

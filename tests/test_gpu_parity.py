@@ -557,3 +557,23 @@ def test_every_allocation_failure_is_reported_and_the_next_call_works(fa):
     finally:
         L.freesasa_gpu_test_fail_after(0)
         L.freesasa_set_verbosity(fa.V_NORMAL)
+
+
+def test_distinct_devices_give_the_single_device_result(fa):
+    """freesasa_gpu_calc_batch_devices on two (or more) DIFFERENT GPUs of the node: contiguous atom-balanced runs
+    of structures, one host thread / context / stream per device, no exchange — bit-identical to one device.
+    Skipped on a one-GPU box (the same-device test above covers the threading there)."""
+    nd = fa.device_count()
+    if nd < 2:
+        pytest.skip("needs two HIP devices")
+    parts = [tools.coil(int(n), 70 + k) for k, n in enumerate([4000, 300, 9000, 1200, 50, 7000, 2500, 800])]
+    xyz = np.concatenate([p[0] for p in parts]); r = np.concatenate([p[1] for p in parts])
+    offs = np.concatenate([[0], np.cumsum([len(p[1]) for p in parts])]).astype(np.int64)
+    for alg, res in ((fa.LEE_RICHARDS, 20), (fa.SHRAKE_RUPLEY, 100)):
+        one = fa.calc_batch(xyz, r, offs, alg=alg, resolution=res, device=0)
+        for devs in (list(range(nd)), list(range(min(nd, 8)))[::-1], [nd - 1, 0]):
+            got = fa.calc_batch_devices(xyz, r, offs, devs, alg=alg, resolution=res)
+            assert np.array_equal(got[0], one[0]) and np.array_equal(got[2], one[2]), devs
+        for d in range(nd):                         # and the pipelined entry on every device of the node
+            got = fa.calc_batch_pipelined(xyz, r, offs, alg=alg, resolution=res, device=d, chunk_atoms=5000)
+            assert np.array_equal(got[0], one[0]), d
