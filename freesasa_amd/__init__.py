@@ -135,6 +135,9 @@ def lib():
                                                C.c_longlong, _dp, _dp, _lp, _ip, C.c_int, C.c_char_p, C.c_int]
         L.freesasa_gpu_trajectory.argtypes = [_dp, _dp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
                                               C.c_int, _dp, _dp, C.c_int, C.c_char_p, C.c_int]
+        L.freesasa_gpu_trajectory_file.argtypes = [C.c_char_p, C.c_int, C.c_longlong, _dp, C.c_int, C.c_longlong, C.c_int, C.c_double,
+                                                   C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_longlong, C.c_int,
+                                                   C.POINTER(C.c_longlong), C.c_char_p, C.c_int]
         _lib = L
     return _lib
 
@@ -266,6 +269,22 @@ def trajectory(xyz_frames, radii, alg=LEE_RICHARDS, probe=1.4, resolution=20, fr
     if ret:
         raise RuntimeError("freesasa_gpu_trajectory: " + err.value.decode())
     return totals, sasa
+
+
+def trajectory_file(frames_path, radii, totals_path, sasa_path=None, done_path=None, f32=False, header_bytes=0,
+                    n_frames=0, alg=LEE_RICHARDS, probe=1.4, resolution=20, frames_per_batch=0, max_new_shards=0, device=-1):
+    """freesasa_gpu_trajectory_file(): raw frame file -> totals file (+ per-atom file), resumable through the
+    done-list at done_path.  Returns (complete, n_frames): complete is False when max_new_shards stopped the run."""
+    radii = _f64(radii)
+    err = C.create_string_buffer(512)
+    total = C.c_longlong(0)
+    enc = lambda p: None if p is None else str(p).encode()
+    ret = lib().freesasa_gpu_trajectory_file(enc(frames_path), 1 if f32 else 0, header_bytes, radii.ctypes.data_as(_dp), radii.size,
+                                             n_frames, alg, probe, resolution, frames_per_batch, enc(totals_path), enc(sasa_path),
+                                             enc(done_path), max_new_shards, device, C.byref(total), err, 512)
+    if ret < 0:
+        raise RuntimeError("freesasa_gpu_trajectory_file: " + err.value.decode())
+    return ret == 0, int(total.value)
 
 
 def test_points(n_points):

@@ -14,7 +14,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <algorithm>
 #include <thread>
 #include <utility>
@@ -306,6 +308,7 @@ struct freesasa_gpu_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool timing = false;
+    bool shared_radii = false; /* d_radii holds ONE structure's radii (trajectory frames) */
     char err[512] = {0};
     freesasa_gpu_stats stats = {};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -720,6 +723,7 @@ static int run_batch_impl(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
     memset(&pa, 0, sizeof pa);
     pa.xyz = d_xyz; pa.radii = d_radii; pa.offsets = (const int64_t *)c->offsets.p;
     pa.n_structs = n_structs; pa.n_atoms = n; pa.probe = probe; pa.max_cells = c->max_cells;
+    pa.shared_radii = c->shared_radii ? 1 : 0;
     pa.n_chunks = c->n_chunks; pa.chunk_struct = (const int *)c->chunk_struct.p; pa.chunk_begin = (const int64_t *)c->chunk_begin.p;
     pa.chunk_len = (const int *)c->chunk_len.p; pa.struct_chunk0 = (const int *)c->struct_chunk0.p; pa.bpart = (double *)c->bpart.p;
     pa.grid = (GridS *)c->grid.p; pa.ncells = (long long *)c->ncells.p;
@@ -1470,21 +1474,172 @@ extern "C" int freesasa_gpu_sweep_files(const char *const *paths, int n_paths, i
 
 /* ------------------------------------------------------------------ trajectory driver */
 
+/* Frames of ONE system (same atoms, same radii) are independent structures: a SHARD is a run of frames_per_batch
+ * frames that goes through the engine as one batch.  A few host lanes take shards from a shared counter; a lane
+ * owns a pooled context (stream, workspace, page-locked staging) and does, for its shard,
+ *     read (memory or frame file) -> host-to-device -> [fp32 frames widened to fp64 on the device: an INPUT format,
+ *     the arithmetic stays fp64] -> cell sort + tile kernels -> device-to-host -> write (memory or files)
+ * while the other lanes are in another stage.  The radii live once per device context (shared by every frame of
+ * a batch).  With a done-list file every finished shard is recorded after its results are on disk; a later call
+ * with the same parameters skips the recorded shards: an interrupted run resumes. */
+__global__ __launch_bounds__(256) void k_widen_f32(const float *in, double *out, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (double)in[i];
+}
+
 namespace {
-struct Pinned { /* pin a caller's buffer in place for the duration of the call; best effort */
-    void *p = nullptr;
-    bool ok = false;
-    Pinned(const void *ptr, size_t bytes)
-    {
-        if (ptr && bytes && hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterDefault) == hipSuccess) {
-            p = const_cast<void *>(ptr);
-            ok = true;
-        } else {
-            (void)hipGetLastError(); /* pageable copies still work, only slower */
-        }
-    }
-    ~Pinned() { if (ok) (void)hipHostUnregister(p); }
+struct TrajIO {
+    const double *mem_in = nullptr; /* frames in host memory (fp64) ... */
+    int fd_in = -1;                 /* ... or in a file of raw frames */
+    int in_f32 = 0;
+    long long in_header = 0;
+    double *totals_mem = nullptr, *sasa_mem = nullptr;
+    int fd_totals = -1, fd_sasa = -1;
+    int fd_done = -1;               /* done-list (append) */
+    std::vector<char> done;         /* shards already recorded */
 };
+
+static bool pread_all(int fd, void *buf, size_t bytes, long long off)
+{
+    char *p = (char *)buf;
+    while (bytes) {
+        const ssize_t r = pread(fd, p, bytes, (off_t)off);
+        if (r <= 0) return false;
+        p += r; off += r; bytes -= (size_t)r;
+    }
+    return true;
+}
+static bool pwrite_all(int fd, const void *buf, size_t bytes, long long off)
+{
+    const char *p = (const char *)buf;
+    while (bytes) {
+        const ssize_t r = pwrite(fd, p, bytes, (off_t)off);
+        if (r <= 0) return false;
+        p += r; off += r; bytes -= (size_t)r;
+    }
+    return true;
+}
+
+/* returns 0: all shards done, 1: stopped after max_new shards (more left), -1: error */
+static int traj_run(TrajIO &io, const double *radii, int n_atoms, long long n_frames, int alg, double probe, int resolution,
+                    int frames_per_batch, int n_lanes, long long max_new, int device, char *err_out, int err_len)
+{
+    const size_t n = (size_t)n_atoms, FB = (size_t)frames_per_batch;
+    const long long n_shards = (n_frames + frames_per_batch - 1) / frames_per_batch;
+    if (io.done.size() < (size_t)n_shards) io.done.resize((size_t)n_shards, 0);
+    if (n_lanes <= 0) n_lanes = 3;
+    if (n_lanes > 8) n_lanes = 8;
+    if (n_lanes > n_shards) n_lanes = (int)n_shards;
+    std::vector<double> tp;
+    if (alg == 1) { tp.resize(3 * (size_t)resolution); freesasa_gpu_test_points(resolution, tp.data()); }
+    std::vector<int64_t> offs(FB + 1);
+    for (size_t k = 0; k <= FB; ++k) offs[k] = (int64_t)(k * n);
+    const bool in_pinned = io.mem_in && host_pinned(io.mem_in);
+    const bool out_pinned = io.totals_mem && host_pinned(io.totals_mem) && (!io.sasa_mem || host_pinned(io.sasa_mem));
+    const bool want_sasa = io.sasa_mem || io.fd_sasa >= 0;
+    std::atomic<long long> next(0), fresh(0);
+    std::atomic<int> failed(0), stopped(0);
+    std::mutex done_mu;
+    std::vector<std::vector<char>> errs(n_lanes, std::vector<char>(256, 0));
+    auto lane = [&](int id) {
+        freesasa_gpu_ctx *c = pool_get(device);
+        if (!c) { snprintf(errs[id].data(), 256, "could not create a GPU context"); failed = 1; return; }
+        bool radii_up = false;
+        for (;;) {
+            const long long k = next.fetch_add(1);
+            if (k >= n_shards || failed.load()) break;
+            if (io.done[(size_t)k]) continue;
+            if (max_new > 0 && fresh.fetch_add(1) >= max_new) { stopped = 1; break; }
+            const long long f0 = k * frames_per_batch;
+            const int nf = (int)(n_frames - f0 < frames_per_batch ? n_frames - f0 : frames_per_batch);
+            const size_t na = n * (size_t)nf;
+            const size_t in_bytes = (io.in_f32 ? 12 : 24) * na;
+            int rc = -1;
+            do {
+                if (hipSetDevice(c->device) != hipSuccess) { ctx_fail(c, "hipSetDevice failed"); break; }
+                if (ensure(c, c->h_xyz, 24 * n * FB) || ensure(c, c->h_radii, 8 * n) || ensure(c, c->h_sasa, 8 * n * FB) ||
+                    ensure(c, c->h_totals, 8 * FB) || (io.in_f32 && ensure(c, c->h_counts, 12 * n * FB)))
+                    break;
+                if (!radii_up) { /* once per lane: the radii of the system */
+                    if (hipMemcpyAsync(c->h_radii.p, radii, 8 * n, hipMemcpyHostToDevice, c->stream) != hipSuccess) { ctx_fail(c, "radii upload failed"); break; }
+                    radii_up = true;
+                }
+                const void *src;
+                if (io.mem_in && in_pinned) {
+                    src = io.mem_in + 3 * n * (size_t)f0;
+                } else {
+                    if (ensure_pinned(c, &c->stage_in, &c->stage_in_cap, in_bytes)) break;
+                    if (io.mem_in) memcpy(c->stage_in, io.mem_in + 3 * n * (size_t)f0, in_bytes);
+                    else if (!pread_all(io.fd_in, c->stage_in, in_bytes, io.in_header + (long long)(io.in_f32 ? 12 : 24) * (long long)n * f0)) {
+                        ctx_fail(c, "could not read frames %lld..%lld of the frame file", f0, f0 + nf - 1);
+                        break;
+                    }
+                    src = c->stage_in;
+                }
+                if (io.in_f32) {
+                    if (hipMemcpyAsync(c->h_counts.p, src, in_bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) { ctx_fail(c, "host-to-device copy failed"); break; }
+                    hipLaunchKernelGGL(k_widen_f32, dim3((unsigned)((3 * na + 255) / 256)), dim3(256), 0, c->stream,
+                                       (const float *)c->h_counts.p, (double *)c->h_xyz.p, (long long)(3 * na));
+                } else if (hipMemcpyAsync(c->h_xyz.p, src, in_bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+                    ctx_fail(c, "host-to-device copy failed");
+                    break;
+                }
+                c->shared_radii = true;
+                const int rb = run_batch(c, alg == 0, (double *)c->h_xyz.p, (double *)c->h_radii.p, offs.data(), nf, probe, resolution,
+                                         alg == 1 ? tp.data() : nullptr, (double *)c->h_sasa.p, nullptr, (double *)c->h_totals.p);
+                c->shared_radii = false;
+                if (rb) break;
+                double *dst_tot = io.totals_mem ? io.totals_mem + f0 : nullptr, *dst_sasa = io.sasa_mem ? io.sasa_mem + n * (size_t)f0 : nullptr;
+                const bool staged = !(io.totals_mem && out_pinned);
+                if (staged) {
+                    if (ensure_pinned(c, &c->stage_out, &c->stage_out_cap, 8 * (size_t)nf + (want_sasa ? 8 * na : 0))) break;
+                    dst_tot = (double *)c->stage_out;
+                    dst_sasa = want_sasa ? (double *)c->stage_out + nf : nullptr;
+                }
+                bool ok = hipMemcpyAsync(dst_tot, c->h_totals.p, 8 * (size_t)nf, hipMemcpyDeviceToHost, c->stream) == hipSuccess;
+                if (ok && want_sasa) ok = hipMemcpyAsync(dst_sasa, c->h_sasa.p, 8 * na, hipMemcpyDeviceToHost, c->stream) == hipSuccess;
+                if (!ok) { ctx_fail(c, "device-to-host copy failed"); break; }
+                if (hipStreamSynchronize(c->stream) != hipSuccess) { ctx_fail(c, "stream synchronize failed"); break; }
+                if (staged) {
+                    if (io.totals_mem) memcpy(io.totals_mem + f0, dst_tot, 8 * (size_t)nf);
+                    if (io.sasa_mem) memcpy(io.sasa_mem + n * (size_t)f0, dst_sasa, 8 * na);
+                    if (io.fd_totals >= 0 && !pwrite_all(io.fd_totals, dst_tot, 8 * (size_t)nf, 8 * f0)) { ctx_fail(c, "could not write the totals file"); break; }
+                    if (io.fd_sasa >= 0 && !pwrite_all(io.fd_sasa, dst_sasa, 8 * na, 8 * (long long)n * f0)) { ctx_fail(c, "could not write the per-atom file"); break; }
+                }
+                if (io.fd_done >= 0) { /* results first, then the record: a shard is listed only when its numbers are on disk */
+                    if (io.fd_totals >= 0) (void)fdatasync(io.fd_totals);
+                    if (io.fd_sasa >= 0) (void)fdatasync(io.fd_sasa);
+                    char line[96];
+                    const int len = snprintf(line, sizeof line, "shard %lld %lld %d\n", k, f0, nf);
+                    std::lock_guard<std::mutex> lk(done_mu);
+                    if (write(io.fd_done, line, (size_t)len) != len) { ctx_fail(c, "could not append to the done-list"); break; }
+                    (void)fdatasync(io.fd_done);
+                }
+                io.done[(size_t)k] = 1;
+                rc = 0;
+            } while (0);
+            if (rc) {
+                c->shared_radii = false;
+                (void)hipStreamSynchronize(c->stream);
+                snprintf(errs[id].data(), 256, "%s", c->err[0] ? c->err : "trajectory shard failed");
+                failed = 1;
+                break;
+            }
+        }
+        pool_put(c);
+    };
+    std::vector<std::thread> th;
+    for (int k = 1; k < n_lanes; ++k) th.emplace_back(lane, k);
+    lane(0);
+    for (auto &t : th) t.join();
+    if (failed.load()) {
+        for (int k = 0; k < n_lanes; ++k)
+            if (errs[k][0]) return set_err(err_out, err_len, errs[k].data());
+        return set_err(err_out, err_len, "trajectory run failed");
+    }
+    return stopped.load() ? 1 : 0;
+}
 }
 
 extern "C" int freesasa_gpu_trajectory(const double *xyz_frames, const double *radii, int n_atoms, int n_frames,
@@ -1495,82 +1650,93 @@ extern "C" int freesasa_gpu_trajectory(const double *xyz_frames, const double *r
     if (!xyz_frames || !radii || !totals_out) return set_err(err_out, err_len, "null argument");
     if (n_atoms <= 0 || n_frames <= 0) return set_err(err_out, err_len, "n_atoms and n_frames must be > 0");
     if (alg != 0 && alg != 1) return set_err(err_out, err_len, "unknown algorithm");
+    if (resolution <= 0) return set_err(err_out, err_len, "resolution must be > 0");
     if (freesasa_gpu_device_count() <= 0)
         return set_err(err_out, err_len, "no HIP device available: libfreesasa_amd has no CPU path");
-    if (frames_per_batch <= 0) frames_per_batch = (int)(2000000 / n_atoms) + 1;
+    if (frames_per_batch <= 0) frames_per_batch = (int)(1250000 / n_atoms) + 1;
     if (frames_per_batch > n_frames) frames_per_batch = n_frames;
     if ((long long)frames_per_batch * n_atoms > (1LL << 30)) return set_err(err_out, err_len, "batch too large");
+    TrajIO io;
+    io.mem_in = xyz_frames; io.totals_mem = totals_out; io.sasa_mem = sasa_out;
+    return traj_run(io, radii, n_atoms, n_frames, alg, probe, resolution, frames_per_batch, 0, 0, device, err_out, err_len) < 0 ? -1 : 0;
+}
 
-    freesasa_gpu_ctx *c = pool_get(device);
-    if (!c) return set_err(err_out, err_len, "could not create a GPU context");
-    const size_t n = (size_t)n_atoms, FB = (size_t)frames_per_batch;
-    hipStream_t copy = nullptr;
-    hipEvent_t ev_in[2] = {nullptr, nullptr};
-    double *d_xyz[2] = {nullptr, nullptr}, *d_sasa[2] = {nullptr, nullptr}, *d_tot[2] = {nullptr, nullptr}, *d_rad = nullptr;
+/* Frame file -> result files, resumable.  frames_path: raw little-endian frames, frame f = 3 * n_atoms values
+ * (x1, y1, z1, x2, ...) of type double (frames_f32 = 0) or float (1) at byte header_bytes + f * frame size.
+ * totals_path: one double per frame at byte 8 * f; sasa_path (may be NULL): n_atoms doubles per frame at byte
+ * 8 * n_atoms * f.  done_path (may be NULL): the done-list — a text file, first line = the run's parameters, then
+ * one line "shard <index> <first frame> <frames>" per finished shard, appended after the shard's results are on
+ * disk.  A call that finds a done-list with the same parameters skips its shards (results stay as they are in the
+ * result files); with different parameters it fails rather than mix two runs.  max_new_shards > 0 stops after
+ * that many shards (returns 1: incomplete; used by the tests to interrupt a run).
+ * n_frames <= 0: as many whole frames as the file holds.  Returns 0 done, 1 incomplete, -1 error. */
+extern "C" int freesasa_gpu_trajectory_file(const char *frames_path, int frames_f32, long long header_bytes, const double *radii,
+                                            int n_atoms, long long n_frames, int alg, double probe, int resolution,
+                                            int frames_per_batch, const char *totals_path, const char *sasa_path,
+                                            const char *done_path, long long max_new_shards, int device,
+                                            long long *frames_total_out, char *err_out, int err_len)
+{
+    if (err_out && err_len > 0) err_out[0] = 0;
+    if (!frames_path || !radii || !totals_path) return set_err(err_out, err_len, "null argument");
+    if (n_atoms <= 0 || header_bytes < 0) return set_err(err_out, err_len, "bad argument");
+    if (alg != 0 && alg != 1) return set_err(err_out, err_len, "unknown algorithm");
+    if (resolution <= 0) return set_err(err_out, err_len, "resolution must be > 0");
+    if (freesasa_gpu_device_count() <= 0)
+        return set_err(err_out, err_len, "no HIP device available: libfreesasa_amd has no CPU path");
+    TrajIO io;
     int ret = -1;
-    std::vector<int64_t> offs(FB + 1);
-    for (size_t k = 0; k <= FB; ++k) offs[k] = (int64_t)(k * n);
-    std::vector<double> tp;
-    if (alg == 1 && resolution > 0) {
-        tp.resize(3 * (size_t)resolution);
-        freesasa_gpu_test_points(resolution, tp.data());
-    }
     do {
-        if (hipSetDevice(c->device) != hipSuccess) { ctx_fail(c, "hipSetDevice failed"); break; }
-        if (hipStreamCreateWithFlags(&copy, hipStreamNonBlocking) != hipSuccess) { ctx_fail(c, "stream create failed"); break; }
-        bool ok = true;
-        for (int b = 0; b < 2 && ok; ++b)
-            ok = hipEventCreateWithFlags(&ev_in[b], hipEventDisableTiming) == hipSuccess &&
-                 dev_malloc((void **)&d_xyz[b], 24 * n * FB) == hipSuccess && dev_malloc((void **)&d_sasa[b], 8 * n * FB) == hipSuccess &&
-                 dev_malloc((void **)&d_tot[b], 8 * FB) == hipSuccess;
-        ok = ok && dev_malloc((void **)&d_rad, 8 * n * FB) == hipSuccess;
-        if (!ok) { ctx_fail(c, "out of device memory for the trajectory buffers"); break; }
-        /* radii: one copy per frame slot of a batch (the batch API takes per-atom radii) */
-        for (size_t k = 0; k < FB && ok; ++k)
-            ok = hipMemcpyAsync(d_rad + k * n, radii, 8 * n, hipMemcpyHostToDevice, copy) == hipSuccess;
-        if (!ok) { ctx_fail(c, "radii upload failed"); break; }
-
-        Pinned pin_in(xyz_frames, 24 * n * (size_t)n_frames);
-        Pinned pin_tot(totals_out, 8 * (size_t)n_frames);
-        Pinned pin_out(sasa_out, sasa_out ? 8 * n * (size_t)n_frames : 0);
-
-        const int n_batches = (n_frames + frames_per_batch - 1) / frames_per_batch;
-        auto frames_in = [&](int k) { int f0 = k * frames_per_batch; return n_frames - f0 < frames_per_batch ? n_frames - f0 : frames_per_batch; };
-        /* prologue: batch 0 in */
-        ok = hipMemcpyAsync(d_xyz[0], xyz_frames, 24 * n * (size_t)frames_in(0), hipMemcpyHostToDevice, copy) == hipSuccess &&
-             hipEventRecord(ev_in[0], copy) == hipSuccess;
-        for (int k = 0; k < n_batches && ok; ++k) {
-            const int b = k & 1, nf = frames_in(k);
-            const size_t f0 = (size_t)k * FB;
-            ok = hipStreamWaitEvent(c->stream, ev_in[b], 0) == hipSuccess;
-            if (ok && k + 1 < n_batches) /* next batch in, while this one computes */
-                ok = hipMemcpyAsync(d_xyz[b ^ 1], xyz_frames + 3 * n * (f0 + FB), 24 * n * (size_t)frames_in(k + 1), hipMemcpyHostToDevice, copy) == hipSuccess &&
-                     hipEventRecord(ev_in[b ^ 1], copy) == hipSuccess;
-            if (!ok) { ctx_fail(c, "host-to-device copy failed"); break; }
-            const int rc = run_batch(c, alg == 0, d_xyz[b], d_rad, offs.data(), nf, probe, resolution,
-                                     alg == 1 ? tp.data() : nullptr, d_sasa[b], nullptr, d_tot[b]);
-            if (rc) { ok = false; break; }
-            /* results out on the copy stream: overlaps the next batch's kernels */
-            ok = hipMemcpyAsync(totals_out + f0, d_tot[b], 8 * (size_t)nf, hipMemcpyDeviceToHost, copy) == hipSuccess;
-            if (ok && sasa_out)
-                ok = hipMemcpyAsync(sasa_out + n * f0, d_sasa[b], 8 * n * (size_t)nf, hipMemcpyDeviceToHost, copy) == hipSuccess;
-            if (!ok) ctx_fail(c, "device-to-host copy failed");
-            /* the copy stream is in order: by the time batch k+2 wants this slot again, these
-               copies have completed (batch k+2's upload is enqueued behind them) */
+        io.fd_in = open(frames_path, O_RDONLY);
+        if (io.fd_in < 0) { set_err(err_out, err_len, "cannot open the frame file"); break; }
+        struct stat st;
+        if (fstat(io.fd_in, &st) != 0) { set_err(err_out, err_len, "cannot stat the frame file"); break; }
+        const long long frame_bytes = (frames_f32 ? 12LL : 24LL) * n_atoms;
+        const long long in_file = ((long long)st.st_size - header_bytes) / frame_bytes;
+        if (n_frames <= 0) n_frames = in_file;
+        if (n_frames <= 0 || n_frames > in_file) { set_err(err_out, err_len, "the frame file holds fewer frames than asked for"); break; }
+        if (frames_total_out) *frames_total_out = n_frames;
+        if (frames_per_batch <= 0) frames_per_batch = (int)(1250000 / n_atoms) + 1;
+        if (frames_per_batch > n_frames) frames_per_batch = (int)n_frames;
+        if ((long long)frames_per_batch * n_atoms > (1LL << 30)) { set_err(err_out, err_len, "batch too large"); break; }
+        io.in_f32 = frames_f32 ? 1 : 0; io.in_header = header_bytes;
+        const long long n_shards = (n_frames + frames_per_batch - 1) / frames_per_batch;
+        io.done.assign((size_t)n_shards, 0);
+        char head[256];
+        snprintf(head, sizeof head, "freesasa_amd trajectory done-list v1 n_atoms=%d n_frames=%lld frames_per_batch=%d alg=%d resolution=%d probe=%.17g f32=%d\n",
+                 n_atoms, n_frames, frames_per_batch, alg, resolution, probe, io.in_f32);
+        bool resume = false;
+        if (done_path) {
+            FILE *fp = fopen(done_path, "r");
+            if (fp) {
+                char line[256];
+                if (fgets(line, sizeof line, fp)) {
+                    if (strcmp(line, head) != 0) { fclose(fp); set_err(err_out, err_len, "the done-list belongs to a run with other parameters"); break; }
+                    resume = true;
+                    long long k, f0; int nf;
+                    while (fgets(line, sizeof line, fp))
+                        if (sscanf(line, "shard %lld %lld %d", &k, &f0, &nf) == 3 && k >= 0 && k < n_shards && f0 == k * frames_per_batch &&
+                            line[strlen(line) - 1] == '\n') /* (a record cut short by a crash does not count) */
+                            io.done[(size_t)k] = 1;
+                }
+                fclose(fp);
+            }
         }
-        if (hipStreamSynchronize(copy) != hipSuccess) { ctx_fail(c, "stream synchronize failed"); ok = false; }
-        if (ok) ret = 0;
+        io.fd_totals = open(totals_path, resume ? O_WRONLY | O_CREAT : O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (io.fd_totals < 0) { set_err(err_out, err_len, "cannot open the totals file"); break; }
+        if (sasa_path) {
+            io.fd_sasa = open(sasa_path, resume ? O_WRONLY | O_CREAT : O_WRONLY | O_CREAT | O_TRUNC, 0644);
+            if (io.fd_sasa < 0) { set_err(err_out, err_len, "cannot open the per-atom file"); break; }
+        }
+        if (done_path) {
+            io.fd_done = open(done_path, resume ? O_WRONLY | O_APPEND : O_WRONLY | O_CREAT | O_TRUNC, 0644);
+            if (io.fd_done < 0) { set_err(err_out, err_len, "cannot open the done-list"); break; }
+            if (!resume && write(io.fd_done, head, strlen(head)) != (ssize_t)strlen(head)) { set_err(err_out, err_len, "cannot write the done-list"); break; }
+        }
+        ret = traj_run(io, radii, n_atoms, n_frames, alg, probe, resolution, frames_per_batch, 0, max_new_shards, device, err_out, err_len);
     } while (0);
-    if (ret) set_err(err_out, err_len, c->err[0] ? c->err : "trajectory run failed");
-    (void)hipStreamSynchronize(c->stream);
-    if (copy) { (void)hipStreamSynchronize(copy); (void)hipStreamDestroy(copy); }
-    for (int b = 0; b < 2; ++b) {
-        if (ev_in[b]) (void)hipEventDestroy(ev_in[b]);
-        if (d_xyz[b]) (void)hipFree(d_xyz[b]);
-        if (d_sasa[b]) (void)hipFree(d_sasa[b]);
-        if (d_tot[b]) (void)hipFree(d_tot[b]);
-    }
-    if (d_rad) (void)hipFree(d_rad);
-    pool_put(c);
+    if (io.fd_in >= 0) close(io.fd_in);
+    if (io.fd_totals >= 0) close(io.fd_totals);
+    if (io.fd_sasa >= 0) close(io.fd_sasa);
+    if (io.fd_done >= 0) close(io.fd_done);
     return ret;
 }

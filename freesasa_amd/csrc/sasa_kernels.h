@@ -138,7 +138,8 @@ struct GridS {
  * ---------------------------------------------------------------------------------- */
 struct PipeArgs {
     const double *xyz;      /* [3*n_atoms] x1,y1,z1,...   (ref layout: src/coord.h:26-38) */
-    const double *radii;    /* [n_atoms] atom radii WITHOUT probe */
+    const double *radii;    /* [n_atoms] atom radii WITHOUT probe; shared_radii: ONE structure's radii, used by every structure */
+    int shared_radii;       /* 1: radii[k] belongs to atom k of every structure (trajectory frames: one copy per device) */
     const int64_t *offsets; /* [n_structs+1] first atom of each structure */
     int n_structs;
     int n_atoms;
@@ -179,6 +180,7 @@ SASA_D void bounds_phase0(const PipeArgs &a, double *red, int chunk, int tid, in
 {
     const int s = a.chunk_struct[chunk];
     const int64_t b = a.chunk_begin[chunk], e = a.chunk_begin[chunk] + a.chunk_len[chunk];
+    const int64_t b0 = a.shared_radii ? a.offsets[s] : 0; /* first atom of the chunk's structure */
     double lo0 = INFINITY, lo1 = INFINITY, lo2 = INFINITY;
     double hi0 = -INFINITY, hi1 = -INFINITY, hi2 = -INFINITY, rmax = 0; /* ref: src/nb.c:246 */
     int bad = 0;
@@ -187,7 +189,7 @@ SASA_D void bounds_phase0(const PipeArgs &a, double *red, int chunk, int tid, in
         lo0 = fmin(x, lo0); hi0 = fmax(x, hi0);
         lo1 = fmin(y, lo1); hi1 = fmax(y, hi1);
         lo2 = fmin(z, lo2); hi2 = fmax(z, hi2);
-        const double rr = a.radii[i];
+        const double rr = a.radii[a.shared_radii ? i - b0 : i];
         rmax = fmax(rr + a.probe, rmax);
         a.sid[i] = s;
         /* fmin/fmax drop NaN and the float-to-int conversion of a NaN is 0 on gfx950 (INT_MIN on x86): a
@@ -452,7 +454,7 @@ SASA_D void scatter_atom(const PipeArgs &a, int i)
     a.sx[p] = a.xyz[3 * i];
     a.sy[p] = a.xyz[3 * i + 1];
     a.sz[p] = a.xyz[3 * i + 2];
-    a.sr[p] = a.radii[i] + a.probe; /* ref: src/sasa_lr.c:136, src/sasa_sr.c:144 */
+    a.sr[p] = a.radii[a.shared_radii ? i - a.offsets[a.sid[i]] : i] + a.probe; /* ref: src/sasa_lr.c:136, src/sasa_sr.c:144 */
     a.s_orig[p] = i;
     if (a.occ_stride > 0 && i % a.occ_stride == 0) { /* ~256 density samples, only while the context has no demand history */
         SASA_ATOMIC_ADD_GLB(&a.status[ST_OCC_SUM], a.cell_start[c + 1] - a.cell_start[c]);

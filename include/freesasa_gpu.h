@@ -122,6 +122,11 @@ int freesasa_gpu_calc_batch_pipelined(const double *xyz, const double *radii, co
                                       int alg, double probe_radius, int resolution, double *sasa_out, int *counts_out,
                                       double *totals_out, int device, int n_lanes, long long chunk_atoms,
                                       char *err, int err_len);
+int freesasa_gpu_trajectory_file(const char *frames_path, int frames_f32, long long header_bytes, const double *radii,
+                                 int n_atoms, long long n_frames, int alg, double probe_radius, int resolution,
+                                 int frames_per_batch, const char *totals_path, const char *sasa_path, const char *done_path,
+                                 long long max_new_shards, int device, long long *frames_total_out, char *err, int err_len);
+
 /* The host-pointer entries (freesasa_calc_coord, freesasa_gpu_calc_batch*, _trajectory, _sweep_files) keep their
    contexts — stream, device workspace, staging buffers — in a pool between calls.  This destroys the idle ones and
    returns their device memory. */
@@ -166,14 +171,25 @@ int freesasa_gpu_calc_batch(const double *xyz, const double *radii, const int64_
                             double *sasa_out, int *counts_out, double *totals_out,
                             int device, char *err_out, int err_len);
 
-/* Trajectory driver (BASELINE configs[4]): n_frames frames of the SAME n_atoms
-   atoms, frame f at xyz_frames + f*3*n_atoms in HOST memory, radii constant.  Frames are
-   processed frames_per_batch at a time as independent structures (<= 0: chosen so that a batch
-   holds about 2M atoms); the host->device copy of batch k+1 and the device->host copy of batch
-   k-1 run on a second HIP stream while batch k computes, from/to buffers pinned in place
-   (hipHostRegister).  totals_out [n_frames] per-frame totals; sasa_out NULL or
-   [n_frames*n_atoms] per-atom areas.  alg/probe/resolution as in freesasa_parameters.
-   Returns 0 / -1 (message in err_out). */
+/* Trajectory drivers (BASELINE configs[4]): frames of the SAME n_atoms atoms, radii constant.
+   Frames are independent structures; a SHARD = frames_per_batch frames (<= 0: about 1.25e6 atoms) goes through the
+   engine as one batch.  A few host lanes take shards from a shared counter, each on its own pooled context and
+   stream, so that reading / uploading one shard, the kernels of another and the download / writing of a third
+   overlap.  The radii are stored ONCE per device context, not once per frame.
+
+   freesasa_gpu_trajectory: frames in HOST memory (frame f at xyz_frames + f*3*n_atoms; DMA in place when the
+   array is page-locked), totals_out [n_frames], sasa_out NULL or [n_frames*n_atoms].  Returns 0 / -1.
+
+   freesasa_gpu_trajectory_file: frames from a file of raw little-endian frames (3*n_atoms doubles, or floats when
+   frames_f32 != 0 — an input format: they are widened on the device and all arithmetic is fp64 — at byte
+   header_bytes + f * frame size), results to files: totals_path (one double per frame at byte 8*f) and, unless
+   NULL, sasa_path (n_atoms doubles per frame).  done_path (may be NULL) is the done-list: a text file whose first
+   line holds the run's parameters, followed by one line "shard <k> <first frame> <frames>" per finished shard,
+   appended after that shard's results are on disk.  A call that finds the done-list of the same run skips the
+   shards listed there, so an interrupted run (crash, kill, max_new_shards) resumes where it stopped and ends
+   with the same files, bit for bit, as an uninterrupted one; a done-list with other parameters is an error.
+   n_frames <= 0: all whole frames of the file; *frames_total_out (may be NULL) receives the count.
+   max_new_shards > 0: stop after that many shards.  Returns 0 all done, 1 stopped early, -1 error. */
 int freesasa_gpu_trajectory(const double *xyz_frames, const double *radii, int n_atoms, int n_frames,
                             int alg, double probe_radius, int resolution, int frames_per_batch,
                             double *totals_out, double *sasa_out, int device,

@@ -2,6 +2,7 @@
 the C-ABI of libfreesasa_amd.so.  Bars: S&R bit-exact (integer counts AND the fp64 areas derived
 from them); L&R within LR_TOL of the reference (north_star allows 1e-4 A^2; the only source of
 difference is the device's acos/atan2, so the test holds the kernel to 1e-9)."""
+import os
 import threading
 
 import numpy as np
@@ -577,3 +578,79 @@ def test_distinct_devices_give_the_single_device_result(fa):
         for d in range(nd):                         # and the pipelined entry on every device of the node
             got = fa.calc_batch_pipelined(xyz, r, offs, alg=alg, resolution=res, device=d, chunk_atoms=5000)
             assert np.array_equal(got[0], one[0]), d
+
+
+def test_trajectory_file_resumes_bit_for_bit(fa, tmp_path):
+    """frames from a raw frame file (fp64, and fp32 widened on the device), per-frame totals and
+    per-atom areas to files, radii once per device, and a done-list: an interrupted run — stopped by
+    max_new_shards, and one really killed with SIGKILL in the middle — resumes and ends with exactly the files of
+    an uninterrupted run."""
+    import signal
+    import subprocess
+    import sys
+    import time
+    n, nf = 2500, 23
+    base, r = tools.coil(n, 31)
+    frames = np.stack([tools.jitter(base, 400 + f, 0.4) for f in range(nf)])
+    want_tot, want_sasa = fa.trajectory(frames, r, frames_per_batch=3)
+    one_by_one = np.array([fa.calc_coord(frames[f], r)[1] for f in (0, 7, nf - 1)])
+    assert np.allclose(want_tot[[0, 7, nf - 1]], one_by_one, rtol=0, atol=1e-7)
+    f64, f32 = tmp_path / "frames.f64", tmp_path / "frames.f32"
+    frames.tofile(f64)
+    frames.astype(np.float32).tofile(f32)
+
+    def read(p, shape):
+        return np.fromfile(p, dtype=np.float64).reshape(shape)
+
+    # uninterrupted
+    done, got = fa.trajectory_file(f64, r, tmp_path / "t0.bin", tmp_path / "s0.bin", frames_per_batch=3)
+    assert done and got == nf
+    assert np.array_equal(read(tmp_path / "t0.bin", (nf,)), want_tot) and np.array_equal(read(tmp_path / "s0.bin", (nf, n)), want_sasa)
+    # interrupted every two shards, resumed through the done-list
+    calls = 0
+    while True:
+        done, _ = fa.trajectory_file(f64, r, tmp_path / "t1.bin", tmp_path / "s1.bin", tmp_path / "d1.txt", frames_per_batch=3,
+                                     max_new_shards=2)
+        calls += 1
+        assert calls < 20
+        if done:
+            break
+    assert calls == 4                                   # 8 shards, two per call
+    assert (tmp_path / "t1.bin").read_bytes() == (tmp_path / "t0.bin").read_bytes()
+    assert (tmp_path / "s1.bin").read_bytes() == (tmp_path / "s0.bin").read_bytes()
+    assert len((tmp_path / "d1.txt").read_text().splitlines()) == 1 + 8
+    # a finished run called again does nothing; another run's done-list is refused
+    assert fa.trajectory_file(f64, r, tmp_path / "t1.bin", tmp_path / "s1.bin", tmp_path / "d1.txt", frames_per_batch=3)[0]
+    with pytest.raises(RuntimeError):
+        fa.trajectory_file(f64, r, tmp_path / "t1.bin", None, tmp_path / "d1.txt", frames_per_batch=4)
+    # fp32 frames are an input format: widened on the device, same result as the widened frames in memory
+    w_tot, w_sasa = fa.trajectory(frames.astype(np.float32).astype(np.float64), r, frames_per_batch=5)
+    done, _ = fa.trajectory_file(f32, r, tmp_path / "t2.bin", tmp_path / "s2.bin", f32=True, frames_per_batch=5)
+    assert done and np.array_equal(read(tmp_path / "t2.bin", (nf,)), w_tot) and np.array_equal(read(tmp_path / "s2.bin", (nf, n)), w_sasa)
+    # killed for real: a child process is shot with SIGKILL once the done-list shows a few shards
+    big = tmp_path / "big.f64"
+    many = np.concatenate([frames] * 12)               # 276 frames
+    many.tofile(big)
+    np.save(tmp_path / "radii.npy", r)
+    child = ("import sys, numpy as np; sys.path.insert(0, %r); import freesasa_amd as fa; "
+             "fa.trajectory_file(%r, np.load(%r), %r, %r, %r, frames_per_batch=2)"
+             % (str(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), str(big), str(tmp_path / "radii.npy"),
+                str(tmp_path / "t3.bin"), str(tmp_path / "s3.bin"), str(tmp_path / "d3.txt")))
+    proc = subprocess.Popen([sys.executable, "-c", child])
+    t0 = time.time()
+    while time.time() - t0 < 120 and proc.poll() is None:
+        if (tmp_path / "d3.txt").exists() and len((tmp_path / "d3.txt").read_text().splitlines()) > 6:
+            break
+        time.sleep(0.002)
+    killed = proc.poll() is None
+    if killed:
+        proc.send_signal(signal.SIGKILL)
+    proc.wait()
+    listed = len((tmp_path / "d3.txt").read_text().splitlines()) - 1
+    done, _ = fa.trajectory_file(big, r, tmp_path / "t3.bin", tmp_path / "s3.bin", tmp_path / "d3.txt", frames_per_batch=2)
+    assert done
+    done, _ = fa.trajectory_file(big, r, tmp_path / "t4.bin", tmp_path / "s4.bin", frames_per_batch=2)
+    assert (tmp_path / "t3.bin").read_bytes() == (tmp_path / "t4.bin").read_bytes()
+    assert (tmp_path / "s3.bin").read_bytes() == (tmp_path / "s4.bin").read_bytes()
+    assert np.array_equal(read(tmp_path / "t4.bin", (12, nf)), np.tile(want_tot, (12, 1)))
+    assert killed and 0 < listed < 138, (killed, listed)   # the child really was stopped part-way
