@@ -133,6 +133,8 @@ def lib():
         L.freesasa_gpu_shard_cuts.restype = None
         L.freesasa_gpu_sweep_files.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
                                                C.c_longlong, _dp, _dp, _lp, _ip, C.c_int, C.c_char_p, C.c_int]
+        L.freesasa_gpu_sweep_files_resumable.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
+                                                         C.c_longlong, _dp, _dp, _lp, _ip, C.c_char_p, C.c_longlong, C.c_int, C.c_char_p, C.c_int]
         L.freesasa_gpu_trajectory.argtypes = [_dp, _dp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
                                               C.c_int, _dp, _dp, C.c_int, C.c_char_p, C.c_int]
         L.freesasa_gpu_trajectory_file.argtypes = [C.c_char_p, C.c_int, C.c_longlong, _dp, C.c_int, C.c_longlong, C.c_int, C.c_double,
@@ -248,6 +250,23 @@ def sweep_files(paths, alg=LEE_RICHARDS, probe=1.4, resolution=20, ingest_option
     if ret:
         raise RuntimeError("freesasa_gpu_sweep_files: " + err.value.decode())
     return totals, cls, atoms, status
+
+
+def sweep_files_resumable(paths, done_path, alg=LEE_RICHARDS, probe=1.4, resolution=20, ingest_options=0, n_threads=0,
+                          batch_atoms=0, max_new_batches=0, device=-1):
+    """freesasa_gpu_sweep_files_resumable(): like sweep_files with a done-list at done_path (+ done_path.bin):
+    returns (complete, totals, class_sums, n_atoms, status); batches listed there are not computed again."""
+    n = len(paths)
+    arr = (C.c_char_p * n)(*[str(p).encode() for p in paths])
+    totals, atoms, status = np.zeros(n), np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int32)
+    cls = np.zeros((n, 3))
+    err = C.create_string_buffer(512)
+    ret = lib().freesasa_gpu_sweep_files_resumable(arr, n, ingest_options, n_threads, alg, probe, resolution, batch_atoms,
+                                                   totals.ctypes.data_as(_dp), cls.ctypes.data_as(_dp), atoms.ctypes.data_as(_lp),
+                                                   status.ctypes.data_as(_ip), str(done_path).encode(), max_new_batches, device, err, 512)
+    if ret < 0:
+        raise RuntimeError("freesasa_gpu_sweep_files_resumable: " + err.value.decode())
+    return ret == 0, totals, cls, atoms, status
 
 
 def trajectory(xyz_frames, radii, alg=LEE_RICHARDS, probe=1.4, resolution=20, frames_per_batch=0,

@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <string>
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -1382,13 +1383,41 @@ extern "C" int freesasa_gpu_calc_batch_pipelined(const double *xyz, const double
 
 /* ------------------------------------------------------------------ structure sweep */
 
+static bool pread_all(int fd, void *buf, size_t bytes, long long off)
+{
+    char *p = (char *)buf;
+    while (bytes) {
+        const ssize_t r = pread(fd, p, bytes, (off_t)off);
+        if (r <= 0) return false;
+        p += r; off += r; bytes -= (size_t)r;
+    }
+    return true;
+}
+static bool pwrite_all(int fd, const void *buf, size_t bytes, long long off)
+{
+    const char *p = (const char *)buf;
+    while (bytes) {
+        const ssize_t r = pwrite(fd, p, bytes, (off_t)off);
+        if (r <= 0) return false;
+        p += r; off += r; bytes -= (size_t)r;
+    }
+    return true;
+}
+
+
+
 /* Files -> per-structure totals: the loader (host threads, include/freesasa_ingest.h) reads batch
  * k+1 while this thread has batch k on the GPU.  Inputs that fail to load get total 0 and their
  * loader status; the call only fails for GPU errors. */
-extern "C" int freesasa_gpu_sweep_files(const char *const *paths, int n_paths, int ingest_options, int n_threads,
-                                        int alg, double probe, int resolution, long long batch_atoms,
-                                        double *totals_out, double *class_sums_out, long long *atoms_out, int *status_out,
-                                        int device, char *err_out, int err_len)
+/* done_path (may be NULL): the sweep's done-list, same idea and format as the trajectory driver's — a first line
+ * with the run's parameters, then "shard <batch> <first file> <files>" per finished batch — next to a result file
+ * <done_path>.bin that holds, per file, total | class sums (3) | atoms | status (fixed 48-byte records), written
+ * before the batch is listed.  A call that finds the done-list of the same run takes the listed batches' results
+ * from the result file and only computes the others.  Returns 0 done, 1 stopped after max_new_batches, -1 error. */
+static int sweep_impl(const char *const *paths, int n_paths, int ingest_options, int n_threads,
+                      int alg, double probe, int resolution, long long batch_atoms,
+                      double *totals_out, double *class_sums_out, long long *atoms_out, int *status_out,
+                      const char *done_path, long long max_new_batches, int device, char *err_out, int err_len)
 {
     if (err_out && err_len > 0) err_out[0] = 0;
     if (!paths || n_paths < 0 || !totals_out || !status_out) return set_err(err_out, err_len, "null argument");
@@ -1408,9 +1437,71 @@ extern "C" int freesasa_gpu_sweep_files(const char *const *paths, int n_paths, i
         }
         cut.push_back(n_paths);
     }
-    freesasa_gpu_ctx *c = pool_get(device);
-    if (!c) return set_err(err_out, err_len, "could not create a GPU context");
     const int n_batches = (int)cut.size() - 1;
+    /* done-list and result file */
+    struct Rec { double total, cls[3]; long long atoms; int status, pad; };
+    static_assert(sizeof(Rec) == 48, "result record");
+    std::vector<char> done((size_t)n_batches, 0);
+    int fd_done = -1, fd_res = -1;
+    if (done_path) {
+        unsigned long long h = 1469598103934665603ULL; /* FNV-1a over the path list: the done-list belongs to these files */
+        for (int k = 0; k < n_paths; ++k)
+            for (const char *q = paths[k] ? paths[k] : ""; ; ++q) { h = (h ^ (unsigned char)*q) * 1099511628211ULL; if (!*q) break; }
+        char head[256];
+        snprintf(head, sizeof head, "freesasa_amd sweep done-list v1 n_files=%d batches=%d paths=%016llx options=%d alg=%d resolution=%d probe=%.17g\n",
+                 n_paths, n_batches, h, ingest_options, alg, resolution, probe);
+        const std::string res_path = std::string(done_path) + ".bin";
+        bool resume = false;
+        if (FILE *fp = fopen(done_path, "r")) {
+            char line[256];
+            if (fgets(line, sizeof line, fp)) {
+                if (strcmp(line, head) != 0) { fclose(fp); return set_err(err_out, err_len, "the done-list belongs to a sweep with other parameters"); }
+                resume = true;
+                int b, first, count;
+                while (fgets(line, sizeof line, fp))
+                    if (sscanf(line, "shard %d %d %d", &b, &first, &count) == 3 && b >= 0 && b < n_batches && first == cut[b] &&
+                        count == cut[b + 1] - cut[b] && line[strlen(line) - 1] == '\n')
+                        done[(size_t)b] = 1;
+            }
+            fclose(fp);
+        }
+        fd_res = open(res_path.c_str(), resume ? O_RDWR | O_CREAT : O_RDWR | O_CREAT | O_TRUNC, 0644);
+        fd_done = open(done_path, resume ? O_WRONLY | O_APPEND : O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (fd_res < 0 || fd_done < 0 || (!resume && write(fd_done, head, strlen(head)) != (ssize_t)strlen(head))) {
+            if (fd_res >= 0) close(fd_res);
+            if (fd_done >= 0) close(fd_done);
+            return set_err(err_out, err_len, "cannot open the done-list or its result file");
+        }
+        for (int b = 0; b < n_batches; ++b) { /* results of the batches already done */
+            if (!done[(size_t)b]) continue;
+            std::vector<Rec> recs((size_t)(cut[b + 1] - cut[b]));
+            if (!pread_all(fd_res, recs.data(), sizeof(Rec) * recs.size(), (long long)sizeof(Rec) * cut[b])) { done[(size_t)b] = 0; continue; }
+            for (size_t k = 0; k < recs.size(); ++k) {
+                const int f = cut[b] + (int)k;
+                totals_out[f] = recs[k].total; status_out[f] = recs[k].status;
+                if (atoms_out) atoms_out[f] = recs[k].atoms;
+                if (class_sums_out) for (int q = 0; q < 3; ++q) class_sums_out[3 * f + q] = recs[k].cls[q];
+            }
+        }
+    }
+    std::vector<int> todo;
+    for (int b = 0; b < n_batches; ++b)
+        if (!done[(size_t)b]) todo.push_back(b);
+    bool stopped = false;
+    if (max_new_batches > 0 && (long long)todo.size() > max_new_batches) { todo.resize((size_t)max_new_batches); stopped = true; }
+    if (todo.empty()) {
+        if (fd_res >= 0) close(fd_res);
+        if (fd_done >= 0) close(fd_done);
+        return stopped ? 1 : 0;
+    }
+    freesasa_gpu_ctx *c = pool_get(device);
+    if (!c) {
+        if (fd_res >= 0) close(fd_res);
+        if (fd_done >= 0) close(fd_done);
+        return set_err(err_out, err_len, "could not create a GPU context");
+    }
+    const bool want_cls = class_sums_out != nullptr || done_path != nullptr;
+    std::vector<double> cls_tmp;
     freesasa_ingest_batch cur, next;
     int cur_rc = 0, next_rc = 0;
     memset(&cur, 0, sizeof cur);
@@ -1420,11 +1511,12 @@ extern "C" int freesasa_gpu_sweep_files(const char *const *paths, int n_paths, i
     };
     std::vector<double> tp;
     if (alg == 1) { tp.resize(3 * (size_t)(resolution > 0 ? resolution : 1)); if (resolution > 0) freesasa_gpu_test_points(resolution, tp.data()); }
-    load(0, &cur, &cur_rc);
+    load(todo[0], &cur, &cur_rc);
     int ret = 0;
-    for (int b = 0; b < n_batches && !ret; ++b) {
+    for (size_t ti = 0; ti < todo.size() && !ret; ++ti) {
+        const int b = todo[ti];
         std::thread loader;
-        if (b + 1 < n_batches) loader = std::thread(load, b + 1, &next, &next_rc);
+        if (ti + 1 < todo.size()) loader = std::thread(load, todo[ti + 1], &next, &next_rc);
         const int first = cut[b], ns = cut[b + 1] - cut[b];
         do {
             if (cur_rc) { ctx_fail(c, "loader failed with code %d", cur_rc); ret = -1; break; }
@@ -1450,16 +1542,37 @@ extern "C" int freesasa_gpu_sweep_files(const char *const *paths, int n_paths, i
             if (run_batch(c, alg == 0, (double *)c->h_xyz.p, (double *)c->h_radii.p, cur.offsets, ns, probe, resolution,
                           alg == 1 ? tp.data() : nullptr, (double *)c->h_sasa.p, nullptr, d_tot))
                 break;
-            if (class_sums_out) {
+            double *cls_dst = class_sums_out ? class_sums_out + 3 * (size_t)first : nullptr;
+            if (want_cls) {
+                if (!cls_dst) { cls_tmp.resize(3 * (size_t)ns); cls_dst = cls_tmp.data(); }
                 if (hipMemcpyAsync(c->h_counts.p, cur.atom_class, n, hipMemcpyHostToDevice, c->stream) != hipSuccess) { ctx_fail(c, "host-to-device copy failed"); break; }
                 if (freesasa_gpu_class_sums_dev(c, (double *)c->h_sasa.p, (const unsigned char *)c->h_counts.p, cur.offsets, ns, d_cls)) break;
-                if (hipMemcpyAsync(class_sums_out + 3 * (size_t)first, d_cls, 8 * 3 * (size_t)ns, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { ctx_fail(c, "device-to-host copy failed"); break; }
+                if (hipMemcpyAsync(cls_dst, d_cls, 8 * 3 * (size_t)ns, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { ctx_fail(c, "device-to-host copy failed"); break; }
             }
             if (hipMemcpyAsync(totals_out + first, d_tot, 8 * (size_t)ns, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { ctx_fail(c, "device-to-host copy failed"); break; }
             if (hipStreamSynchronize(c->stream) != hipSuccess) { ctx_fail(c, "stream synchronize failed"); break; }
             ret = 0;
         } while (0);
         if (ret) (void)hipStreamSynchronize(c->stream); /* no copy may still read the batch when it is freed */
+        if (!ret && fd_done >= 0) { /* the batch's results to the result file, then its line in the done-list */
+            std::vector<Rec> recs((size_t)ns);
+            const bool have_cls = cur.n_atoms > 0;
+            const double *cls_src = class_sums_out ? class_sums_out + 3 * (size_t)first : (have_cls ? cls_tmp.data() : nullptr);
+            for (int k = 0; k < ns; ++k) {
+                Rec &r = recs[(size_t)k];
+                memset(&r, 0, sizeof r);
+                r.total = totals_out[first + k]; r.status = status_out[first + k];
+                r.atoms = cur.offsets ? cur.offsets[k + 1] - cur.offsets[k] : 0;
+                if (cls_src) for (int q = 0; q < 3; ++q) r.cls[q] = cls_src[3 * k + q];
+            }
+            char line[96];
+            const int len = snprintf(line, sizeof line, "shard %d %d %d\n", b, first, ns);
+            if (!pwrite_all(fd_res, recs.data(), sizeof(Rec) * recs.size(), (long long)sizeof(Rec) * first) || fdatasync(fd_res) != 0 ||
+                write(fd_done, line, (size_t)len) != len || fdatasync(fd_done) != 0) {
+                ctx_fail(c, "could not record the finished batch in the done-list");
+                ret = -1;
+            }
+        }
         if (loader.joinable()) loader.join();
         freesasa_ingest_free(&cur);
         cur = next;
@@ -1469,8 +1582,29 @@ extern "C" int freesasa_gpu_sweep_files(const char *const *paths, int n_paths, i
     freesasa_ingest_free(&cur);
     if (ret) set_err(err_out, err_len, c->err[0] ? c->err : "GPU sweep failed");
     pool_put(c);
-    return ret;
+    if (fd_res >= 0) close(fd_res);
+    if (fd_done >= 0) close(fd_done);
+    return ret ? ret : (stopped ? 1 : 0);
 }
+
+extern "C" int freesasa_gpu_sweep_files(const char *const *paths, int n_paths, int ingest_options, int n_threads,
+                                        int alg, double probe, int resolution, long long batch_atoms,
+                                        double *totals_out, double *class_sums_out, long long *atoms_out, int *status_out,
+                                        int device, char *err_out, int err_len)
+{
+    return sweep_impl(paths, n_paths, ingest_options, n_threads, alg, probe, resolution, batch_atoms, totals_out, class_sums_out,
+                      atoms_out, status_out, nullptr, 0, device, err_out, err_len);
+}
+
+extern "C" int freesasa_gpu_sweep_files_resumable(const char *const *paths, int n_paths, int ingest_options, int n_threads,
+                                                  int alg, double probe, int resolution, long long batch_atoms,
+                                                  double *totals_out, double *class_sums_out, long long *atoms_out, int *status_out,
+                                                  const char *done_path, long long max_new_batches, int device, char *err_out, int err_len)
+{
+    return sweep_impl(paths, n_paths, ingest_options, n_threads, alg, probe, resolution, batch_atoms, totals_out, class_sums_out,
+                      atoms_out, status_out, done_path, max_new_batches, device, err_out, err_len);
+}
+
 
 /* ------------------------------------------------------------------ trajectory driver */
 
@@ -1499,27 +1633,6 @@ struct TrajIO {
     int fd_done = -1;               /* done-list (append) */
     std::vector<char> done;         /* shards already recorded */
 };
-
-static bool pread_all(int fd, void *buf, size_t bytes, long long off)
-{
-    char *p = (char *)buf;
-    while (bytes) {
-        const ssize_t r = pread(fd, p, bytes, (off_t)off);
-        if (r <= 0) return false;
-        p += r; off += r; bytes -= (size_t)r;
-    }
-    return true;
-}
-static bool pwrite_all(int fd, const void *buf, size_t bytes, long long off)
-{
-    const char *p = (const char *)buf;
-    while (bytes) {
-        const ssize_t r = pwrite(fd, p, bytes, (off_t)off);
-        if (r <= 0) return false;
-        p += r; off += r; bytes -= (size_t)r;
-    }
-    return true;
-}
 
 /* returns 0: all shards done, 1: stopped after max_new shards (more left), -1: error */
 static int traj_run(TrajIO &io, const double *radii, int n_atoms, long long n_frames, int alg, double probe, int resolution,

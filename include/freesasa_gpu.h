@@ -163,6 +163,17 @@ int freesasa_gpu_sweep_files(const char *const *paths, int n_paths, int ingest_o
                              double *totals_out, double *class_sums_out, long long *atoms_out, int *status_out,
                              int device, char *err, int err_len);
 
+/* The same sweep with a done-list (see freesasa_gpu_trajectory_file): done_path holds a first line with the sweep's
+   parameters and one line "shard <batch> <first file> <files>" per finished batch; <done_path>.bin holds the
+   results of the finished batches (per file a 48-byte record: total, three class sums, atoms, status), written
+   before the batch is listed.  A later call with the same files and parameters takes the listed batches' results
+   from there and computes only the others.  max_new_batches > 0: stop after that many batches.
+   Returns 0 done, 1 stopped early, -1 error. */
+int freesasa_gpu_sweep_files_resumable(const char *const *paths, int n_paths, int ingest_options, int n_threads,
+                                       int alg, double probe_radius, int resolution, long long batch_atoms,
+                                       double *totals_out, double *class_sums_out, long long *atoms_out, int *status_out,
+                                       const char *done_path, long long max_new_batches, int device, char *err, int err_len);
+
 /* Host-pointer batch on a pooled per-thread context of `device` (-1: current default).
    alg/probe/resolution as in freesasa_parameters; counts_out may be NULL (S&R only);
    totals_out may be NULL.  Thread-safe.  Returns 0 / -1; message via err_out (>= len 1). */

@@ -309,6 +309,33 @@ def test_sweep_entry_point_equals_load_then_batch():
     assert abs(fa.sweep_files([fixture("1ubq.pdb")])[0][0] - 4804.055641) < 1e-5 * 4804.055641
 
 
+@pytest.mark.gpu
+def test_resumable_sweep_equals_the_uninterrupted_one(tmp_path):
+    """freesasa_gpu_sweep_files_resumable: a sweep stopped after every batch and restarted through its done-list
+    (results of finished batches come from <done>.bin, only the others are computed) gives exactly the arrays of
+    the plain sweep; a finished sweep called again computes nothing; other parameters are refused."""
+    import freesasa_amd as fa
+    names = ["1ubq.pdb", "empty.pdb", "3bkr.cif", "1a0q.pdb", "does_not_exist.pdb", "5dx9.pdb", "icode.pdb", "1ubq.cif", "3bzd_trimmed.pdb"]
+    paths = [fixture(n) for n in names] * 2
+    want = fa.sweep_files(paths, batch_atoms=3000, n_threads=2)
+    done = tmp_path / "sweep.done"
+    calls = 0
+    while True:
+        complete, totals, cls, atoms, status = fa.sweep_files_resumable(paths, done, batch_atoms=3000, n_threads=2, max_new_batches=1)
+        calls += 1
+        assert calls < 40
+        if complete:
+            break
+    assert calls > 3
+    for got, exp in zip((totals, cls, atoms, status), want):
+        assert np.array_equal(got, exp)
+    n_lines = len(done.read_text().splitlines())
+    complete, totals2, *_ = fa.sweep_files_resumable(paths, done, batch_atoms=3000, n_threads=2)
+    assert complete and np.array_equal(totals2, want[0]) and len(done.read_text().splitlines()) == n_lines
+    with pytest.raises(RuntimeError):
+        fa.sweep_files_resumable(paths, done, batch_atoms=3000, resolution=21)
+
+
 def test_mmcif_row_scanner_equals_the_byte_at_a_time_tokenizer():
     """The SSE2 row scanner of the mmCIF reader (whitespace bit masks, freesasa_amd/csrc/ingest.c
     cif_row_next) against its scalar twin (tests/emu/libingest_scalar.so, the same source built with
