@@ -14,9 +14,11 @@ bracketed by barrier + synchronize and the MAX over ranks is reported.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline     — achieved = ALGORITHMIC bytes (40 B/atom: x,y,z,R in, SASA out) of the dominant
-                 kernel (k_lr_tile) / its HIP-event duration measured live on the launch stream;
+                 kernel (k_lr2_tile) / its HIP-event duration measured live on the launch stream;
+  end_to_end   — SURVEY 8(d)(i): the same batch from host arrays to host per-atom areas, PCIe included;
   cpu_baseline — the real reference (oracle/_ref, kind "reference") or the oracle port, timed on
-                 this box's host cores on a bounded sample of the same batch.
+                 this box's host cores on a bounded sample of the same batch (own process: one worker
+                 process per core, plus the reference's own n_threads 1 / 2 / 16 on one structure).
 """
 import argparse
 import json
@@ -104,13 +106,17 @@ def profiled_traffic(args):
         return None, None
     with open(os.path.join(ROOT, "profiles", best)) as fh:
         d = json.load(fh)
-    # steady state = main launch (tier 0) of the tuned variant (5 waves/SIMD), else the 4-wave one
-    for tag in ("false, 0, 5, false>", "false, 0, 4, false>", "false, 0, 5>", "false, 0, 4>"):
-        for k, v in d.items():
-            if "k_lr_tile" in k and tag in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-                global PROFILED_VALU
-                PROFILED_VALU = v.get("SQ_INSTS_VALU", {}).get("per_launch")
-                return (v["FETCH_SIZE"]["per_launch_KB"] + v["WRITE_SIZE"]["per_launch_KB"]) * 1024.0, "profiles/" + best
+    # the main launch (tier 0) of the L&R tile kernel: k_lr2_tile<rounds, 0, waves> (round 1: k_lr_tile<64, false, 0, ...>)
+    best_k, best_v = None, None
+    for k, v in d.items():
+        main = ("k_lr2_tile<" in k and ", 0, " in k) or ("k_lr_tile<" in k and "false, 0, " in k)
+        if main and "FETCH_SIZE" in v and "WRITE_SIZE" in v and "SQ_INSTS_VALU" in v:
+            if best_v is None or v["SQ_INSTS_VALU"]["per_launch"] > best_v["SQ_INSTS_VALU"]["per_launch"]:
+                best_k, best_v = k, v
+    if best_v is not None:
+        global PROFILED_VALU
+        PROFILED_VALU = best_v["SQ_INSTS_VALU"]["per_launch"]
+        return (best_v["FETCH_SIZE"]["per_launch_KB"] + best_v["WRITE_SIZE"]["per_launch_KB"]) * 1024.0, "profiles/" + best
     return None, None
 
 
@@ -281,7 +287,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,
                          "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ATOM * n_atoms,
-                         "kernel": "k_sr_tile" if sr else "k_lr_tile", "kernel_ms": 1e3 * kern_s, "prep_ms": float(np.mean(prep_ms)),
+                         "kernel": "k_sr_tile" if sr else ("k_lr2_tile" if args.slices <= 256 else "k_lr_tile"), "kernel_ms": 1e3 * kern_s, "prep_ms": float(np.mean(prep_ms)),
                          "kernel_atoms_per_s": n_atoms / kern_s if kern_s > 0 else None,
                          "note": "nominal HBM roofline per north_star (40 B/atom); the kernel is fp64-VALU bound, "
                                  "see DESIGN.md",

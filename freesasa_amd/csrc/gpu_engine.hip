@@ -331,6 +331,7 @@ struct freesasa_gpu_ctx {
     int hint_res[2] = {0, 0}, hint_ta[2] = {0, 0}, hint_pool[2] = {0, 0};
     bool hint_bucket = false; /* L&R: the last batch had long neighbor lists */
     double hint_nn = 0;       /* L&R (lr2): neighbor records per atom the main launch should hold */
+    int hint_nn_max = 0;      /* ... and the longest neighbor list expected (mask words per item) */
     int *dbg_nn = nullptr, *dbg_nb = nullptr; /* test hook: freesasa_gpu_lr_neighbors_dev */
     int dbg_cap = 0;
 };
@@ -555,9 +556,10 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
         HIP_TRY(c, hipMemcpyAsync(status_h, (int *)c->status.p + ST_OCC_SUM, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
         c->hint_nn = status_h[1] > 0 ? 1.25 * 3.1 * (double)status_h[0] / (double)status_h[1] + 2.0 : 0.0;
+        c->hint_nn_max = (int)(1.45 * c->hint_nn); /* longest list ~ 1.6 x the mean on coils, globules and proteins alike */
         c->hint_res[0] = resolution;
     }
-    Lr2Cfg cfg = lr2_choose_cfg(resolution, c->hint_nn, ta_env);
+    Lr2Cfg cfg = lr2_choose_cfg(resolution, c->hint_nn, ta_env, c->hint_nn_max);
     if (pool_env > 0) cfg.pool = (pool_env + 1) & ~1;
     if (ds_env >= 0) cfg.ds = ds_env;
     if (refill_env > 0) cfg.refill = refill_env;
@@ -656,6 +658,7 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
     /* learn the pool size for the next batch of this kind (trajectory frames, sweeps) */
     const int learnt = lr2_pool_from_hist(status_h + ST_HIST, cfg.TA);
     if (learnt > 0) c->hint_nn = (double)(learnt - 8) / cfg.TA;
+    c->hint_nn_max = status_h[ST_MAX_NN] + 4; /* the longest list of this batch, a little room */
     return 0;
 }
 

@@ -763,19 +763,20 @@ struct Lr2Cfg {
 
 static inline bool lr2_supported(int ns) { return ns >= 1 && ns <= LR2_NS_MAX; }
 
-/* nn_hint: neighbor records one atom needs (with its safety margin), 0 = unknown */
-static inline Lr2Cfg lr2_choose_cfg(int ns, double nn_hint = 0, int ta_override = 0)
+/* nn_hint: neighbor records one atom needs (with its safety margin), 0 = unknown; nn_max_hint: the longest
+ * neighbor list expected (0 = unknown): the masks of an item get ceil(nn_max / 32) words, two at least */
+static inline Lr2Cfg lr2_choose_cfg(int ns, double nn_hint = 0, int ta_override = 0, int nn_max_hint = 0)
 {
     Lr2Cfg c;
     c.ns = ns;
-    /* about two items per lane let the queue balance the arc pass; more atoms cost LDS (occupancy) */
-    int ta = (2 * LR2_LANES + ns / 2) / ns;
+    /* a few items per lane let the queue balance the arc pass; more atoms cost LDS (occupancy) */
+    int ta = (6 * LR2_LANES + ns) / (2 * ns); /* ~ 3 items per lane: 20 slices -> 6 atoms (capped), 100 slices -> 2 */
     if (ta < 1) ta = 1;
     if (ta > 6) ta = 6;
     while (ta > 1 && ta * ns > LR2_ITEMS_CAP) --ta;
     const int pool_max = LR2_LANES * LR2_RMAX_MAIN;
-    if (nn_hint > 0) /* dense inputs: fewer atoms per tile, so that a tile's records fit the registers of P3 */
-        while (ta > 1 && nn_hint * ta + 8 > pool_max) --ta;
+    if (nn_hint > 0) /* dense inputs: fewer atoms per tile, so that a tile's records fit the registers of P3 with some room */
+        while (ta > 1 && 1.12 * nn_hint * ta + 8 > pool_max) --ta;
     if (ta_override > 0 && ta_override <= 7 && ta_override * ns <= LR2_ITEMS_CAP) ta = ta_override;
     c.TA = ta;
     c.rmax = LR2_RMAX_MAIN;
@@ -783,7 +784,8 @@ static inline Lr2Cfg lr2_choose_cfg(int ns, double nn_hint = 0, int ta_override 
     c.pool = (c.pool + 1) & ~1;
     if (c.pool > pool_max) c.pool = pool_max;
     if (c.pool < 16) c.pool = 16;
-    c.mw = 2;
+    c.mw = nn_max_hint > 64 ? (nn_max_hint + 31) / 32 : 2;
+    if (c.mw > 4) c.mw = 4;
     c.ds = 2;
     c.refill = 16;
     c.lds = lr2_layout(c.TA, c.ns, c.pool, c.mw, c.ds).total;
