@@ -784,7 +784,10 @@ static inline Lr2Cfg lr2_choose_cfg(int ns, double nn_hint = 0, int ta_override 
     c.pool = (c.pool + 1) & ~1;
     if (c.pool > pool_max) c.pool = pool_max;
     if (c.pool < 16) c.pool = 16;
-    c.mw = nn_max_hint > 64 ? (nn_max_hint + 31) / 32 : 2;
+    /* mask words per item: two (64 neighbors) unless lists that long are common — the rare atom above the
+       capacity sends its tile to the next launch, which costs less than LDS for every tile (occupancy) */
+    c.mw = 2;
+    if (nn_hint > 0 && 1.45 * nn_hint > 64 && nn_max_hint > 64) c.mw = (nn_max_hint + 31) / 32;
     if (c.mw > 4) c.mw = 4;
     c.ds = 2;
     c.refill = 16;

@@ -74,6 +74,27 @@ def cpu_model():
     return "unknown"
 
 
+def cpu_limit():
+    """CPUs this process may actually use at once: the affinity mask, capped by the cgroup's CPU quota (a
+    container can show 256 logical CPUs and be allowed ten of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:                      # cgroup v2: "<quota> <period>" or "max <period>"
+            q, p = fh.read().split()
+            if q != "max":
+                quota = float(q) / float(p)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, p = float(fq.read()), float(fp.read())
+                if q > 0:
+                    quota = q / p
+        except (OSError, ValueError):
+            pass
+    return n, quota
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--atoms", type=int, default=10000)
@@ -86,7 +107,10 @@ def main():
     args = ap.parse_args()
 
     import tools
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    logical, quota = cpu_limit()
+    cores = logical if quota is None else max(1, min(logical, int(quota + 0.5)))
+    if os.environ.get("FREESASA_CPU_BASELINE_PROCS"):  # dev: scaling curve (tools/dev/cpu_scaling.py)
+        cores = max(1, int(os.environ["FREESASA_CPU_BASELINE_PROCS"]))
     _init()
     kind = _calc[1]
     xyz, r = tools.coil(args.atoms, args.seed0)
@@ -133,7 +157,7 @@ def main():
         "sample": f"first {sample} of {args.structs} structures ({atoms} atoms), one process per core "
                   f"({len(jobs)} processes, each with its own copy of the library), n_threads=1, L&R {args.slices} slices; "
                   f"slowest process {busy:.2f} s (wall incl. structure generation {wall:.2f} s)",
-        "cpu_model": cpu_model(), "host_cores": cores,
+        "cpu_model": cpu_model(), "host_logical_cpus": logical, "cgroup_cpu_quota": quota, "host_cores": cores,
         "single_thread": single,
         "per_structure_threads": {"n_threads": per_structure, "unit": "atoms/s",
                                   "note": "one 10k-atom structure, the reference's own pthreads split (src/sasa_lr.c:219-253)"},
