@@ -252,15 +252,16 @@ __global__ __launch_bounds__(256) void k_lr2_compact(const unsigned char *flag, 
     lr2_compact_write(flag, n_tiles, cnt, ovf_tiles, blockIdx.x, threadIdx.x, 256);
 }
 
-/* main launch: the instantiation is picked by the rounds of pair records the pool needs and by the waves per
- * SIMD the tile's LDS footprint allows */
-static hipError_t launch_lr2_main(int rmax, int wpe, int grid, size_t lds, hipStream_t st, const Lr2Args &la)
+/* main launch (TIER 0) and the launch that redoes overflowed tiles as halves (TIER 1: the same code and capacities,
+ * named apart so that profiles list the two separately): the instantiation is picked by the rounds of pair
+ * records the pool needs; registers are capped for 4 waves per SIMD (a 5-wave build spilled and was not faster) */
+static hipError_t launch_lr2_main(int rmax, int tier, int grid, size_t lds, hipStream_t st, const Lr2Args &la)
 {
-#define LR2_LAUNCH(R, W) hipLaunchKernelGGL((k_lr2_tile<R, 0, W>), dim3(grid), dim3(64), lds, st, la)
-    if (wpe >= 5) {
-        if (rmax <= 2) LR2_LAUNCH(2, 5); else if (rmax == 3) LR2_LAUNCH(3, 5); else LR2_LAUNCH(4, 5);
+#define LR2_LAUNCH(R, T) hipLaunchKernelGGL((k_lr2_tile<R, T, 4>), dim3(grid), dim3(64), lds, st, la)
+    if (tier == 0) {
+        if (rmax <= 2) LR2_LAUNCH(2, 0); else if (rmax == 3) LR2_LAUNCH(3, 0); else LR2_LAUNCH(4, 0);
     } else {
-        if (rmax <= 2) LR2_LAUNCH(2, 4); else if (rmax == 3) LR2_LAUNCH(3, 4); else LR2_LAUNCH(4, 4);
+        if (rmax <= 2) LR2_LAUNCH(2, 1); else if (rmax == 3) LR2_LAUNCH(3, 1); else LR2_LAUNCH(4, 1);
     }
 #undef LR2_LAUNCH
     return hipGetLastError();
@@ -590,9 +591,7 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
     }
     la.nn_out = c->dbg_nn; la.nb_out = c->dbg_nb; la.nb_cap = c->dbg_cap;
     if (c->dbg_nn) la.ovf_flag = nullptr; /* (the hook returns before anything could overflow) */
-    int wpe = 160 * 1024 / cfg.lds >= 20 ? 5 : 4; /* five waves per SIMD need the registers capped at 96 */
-    if (const char *e = getenv("FREESASA_AMD_WPE")) wpe = atoi(e); /* tuning aid */
-    hipError_t le = launch_lr2_main(cfg.rmax, wpe, grid_main, (size_t)cfg.lds, st, la);
+    hipError_t le = launch_lr2_main(cfg.rmax, 0, grid_main, (size_t)cfg.lds, st, la);
     if (le != hipSuccess) return ctx_fail(c, "tile kernel launch failed: %s", hipGetErrorString(le));
     if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[2], st));
     if (c->dbg_nn) return finish_batch(c, pa, n, n_structs, total_cells, d_sasa, nullptr, cfg.TA, 64, cfg.lds, status_h);
@@ -611,7 +610,7 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
         ls.ovf_tiles = (int *)c->ovf_tiles2.p;
         ls.ovf_count = (int *)c->status.p + ST_OVF2_TILES;
         const int grid_split = 2 * n_tiles < 8 * SASA_MID_BLOCKS ? 2 * n_tiles : 8 * SASA_MID_BLOCKS;
-        le = launch_lr2_main(cfg.rmax, wpe, grid_split, (size_t)cfg.lds, st, ls);
+        le = launch_lr2_main(cfg.rmax, 1, grid_split, (size_t)cfg.lds, st, ls);
         if (le != hipSuccess) return ctx_fail(c, "second tile launch failed: %s", hipGetErrorString(le));
     }
     /* third launch: halves that still do not fit: larger LDS lists, more registers */
@@ -628,7 +627,7 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
         lm.ovf_count = (int *)c->status.p + ST_OVF3_ATOMS;
         lm.ovf_atoms = 1;
         const int grid_mid = n_tiles < SASA_MID_BLOCKS ? n_tiles : SASA_MID_BLOCKS;
-        hipLaunchKernelGGL((k_lr2_tile<LR2_RMAX_MID, 1, 3>), dim3(grid_mid), dim3(64), (size_t)cm.lds, st, lm);
+        hipLaunchKernelGGL((k_lr2_tile<LR2_RMAX_MID, 2, 3>), dim3(grid_mid), dim3(64), (size_t)cm.lds, st, lm);
         le = hipGetLastError();
         if (le != hipSuccess) return ctx_fail(c, "third tile launch failed: %s", hipGetErrorString(le));
     }
