@@ -263,6 +263,15 @@ SASA_D void lr2_union_step(double inf, double sup, Lr2Union &u, Arc *stk, int ds
 
 /* exposed arc length from the final components (ascending).
  * ref: src/sasa_lr.c:340-351 (arcs through the origin) and :389-408 (sweep) */
+SASA_D double lr2_sweep_step(bool wrap, double V, double ks, double ke, double &sum, double &sup, bool &covered)
+{
+    covered = covered || (wrap && ks >= V); /* sorted behind the [V, 2pi] piece: covered, and so is everything after it */
+    if (!covered) {
+        if (sup < ks) sum += ks - sup;
+        if (ke > sup) sup = ke;
+    }
+    return sum;
+}
 SASA_D double lr2_sweep(const Lr2Union &u, const Arc *stk, int ds)
 {
     const int depth = u.depth;
@@ -273,16 +282,15 @@ SASA_D double lr2_sweep(const Lr2Union &u, const Arc *stk, int ds)
     const double Vhi = u.te > SASA_TWOPI ? u.ts : SASA_TWOPI;     /* the piece [inf, 2pi] of an arc whose sup wraps */
     const double V = Vlo < Vhi ? Vlo : Vhi;
     const double W = u.te > SASA_TWOPI ? u.te - SASA_TWOPI : 0.0; /* ref: :341 */
+    const double top_e = u.te > SASA_TWOPI ? SASA_TWOPI : u.te;
     double sum = 0, sup = W;
-    for (int c = 0; c < depth; ++c) {
-        double ks, ke;
-        if (c == depth - 1) { ks = u.ts; ke = u.te > SASA_TWOPI ? SASA_TWOPI : u.te; }
-        else if (c == depth - 2) { ks = u.bs; ke = u.be; }
-        else { const Arc k = stk[(c < ds ? c : 0) * LR2_LANES]; ks = k.s; ke = k.e; }
-        if (wrap && ks >= V) break; /* sorted behind the [V, 2pi] piece: covered */
-        if (sup < ks) sum += ks - sup;
-        if (ke > sup) sup = ke;
+    bool covered = false;
+    for (int c = 0; c < depth - 2; ++c) { /* components in the LDS column (rare: more than two) */
+        const Arc k = stk[(c < ds ? c : 0) * LR2_LANES];
+        lr2_sweep_step(wrap, V, k.s, k.e, sum, sup, covered);
     }
+    if (depth >= 2) lr2_sweep_step(wrap, V, u.bs, u.be, sum, sup, covered); /* the two in registers: straight-line code */
+    lr2_sweep_step(wrap, V, u.ts, top_e, sum, sup, covered);
     if (wrap) {
         if (sup < V) sum += V - sup;
         sup = SASA_TWOPI;
@@ -518,28 +526,32 @@ SASA_D void lr2_tile(const Lr2Args &a, const Lr2Mem &m, int tile, int lane, int 
         return;
     }
     /* ------------------------------------------------------------ P2 offsets */
-    if (lane < TA) {
-        int off = 0;
-        for (int k = 0; k < lane; ++k) off += (m.acnt[k] + 1) & ~1; /* lists padded to an even length */
-        const int c = m.acnt[lane];
-        m.aoff[lane] = off;
-        if (c > 32 * mw) m.flags[0] = 1;
-        if (lane == TA - 1) {
-            m.aoff[TA] = off + ((c + 1) & ~1);
-            if (off + ((c + 1) & ~1) > a.pool) m.flags[0] = 1;
+    /* offsets of the atoms' lists in the pool (lists padded to an even length): a prefix over the first lanes of
+       the wave; whether the tile fits is a ballot, so every lane knows it without a flag in LDS */
+    bool ovf;
+    int nn_max;
+    {
+        const int c = lane < TA ? m.acnt[lane] : 0, pc = (c + 1) & ~1;
+        int incl = pc, cmax = c;
+        for (int d = 1; d < 8; d <<= 1) { /* TA <= 7 */
+            const int v = LR2_SHFL(incl, lane >= d ? lane - d : lane), w = LR2_SHFL(cmax, lane >= d ? lane - d : lane);
+            if (lane >= d) { incl += v; cmax = cmax > w ? cmax : w; }
         }
-        SASA_ATOMIC_MAX_LDS(&m.flags[2], c);
+        if (lane < TA) m.aoff[lane] = incl - pc;
+        if (lane == TA - 1) m.aoff[TA] = incl;
+        const int total = LR2_SHFL(incl, TA - 1);
+        nn_max = LR2_SHFL(cmax, TA - 1);
+        ovf = nn_max > 32 * mw || total > a.pool || nh > a.pool || nh > LR2_LANES * RMAX;
+        if (lane == 0) {
+            if (nn_max > wg_max_nn) wg_max_nn = nn_max;
+            if (!a.work_tiles && !a.work_count && (tile & 31) == 0) { /* demand histogram for the next batch's pool size: 1 tile in 32 of the main launch */
+                const int need = total / hist_bin_width(TA);
+                SASA_ATOMIC_ADD_GLB(&a.status[ST_HIST + (need < 63 ? need : 63)], 1);
+            }
+        }
     }
-    if (lane == 0 && (nh > a.pool || nh > LR2_LANES * RMAX)) m.flags[0] = 1;
     LR2_SYNC();
-    if (lane == 0) {
-        if (m.flags[2] > wg_max_nn) wg_max_nn = m.flags[2];
-        if (!a.work_tiles && (tile & 31) == 0) { /* demand histogram for the next batch's pool size: 1 tile in 32 */
-            const int need = m.aoff[TA] / hist_bin_width(TA);
-            SASA_ATOMIC_ADD_GLB(&a.status[ST_HIST + (need < 63 ? need : 63)], 1);
-        }
-    }
-    if (m.flags[0]) { /* uniform: the tile goes to the next launch */
+    if (ovf) { /* uniform: the tile goes to the next launch */
         if (lane == 0) lr2_overflow(a, tile, p0, na, ERR_NEIGHBOR_CAP);
         LR2_SYNC();
         return;
@@ -790,7 +802,7 @@ static inline Lr2Cfg lr2_choose_cfg(int ns, double nn_hint = 0, int ta_override 
     if (nn_hint > 0 && 1.45 * nn_hint > 64 && nn_max_hint > 64) c.mw = (nn_max_hint + 31) / 32;
     if (c.mw > 4) c.mw = 4;
     c.ds = 2;
-    c.refill = 16;
+    c.refill = 32; /* (measured: 12 / 16 / 24 / 32 / 40 waiting lanes -> 4.00 / 3.93 / 3.92 / 3.89 / 3.90 ms per 3e6 coil atoms) */
     c.lds = lr2_layout(c.TA, c.ns, c.pool, c.mw, c.ds).total;
     /* occupancy comes in steps of whole tiles per CU (160 KB of LDS, at most 16 one-wave tiles with the
        registers of the 4-waves-per-SIMD build): spend the slack of the current step on a larger pool */
