@@ -225,14 +225,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     Lr2Mem m = lr2_carve(a, smem);
-    /* work items: all tiles (main launch), both halves of every tile of split_src, or the items of a work list */
-    const int n_work = a.work_count ? (a.work_tiles ? *a.work_count : 2 * *a.work_count) : ((a.n_tiles + 7) >> 3) << 3;
     int wg_max_nn = 0;
-    for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
-        const int tile = a.work_tiles ? a.work_tiles[w] : (a.work_count ? w : xcd_tile(w, a.n_tiles));
-        if (!a.work_count && tile >= a.n_tiles) continue; /* uniform per workgroup */
-        lr2_tile<RMAX>(a, m, tile, lane, wg_max_nn);
-    }
+    lr2_wave<RMAX>(a, m, blockIdx.x, gridDim.x, lane, wg_max_nn);
     if (lane == 0 && wg_max_nn > a.status[ST_MAX_NN]) atomicMax(&a.status[ST_MAX_NN], wg_max_nn);
 }
 __global__ __launch_bounds__(64) void k_lr2_arc_kat(const double *arcs, const int *first, int n_sets, double *out)
@@ -242,27 +236,12 @@ __global__ __launch_bounds__(64) void k_lr2_arc_kat(const double *arcs, const in
     if (k < n_sets) out[k] = lr2_arc_kat(arcs, first, k, stack + k, 8);
 }
 
-__global__ __launch_bounds__(256) void k_lr2_compact(const unsigned char *flag, int n_tiles, int *ovf_count, int *ovf_tiles)
+/* main launch: the instantiation is picked by the rounds of pair records the pool needs; registers are capped for
+ * 4 waves per SIMD (a 5-wave build spilled and was not faster) */
+static hipError_t launch_lr2_main(int rmax, int grid, size_t lds, hipStream_t st, const Lr2Args &la)
 {
-    __shared__ int cnt[257];
-    cnt[threadIdx.x] = lr2_compact_count(flag, n_tiles, blockIdx.x, threadIdx.x, 256);
-    __syncthreads();
-    lr2_compact_base(cnt, ovf_count, threadIdx.x, 256);
-    __syncthreads();
-    lr2_compact_write(flag, n_tiles, cnt, ovf_tiles, blockIdx.x, threadIdx.x, 256);
-}
-
-/* main launch (TIER 0) and the launch that redoes overflowed tiles as halves (TIER 1: the same code and capacities,
- * named apart so that profiles list the two separately): the instantiation is picked by the rounds of pair
- * records the pool needs; registers are capped for 4 waves per SIMD (a 5-wave build spilled and was not faster) */
-static hipError_t launch_lr2_main(int rmax, int tier, int grid, size_t lds, hipStream_t st, const Lr2Args &la)
-{
-#define LR2_LAUNCH(R, T) hipLaunchKernelGGL((k_lr2_tile<R, T, 4>), dim3(grid), dim3(64), lds, st, la)
-    if (tier == 0) {
-        if (rmax <= 2) LR2_LAUNCH(2, 0); else if (rmax == 3) LR2_LAUNCH(3, 0); else LR2_LAUNCH(4, 0);
-    } else {
-        if (rmax <= 2) LR2_LAUNCH(2, 1); else if (rmax == 3) LR2_LAUNCH(3, 1); else LR2_LAUNCH(4, 1);
-    }
+#define LR2_LAUNCH(R) hipLaunchKernelGGL((k_lr2_tile<R, 0, 4>), dim3(grid), dim3(64), lds, st, la)
+    if (rmax <= 2) LR2_LAUNCH(2); else if (rmax == 3) LR2_LAUNCH(3); else LR2_LAUNCH(4);
 #undef LR2_LAUNCH
     return hipGetLastError();
 }
@@ -319,7 +298,7 @@ struct freesasa_gpu_ctx {
     DevBuf chunk_struct, chunk_begin, chunk_len, struct_chunk0, bpart;
     int n_chunks = 0;
     DevBuf sx, sy, sz, sr, s_orig, s_cell, s_struct;
-    DevBuf status, ovf_tiles, ovf_tiles2, ovf_atoms, ovf_flags, unit_pts, slab, seg;
+    DevBuf status, ovf_tiles, ovf_tiles2, ovf_atoms, unit_pts, slab, seg;
     std::vector<int64_t> offsets_host; /* last uploaded offsets */
     std::vector<double> unit_host;     /* last uploaded S&R unit points */
     /* host staging for freesasa_gpu_calc_batch */
@@ -432,7 +411,7 @@ extern "C" void freesasa_gpu_ctx_destroy(freesasa_gpu_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->chunk_struct, &c->chunk_begin, &c->chunk_len, &c->struct_chunk0, &c->bpart, &c->offsets, &c->grid, &c->ncells, &c->sid, &c->cell_of, &c->rank, &c->cell_start,
                      &c->blk_sums, &c->sx, &c->sy, &c->sz, &c->sr, &c->s_orig, &c->s_cell, &c->s_struct,
-                     &c->status, &c->ovf_tiles, &c->ovf_tiles2, &c->ovf_atoms, &c->ovf_flags, &c->unit_pts, &c->slab, &c->seg,
+                     &c->status, &c->ovf_tiles, &c->ovf_tiles2, &c->ovf_atoms, &c->unit_pts, &c->slab, &c->seg,
                      &c->h_xyz, &c->h_radii, &c->h_sasa, &c->h_counts, &c->h_totals};
     for (DevBuf *b : all)
         if (b->p) (void)hipFree(b->p);
@@ -530,6 +509,7 @@ static int finish_batch(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_st
     freesasa_gpu_stats &S = c->stats;
     S.n_atoms = n; S.n_cells = total_cells; S.n_structs = n_structs;
     S.max_neighbors = status_h[ST_MAX_NN]; S.fallback_tiles = status_h[ST_OVF_TILES];
+    for (int k = 0; k < 64; ++k) S.fallback_tiles += status_h[ST_SPLIT + k]; /* (L&R: tiles redone as halves) */
     S.tile_atoms = tile_atoms; S.block_threads = block_threads; S.lds_bytes = lds;
     S.ms_prep = S.ms_kernel = S.ms_total = 0;
     if (c->timing) {
@@ -566,8 +546,7 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
     if (refill_env > 0) cfg.refill = refill_env;
     cfg.lds = lr2_layout(cfg.TA, cfg.ns, cfg.pool, cfg.mw, cfg.ds).total;
     const int n_tiles = (n + cfg.TA - 1) / cfg.TA;
-    if (ensure(c, c->ovf_tiles, sizeof(int) * ((size_t)n_tiles + 1)) || ensure(c, c->ovf_tiles2, sizeof(int) * (2 * (size_t)n_tiles + 2)) ||
-        ensure(c, c->ovf_atoms, sizeof(int) * ((size_t)n + 8)))
+    if (ensure(c, c->ovf_tiles, sizeof(long long) * (2 * (size_t)n_tiles + 2)) || ensure(c, c->ovf_atoms, sizeof(int) * ((size_t)n + 8)))
         return -1;
 
     Lr2Args la;
@@ -578,10 +557,9 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
     la.n_atoms = n; la.n_tiles = n_tiles; la.TA = cfg.TA; la.ns = resolution;
     la.pool = cfg.pool; la.mw = cfg.mw; la.ds = cfg.ds; la.refill = cfg.refill;
     la.sasa = d_sasa; la.status = (int *)c->status.p;
-    /* overflow flags of the main launch: one byte per tile, behind the second work list */
-    if (ensure(c, c->ovf_flags, (size_t)n_tiles + 16)) return -1;
-    HIP_TRY(c, hipMemsetAsync(c->ovf_flags.p, 0, (size_t)n_tiles, st));
-    la.ovf_flag = (unsigned char *)c->ovf_flags.p;
+    la.ovf_items = (long long *)c->ovf_tiles.p;
+    la.ovf_count = (int *)c->status.p + ST_OVF2_TILES;
+    la.split_count = (int *)c->status.p + ST_SPLIT;
 
     int grid_main = ((n_tiles + 7) / 8) * 8;
     if (grid_main > 147456) grid_main = 147456;
@@ -590,46 +568,25 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
         if (g >= 8 && g < grid_main) grid_main = (g / 8) * 8;
     }
     la.nn_out = c->dbg_nn; la.nb_out = c->dbg_nb; la.nb_cap = c->dbg_cap;
-    if (c->dbg_nn) la.ovf_flag = nullptr; /* (the hook returns before anything could overflow) */
-    hipError_t le = launch_lr2_main(cfg.rmax, 0, grid_main, (size_t)cfg.lds, st, la);
+    hipError_t le = launch_lr2_main(cfg.rmax, grid_main, (size_t)cfg.lds, st, la);
     if (le != hipSuccess) return ctx_fail(c, "tile kernel launch failed: %s", hipGetErrorString(le));
     if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[2], st));
     if (c->dbg_nn) return finish_batch(c, pa, n, n_structs, total_cells, d_sasa, nullptr, cfg.TA, 64, cfg.lds, status_h);
-    hipLaunchKernelGGL(k_lr2_compact, dim3((n_tiles + 256 * LR2_COMPACT_PER - 1) / (256 * LR2_COMPACT_PER)), dim3(256), 0, st,
-                       (const unsigned char *)c->ovf_flags.p, n_tiles, (int *)c->status.p + ST_OVF_TILES, (int *)c->ovf_tiles.p);
-
-    /* second launch: the tiles whose lists did not fit (a few percent), as two halves each, through the same
-       kernel with the same capacities */
-    {
-        Lr2Args ls = la;
-        ls.ovf_flag = nullptr;
-        ls.split_ta = (cfg.TA + 1) / 2;
-        ls.split_src = (const int *)c->ovf_tiles.p;
-        ls.work_tiles = nullptr;
-        ls.work_count = (const int *)c->status.p + ST_OVF_TILES;
-        ls.ovf_tiles = (int *)c->ovf_tiles2.p;
-        ls.ovf_count = (int *)c->status.p + ST_OVF2_TILES;
-        const int grid_split = 2 * n_tiles < 8 * SASA_MID_BLOCKS ? 2 * n_tiles : 8 * SASA_MID_BLOCKS;
-        le = launch_lr2_main(cfg.rmax, 1, grid_split, (size_t)cfg.lds, st, ls);
-        if (le != hipSuccess) return ctx_fail(c, "second tile launch failed: %s", hipGetErrorString(le));
-    }
-    /* third launch: halves that still do not fit: larger LDS lists, more registers */
+    /* second launch: halves that did not fit either: larger LDS lists, more registers */
     const Lr2Cfg cm = lr2_mid_cfg(cfg);
     {
         Lr2Args lm = la;
-        lm.ovf_flag = nullptr;
-        lm.split_ta = (cfg.TA + 1) / 2;
-        lm.split_src = (const int *)c->ovf_tiles.p;
         lm.pool = cm.pool; lm.mw = cm.mw; lm.ds = cm.ds;
-        lm.work_tiles = (const int *)c->ovf_tiles2.p;
+        lm.work_items = (const long long *)c->ovf_tiles.p;
         lm.work_count = (const int *)c->status.p + ST_OVF2_TILES;
-        lm.ovf_tiles = (int *)c->ovf_atoms.p;
+        lm.ovf_items = nullptr;
+        lm.ovf_atoms = (int *)c->ovf_atoms.p;
         lm.ovf_count = (int *)c->status.p + ST_OVF3_ATOMS;
-        lm.ovf_atoms = 1;
+        lm.split_count = nullptr;
         const int grid_mid = n_tiles < SASA_MID_BLOCKS ? n_tiles : SASA_MID_BLOCKS;
         hipLaunchKernelGGL((k_lr2_tile<LR2_RMAX_MID, 2, 3>), dim3(grid_mid), dim3(64), (size_t)cm.lds, st, lm);
         le = hipGetLastError();
-        if (le != hipSuccess) return ctx_fail(c, "third tile launch failed: %s", hipGetErrorString(le));
+        if (le != hipSuccess) return ctx_fail(c, "second tile launch failed: %s", hipGetErrorString(le));
     }
     /* last launch: whatever is left (pathological densities), atom by atom: the first-generation kernel with its
        lists in a global slab */

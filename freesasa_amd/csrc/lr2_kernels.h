@@ -24,8 +24,8 @@
  *                  end points
  *   P7 store       per-atom sum in slice order (ref: src/sasa_lr.c:360)
  *
- * Tiles that do not fit the LDS capacities of a launch go to the next launch's work list exactly
- * as in sasa_kernels.h (larger LDS lists, then the slab-backed first-generation kernel).
+ * A tile that does not fit the LDS capacities of the launch is redone at once as two halves; what still does not
+ * fit goes to the next launch's work list (larger LDS lists, then the slab-backed first-generation kernel, atom by atom).
  *
  * Arithmetic: fp64 only; -ffp-contract=off; fma only where written.
  */
@@ -73,7 +73,7 @@ namespace sasa {
 #ifndef LR2_STOP_AFTER /* dev only (tools/build_variant.sh): return after phase k, for instruction attribution */
 #define LR2_STOP_AFTER 99
 #endif
-#define LR2_STOP(k) do { if (LR2_STOP_AFTER == (k)) return; } while (0)
+#define LR2_STOP(k) do { if (LR2_STOP_AFTER == (k)) return 0; } while (0)
 #ifndef LR2_MARK /* dev only (-DSASA_PHASE_TIMING in gpu_engine.hip): wall clock of lane 0 at the phase boundaries */
 #define LR2_MARK(k) do { } while (0)
 #define LR2_MARK_BEGIN do { } while (0)
@@ -96,22 +96,20 @@ struct Lr2Args {
     int ds;     /* spilled levels of the arc stack */
     int refill; /* waiting lanes that trigger a refill of the arc pass */
     double *sasa;
-    /* tiles that do not fit this launch's capacities go to the next launch: the main launch marks them in a
-       byte per tile (compacted into a work list by lr2_compact: no same-address atomics among half a million
-       tiles), the later launches append to a list */
-    unsigned char *ovf_flag;
+    /* Work that does not fit this launch's LDS capacities: the wave redoes the tile as two halves on the spot; a
+       half (or a single atom's tile) that still does not fit is appended to the next launch's work list as
+       (first atom | atoms << 32), or — ovf_atoms — atom by atom for the last launch.  No list: an error. */
     int *ovf_count;
-    int *ovf_tiles;
-    int ovf_atoms;         /* 1: append the atoms of the work item (the next launch works on single atoms) */
-    int split_ta;          /* > 0: work items are the two halves of the tiles in split_src (first half: split_ta atoms) */
-    const int *split_src;
+    long long *ovf_items;
+    int *ovf_atoms;               /* instead of ovf_items: a list of single atoms (the last launch works atom by atom) */
+    int *split_count;             /* [64] tiles split in place, counted in 64 buckets (statistics) */
+    const long long *work_items;  /* (first atom | atoms << 32) to (re)do; null in the main launch (all tiles) */
+    const int *work_count;
     /* test hook (freesasa_gpu_lr_neighbors_dev): stop after the neighbor discovery and report, in original atom
        order, every atom's neighbor count and (optionally, nb_cap per atom) its neighbors */
     int *nn_out;
     int *nb_out;
     int nb_cap;
-    const int *work_tiles; /* tile ids to (re)do; null in the main launch (all tiles) */
-    const int *work_count;
     int *status;
 };
 
@@ -311,71 +309,28 @@ SASA_D double lr2_arc_kat(const double *arcs, const int *first, int k, Arc *stk,
 
 #define LR2_NB_UNROLL 2
 
-/* work item -> first atom and number of atoms */
-SASA_D void lr2_decode(const Lr2Args &a, int item, int &p0, int &na)
+/* a work item that fits no capacity of this launch, even halved */
+SASA_D void lr2_overflow(const Lr2Args &a, int p0, int na, int err_code)
 {
-    if (a.split_ta <= 0) {
-        p0 = item * a.TA;
-        na = a.n_atoms - p0 < a.TA ? a.n_atoms - p0 : a.TA;
-    } else { /* a half of a tile that did not fit the main launch */
-        const int t0 = a.split_src[item >> 1] * a.TA;
-        const int full = a.n_atoms - t0 < a.TA ? a.n_atoms - t0 : a.TA;
-        const int first = full < a.split_ta ? full : a.split_ta;
-        p0 = (item & 1) ? t0 + first : t0;
-        na = (item & 1) ? full - first : first;
-    }
-}
-
-SASA_D void lr2_overflow(const Lr2Args &a, int item, int p0, int na, int err_code)
-{
-    if (a.ovf_flag) {
-        a.ovf_flag[item] = 1;
-    } else if (a.ovf_tiles && a.ovf_atoms) {
+    if (a.ovf_atoms) {
         const int w = SASA_ATOMIC_ADD_GLB(a.ovf_count, na);
-        for (int k = 0; k < na; ++k) a.ovf_tiles[w + k] = p0 + k;
-    } else if (a.ovf_tiles) {
+        for (int k = 0; k < na; ++k) a.ovf_atoms[w + k] = p0 + k;
+    } else if (a.ovf_items) {
         const int w = SASA_ATOMIC_ADD_GLB(a.ovf_count, 1);
-        a.ovf_tiles[w] = item;
+        a.ovf_items[w] = (long long)p0 | ((long long)na << 32);
     } else {
-        SASA_ATOMIC_MAX_GLB(&a.status[ST_ERROR], err_code); /* the last launch: nothing left to hand the tile to */
+        SASA_ATOMIC_MAX_GLB(&a.status[ST_ERROR], err_code); /* the last launch: nothing left to hand the work to */
     }
 }
 
-/* flags -> work list.  One workgroup of B threads per LR2_COMPACT_PER * B tiles: every thread collects the
- * marked ones among its LR2_COMPACT_PER consecutive tiles, the workgroup reserves its run of the list with ONE
- * atomic.  cnt = LDS int [B + 1]. */
-#define LR2_COMPACT_PER 8
-SASA_D int lr2_compact_count(const unsigned char *flag, int n_tiles, int blk, int tid, int B)
-{
-    const int t0 = (blk * B + tid) * LR2_COMPACT_PER;
-    int c = 0;
-    for (int k = 0; k < LR2_COMPACT_PER; ++k) c += t0 + k < n_tiles && flag[t0 + k] ? 1 : 0;
-    return c;
-}
-SASA_D void lr2_compact_base(int *cnt, int *ovf_count, int tid, int B)
-{
-    if (tid != 0) return;
-    int run = 0;
-    for (int t = 0; t < B; ++t) { const int v = cnt[t]; cnt[t] = run; run += v; }
-    cnt[B] = run > 0 ? SASA_ATOMIC_ADD_GLB(ovf_count, run) : 0;
-}
-SASA_D void lr2_compact_write(const unsigned char *flag, int n_tiles, const int *cnt, int *ovf_tiles, int blk, int tid, int B)
-{
-    const int t0 = (blk * B + tid) * LR2_COMPACT_PER;
-    int w = cnt[B] + cnt[tid];
-    for (int k = 0; k < LR2_COMPACT_PER; ++k)
-        if (t0 + k < n_tiles && flag[t0 + k]) ovf_tiles[w++] = t0 + k;
-}
 
 /* The whole tile, executed by the 64 lanes of one wave.  RMAX = rounds of 64 pair records a lane
  * keeps in registers in P3 (pool <= 64 * RMAX). */
+/* returns 0: the atoms' areas are stored; 1: the tile does not fit this launch's capacities (nothing stored) */
 template <int RMAX>
-SASA_D void lr2_tile(const Lr2Args &a, const Lr2Mem &m, int tile, int lane, int &wg_max_nn)
+SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool sample, int lane, int &wg_max_nn)
 {
     const int TA = a.TA, ns = a.ns, mw = a.mw;
-    int p0, na; /* `tile` is the work item: a tile of the main launch, later a half of one */
-    lr2_decode(a, tile, p0, na);
-    if (na <= 0) return;
     const int items = na * ns;
     LR2_MARK_BEGIN;
     LR2_COUNT(0, 1);
@@ -523,7 +478,7 @@ SASA_D void lr2_tile(const Lr2Args &a, const Lr2Mem &m, int tile, int lane, int 
     if (a.nn_out) { /* (uniform) test hook: the neighbor counts are the result */
         if (lane < na) a.nn_out[m.sorig[lane]] = m.acnt[lane];
         LR2_SYNC();
-        return;
+        return 0;
     }
     /* ------------------------------------------------------------ P2 offsets */
     /* offsets of the atoms' lists in the pool (lists padded to an even length): a prefix over the first lanes of
@@ -544,18 +499,14 @@ SASA_D void lr2_tile(const Lr2Args &a, const Lr2Mem &m, int tile, int lane, int 
         ovf = nn_max > 32 * mw || total > a.pool || nh > a.pool || nh > LR2_LANES * RMAX;
         if (lane == 0) {
             if (nn_max > wg_max_nn) wg_max_nn = nn_max;
-            if (!a.work_tiles && !a.work_count && (tile & 31) == 0) { /* demand histogram for the next batch's pool size: 1 tile in 32 of the main launch */
+            if (sample) { /* demand histogram for the next batch's pool size: 1 tile in 32 of the main launch */
                 const int need = total / hist_bin_width(TA);
                 SASA_ATOMIC_ADD_GLB(&a.status[ST_HIST + (need < 63 ? need : 63)], 1);
             }
         }
     }
     LR2_SYNC();
-    if (ovf) { /* uniform: the tile goes to the next launch */
-        if (lane == 0) lr2_overflow(a, tile, p0, na, ERR_NEIGHBOR_CAP);
-        LR2_SYNC();
-        return;
-    }
+    if (ovf) return 1; /* (uniform) */
 
     LR2_STOP(2);
     LR2_MARK(2);
@@ -747,20 +698,50 @@ SASA_D void lr2_tile(const Lr2Args &a, const Lr2Mem &m, int tile, int lane, int 
         }
 #undef LR2_FETCH
     }
-    if (maxd - 2 > a.ds) m.flags[1] = 1;
     LR2_SYNC();
     LR2_MARK(6);
 
     /* ------------------------------------------------------------ P7 store */
-    if (m.flags[1]) { /* an arc stack overflowed: the tile is redone by the next launch */
-        if (lane == 0) lr2_overflow(a, tile, p0, na, ERR_STACK_CAP);
-    } else if (lane < na) {
+    const bool deep = LR2_BALLOT(maxd - 2 > a.ds) != 0; /* an arc stack column was too short: the tile is redone */
+    if (!deep && lane < na) {
         double s = 0;
         for (int k = 0; k < ns; ++k) s += m.it_tc[lane * ns + k]; /* slice order, ref: :305-361 */
         a.sasa[m.sorig[lane]] = s;
     }
     LR2_SYNC();
     LR2_MARK(7);
+    return deep ? 1 : 0;
+}
+
+/* The work items of one wave (items first, first + stride, ... of the launch).  A tile that does not fit is redone
+ * at once as two halves (3 % of the 6-atom tiles of random coils at a pool of 204 records); what still does not fit
+ * goes to the next launch's list. */
+template <int RMAX>
+SASA_D void lr2_wave(const Lr2Args &a, const Lr2Mem &m, int first, int stride, int lane, int &wg_max_nn)
+{
+    /* all tiles (main launch, rounded up to whole XCD groups) or the items of a work list */
+    const int n_work = a.work_items ? *a.work_count : ((a.n_tiles + 7) >> 3) << 3;
+    int splits = 0;
+    for (int w = first; w < n_work; w += stride) {
+        int p0, na, tile = 0;
+        if (a.work_items) {
+            const long long e = a.work_items[w];
+            p0 = (int)(e & 0xffffffffLL); na = (int)(e >> 32);
+        } else {
+            tile = xcd_tile(w, a.n_tiles);
+            if (tile >= a.n_tiles) continue; /* uniform per wave */
+            p0 = tile * a.TA;
+            na = a.n_atoms - p0 < a.TA ? a.n_atoms - p0 : a.TA;
+        }
+        if (na <= 0) continue;
+        if (lr2_tile<RMAX>(a, m, p0, na, !a.work_items && (tile & 31) == 0, lane, wg_max_nn) == 0) continue;
+        ++splits;
+        if (na == 1) { if (lane == 0) lr2_overflow(a, p0, 1, ERR_NEIGHBOR_CAP); continue; }
+        const int h = (na + 1) >> 1;
+        if (lr2_tile<RMAX>(a, m, p0, h, false, lane, wg_max_nn) && lane == 0) lr2_overflow(a, p0, h, ERR_NEIGHBOR_CAP);
+        if (lr2_tile<RMAX>(a, m, p0 + h, na - h, false, lane, wg_max_nn) && lane == 0) lr2_overflow(a, p0 + h, na - h, ERR_NEIGHBOR_CAP);
+    }
+    if (lane == 0 && splits > 0 && a.split_count) SASA_ATOMIC_ADD_GLB(&a.split_count[first & 63], splits);
 }
 
 /* launch configuration (host side; shared by gpu_engine.hip and the test emulation) */

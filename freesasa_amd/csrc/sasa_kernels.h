@@ -115,7 +115,8 @@ enum {
     ST_OCC_N = 5,      /* ... and how many atoms were sampled: local density -> first launch shape */
     ST_OVF3_ATOMS = 6, /* L&R (lr2_kernels.h): atoms handed to the last (slab) launch */
     ST_HIST = 8,       /* [64] tiles by neighbor records needed, bins of hist_bin_width(TA) */
-    ST_WORDS = 72
+    ST_SPLIT = 72,     /* [64] L&R (lr2_kernels.h): tiles redone as two halves, counted in 64 buckets */
+    ST_WORDS = 136
 };
 enum {
     ERR_NONE = 0,

@@ -143,26 +143,21 @@ static int emu_lr2 = 1, emu_lr2_ta = 0, emu_lr2_refill = 0;
 extern "C" void emu_lr2_counts(long long *out, int reset) { for (int k = 0; k < 16; ++k) { out[k] = sasa_emu::lr2_count[k]; if (reset) sasa_emu::lr2_count[k] = 0; } }
 extern "C" void emu_set_lr2(int on, int ta, int refill) { emu_lr2 = on; emu_lr2_ta = ta; emu_lr2_refill = refill; }
 
-struct Lr2Run { const Lr2Args *a; Lr2Mem *m; int tile; int rmax; int *wg_max; };
+struct Lr2Run { const Lr2Args *a; Lr2Mem *m; int first, stride; int rmax; int *wg_max; };
 static void lr2_lane_body(int lane, void *ctx)
 {
     Lr2Run *r = (Lr2Run *)ctx;
-    if (r->rmax == LR2_RMAX_MAIN) lr2_tile<LR2_RMAX_MAIN>(*r->a, *r->m, r->tile, lane, r->wg_max[lane]);
-    else lr2_tile<LR2_RMAX_MID>(*r->a, *r->m, r->tile, lane, r->wg_max[lane]);
+    if (r->rmax == LR2_RMAX_MAIN) lr2_wave<LR2_RMAX_MAIN>(*r->a, *r->m, r->first, r->stride, lane, r->wg_max[lane]);
+    else lr2_wave<LR2_RMAX_MID>(*r->a, *r->m, r->first, r->stride, lane, r->wg_max[lane]);
 }
 static void emu_lr2_kernel(const Lr2Cfg &cfg, Lr2Args a, int grid)
 {
     std::vector<char> smem(cfg.lds + 64);
     for (int blk = 0; blk < grid; ++blk) {
         Lr2Mem m = lr2_carve(a, smem.data());
-        const int n_work = a.work_count ? (a.work_tiles ? *a.work_count : 2 * *a.work_count) : ((a.n_tiles + 7) >> 3) << 3;
         std::vector<int> wg_max(64, 0);
-        for (int w = blk; w < n_work; w += grid) {
-            const int tile = a.work_tiles ? a.work_tiles[w] : (a.work_count ? w : xcd_tile(w, a.n_tiles));
-            if (!a.work_count && tile >= a.n_tiles) continue;
-            Lr2Run run = {&a, &m, tile, cfg.rmax, wg_max.data()};
-            sasa_emu::run_wave(lr2_lane_body, &run);
-        }
+        Lr2Run run = {&a, &m, blk, grid, cfg.rmax, wg_max.data()};
+        sasa_emu::run_wave(lr2_lane_body, &run);
         if (wg_max[0] > a.status[ST_MAX_NN]) a.status[ST_MAX_NN] = wg_max[0];
     }
 }
@@ -267,34 +262,17 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
         if (emu_lr2_refill > 0) c2.refill = emu_lr2_refill;
         c2.lds = lr2_layout(c2.TA, c2.ns, c2.pool, c2.mw, c2.ds).total;
         const int n_tiles2 = (n + c2.TA - 1) / c2.TA;
-        std::vector<int> ovf1(n_tiles2 + 1), ovf2(n_tiles2 + 1);
+        std::vector<long long> ovf2x(2 * n_tiles2 + 2);
+        std::vector<int> ovf3(n + 8);
         Lr2Args la;
         memset(&la, 0, sizeof la);
         la.sx = pa.sx; la.sy = pa.sy; la.sz = pa.sz; la.sr = pa.sr; la.s_orig = pa.s_orig; la.s_struct = pa.s_struct;
         la.s_cell = pa.s_cell; la.grid = pa.grid; la.cell_start = pa.cell_start; la.n_atoms = n; la.n_tiles = n_tiles2;
         la.TA = c2.TA; la.ns = resolution; la.pool = c2.pool; la.mw = c2.mw; la.ds = c2.ds; la.refill = c2.refill;
         la.sasa = sasa; la.status = status.data();
-        std::vector<unsigned char> flags(n_tiles2 + 16, 0);
-        la.ovf_flag = flags.data();
+        /* main launch: a tile that does not fit is split in place; halves that still do not fit go to the list */
+        la.ovf_items = ovf2x.data(); la.ovf_count = status.data() + ST_OVF2_TILES; la.split_count = status.data() + ST_SPLIT;
         emu_lr2_kernel(c2, la, ((n_tiles2 + 7) / 8) * 8);
-        { /* k_lr2_compact */
-            const int B = 256;
-            std::vector<int> cnt(B + 1);
-            for (int blk = 0; blk < (n_tiles2 + B * LR2_COMPACT_PER - 1) / (B * LR2_COMPACT_PER); ++blk) {
-                for (int t = 0; t < B; ++t) cnt[t] = lr2_compact_count(flags.data(), n_tiles2, blk, t, B);
-                for (int t = 0; t < B; ++t) lr2_compact_base(cnt.data(), status.data() + ST_OVF_TILES, t, B);
-                for (int t = 0; t < B; ++t) lr2_compact_write(flags.data(), n_tiles2, cnt.data(), ovf1.data(), blk, t, B);
-            }
-        }
-        std::vector<int> ovf2x(2 * n_tiles2 + 2), ovf3(n + 8);
-        { /* the halves of the tiles that did not fit, same kernel, same capacities */
-            Lr2Args ls = la;
-            ls.ovf_flag = nullptr;
-            ls.split_ta = (c2.TA + 1) / 2; ls.split_src = ovf1.data();
-            ls.work_tiles = nullptr; ls.work_count = status.data() + ST_OVF_TILES;
-            ls.ovf_tiles = ovf2x.data(); ls.ovf_count = status.data() + ST_OVF2_TILES;
-            emu_lr2_kernel(c2, ls, 7);
-        }
         Lr2Cfg cm = lr2_mid_cfg(c2);
         if (mid_cap_idx > 0) cm.mw = (mid_cap_idx + 31) / 32;
         if (mid_pool > 0) cm.pool = mid_pool;
@@ -302,11 +280,10 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
         cm.lds = lr2_layout(cm.TA, cm.ns, cm.pool, cm.mw, cm.ds).total;
         {
             Lr2Args lm = la;
-            lm.ovf_flag = nullptr;
-            lm.split_ta = (c2.TA + 1) / 2; lm.split_src = ovf1.data();
             lm.pool = cm.pool; lm.mw = cm.mw; lm.ds = cm.ds;
-            lm.work_tiles = ovf2x.data(); lm.work_count = status.data() + ST_OVF2_TILES;
-            lm.ovf_tiles = ovf3.data(); lm.ovf_count = status.data() + ST_OVF3_ATOMS; lm.ovf_atoms = 1;
+            lm.work_items = ovf2x.data(); lm.work_count = status.data() + ST_OVF2_TILES;
+            lm.ovf_items = nullptr; lm.ovf_atoms = ovf3.data(); lm.ovf_count = status.data() + ST_OVF3_ATOMS;
+            lm.split_count = nullptr;
             emu_lr2_kernel(cm, lm, 5);
         }
         {
@@ -336,7 +313,9 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
             }
             for (int s = 0; s < ((n_structs + 255) / 256) * 256; ++s) totals_struct(pa, chunk_tot.data(), totals, s);
         }
-        stats_out[0] = status[ST_ERROR]; stats_out[1] = status[ST_OVF_TILES]; stats_out[2] = status[ST_MAX_NN];
+        long long splits = 0;
+        for (int k = 0; k < 64; ++k) splits += status[ST_SPLIT + k];
+        stats_out[0] = status[ST_ERROR]; stats_out[1] = splits; stats_out[2] = status[ST_MAX_NN];
         stats_out[3] = c2.TA; stats_out[4] = 64; stats_out[5] = (long long)c2.lds; stats_out[6] = total_cells;
         stats_out[7] = c2.TA * resolution;
         stats_out[8] = status[ST_OVF3_ATOMS]; stats_out[9] = status[ST_OVF2_TILES];
