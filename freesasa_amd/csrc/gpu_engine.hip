@@ -61,9 +61,33 @@ __global__ __launch_bounds__(SASA_PIPE_B) void k_cell_base(PipeArgs a)
     cellbase_phase2(a, part, threadIdx.x, SASA_PIPE_B);
 }
 
+/* Everything behind K2 is launched without the host having seen K2's result (no readback in the middle of the
+ * pipeline: the next batch of a driver loop can be enqueued behind this one).  A batch that turned out to be in
+ * error (non-finite input, grid too big) or to need a larger cell table than was allocated does nothing from here
+ * on - uniformly, first thing in every kernel - and the host, which reads the status once at the end, reports the
+ * error or redoes the batch with the table K2 asked for. */
+#define PIPE_GATE(st) do { if ((st)[ST_ERROR] | (st)[ST_RETRY]) return; } while (0)
+
+/* zero the histogram: cell_start[0 .. total cells + 1] (the total is on the device) */
+__global__ __launch_bounds__(SASA_PIPE_B) void k_zero_cells(PipeArgs a)
+{
+    PIPE_GATE(a.status);
+    const long long n = a.ncells[a.n_structs] + 2;
+    const long long base = ((long long)blockIdx.x * SASA_PIPE_B + threadIdx.x) * 16;
+    if (base >= n) return;
+    if (base + 16 <= n) {
+        Int4 *p = (Int4 *)(a.cell_start + base);
+        const Int4 z = {0, 0, 0, 0};
+        p[0] = z; p[1] = z; p[2] = z; p[3] = z;
+    } else {
+        for (long long k = base; k < n; ++k) a.cell_start[k] = 0;
+    }
+}
+
 __global__ __launch_bounds__(SASA_PIPE_B) void k_count(PipeArgs a)
 {
     __shared__ int cells[SASA_PIPE_B], base[SASA_PIPE_B];
+    PIPE_GATE(a.status);
     const int i = blockIdx.x * SASA_PIPE_B + threadIdx.x;
     count_phase0(a, cells, i, threadIdx.x);
     __syncthreads();
@@ -73,18 +97,29 @@ __global__ __launch_bounds__(SASA_PIPE_B) void k_count(PipeArgs a)
 }
 
 static_assert(SASA_PIPE_B == SASA_SCAN_GROUP * SASA_SCAN_GROUP, "two-level combine of the scan partials");
-__global__ __launch_bounds__(SASA_PIPE_B) void k_scan1(PipeArgs a, long long n)
+/* n = total cells and the number of scan blocks follow from K2's total on the device; the launches are sized for
+ * the table's capacity, blocks beyond the end leave at once */
+__device__ __forceinline__ int scan_blocks(long long n)
+{
+    return (int)((n + 1 + (long long)SASA_PIPE_B * SASA_SCAN_ITEMS - 1) / ((long long)SASA_PIPE_B * SASA_SCAN_ITEMS));
+}
+__global__ __launch_bounds__(SASA_PIPE_B) void k_scan1(PipeArgs a)
 {
     __shared__ int part[SASA_PIPE_B], part2[SASA_SCAN_GROUP];
+    PIPE_GATE(a.status);
+    const long long n = a.ncells[a.n_structs];
+    if ((int)blockIdx.x >= scan_blocks(n)) return;
     scan1_phase0(a, n, part, blockIdx.x, threadIdx.x, SASA_PIPE_B);
     __syncthreads();
     scan_group_sums(part, part2, threadIdx.x);
     __syncthreads();
     scan1_phase2(a, part2, blockIdx.x, threadIdx.x);
 }
-__global__ __launch_bounds__(SASA_PIPE_B) void k_scan2(PipeArgs a, int nblk)
+__global__ __launch_bounds__(SASA_PIPE_B) void k_scan2(PipeArgs a)
 {
     __shared__ int part[SASA_PIPE_B];
+    PIPE_GATE(a.status);
+    const int nblk = scan_blocks(a.ncells[a.n_structs]);
     scan2_phase0(a, nblk, part, threadIdx.x, SASA_PIPE_B);
     __syncthreads();
     scan2_phase1(part, threadIdx.x, SASA_PIPE_B);
@@ -92,10 +127,13 @@ __global__ __launch_bounds__(SASA_PIPE_B) void k_scan2(PipeArgs a, int nblk)
     scan2_phase2(a, nblk, part, threadIdx.x, SASA_PIPE_B);
 }
 
-__global__ __launch_bounds__(SASA_PIPE_B) void k_scan3(PipeArgs a, long long n)
+__global__ __launch_bounds__(SASA_PIPE_B) void k_scan3(PipeArgs a)
 {
     __shared__ int part[SASA_PIPE_B], part2[SASA_SCAN_GROUP];
     ScanRegs r;
+    PIPE_GATE(a.status);
+    const long long n = a.ncells[a.n_structs];
+    if ((int)blockIdx.x >= scan_blocks(n)) return;
     scan3_phase0(a, n, part, blockIdx.x, threadIdx.x, SASA_PIPE_B, r);
     __syncthreads();
     scan3_phase1(part, part2, threadIdx.x);
@@ -107,6 +145,7 @@ __global__ __launch_bounds__(SASA_PIPE_B) void k_scan3(PipeArgs a, long long n)
 
 __global__ __launch_bounds__(SASA_PIPE_B) void k_scatter(PipeArgs a)
 {
+    PIPE_GATE(a.status);
     scatter_atom(a, blockIdx.x * SASA_PIPE_B + threadIdx.x);
 }
 
@@ -166,6 +205,7 @@ __global__ __launch_bounds__(B) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) v
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
+    PIPE_GATE(a.status);
     TileMem m = tile_carve<GLOBAL>(a, smem, items, B, blockIdx.x);
     const int n_work = a.work_tiles ? *a.work_count : ((a.n_tiles + 7) >> 3) << 3;
     int wg_max_nn = 0;
@@ -224,6 +264,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
+    PIPE_GATE(a.status);
     Lr2Mem m = lr2_carve(a, smem);
     int wg_max_nn = 0;
     lr2_wave<RMAX>(a, m, blockIdx.x, gridDim.x, lane, wg_max_nn);
@@ -251,6 +292,7 @@ __global__ __launch_bounds__(B) void k_sr_tile(TileArgs a, int items)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
+    PIPE_GATE(a.status);
     TileMem m = tile_carve<GLOBAL>(a, smem, items, B, blockIdx.x);
     const int n_work = a.work_tiles ? *a.work_count : ((a.n_tiles + 7) >> 3) << 3;
     int wg_max_nn = 0;
@@ -307,11 +349,13 @@ struct freesasa_gpu_ctx {
     size_t stage_in_cap = 0, stage_out_cap = 0;
     int *pinned = nullptr; /* page-locked host words for the small device->host readbacks */
     long long max_cells = 1LL << 30;
+    long long cells_hint = 0; /* cells the last batch needed, with a margin: the table is never sized below it */
     /* adaptive neighbor-pool size, per algorithm: (resolution, TA) it was learnt for and the value */
     int hint_res[2] = {0, 0}, hint_ta[2] = {0, 0}, hint_pool[2] = {0, 0};
     bool hint_bucket = false; /* L&R: the last batch had long neighbor lists */
     double hint_nn = 0;       /* L&R (lr2): neighbor records per atom the main launch should hold */
     int hint_nn_max = 0;      /* ... and the longest neighbor list expected (mask words per item) */
+    int hint_pool2 = 0, hint_ta2 = 0, hint_mw2 = 0; /* ... and the pool the last batch's demand histogram asks for, for tiles of that shape */
     int *dbg_nn = nullptr, *dbg_nb = nullptr; /* test hook: freesasa_gpu_lr_neighbors_dev */
     int dbg_cap = 0;
 };
@@ -493,7 +537,30 @@ static void dump_phase_clocks()
 #endif
 }
 
-static int finish_batch(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs, long long total_cells, double *d_sasa,
+/* run_batch_once's third outcome: the cell table was too small, redo the batch (c->cells_hint has the size) */
+#define RC_RETRY 2
+
+/* Status words [0, words) and K2's cell total, read back behind everything enqueued so far.  Returns 0, RC_RETRY,
+ * or -1 with the batch's error text set. */
+static int collect_status(freesasa_gpu_ctx *c, int n_structs, int words, long long *total_cells)
+{
+    hipStream_t st = c->stream;
+    int *status_h = c->pinned;
+    long long *total_p = (long long *)(c->pinned + ST_WORDS + 2);
+    HIP_TRY(c, hipMemcpyAsync(total_p, (long long *)c->ncells.p + n_structs, sizeof(long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(status_h, c->status.p, sizeof(int) * (size_t)words, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    *total_cells = *total_p;
+    if (status_h[ST_ERROR]) return ctx_fail(c, "%s", err_text(status_h[ST_ERROR]));
+    if (*total_p <= 0 || *total_p > c->max_cells) return ctx_fail(c, "%s", err_text(ERR_GRID_TOO_BIG));
+    if (status_h[ST_RETRY]) {
+        c->cells_hint = *total_p + *total_p / 16 + 1024;
+        return RC_RETRY;
+    }
+    return 0;
+}
+
+static int finish_batch(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs, double *d_sasa,
                         double *d_totals, int tile_atoms, int block_threads, int lds, int *status_h)
 {
     hipStream_t st = c->stream;
@@ -504,8 +571,8 @@ static int finish_batch(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_st
         HIP_TRY(c, hipGetLastError());
     }
     if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[3], st));
-    HIP_TRY(c, hipMemcpyAsync(status_h, c->status.p, sizeof(int) * ST_WORDS, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
+    long long total_cells = 0;
+    const int rcs = collect_status(c, n_structs, ST_WORDS, &total_cells);
     freesasa_gpu_stats &S = c->stats;
     S.n_atoms = n; S.n_cells = total_cells; S.n_structs = n_structs;
     S.max_neighbors = status_h[ST_MAX_NN]; S.fallback_tiles = status_h[ST_OVF_TILES];
@@ -518,13 +585,14 @@ static int finish_batch(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_st
         if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) S.ms_kernel = ms;
         if (hipEventElapsedTime(&ms, c->ev[0], c->ev[3]) == hipSuccess) S.ms_total = ms;
     }
-    if (status_h[ST_ERROR]) return ctx_fail(c, "%s", err_text(status_h[ST_ERROR]));
+    if (rcs) return rcs;
+    if (total_cells + total_cells / 32 > c->cells_hint) c->cells_hint = total_cells + total_cells / 32;
     dump_phase_clocks();
     return 0;
 }
 
 static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs, int resolution, double *d_sasa,
-                   double *d_totals, long long total_cells)
+                   double *d_totals)
 {
     hipStream_t st = c->stream;
     int *status_h = c->pinned;
@@ -534,14 +602,20 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
         /* no demand history for this resolution on this context: size the neighbor pool from the local
            density (atoms in an atom's own cell; ~3.1 neighbors per such atom on coils, globules and
            proteins alike).  One 8-byte readback, first call only. */
-        HIP_TRY(c, hipMemcpyAsync(status_h, (int *)c->status.p + ST_OCC_SUM, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipStreamSynchronize(st));
-        c->hint_nn = status_h[1] > 0 ? 1.25 * 3.1 * (double)status_h[0] / (double)status_h[1] + 2.0 : 0.0;
+        long long total_cells = 0;
+        const int rcs = collect_status(c, n_structs, 8, &total_cells);
+        if (rcs) return rcs;
+        c->hint_nn = status_h[ST_OCC_N] > 0 ? 1.25 * 3.1 * (double)status_h[ST_OCC_SUM] / (double)status_h[ST_OCC_N] + 2.0 : 0.0;
         c->hint_nn_max = (int)(1.45 * c->hint_nn); /* longest list ~ 1.6 x the mean on coils, globules and proteins alike */
         c->hint_res[0] = resolution;
+        c->hint_pool2 = 0;
     }
     Lr2Cfg cfg = lr2_choose_cfg(resolution, c->hint_nn, ta_env, c->hint_nn_max);
-    if (pool_env > 0) cfg.pool = (pool_env + 1) & ~1;
+    if (c->hint_pool2 > 0 && c->hint_ta2 == cfg.TA && c->hint_mw2 == cfg.mw) { /* same tile shape as the last batch: its demand histogram decides */
+        cfg.pool = c->hint_pool2;
+        cfg.rmax = (cfg.pool + LR2_LANES - 1) / LR2_LANES;
+    }
+    if (pool_env > 0) { cfg.pool = (pool_env + 1) & ~1; cfg.rmax = (cfg.pool + LR2_LANES - 1) / LR2_LANES; }
     if (ds_env >= 0) cfg.ds = ds_env;
     if (refill_env > 0) cfg.refill = refill_env;
     cfg.lds = lr2_layout(cfg.TA, cfg.ns, cfg.pool, cfg.mw, cfg.ds).total;
@@ -571,7 +645,7 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
     hipError_t le = launch_lr2_main(cfg.rmax, grid_main, (size_t)cfg.lds, st, la);
     if (le != hipSuccess) return ctx_fail(c, "tile kernel launch failed: %s", hipGetErrorString(le));
     if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[2], st));
-    if (c->dbg_nn) return finish_batch(c, pa, n, n_structs, total_cells, d_sasa, nullptr, cfg.TA, 64, cfg.lds, status_h);
+    if (c->dbg_nn) return finish_batch(c, pa, n, n_structs, d_sasa, nullptr, cfg.TA, 64, cfg.lds, status_h);
     /* second launch: halves that did not fit either: larger LDS lists, more registers */
     const Lr2Cfg cm = lr2_mid_cfg(cfg);
     {
@@ -609,18 +683,20 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
         le = launch_lr<true, 2>(fb, tf, SASA_FB_BLOCKS, fb.lds, st);
         if (le != hipSuccess) return ctx_fail(c, "fallback kernel launch failed: %s", hipGetErrorString(le));
     }
-    const int rc = finish_batch(c, pa, n, n_structs, total_cells, d_sasa, d_totals, cfg.TA, 64, cfg.lds, status_h);
+    const int rc = finish_batch(c, pa, n, n_structs, d_sasa, d_totals, cfg.TA, 64, cfg.lds, status_h);
     if (rc) return rc;
     /* learn the pool size for the next batch of this kind (trajectory frames, sweeps) */
-    const int learnt = lr2_pool_from_hist(status_h + ST_HIST, cfg.TA);
+    const int learnt = lr2_need_from_hist(status_h + ST_HIST, cfg.TA);
     if (learnt > 0) c->hint_nn = (double)(learnt - 8) / cfg.TA;
+    c->hint_pool2 = lr2_pool_from_hist(status_h + ST_HIST, cfg.TA, cfg.ns, cfg.mw, cfg.ds); /* (see there: pool vs occupancy) */
+    c->hint_ta2 = cfg.TA; c->hint_mw2 = cfg.mw;
     c->hint_nn_max = status_h[ST_MAX_NN] + 4; /* the longest list of this batch, a little room */
     return 0;
 }
 
 /* ------------------------------------------------------------------ one batch */
 
-static int run_batch_impl(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, const double *d_radii,
+static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, const double *d_radii,
                      const int64_t *offsets, int n_structs, double probe, int resolution,
                      const double *unit_points, double *d_sasa, int *d_counts, double *d_totals)
 {
@@ -693,40 +769,39 @@ static int run_batch_impl(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
     pa.status = (int *)c->status.p;
     pa.occ_stride = c->hint_res[lr ? 0 : 1] == resolution ? 0 : (n / 256 > 0 ? n / 256 : 1);
 
+    /* The cell table is sized WITHOUT waiting for K2's total: for what the context has seen so far, and for a
+       first batch 20 cells per atom (sparse random coils need 9, proteins 1-2) plus 2048 per structure.  K2 checks
+       the real total against it on the device (ST_RETRY, see PIPE_GATE); the total itself reaches the host with
+       the status words at the end of the batch. */
+    int *status_h = c->pinned;
+    long long cells_cap = 20LL * n + 2048LL * n_structs;
+    if (cells_cap < c->cells_hint) cells_cap = c->cells_hint;
+    if (cells_cap > c->max_cells) cells_cap = c->max_cells;
+    const int nblk_scan = (int)((cells_cap + 1 + (long long)SASA_PIPE_B * SASA_SCAN_ITEMS - 1) / ((long long)SASA_PIPE_B * SASA_SCAN_ITEMS));
+    if (ensure(c, c->cell_start, sizeof(int) * ((size_t)cells_cap + 2)) || ensure(c, c->blk_sums, sizeof(int) * ((size_t)nblk_scan + 1)))
+        return -1;
+    pa.cell_start = (int *)c->cell_start.p;
+    pa.blk_sums = (int *)c->blk_sums.p;
+    pa.cells_cap = cells_cap;
+
     hipLaunchKernelGGL(k_bounds, dim3(c->n_chunks), dim3(SASA_PIPE_B), 0, st, pa);
     hipLaunchKernelGGL(k_grid, dim3((n_structs + 63) / 64), dim3(64), 0, st, pa);
     hipLaunchKernelGGL(k_cell_base, dim3(1), dim3(SASA_PIPE_B), 0, st, pa);
     HIP_TRY(c, hipGetLastError());
 
-    /* the one mid-pipeline readback: total cells sizes the histogram */
-    int *status_h = c->pinned;
-    long long *total_cells_p = (long long *)(c->pinned + ST_WORDS + 2);
-    HIP_TRY(c, hipMemcpyAsync(total_cells_p, (long long *)c->ncells.p + n_structs, sizeof(long long), hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(status_h, c->status.p, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
-    const long long total_cells = *total_cells_p;
-    if (status_h[ST_ERROR]) return ctx_fail(c, "%s", err_text(status_h[ST_ERROR]));
-    if (total_cells <= 0 || total_cells > c->max_cells) return ctx_fail(c, "%s", err_text(ERR_GRID_TOO_BIG));
-
-    const int nblk_scan = (int)((total_cells + 1 + (long long)SASA_PIPE_B * SASA_SCAN_ITEMS - 1) / ((long long)SASA_PIPE_B * SASA_SCAN_ITEMS));
-    if (ensure(c, c->cell_start, sizeof(int) * ((size_t)total_cells + 2)) || ensure(c, c->blk_sums, sizeof(int) * ((size_t)nblk_scan + 1)))
-        return -1;
-    pa.cell_start = (int *)c->cell_start.p;
-    pa.blk_sums = (int *)c->blk_sums.p;
-    HIP_TRY(c, hipMemsetAsync(c->cell_start.p, 0, sizeof(int) * ((size_t)total_cells + 2), st));
-
     const int nblk_atoms = (n + SASA_PIPE_B - 1) / SASA_PIPE_B;
+    hipLaunchKernelGGL(k_zero_cells, dim3((unsigned)((cells_cap + 2 + 16LL * SASA_PIPE_B - 1) / (16LL * SASA_PIPE_B))), dim3(SASA_PIPE_B), 0, st, pa);
     hipLaunchKernelGGL(k_count, dim3(nblk_atoms), dim3(SASA_PIPE_B), 0, st, pa);
-    hipLaunchKernelGGL(k_scan1, dim3(nblk_scan), dim3(SASA_PIPE_B), 0, st, pa, total_cells);
-    hipLaunchKernelGGL(k_scan2, dim3(1), dim3(SASA_PIPE_B), 0, st, pa, nblk_scan);
-    hipLaunchKernelGGL(k_scan3, dim3(nblk_scan), dim3(SASA_PIPE_B), 0, st, pa, total_cells);
+    hipLaunchKernelGGL(k_scan1, dim3(nblk_scan), dim3(SASA_PIPE_B), 0, st, pa);
+    hipLaunchKernelGGL(k_scan2, dim3(1), dim3(SASA_PIPE_B), 0, st, pa);
+    hipLaunchKernelGGL(k_scan3, dim3(nblk_scan), dim3(SASA_PIPE_B), 0, st, pa);
     hipLaunchKernelGGL(k_scatter, dim3(nblk_atoms), dim3(SASA_PIPE_B), 0, st, pa);
     HIP_TRY(c, hipGetLastError());
     if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[1], st));
 
     /* Lee & Richards at ordinary resolutions: the second-generation kernel (lr2_kernels.h) */
     if (lr && lr2_supported(resolution) && !getenv("FREESASA_AMD_LR1"))
-        return run_lr2(c, pa, n, n_structs, resolution, d_sasa, d_totals, total_cells);
+        return run_lr2(c, pa, n, n_structs, resolution, d_sasa, d_totals);
 
     /* fused tile kernel */
     const int hi = lr ? 0 : 1;
@@ -735,10 +810,11 @@ static int run_batch_impl(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
            local density (atoms in an atom's own cell; ~3.1 neighbors per such atom on coils, globules
            and proteins alike) so that the very first launch already has a fitting neighbor pool and,
            for dense inputs, the bucket-sort variant.  One 8-byte readback, first call only. */
-        HIP_TRY(c, hipMemcpyAsync(status_h, (int *)c->status.p + ST_OCC_SUM, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipStreamSynchronize(st));
-        if (status_h[1] > 0) {
-            const double nn_est = 3.1 * (double)status_h[0] / (double)status_h[1];
+        long long total_cells = 0;
+        const int rcs = collect_status(c, n_structs, 8, &total_cells);
+        if (rcs) return rcs;
+        if (status_h[ST_OCC_N] > 0) {
+            const double nn_est = 3.1 * (double)status_h[ST_OCC_SUM] / (double)status_h[ST_OCC_N];
             const TileCfg probe_cfg = choose_cfg(resolution, lr, 0);
             int pool = (int)(1.35 * nn_est * probe_cfg.TA + 16.0);
             pool = (pool + 1) & ~1;
@@ -865,8 +941,8 @@ static int run_batch_impl(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
     }
     if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[3], st));
 
-    HIP_TRY(c, hipMemcpyAsync(status_h, c->status.p, sizeof(int) * ST_WORDS, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
+    long long total_cells = 0;
+    const int rcs = collect_status(c, n_structs, ST_WORDS, &total_cells);
 
     freesasa_gpu_stats &S = c->stats;
     S.n_atoms = n; S.n_cells = total_cells; S.n_structs = n_structs;
@@ -879,7 +955,8 @@ static int run_batch_impl(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
         if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) S.ms_kernel = ms;
         if (hipEventElapsedTime(&ms, c->ev[0], c->ev[3]) == hipSuccess) S.ms_total = ms;
     }
-    if (status_h[ST_ERROR]) return ctx_fail(c, "%s", err_text(status_h[ST_ERROR]));
+    if (rcs) return rcs;
+    if (total_cells + total_cells / 32 > c->cells_hint) c->cells_hint = total_cells + total_cells / 32;
     dump_phase_clocks();
     /* learn the pool size for the next batch of this kind (trajectory frames, sweeps) */
     c->hint_res[hi] = resolution;
@@ -887,6 +964,17 @@ static int run_batch_impl(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
     c->hint_pool[hi] = pool_from_hist(status_h + ST_HIST, cfg.TA);
     if (lr) c->hint_bucket = mean_from_hist(status_h + ST_HIST, cfg.TA) > 30.0 * cfg.TA;
     return 0;
+}
+
+static int run_batch_impl(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, const double *d_radii,
+                     const int64_t *offsets, int n_structs, double probe, int resolution,
+                     const double *unit_points, double *d_sasa, int *d_counts, double *d_totals)
+{
+    int rc = run_batch_once(c, lr, d_xyz, d_radii, offsets, n_structs, probe, resolution, unit_points, d_sasa, d_counts, d_totals);
+    if (rc == RC_RETRY) /* the cell table was too small (first batch of a very sparse kind): once more, with K2's size */
+        rc = run_batch_once(c, lr, d_xyz, d_radii, offsets, n_structs, probe, resolution, unit_points, d_sasa, d_counts, d_totals);
+    if (rc == RC_RETRY) return ctx_fail(c, "cell table sizing did not converge");
+    return rc;
 }
 
 /* On failure nothing may still be running on the stream when the caller gets control back (it

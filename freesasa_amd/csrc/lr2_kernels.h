@@ -734,12 +734,28 @@ SASA_D void lr2_wave(const Lr2Args &a, const Lr2Mem &m, int first, int stride, i
             na = a.n_atoms - p0 < a.TA ? a.n_atoms - p0 : a.TA;
         }
         if (na <= 0) continue;
-        if (lr2_tile<RMAX>(a, m, p0, na, !a.work_items && (tile & 31) == 0, lane, wg_max_nn) == 0) continue;
-        ++splits;
-        if (na == 1) { if (lane == 0) lr2_overflow(a, p0, 1, ERR_NEIGHBOR_CAP); continue; }
-        const int h = (na + 1) >> 1;
-        if (lr2_tile<RMAX>(a, m, p0, h, false, lane, wg_max_nn) && lane == 0) lr2_overflow(a, p0, h, ERR_NEIGHBOR_CAP);
-        if (lr2_tile<RMAX>(a, m, p0 + h, na - h, false, lane, wg_max_nn) && lane == 0) lr2_overflow(a, p0 + h, na - h, ERR_NEIGHBOR_CAP);
+        /* one call site (the tile is ~9000 instructions): a tile that does not fit is redone as two halves, a
+           half that does not fit either goes to the next launch's list */
+        int rest0 = 0, rest_n = 0;
+        bool whole = true, sample = !a.work_items && (tile & 31) == 0;
+        for (;;) {
+            const int fail = lr2_tile<RMAX>(a, m, p0, na, sample, lane, wg_max_nn);
+            sample = false;
+            if (fail && whole && na > 1) {
+                ++splits;
+                whole = false;
+                const int h = (na + 1) >> 1;
+                rest0 = p0 + h; rest_n = na - h; na = h;
+                continue;
+            }
+            if (fail) {
+                if (whole) ++splits;
+                if (lane == 0) lr2_overflow(a, p0, na, ERR_NEIGHBOR_CAP);
+            }
+            whole = false;
+            if (rest_n == 0) break;
+            p0 = rest0; na = rest_n; rest_n = 0;
+        }
     }
     if (lane == 0 && splits > 0 && a.split_count) SASA_ATOMIC_ADD_GLB(&a.split_count[first & 63], splits);
 }
@@ -800,8 +816,8 @@ static inline Lr2Cfg lr2_choose_cfg(int ns, double nn_hint = 0, int ta_override 
 }
 
 /* neighbor records per tile that all but ~4 % of the tiles of the last batch needed (sampled demand
- * histogram of P2): the tiles above it are redone by the second launch */
-static inline int lr2_pool_from_hist(const int *hist, int TA)
+ * histogram of P2): what decides how many atoms a tile of the next batch of this kind gets */
+static inline int lr2_need_from_hist(const int *hist, int TA)
 {
     long long total = 0;
     for (int k = 0; k < 64; ++k) total += hist[k];
@@ -814,6 +830,39 @@ static inline int lr2_pool_from_hist(const int *hist, int TA)
     }
     if (k >= 63) return 0;
     return ((k + 1) * hist_bin_width(TA) + 1) & ~1;
+}
+
+/* The pool (neighbor records per tile) the next batch of this kind should run with, from the sampled demand
+ * histogram of P2.  LDS per tile sets how many one-wave tiles a CU holds (160 KB, at most 16 with the registers of
+ * the 4-waves-per-SIMD build); a tile above the pool is redone as two halves (~1.3 tiles of extra work).  Measured
+ * on 3e6 coil atoms: 16 tiles per CU with 3.1 % of the tiles split beat 15 per CU with 1.5 % by 1.4 %, i.e. one
+ * resident tile is worth ~3.4 % - the kernel leans on its neighbors in the SIMD to hide LDS and global latency.
+ * So: for every occupancy step, the largest pool that fits it and the fraction of tiles above it; take the step
+ * with the least (1 + 1.3 f) / (1 - 0.034 (16 - tiles per CU)).  0: no histogram. */
+static inline int lr2_pool_from_hist(const int *hist, int TA, int ns, int mw, int ds)
+{
+    long long total = 0;
+    for (int k = 0; k < 64; ++k) total += hist[k];
+    if (total <= 0) return 0;
+    const int w = hist_bin_width(TA), pool_max = LR2_LANES * LR2_RMAX_MAIN, cu_lds = 160 * 1024;
+    double best_cost = 0;
+    int best_pool = 0;
+    for (int nblk = 16; nblk >= 6; --nblk) {
+        int pool = 16;
+        if (lr2_layout(TA, ns, pool, mw, ds).total * nblk > cu_lds) continue;
+        while (pool + 2 <= pool_max && lr2_layout(TA, ns, pool + 2, mw, ds).total * nblk <= cu_lds) pool += 2;
+        double above = 0; /* tiles needing more than pool records (uniform within a bin; the last bin is open) */
+        for (int k = 0; k < 64; ++k) {
+            const int lo = k * w, hi = lo + w - 1;
+            if (k == 63 || lo > pool) above += hist[k];
+            else if (hi > pool) above += hist[k] * (double)(hi - pool) / w;
+        }
+        const double f = above / (double)total;
+        const double cost = (1.0 + 1.3 * f) / (1.0 - 0.034 * (16 - nblk));
+        if (best_pool == 0 || cost < best_cost) { best_cost = cost; best_pool = pool; }
+        if (f == 0) break; /* larger pools only cost occupancy */
+    }
+    return best_pool;
 }
 static inline Lr2Cfg lr2_mid_cfg(const Lr2Cfg &main_cfg)
 {

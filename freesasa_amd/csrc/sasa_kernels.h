@@ -114,6 +114,8 @@ enum {
     ST_OCC_SUM = 4,    /* sum over sampled atoms of the number of atoms in their own cell ... */
     ST_OCC_N = 5,      /* ... and how many atoms were sampled: local density -> first launch shape */
     ST_OVF3_ATOMS = 6, /* L&R (lr2_kernels.h): atoms handed to the last (slab) launch */
+    ST_RETRY = 7,      /* the batch needs more cells than the table was sized for: nothing after K2 ran, the host
+                          redoes the batch with a table of ncells[n_structs] cells (gpu_engine.hip) */
     ST_HIST = 8,       /* [64] tiles by neighbor records needed, bins of hist_bin_width(TA) */
     ST_SPLIT = 72,     /* [64] L&R (lr2_kernels.h): tiles redone as two halves, counted in 64 buckets */
     ST_WORDS = 136
@@ -156,6 +158,7 @@ struct PipeArgs {
     /* per structure */
     GridS *grid;
     long long *ncells; /* [n_structs] cells of each structure; [n_structs] = total after K2 */
+    long long cells_cap; /* > 0: cells the table cell_start[] has room for (K2 raises ST_RETRY beyond it) */
     /* per atom, original order */
     int *sid;     /* structure of atom i */
     long long *cell_of; /* batch-wide cell index | grid-border flags << 32 (CELL_*) */
@@ -278,6 +281,7 @@ SASA_D void cellbase_phase1(const PipeArgs &a, long long *part, int tid, int B)
     for (int t = 0; t < B; ++t) { long long v = part[t]; part[t] = run; run += v; }
     a.ncells[a.n_structs] = run;
     if (run > a.max_cells) SASA_ATOMIC_MAX_GLB(&a.status[ST_ERROR], (int)ERR_GRID_TOO_BIG);
+    else if (a.cells_cap > 0 && run > a.cells_cap) a.status[ST_RETRY] = 1;
 }
 SASA_D void cellbase_phase2(const PipeArgs &a, const long long *part, int tid, int B)
 {

@@ -107,6 +107,35 @@ def test_single_and_isolated_atoms(fa):
     assert sr[0] == (4.0 * np.pi * R * R * 100) / 100
 
 
+def test_sparse_batch_outgrows_the_first_cell_table_and_is_redone(fa, oracle_lib):
+    """The cell table is sized before the device knows the batch's bounding boxes (no readback in the middle of the
+    pipeline).  A handful of atoms spread over hundreds of Angstrom needs far more cells than the first guess:
+    the device notices (ST_RETRY), the host redoes the batch with the size the device asked for; the next call
+    of that kind fits at once.  Results as the oracle's either way."""
+    rng = np.random.default_rng(77)
+    parts = []
+    for k in range(3):
+        pts = np.concatenate([rng.uniform(0, 12, (6, 3)), rng.uniform(380, 400, (5, 3)) + 150.0 * k])
+        parts.append((pts, rng.uniform(1.2, 1.9, len(pts))))
+    xyz = np.concatenate([p[0] for p in parts])
+    r = np.concatenate([p[1] for p in parts])
+    offsets = np.concatenate([[0], np.cumsum([len(p[1]) for p in parts])])
+    for attempt in range(2):
+        lr, _, ltot = fa.calc_batch(xyz, r, offsets, fa.LEE_RICHARDS, 1.4, 20)
+        sr, cnt, _ = fa.calc_batch(xyz, r, offsets, fa.SHRAKE_RUPLEY, 1.4, 100)
+        for k, (px, pr) in enumerate(parts):
+            sl = slice(offsets[k], offsets[k + 1])
+            assert np.max(np.abs(lr[sl] - oracle_lib.lee_richards(px, pr))) < LR_TOL
+            ws, wc = oracle_lib.shrake_rupley(px, pr)
+            assert np.array_equal(cnt[sl], wc) and np.array_equal(sr[sl], ws)
+    # a batch in error behind the same entry: nothing hangs, the error is the reference's
+    bad = xyz.copy(); bad[3, 1] = np.nan
+    with pytest.raises(Exception):
+        fa.calc_batch(bad, r, offsets, fa.LEE_RICHARDS, 1.4, 20)
+    lr2, _, _ = fa.calc_batch(xyz, r, offsets, fa.LEE_RICHARDS, 1.4, 20)
+    assert np.array_equal(lr2, lr)
+
+
 def test_ragged_batch_matches_oracle(fa, oracle_lib):
     parts = [tools.coil(1500, 21), tools.globule(777, 22), (np.zeros((0, 3)), np.zeros(0)),
              (np.array([[5.0, 5.0, 5.0]]), np.array([1.7])), tools.coil(33, 23),

@@ -31,6 +31,7 @@ int main(int argc, char **argv)
     double sum_split6 = 0, sum_plain6 = 0, sum_lane6 = 0, sum_ideal6 = 0, tiles6 = 0, sum_tilemax_gaps = 0;
     double sum_pairs_tile_rounds = 0;
     static double qsim_iters[2][3][4][2], qsim_events[2][3][4][2], qsim_tiles[2][3][4][2];
+    double sk_arcs = 0, sk_exact = 0, sk_ub = 0, sk_exit = 0, sk_exit_ub = 0; /* arcs the union could skip */
     double hist[64] = {0}, ghist[8] = {0}, sum_tilemax_open = 0, sum_tilemax_top2 = 0, arcs_open = 0;
     for (int st = 0; st < nstruct; ++st) {
         std::vector<double> xyz(3 * n), rad(n);
@@ -140,6 +141,7 @@ int main(int argc, char **argv)
                     const double Rip = sqrt(A);
                     bool buried = false;
                     std::vector<std::pair<double, double>> as;
+                    std::vector<double> cs, bs;
                     for (auto &p : L) {
                         if (p.culled) continue;
                         const double Kp = Ri * Ri - R[p.j] * R[p.j] + p.d3sq;
@@ -148,10 +150,39 @@ int main(int argc, char **argv)
                         if (c <= -1) { buried = true; break; }
                         const double al = acos(c);
                         as.push_back({p.beta - al, p.beta + al});
+                        cs.push_back(c); bs.push_back(p.beta);
                     }
                     if (buried) { if (kc == 0) sum_buried += 1; continue; }
                     arcs[i][s] = (int)as.size();
                     if (kc == 0) {
+                        /* what a containment test before the acos could skip: the beta-ordered stack union */
+                        std::vector<std::pair<double, double>> stk;
+                        bool done = false, done_ub = false;
+                        for (size_t k = 0; k < as.size(); ++k) {
+                            sk_arcs += 1;
+                            if (done) sk_exit += 1;
+                            const double c = cs[k];
+                            const double ub = c < 0 ? 1.5707963267948966 * (1 - c)
+                                : std::min(acos(0.3) - (c - 0.3) / sqrt(1 - 0.09), acos(0.85) - (c - 0.85) / sqrt(1 - 0.85 * 0.85));
+                            if (!stk.empty()) {
+                                const double m = std::min(bs[k] - stk.back().first, stk.back().second - bs[k]);
+                                if (as[k].first >= stk.back().first && as[k].second <= stk.back().second) sk_exact += 1;
+                                if (ub <= m) { sk_ub += 1; if (!done) { if (done_ub) sk_exit_ub += 0; } }
+                                else if (done) sk_exit_ub += 1; /* skipped by the exit but not by the bound */
+                            }
+                            if (stk.empty() || as[k].first > stk.back().second) stk.push_back(as[k]);
+                            else {
+                                stk.back().first = std::min(stk.back().first, as[k].first);
+                                stk.back().second = std::max(stk.back().second, as[k].second);
+                                while (stk.size() > 1 && stk[stk.size() - 2].second >= stk.back().first) {
+                                    stk[stk.size() - 2].first = std::min(stk[stk.size() - 2].first, stk.back().first);
+                                    stk[stk.size() - 2].second = stk.back().second;
+                                    stk.pop_back();
+                                }
+                            }
+                            if (stk.size() == 1 && stk[0].second - stk[0].first >= 2 * M_PI) done = true;
+                        }
+                        (void)done_ub;
                         /* gaps of the union (on the circle) */
                         std::vector<std::pair<double, double>> iv;
                         for (auto &a : as) {
@@ -246,6 +277,7 @@ int main(int argc, char **argv)
         printf("containers %d: culled %.1f%% of neighbors; arcs/slice %.2f; tile max arcs (iterations) %.2f; tile max nn (padded) %.2f\n", Ks[kc],
                100 * culled[kc] / sum_nn, sum_arcs[kc] / (sum_tiles * 60), sum_tilemax[kc] / sum_tiles, sum_nnmax[kc] / sum_tiles);
     printf("6-atom tiles: plain two rounds %.2f iterations, heavy/light split %.2f, per-lane heavy/light %.2f, perfect balance %.2f\n", sum_plain6 / tiles6, sum_split6 / tiles6, sum_lane6 / tiles6, sum_ideal6 / tiles6);
+    printf("containment before acos: arcs %.0f, exactly inside the top component %.3f, linear bound says so %.3f, after full coverage (exit) %.3f, exit-only on top of bound %.3f\n", sk_arcs, sk_exact / sk_arcs, sk_ub / sk_arcs, sk_exit / sk_arcs, sk_exit_ub / sk_arcs);
     printf("gap count histogram:"); for (int k = 0; k < 8; ++k) printf(" %d:%.3f", k, ghist[k] / sum_slices);
     printf("\ntile max arcs over slices with >=1 gap: %.2f; 5th largest lane: %.2f; arcs in open slices %.2f of all\n", sum_tilemax_open / sum_tiles, sum_tilemax_top2 / sum_tiles, arcs_open / sum_arcs[0]);
     for (int c = 0; c < 2; ++c) for (int ti = 0; ti < 3; ++ti) for (int th = 0; th < 4; ++th) for (int so = 0; so < 2; ++so)

@@ -1,13 +1,21 @@
 """DEV: one process, many launch shapes of the L&R kernel on the headline batch geometry (kernel ms per step).
-usage: python tools/gpu_r2_sweep.py [structs] [spec ...]   spec = LR1 | TA,pool,ds,refill"""
+usage: python tools/gpu_r2_sweep.py [[g]structs] [spec ...]   spec = LR1 | TA,pool,ds,refill"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import freesasa_amd as fa, tools
 
+geom = "coil"
+if len(sys.argv) > 1 and sys.argv[1].startswith("g"):  # g100 = 100 protein-like globules of 10k atoms
+    geom = "globule"; sys.argv[1] = sys.argv[1][1:]
 structs = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 specs = sys.argv[2:] or ["LR1", "0,0,-1,0", "4,0,-1,16", "5,0,-1,16", "6,0,-1,8", "6,0,-1,24", "6,0,2,16", "3,0,-1,16"]
-xyz, r, offs = tools.coil_batch(structs, 10000, seed0=1000)
+if geom == "coil":
+    xyz, r, offs = tools.coil_batch(structs, 10000, seed0=1000)
+else:
+    parts = [tools.globule(10000, 500 + k) for k in range(structs)]
+    xyz = np.concatenate([p[0] for p in parts]); r = np.concatenate([p[1] for p in parts])
+    offs = np.arange(structs + 1, dtype=np.int64) * 10000
 dev = torch.device("cuda:0")
 dx, dr = torch.from_numpy(xyz).to(dev), torch.from_numpy(r).to(dev)
 out = torch.empty(len(r), dtype=torch.float64, device=dev)
