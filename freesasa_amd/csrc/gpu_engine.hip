@@ -28,8 +28,8 @@
 #include "sasa_kernels.h"
 #ifdef SASA_PHASE_TIMING /* dev only (tools/build_variant.sh X -DSASA_PHASE_TIMING): where a wave's time per tile goes */
 __device__ unsigned long long g_phase_clock[16];
-#define LR2_MARK_BEGIN unsigned long long lr2_last_ = wall_clock64(); if (lane == 0 && !a.work_tiles && (tile & 255) == 0) atomicAdd(&g_phase_clock[15], 1ULL)
-#define LR2_MARK(k) do { if (lane == 0 && !a.work_tiles && (tile & 255) == 0) { const unsigned long long now_ = wall_clock64(); \
+#define LR2_MARK_BEGIN unsigned long long lr2_last_ = wall_clock64(); if (lane == 0 && !a.work_items && ((p0 / a.TA) & 255) == 0) atomicAdd(&g_phase_clock[15], 1ULL)
+#define LR2_MARK(k) do { if (lane == 0 && !a.work_items && ((p0 / a.TA) & 255) == 0) { const unsigned long long now_ = wall_clock64(); \
         atomicAdd(&g_phase_clock[(k)], now_ - lr2_last_); lr2_last_ = now_; } } while (0)
 #endif
 #include "lr2_kernels.h"

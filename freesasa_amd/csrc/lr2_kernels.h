@@ -307,7 +307,10 @@ SASA_D double lr2_arc_kat(const double *arcs, const int *first, int k, Arc *stk,
     return maxd - 2 > ds ? NAN : lr2_sweep(u, stk, ds);
 }
 
+#ifndef LR2_NB_UNROLL
 #define LR2_NB_UNROLL 2
+#endif
+#define LR2_P1_G 3 /* atoms of a cell group one work item of P1 tests its candidate against */
 
 /* a work item that fits no capacity of this launch, even halved */
 SASA_D void lr2_overflow(const Lr2Args &a, int p0, int na, int err_code)
@@ -385,13 +388,13 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         m.gsz[lane] = gs;
         if (gs > 0) SASA_ATOMIC_MAX_LDS(&m.flags[5], gs);
     }
-    /* P1's work items: (candidate, two atoms of the cell group the candidate belongs to); inclusive prefix of
-       the item counts over the rows */
+    /* P1's work items: (candidate, up to LR2_P1_G atoms of the cell group the candidate belongs to); inclusive
+       prefix of the item counts over the rows */
     if (my_cnt > 0) {
         const int la = lane / 9;
         int gs = 1;
         while (la + gs < na && m.acell[la + gs] == m.acell[la]) ++gs;
-        my_cnt *= (gs + 1) >> 1;
+        my_cnt *= (gs + LR2_P1_G - 1) / LR2_P1_G;
     }
     int incl = my_cnt;
     for (int d = 1; d < LR2_LANES; d <<= 1) {
@@ -417,7 +420,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             for (int step = 32; step >= 1; step >>= 1)
                 if (t + step <= nrows && m.cpre[t + step] <= f) t += step;
         }
-        LR2_COUNT(3, (per + LR2_NB_UNROLL - 1) / LR2_NB_UNROLL * LR2_NB_UNROLL * 2);
+        LR2_COUNT(3, (per + LR2_NB_UNROLL - 1) / LR2_NB_UNROLL * LR2_NB_UNROLL * LR2_P1_G);
         for (int base = 0; base < per; base += LR2_NB_UNROLL) { /* (wave-uniform trip count) */
             int q[LR2_NB_UNROLL], la0[LR2_NB_UNROLL], two[LR2_NB_UNROLL];
             double x[LR2_NB_UNROLL], y[LR2_NB_UNROLL], z[LR2_NB_UNROLL], rq[LR2_NB_UNROLL];
@@ -426,29 +429,29 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                 q[j] = -1; la0[j] = 0; two[j] = 0;
                 if (base + j < per && fj < fend) {
                     while (fj >= m.cpre[t + 1]) ++t;
-                    const int lead = t / 9, gs = m.gsz[lead], hc = (gs + 1) >> 1;
+                    const int lead = t / 9, gs = m.gsz[lead], hc = (gs + LR2_P1_G - 1) / LR2_P1_G;
                     const unsigned i = (unsigned)(fj - m.cpre[t]);
-                    const unsigned c = hc == 1 ? i : (hc == 2 ? i >> 1 : (hc == 3 ? (i * 0xaaabu) >> 17 : i >> 2)); /* i / hc, hc <= 4 */
+                    const unsigned c = hc == 1 ? i : (hc == 2 ? i >> 1 : (i * 0xaaabu) >> 17); /* i / hc, hc <= 3 (gs <= 7) */
                     const int h = (int)(i - c * (unsigned)hc);
                     q[j] = m.rowlo[t] + (int)c;
-                    la0[j] = lead + 2 * h;
-                    two[j] = 2 * h + 1 < gs ? 1 : 0;
+                    la0[j] = lead + LR2_P1_G * h;
+                    two[j] = gs - LR2_P1_G * h < LR2_P1_G ? gs - LR2_P1_G * h : LR2_P1_G; /* atoms of this item */
                 }
             }
             for (int j = 0; j < LR2_NB_UNROLL; ++j) {
                 const unsigned u = (unsigned)(q[j] < 0 ? 0 : q[j]);
                 x[j] = a.sx[u]; y[j] = a.sy[u]; z[j] = a.sz[u]; rq[j] = a.sr[u];
             }
-            for (int g = 0; g < 2; ++g) {
+            for (int g = 0; g < LR2_P1_G; ++g) {
                 bool hit[LR2_NB_UNROLL];
                 double dx[LR2_NB_UNROLL], dy[LR2_NB_UNROLL], dz[LR2_NB_UNROLL];
                 Quad ai[LR2_NB_UNROLL];
-                for (int j = 0; j < LR2_NB_UNROLL; ++j) ai[j] = m.atom[la0[j] + (g <= two[j] ? g : 0)];
+                for (int j = 0; j < LR2_NB_UNROLL; ++j) ai[j] = m.atom[la0[j] + (g < two[j] ? g : 0)];
                 for (int j = 0; j < LR2_NB_UNROLL; ++j) {
                     /* the reference's contact test, operand for operand (src/nb.c:483-492) */
                     const double cut2 = (ai[j].w + rq[j]) * (ai[j].w + rq[j]);
                     dx[j] = x[j] - ai[j].x; dy[j] = y[j] - ai[j].y; dz[j] = z[j] - ai[j].z;
-                    hit[j] = q[j] >= 0 && g <= two[j] && q[j] != p0 + la0[j] + g &&
+                    hit[j] = q[j] >= 0 && g < two[j] && q[j] != p0 + la0[j] + g &&
                              dx[j] * dx[j] + dy[j] * dy[j] + dz[j] * dz[j] < cut2;
                 }
                 for (int j = 0; j < LR2_NB_UNROLL; ++j) {
