@@ -68,19 +68,17 @@ __global__ __launch_bounds__(SASA_PIPE_B) void k_cell_base(PipeArgs a)
  * error or redoes the batch with the table K2 asked for. */
 #define PIPE_GATE(st) do { if ((st)[ST_ERROR] | (st)[ST_RETRY]) return; } while (0)
 
-/* zero the histogram: cell_start[0 .. total cells + 1] (the total is on the device) */
+/* zero the histogram: cell_start[0 .. total cells + 1] (the total is on the device).  A workgroup clears 16 KB:
+ * four rounds of one 16-byte store per thread, consecutive threads at consecutive addresses. */
 __global__ __launch_bounds__(SASA_PIPE_B) void k_zero_cells(PipeArgs a)
 {
     PIPE_GATE(a.status);
     const long long n = a.ncells[a.n_structs] + 2;
-    const long long base = ((long long)blockIdx.x * SASA_PIPE_B + threadIdx.x) * 16;
-    if (base >= n) return;
-    if (base + 16 <= n) {
-        Int4 *p = (Int4 *)(a.cell_start + base);
-        const Int4 z = {0, 0, 0, 0};
-        p[0] = z; p[1] = z; p[2] = z; p[3] = z;
-    } else {
-        for (long long k = base; k < n; ++k) a.cell_start[k] = 0;
+    const Int4 z = {0, 0, 0, 0};
+    for (int k = 0; k < 4; ++k) {
+        const long long base = (((long long)blockIdx.x * 4 + k) * SASA_PIPE_B + threadIdx.x) * 4;
+        if (base + 4 <= n) *(Int4 *)(a.cell_start + base) = z;
+        else for (long long i = base; i < n; ++i) a.cell_start[i] = 0;
     }
 }
 
