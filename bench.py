@@ -85,7 +85,7 @@ def end_to_end(fa, torch, xyz, r, offs, args, device, resident_sasa):
                      "pcie_GBps_in_plus_out": ALGO_BYTES_PER_ATOM * n / best / 1e9,
                      "identical_to_resident_run": bool(np.array_equal(got[0], resident_sasa))}
     top = dict(res["page-locked"])
-    top["host_memory"] = "page-locked (DMA in place), 2 lanes x chunks of 1.25e6 atoms"
+    top["host_memory"] = "page-locked (DMA in place), 3 host lanes x chunks of 1.25e6 atoms"
     top["pageable_host_memory"] = res["pageable"]
     top["note"] = "host xyz/radii -> host per-atom SASA and per-structure totals, H2D 32 B/atom + D2H 8 B/atom included"
     return top

@@ -1335,8 +1335,9 @@ extern "C" int freesasa_gpu_calc_batch_pipelined(const double *xyz, const double
         return set_err(err_out, err_len, "no HIP device available: libfreesasa_amd has no CPU path");
     const bool pin_in = host_pinned(xyz) && host_pinned(radii);
     const bool pin_out = host_pinned(sasa_out) && (!counts_out || host_pinned(counts_out)) && (!totals_out || host_pinned(totals_out));
-    if (n_lanes <= 0) n_lanes = pin_in && pin_out ? 2 : 4; /* (measured: DMA in place needs one lane to copy while one computes; staging
-                                                              through page-locked buffers also spends host memcpy time) */
+    if (n_lanes <= 0) n_lanes = pin_in && pin_out ? 3 : 4; /* (measured, 1e7 atoms: 1 / 2 / 3 / 4 / 6 lanes with DMA in place 24.0 / 22.4 /
+                                                              15.9 / 17.1 / 16.6 ms - one lane each in PCIe in, kernels, PCIe out;
+                                                              staging through page-locked buffers also spends host memcpy time) */
     if (n_lanes > 8) n_lanes = 8;
     if (chunk_atoms <= 0) chunk_atoms = 1250000;
     std::vector<int> cut(1, 0);

@@ -111,7 +111,7 @@ int freesasa_gpu_calc_batch_multi(const double *xyz, const double *radii, const 
                                   int alg, double probe_radius, int resolution, double *sasa_out, int *counts_out,
                                   double *totals_out, unsigned device_mask, char *err, int err_len);
 /* Host arrays in, host arrays out, with the PCIe copies under the kernels: the batch is cut into chunks of whole
-   structures (about chunk_atoms atoms, <= 0: 1.25e6) that n_lanes host threads (<= 0: 2 for page-locked arrays, 4 for
+   structures (about chunk_atoms atoms, <= 0: 1.25e6) that n_lanes host threads (<= 0: 3 for page-locked arrays, 4 for
    pageable ones; at most 8) take from a
    shared counter, each lane on its own pooled context and stream, so that the upload of one chunk, the kernels of
    another and the download of a third overlap.  Page-locked caller arrays (hipHostMalloc / hipHostRegister, a
