@@ -139,7 +139,8 @@ def bench_trajectory(args, rank, world, local_rank):
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
                           "data": "synthetic",
                           "config": {"workload": f"{n_frames} frames x {n_atoms} atoms (globule + 0.5 A jitter), frames in pageable "
-                                                 "host memory pinned in place, per-atom SASA streamed back; PCIe-inclusive",
+                                                 "host memory, staged through page-locked buffers by the driver's host lanes, per-atom "
+                                                 "SASA streamed back; PCIe-inclusive",
                                      "mean_total": float(np.mean(totals))}}), flush=True)
 
 

@@ -1687,7 +1687,10 @@ static int traj_run(TrajIO &io, const double *radii, int n_atoms, long long n_fr
     const size_t n = (size_t)n_atoms, FB = (size_t)frames_per_batch;
     const long long n_shards = (n_frames + frames_per_batch - 1) / frames_per_batch;
     if (io.done.size() < (size_t)n_shards) io.done.resize((size_t)n_shards, 0);
-    if (n_lanes <= 0) n_lanes = 3;
+    if (n_lanes <= 0) {
+        n_lanes = 3;
+        if (const char *e = getenv("FREESASA_AMD_TRAJ_LANES")) n_lanes = atoi(e) > 0 ? atoi(e) : 3; /* tuning aid */
+    }
     if (n_lanes > 8) n_lanes = 8;
     if (n_lanes > n_shards) n_lanes = (int)n_shards;
     std::vector<double> tp;
