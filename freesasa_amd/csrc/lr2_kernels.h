@@ -47,6 +47,7 @@ long long wave_exchange(long long v, int src);
 #define LR2_POPC32(m) __builtin_popcount(m)
 #define LR2_RANK(m, lane) __builtin_popcountll((m) & ((1ull << (lane)) - 1ull))
 #define LR2_SHIFT_IN_LT1(w, c) (((w) << 1) | ((c) < 1.0 ? 1u : 0u))
+#define LR2_UNIFORM(v) (v)
 namespace sasa_emu { extern long long lr2_count[16]; } /* wave-level trip counts (lane 0 counts): 0 tiles, 1 arc iterations, 2 refills, 3 P1 test rounds, 4 rank trips, 5 screening trips, 6 P3 rounds */
 #define LR2_COUNT(k, n) do { if (lane == 0) sasa_emu::lr2_count[(k)] += (n); } while (0)
 #else
@@ -66,6 +67,9 @@ namespace sasa_emu { extern long long lr2_count[16]; } /* wave-level trip counts
 #define LR2_POPC32(m) __popc(m)
 #define LR2_RANK(m, lane) ((int)__builtin_amdgcn_mbcnt_hi((unsigned)((m) >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)(m), 0u)))
 #define LR2_SHIFT_IN_LT1(w, c) sasa_shift_in_lt1((w), (c))
+/* a value every lane of the wave holds alike, moved to a scalar register: loops and branches on it become scalar
+   control flow instead of exec-mask bookkeeping (the compiler cannot see that an LDS read or a shuffle is uniform) */
+#define LR2_UNIFORM(v) __builtin_amdgcn_readfirstlane(v)
 #endif
 
 namespace sasa {
@@ -409,7 +413,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     LR2_MARK(0);
     /* ------------------------------------------------------------ P1 neighbors */
     const int nrows = 9 * TA;
-    const int total_c = m.cpre[nrows];
+    const int total_c = LR2_UNIFORM(m.cpre[nrows]);
     int nh = 0; /* hits so far (wave-uniform) */
     {
         const int per = (total_c + LR2_LANES - 1) / LR2_LANES; /* consecutive work items per lane */
@@ -632,7 +636,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             const int v = LR2_SHFL(incl2, lane >= d ? lane - d : lane);
             if (lane >= d) incl2 += v;
         }
-        nq = LR2_SHFL(incl2, LR2_LANES - 1);
+        nq = LR2_UNIFORM(LR2_SHFL(incl2, LR2_LANES - 1));
         m.hist[lane] = incl2 - hv; /* first queue position of the bin */
         LR2_SYNC();
         for (int it = lane; it < items; it += LR2_LANES) {

@@ -5,7 +5,7 @@ import re, sys
 lines = open(sys.argv[1]).read().split("\n")
 pref = sys.argv[2]
 start = next(i for i, l in enumerate(lines) if l.startswith(pref) and l.rstrip().split(";")[0].strip().endswith(":"))
-end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
 body = lines[start:end + 1]
 label = {}
 for i, l in enumerate(body):
