@@ -168,6 +168,41 @@ def test_launch_configurations():
         assert np.array_equal(c, o.shrake_rupley(xyz, r, 1.4, npts)[1]), (npts, st)
 
 
+def test_lr_launch_shape_follows_density_and_demand():
+    """Host side of the L&R launch: atoms per tile from slices and density, the pool from the demand histogram of
+    the last batch weighed against the occupancy step it costs (lr2_choose_cfg, lr2_pool_from_hist)."""
+    import ctypes as C
+    lib = emu._load()
+    lib.emu_lr2_shape.argtypes = [C.c_int, C.c_double, C.c_int, C.POINTER(C.c_int)]
+    lib.emu_lr2_pool_from_hist.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.emu_lr2_lds.argtypes = [C.c_int] * 5
+
+    def shape(ns, nn=0.0, nn_max=0):
+        out = (C.c_int * 6)()
+        lib.emu_lr2_shape(ns, nn, nn_max, out)
+        return dict(zip(("TA", "pool", "mw", "ds", "lds", "rmax"), out))
+
+    def pool(hist, TA=6, ns=20, mw=2, ds=2):
+        return lib.emu_lr2_pool_from_hist((C.c_int * 64)(*hist), TA, ns, mw, ds)
+
+    coil, dense = shape(20, 27.0, 40), shape(20, 75.0, 110)
+    assert coil["TA"] == 6 and coil["mw"] == 2 and coil["lds"] * 16 <= 160 * 1024 < (coil["lds"] + 96) * 16
+    assert dense["TA"] < coil["TA"] and dense["mw"] >= 3 and dense["pool"] <= 256
+    assert shape(100)["TA"] == 2 and shape(256)["TA"] == 1
+    for s in (coil, dense, shape(100), shape(1)):
+        assert s["pool"] <= 64 * s["rmax"] and s["lds"] <= 160 * 1024
+
+    width = 2 * 6 + 2  # hist_bin_width(6)
+    p16 = max(p for p in range(16, 258, 2) if lib.emu_lr2_lds(6, 20, p, 2, 2) * 16 <= 160 * 1024)
+    assert pool([0] * 64) == 0
+    low = [0] * 64; low[5] = 1000                       # every tile needs ~75 records: the smallest step that holds them all
+    assert pool(low) >= 6 * width and lib.emu_lr2_lds(6, 20, pool(low), 2, 2) * 16 <= 160 * 1024
+    few_above = [0] * 64; few_above[10] = 980; few_above[p16 // width + 1] = 20   # 2 % above the 16-tile pool: stay
+    assert pool(few_above) == p16
+    most_above = [0] * 64; most_above[p16 // width + 1] = 1000                   # nearly all above it: give up a tile of occupancy
+    assert pool(most_above) > p16
+
+
 def test_device_math_helpers_accuracy():
     """acos_fast / sqrt_rh (the only transcendental code of the L&R arc pass besides atan2) against
     correctly rounded references everywhere on (-1,1), including next to +-1 and +-0.5: acos within
