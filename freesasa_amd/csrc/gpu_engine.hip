@@ -353,6 +353,7 @@ struct freesasa_gpu_ctx {
     bool hint_bucket = false; /* L&R: the last batch had long neighbor lists */
     double hint_nn = 0;       /* L&R (lr2): neighbor records per atom the main launch should hold */
     int hint_nn_max = 0;      /* ... and the longest neighbor list expected (mask words per item) */
+    double hint_split2 = 0;   /* ... the share of its tiles above the 16-tiles-per-CU pool */
     int hint_pool2 = 0, hint_ta2 = 0, hint_mw2 = 0; /* ... and the pool the last batch's demand histogram asks for, for tiles of that shape */
     int *dbg_nn = nullptr, *dbg_nb = nullptr; /* test hook: freesasa_gpu_lr_neighbors_dev */
     int dbg_cap = 0;
@@ -608,7 +609,7 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
         c->hint_res[0] = resolution;
         c->hint_pool2 = 0;
     }
-    Lr2Cfg cfg = lr2_choose_cfg(resolution, c->hint_nn, ta_env, c->hint_nn_max);
+    Lr2Cfg cfg = lr2_choose_cfg(resolution, c->hint_nn, ta_env, c->hint_nn_max, c->hint_pool2 > 0 ? c->hint_ta2 : 0, c->hint_split2);
     if (c->hint_pool2 > 0 && c->hint_ta2 == cfg.TA && c->hint_mw2 == cfg.mw) { /* same tile shape as the last batch: its demand histogram decides */
         cfg.pool = c->hint_pool2;
         cfg.rmax = (cfg.pool + LR2_LANES - 1) / LR2_LANES;
@@ -686,7 +687,7 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
     /* learn the pool size for the next batch of this kind (trajectory frames, sweeps) */
     const int learnt = lr2_need_from_hist(status_h + ST_HIST, cfg.TA);
     if (learnt > 0) c->hint_nn = (double)(learnt - 8) / cfg.TA;
-    c->hint_pool2 = lr2_pool_from_hist(status_h + ST_HIST, cfg.TA, cfg.ns, cfg.mw, cfg.ds); /* (see there: pool vs occupancy) */
+    c->hint_pool2 = lr2_pool_from_hist(status_h + ST_HIST, cfg.TA, cfg.ns, cfg.mw, cfg.ds, &c->hint_split2); /* (see there: pool vs occupancy) */
     c->hint_ta2 = cfg.TA; c->hint_mw2 = cfg.mw;
     c->hint_nn_max = status_h[ST_MAX_NN] + 4; /* the longest list of this batch, a little room */
     return 0;

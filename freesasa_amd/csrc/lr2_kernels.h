@@ -781,43 +781,77 @@ static inline bool lr2_supported(int ns) { return ns >= 1 && ns <= LR2_NS_MAX; }
 
 /* nn_hint: neighbor records one atom needs (with its safety margin), 0 = unknown; nn_max_hint: the longest
  * neighbor list expected (0 = unknown): the masks of an item get ceil(nn_max / 32) words, two at least */
-static inline Lr2Cfg lr2_choose_cfg(int ns, double nn_hint = 0, int ta_override = 0, int nn_max_hint = 0)
+/* LDS decides how many one-wave tiles a CU holds (160 KB; at most 16 with the registers of the 4-waves-per-SIMD
+ * build).  Measured on coils at 20 / 40 / 60 / 100 slices and on globules: a launch at 16 tiles per CU beats the
+ * same tile shape one LDS step down by 6-9 % (two steps: 20 %).  A tile whose neighbor records exceed the pool is
+ * redone as two halves: each % of such tiles costs ~0.5 % while a half still has an item for every lane (>= 64
+ * items), ~1.2 % when it does not (6 atoms x 20 slices -> halves of 60 items).  More atoms per tile beat fewer at
+ * equal occupancy (the queue of the arc pass has more to balance).
+ * lr2_step_eff: throughput relative to 16 tiles per CU; lr2_split_cost: cost of a split tile, in tiles. */
+static inline double lr2_step_eff(int tiles_per_cu)
+{
+    return tiles_per_cu >= 16 ? 1.0 : (tiles_per_cu >= 14 ? 0.92 : (tiles_per_cu >= 12 ? 0.80 : 0.80 * tiles_per_cu / 12.0));
+}
+static inline bool lr2_halves_fill_the_wave(int TA, int ns) { return ((TA + 1) / 2) * ns >= LR2_LANES; }
+static inline double lr2_split_cost(int TA, int ns) { return lr2_halves_fill_the_wave(TA, ns) ? 0.5 : 1.2; }
+/* share of split tiles a shape may have before one atom less per tile is the better shape */
+static inline double lr2_split_limit(int TA, int ns) { return lr2_halves_fill_the_wave(TA, ns) ? 0.12 : 0.06; }
+/* largest pool (even, <= pool_max) with which tiles_per_cu tiles fit a CU; 0: not even the smallest */
+static inline int lr2_pool_for_step(int TA, int ns, int mw, int ds, int tiles_per_cu, int pool_max)
+{
+    const int cu_lds = 160 * 1024;
+    int pool = 16;
+    if (lr2_layout(TA, ns, pool, mw, ds).total * tiles_per_cu > cu_lds) return 0;
+    while (pool + 2 <= pool_max && lr2_layout(TA, ns, pool + 2, mw, ds).total * tiles_per_cu <= cu_lds) pool += 2;
+    return pool;
+}
+
+/* nn_hint: neighbor records per atom of the tile at the 96th percentile of demand (0: unknown); nn_max_hint: the
+ * longest list expected; last_ta / last_split: atoms per tile of the previous batch of this kind on the context
+ * and the share of its tiles that exceeded the 16-per-CU pool (last_ta 0: no history) */
+static inline Lr2Cfg lr2_choose_cfg(int ns, double nn_hint = 0, int ta_override = 0, int nn_max_hint = 0, int last_ta = 0,
+                                    double last_split = 0)
 {
     Lr2Cfg c;
     c.ns = ns;
-    /* a few items per lane let the queue balance the arc pass; more atoms cost LDS (occupancy) */
-    int ta = (6 * LR2_LANES + ns) / (2 * ns); /* ~ 3 items per lane: 20 slices -> 6 atoms (capped), 100 slices -> 2 */
-    if (ta < 1) ta = 1;
-    if (ta > 6) ta = 6;
-    while (ta > 1 && ta * ns > LR2_ITEMS_CAP) --ta;
     const int pool_max = LR2_LANES * LR2_RMAX_MAIN;
-    if (nn_hint > 0) /* dense inputs: fewer atoms per tile, so that a tile's records fit the registers of P3 with some room */
-        while (ta > 1 && 1.12 * nn_hint * ta + 8 > pool_max) --ta;
-    if (ta_override > 0 && ta_override <= 7 && ta_override * ns <= LR2_ITEMS_CAP) ta = ta_override;
-    c.TA = ta;
-    c.rmax = LR2_RMAX_MAIN;
-    c.pool = nn_hint > 0 ? (int)(nn_hint * ta + 8) : 32 * ta;
-    c.pool = (c.pool + 1) & ~1;
-    if (c.pool > pool_max) c.pool = pool_max;
-    if (c.pool < 16) c.pool = 16;
-    /* mask words per item: two (64 neighbors) unless lists that long are common — the rare atom above the
+    /* mask words per item: two (64 neighbors) unless lists that long are common - the rare atom above the
        capacity sends its tile to the next launch, which costs less than LDS for every tile (occupancy) */
     c.mw = 2;
     if (nn_hint > 0 && 1.45 * nn_hint > 64 && nn_max_hint > 64) c.mw = (nn_max_hint + 31) / 32;
     if (c.mw > 4) c.mw = 4;
     c.ds = 2;
-    c.refill = 32; /* (measured: 12 / 16 / 24 / 32 / 40 waiting lanes -> 4.00 / 3.93 / 3.92 / 3.89 / 3.90 ms per 3e6 coil atoms) */
-    c.lds = lr2_layout(c.TA, c.ns, c.pool, c.mw, c.ds).total;
-    /* occupancy comes in steps of whole tiles per CU (160 KB of LDS, at most 16 one-wave tiles with the
-       registers of the 4-waves-per-SIMD build): spend the slack of the current step on a larger pool */
-    {
-        const int cu_lds = 160 * 1024;
-        int nblk = cu_lds / c.lds;
-        if (nblk > 16) nblk = 16;
-        if (nblk >= 1)
-            while (c.pool + 2 <= pool_max && lr2_layout(c.TA, c.ns, c.pool + 2, c.mw, c.ds).total * nblk <= cu_lds) c.pool += 2;
-        c.lds = lr2_layout(c.TA, c.ns, c.pool, c.mw, c.ds).total;
+    c.refill = 32; /* (measured: 16 / 24 / 32 / 40 / 48 waiting lanes -> 4.11 / 4.09 / 4.09 / 4.09 / 4.10 ms per 3e6 coil atoms) */
+    /* atoms per tile: as many as give at most ~320 items and run 16 tiles per CU with few enough split tiles */
+    int ta_cap = 320 / ns;
+    if (ta_cap < 1) ta_cap = 1;
+    if (ta_cap > 6) ta_cap = 6;
+    while (ta_cap > 1 && ta_cap * ns > LR2_ITEMS_CAP) --ta_cap;
+    const double per_atom = nn_hint > 0 ? nn_hint : 32.0;
+    int ta;
+    if (last_ta > 0) {
+        /* history: stay, unless too many tiles were split (one atom less) or one atom more clearly fits */
+        ta = last_ta < ta_cap ? last_ta : ta_cap;
+        if (ta > 1 && last_split > lr2_split_limit(ta, ns)) --ta;
+        else if (ta < ta_cap && per_atom * (ta + 1) + 8 <= lr2_pool_for_step(ta + 1, ns, c.mw, c.ds, 16, pool_max)) ++ta;
+    } else {
+        /* first batch: from the density estimate; 0.8 (0.95) of the 96th-percentile demand in the pool leaves
+           ~10 % (~5 %) of the tiles to be split */
+        ta = ta_cap;
+        while (ta > 1 && (lr2_halves_fill_the_wave(ta, ns) ? 0.8 : 0.95) * (per_atom * ta + 8) >
+                             lr2_pool_for_step(ta, ns, c.mw, c.ds, 16, pool_max))
+            --ta;
     }
+    if (ta_override > 0 && ta_override <= 7 && ta_override * ns <= LR2_ITEMS_CAP) ta = ta_override;
+    c.TA = ta;
+    /* the pool: everything the 16-tile step has room for; a shape that needs more than that even for 80 % of its
+       demand (very dense input at one atom per tile, or a forced shape) runs at the step that holds it */
+    c.pool = lr2_pool_for_step(ta, ns, c.mw, c.ds, 16, pool_max);
+    int want = (int)(0.8 * (per_atom * ta + 8));
+    if (want > pool_max) want = pool_max;
+    for (int nblk = 15; c.pool < want && nblk >= 1; --nblk) c.pool = lr2_pool_for_step(ta, ns, c.mw, c.ds, nblk, pool_max);
+    if (c.pool < 16) c.pool = 16;
+    c.lds = lr2_layout(c.TA, c.ns, c.pool, c.mw, c.ds).total;
     c.rmax = (c.pool + LR2_LANES - 1) / LR2_LANES;
     return c;
 }
@@ -840,24 +874,22 @@ static inline int lr2_need_from_hist(const int *hist, int TA)
 }
 
 /* The pool (neighbor records per tile) the next batch of this kind should run with, from the sampled demand
- * histogram of P2.  LDS per tile sets how many one-wave tiles a CU holds (160 KB, at most 16 with the registers of
- * the 4-waves-per-SIMD build); a tile above the pool is redone as two halves (~1.3 tiles of extra work).  Measured
- * on 3e6 coil atoms: 16 tiles per CU with 3.1 % of the tiles split beat 15 per CU with 1.5 % by 1.4 %, i.e. one
- * resident tile is worth ~3.4 % - the kernel leans on its neighbors in the SIMD to hide LDS and global latency.
- * So: for every occupancy step, the largest pool that fits it and the fraction of tiles above it; take the step
- * with the least (1 + 1.3 f) / (1 - 0.034 (16 - tiles per CU)).  0: no histogram. */
-static inline int lr2_pool_from_hist(const int *hist, int TA, int ns, int mw, int ds)
+ * histogram of P2: for every occupancy step, the largest pool that fits it and the share f of tiles above it; the
+ * step with the least (1 + lr2_split_cost f) / lr2_step_eff(tiles per CU).  split16: f at 16 tiles per CU (what
+ * lr2_choose_cfg wants to know about this tile shape).  0: no histogram. */
+static inline int lr2_pool_from_hist(const int *hist, int TA, int ns, int mw, int ds, double *split16 = nullptr)
 {
     long long total = 0;
     for (int k = 0; k < 64; ++k) total += hist[k];
+    if (split16) *split16 = 0;
     if (total <= 0) return 0;
-    const int w = hist_bin_width(TA), pool_max = LR2_LANES * LR2_RMAX_MAIN, cu_lds = 160 * 1024;
+    const int w = hist_bin_width(TA), pool_max = LR2_LANES * LR2_RMAX_MAIN;
     double best_cost = 0;
-    int best_pool = 0;
+    int best_pool = 0, last_pool = 0;
     for (int nblk = 16; nblk >= 6; --nblk) {
-        int pool = 16;
-        if (lr2_layout(TA, ns, pool, mw, ds).total * nblk > cu_lds) continue;
-        while (pool + 2 <= pool_max && lr2_layout(TA, ns, pool + 2, mw, ds).total * nblk <= cu_lds) pool += 2;
+        const int pool = lr2_pool_for_step(TA, ns, mw, ds, nblk, pool_max);
+        if (pool == 0 || pool == last_pool) continue;
+        last_pool = pool;
         double above = 0; /* tiles needing more than pool records (uniform within a bin; the last bin is open) */
         for (int k = 0; k < 64; ++k) {
             const int lo = k * w, hi = lo + w - 1;
@@ -865,7 +897,8 @@ static inline int lr2_pool_from_hist(const int *hist, int TA, int ns, int mw, in
             else if (hi > pool) above += hist[k] * (double)(hi - pool) / w;
         }
         const double f = above / (double)total;
-        const double cost = (1.0 + 1.3 * f) / (1.0 - 0.034 * (16 - nblk));
+        if (nblk == 16 && split16) *split16 = f;
+        const double cost = (1.0 + lr2_split_cost(TA, ns) * f) / lr2_step_eff(nblk);
         if (best_pool == 0 || cost < best_cost) { best_cost = cost; best_pool = pool; }
         if (f == 0) break; /* larger pools only cost occupancy */
     }

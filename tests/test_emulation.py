@@ -173,13 +173,13 @@ def test_lr_launch_shape_follows_density_and_demand():
     the last batch weighed against the occupancy step it costs (lr2_choose_cfg, lr2_pool_from_hist)."""
     import ctypes as C
     lib = emu._load()
-    lib.emu_lr2_shape.argtypes = [C.c_int, C.c_double, C.c_int, C.POINTER(C.c_int)]
+    lib.emu_lr2_shape.argtypes = [C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int)]
     lib.emu_lr2_pool_from_hist.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int]
     lib.emu_lr2_lds.argtypes = [C.c_int] * 5
 
-    def shape(ns, nn=0.0, nn_max=0):
+    def shape(ns, nn=0.0, nn_max=0, last_ta=0, last_split=0.0):
         out = (C.c_int * 6)()
-        lib.emu_lr2_shape(ns, nn, nn_max, out)
+        lib.emu_lr2_shape(ns, nn, nn_max, last_ta, last_split, out)
         return dict(zip(("TA", "pool", "mw", "ds", "lds", "rmax"), out))
 
     def pool(hist, TA=6, ns=20, mw=2, ds=2):
@@ -188,9 +188,18 @@ def test_lr_launch_shape_follows_density_and_demand():
     coil, dense = shape(20, 27.0, 40), shape(20, 75.0, 110)
     assert coil["TA"] == 6 and coil["mw"] == 2 and coil["lds"] * 16 <= 160 * 1024 < (coil["lds"] + 96) * 16
     assert dense["TA"] < coil["TA"] and dense["mw"] >= 3 and dense["pool"] <= 256
-    assert shape(100)["TA"] == 2 and shape(256)["TA"] == 1
-    for s in (coil, dense, shape(100), shape(1)):
-        assert s["pool"] <= 64 * s["rmax"] and s["lds"] <= 160 * 1024
+    # atoms per tile: as many as keep ~320 items AND 16 tiles per CU with a pool for ~90 % of the tiles
+    assert [shape(ns, 30.0, 45)["TA"] for ns in (20, 40, 60, 100, 200, 256)] == [6, 5, 4, 3, 1, 1]
+    for s in (coil, dense, shape(40, 30.0, 45), shape(60, 30.0, 45), shape(100, 30.0, 45), shape(100), shape(1)):
+        assert s["pool"] <= 64 * s["rmax"] and s["lds"] * 16 <= 160 * 1024
+    # with history: stay, one atom less when too many tiles were split, one more only when it clearly fits
+    assert shape(20, 33.7, 77, last_ta=6, last_split=0.03)["TA"] == 6       # coils: 3 % split, halves of 60 items
+    assert shape(20, 58.0, 74, last_ta=4, last_split=0.12)["TA"] == 3       # globules at TA 4: 12 % split
+    assert shape(20, 62.0, 74, last_ta=3, last_split=0.005)["TA"] == 3      # ... and TA 3 stays
+    assert shape(100, 33.7, 77, last_ta=3, last_split=0.075)["TA"] == 3     # 100 slices: halves fill the wave
+    assert shape(20, 12.0, 30, last_ta=4, last_split=0.0)["TA"] == 5        # sparse: one more fits
+    very_dense = shape(20, 400.0, 500)     # one atom per tile and still more records than 16 tiles per CU leave room for
+    assert very_dense["TA"] == 1 and very_dense["pool"] == 256 and very_dense["lds"] * 16 > 160 * 1024
 
     width = 2 * 6 + 2  # hist_bin_width(6)
     p16 = max(p for p in range(16, 258, 2) if lib.emu_lr2_lds(6, 20, p, 2, 2) * 16 <= 160 * 1024)

@@ -192,7 +192,9 @@ def test_device_resident_batch_full_size_properties(fa, oracle_lib):
     a = d_out.cpu().numpy()
     tot = d_tot.cpu().numpy()
     st = ctx.stats()
-    assert st["fallback_tiles"] < 0.02 * (len(r) / st["tile_atoms"])      # first call: pool sized from the density sample
+    # first call: the tile shape comes from the density sample; by design a few % of the tiles exceed the pool that
+    # 16 tiles per CU leave room for and are redone as halves inside the launch (cheaper than a step of occupancy)
+    assert st["fallback_tiles"] < 0.08 * (len(r) / st["tile_atoms"])
     # 1. bounds: 0 <= sasa <= area of the free sphere
     R = r + 1.4
     assert np.all(a >= 0) and np.all(a <= 4 * np.pi * R * R * (1 + 1e-12))
