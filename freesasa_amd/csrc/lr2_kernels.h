@@ -126,7 +126,8 @@ struct Lr2Layout {
     int o_atoms, o_ints, o_rec, o_mask, o_queue, o_tc, o_r2, o_tag, total;
 };
 SASA_HD int lr2_a16(int v) { return (v + 15) & ~15; }
-SASA_HD int lr2_n_ints(int TA) { return 6 * TA + 1 + 8 + 18 * TA + (9 * TA + 2); }
+SASA_HD int lr2_n_ints(int TA) { return 6 * TA + 1 + 8; }
+SASA_HD int lr2_n_row_ints(int TA) { return 9 * TA + (9 * TA + 2); } /* rowlo, cpre: P0 and P1 only */
 SASA_HD Lr2Layout lr2_layout(int TA, int ns, int pool, int mw, int ds)
 {
     Lr2Layout L;
@@ -141,13 +142,16 @@ SASA_HD Lr2Layout lr2_layout(int TA, int ns, int pool, int mw, int ds)
     L.o_queue = p; p += lr2_a16(2 * items);
     L.o_tc = p;    p += lr2_a16(8 * items);
     if (p - L.o_rec < 32 * pool) p = L.o_rec + 32 * pool;
-    /* R2: sort keys and hit tags (P1..P3), then queue scratch (P4, P5), then the arc stack (P6) */
-    int r2 = lr2_a16(8 * pool) + lr2_a16(2 * pool);
+    /* R2: the candidate rows of P0/P1 where the sort keys of P3 will be, and the hit tags (P1..P3); then queue
+       scratch (P4, P5), then the arc stack (P6) */
+    int r2k = lr2_a16(8 * pool);
+    if (r2k < lr2_a16(4 * lr2_n_row_ints(TA))) r2k = lr2_a16(4 * lr2_n_row_ints(TA));
+    int r2 = r2k + lr2_a16(2 * pool);
     const int r2q = lr2_a16(2 * items) + 256, r2s = 16 * LR2_LANES * (ds > 0 ? ds : 1); /* (one column level even when ds == 0: see lr2_union_step) */
     if (r2q > r2) r2 = r2q;
     if (r2s > r2) r2 = r2s;
     L.o_r2 = p;
-    L.o_tag = p + lr2_a16(8 * pool);
+    L.o_tag = p + r2k;
     p += r2;
     L.total = p;
     return L;
@@ -156,7 +160,8 @@ SASA_HD Lr2Layout lr2_layout(int TA, int ns, int pool, int mw, int ds)
 struct Lr2Mem {
     Quad *atom;   /* [TA] x, y, z, R + probe of the tile atoms */
     double *adel; /* [TA] 2 Ri / ns (ref: src/sasa_lr.c:304) */
-    int *acell, *lead, *gsz, *acnt, *aoff, *sorig, *flags, *rowlo, *rowcnt, *cpre, *hist;
+    int *acell, *lead, *gsz, *acnt, *aoff, *sorig, *flags, *hist;
+    int *rowlo, *cpre; /* [9 TA], [9 TA + 2]: first candidate of a row, prefix of P1's work items (over the keys until P3) */
     double *it_tc;  /* [items] slice height relative to the atom centre (z - zi) until the item's slice is done, then its area */
     unsigned *it_mask; /* [items*mw] neighbors that cut an arc */
     unsigned short *queue; /* [items] items with arcs, heaviest first: item | atom << 10 */
@@ -177,7 +182,8 @@ SASA_D Lr2Mem lr2_carve(const Lr2Args &a, char *smem)
     m.atom = (Quad *)(smem + L.o_atoms); m.adel = (double *)(smem + L.o_atoms + 32 * TA);
     int *q = (int *)(smem + L.o_ints);
     m.acell = q; q += TA; m.lead = q; q += TA; m.gsz = q; q += TA; m.acnt = q; q += TA; m.aoff = q; q += TA + 1;
-    m.sorig = q; q += TA; m.flags = q; q += 8; m.rowlo = q; q += 9 * TA; m.rowcnt = q; q += 9 * TA; m.cpre = q;
+    m.sorig = q; q += TA; m.flags = q;
+    m.rowlo = (int *)(smem + L.o_r2); m.cpre = m.rowlo + 9 * TA;
     m.it_tc = (double *)(smem + L.o_tc);
     m.it_mask = (unsigned *)(smem + L.o_mask);
     m.queue = (unsigned short *)(smem + L.o_queue);
@@ -381,7 +387,6 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             my_cnt = leads ? cnt : 0;
         }
         m.rowlo[lane] = lo;
-        m.rowcnt[lane] = cnt;
     }
     LR2_SYNC();
     if (lane < TA) {
@@ -721,7 +726,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
 }
 
 /* The work items of one wave (items first, first + stride, ... of the launch).  A tile that does not fit is redone
- * at once as two halves (3 % of the 6-atom tiles of random coils at a pool of 204 records); what still does not fit
+ * at once as two halves (1.5 % of the 6-atom tiles of random coils at a pool of 224 records); what still does not fit
  * goes to the next launch's list. */
 template <int RMAX>
 SASA_D void lr2_wave(const Lr2Args &a, const Lr2Mem &m, int first, int stride, int lane, int &wg_max_nn)
