@@ -33,9 +33,10 @@ for alg in ('lr', 'sr'):
     st = ctx.stats()
     print('globule100x10k %s: %.4g atoms/s  kernel_ms %.3f prep_ms %.3f fallback %d lds %d TA %d maxnn %d' % (alg, len(r)/best, st['ms_kernel'], st['ms_prep'], st['fallback_tiles'], st['lds_bytes'], st['tile_atoms'], st['max_neighbors']))
 g = np.load('tests/golden/1ubq.npz')
+gx, gr = g['xyz'], g['radii']   # (an NpzFile reads the archive member again on every access)
 for alg, name in ((fa.LEE_RICHARDS, 'L&R-20'), (fa.SHRAKE_RUPLEY, 'S&R-100')):
-    fa.calc_coord(g['xyz'], g['radii'], alg)
+    fa.calc_coord(gx, gr, alg)
     t0 = time.perf_counter()
-    for _ in range(50): fa.calc_coord(g['xyz'], g['radii'], alg)
+    for _ in range(50): fa.calc_coord(gx, gr, alg)
     print('1UBQ freesasa_calc_coord %s: %.0f us per call' % (name, (time.perf_counter() - t0) / 50 * 1e6))
 PY
