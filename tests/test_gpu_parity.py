@@ -234,6 +234,31 @@ def test_lr100_batch_config2(fa, oracle_lib):
         assert np.max(np.abs(lr[sl] - oracle_lib.lee_richards(xyz[sl], r[sl], 1.4, 100))) < LR_TOL
 
 
+@pytest.mark.parametrize("n_slices", [30, 40, 60, 200, 256, 300])
+def test_lr_tile_shapes_across_slice_counts(fa, oracle_lib, n_slices):
+    """The launch shape of the L&R kernel follows the slice count (6 ... 1 atoms per tile, 16 tiles per CU, a few %
+    of the tiles split in place; above 256 slices the first-generation kernel): every shape against the oracle, on
+    coils and on a protein-like globule, twice on the same context (the second batch runs with the shape learnt
+    from the first one's demand histogram) with identical results."""
+    import torch
+    parts = [tools.coil(3000, 900 + k) for k in range(12)] + [tools.globule(2500, 77)]
+    xyz = np.concatenate([p[0] for p in parts]); r = np.concatenate([p[1] for p in parts])
+    offs = np.concatenate([[0], np.cumsum([len(p[1]) for p in parts])]).astype(np.int64)
+    dev = torch.device("cuda:0")
+    d_xyz, d_r = torch.from_numpy(xyz).to(dev), torch.from_numpy(r).to(dev)
+    d_out = torch.empty(len(r), dtype=torch.float64, device=dev)
+    ctx = fa.GpuContext(0)
+    runs = []
+    for _ in range(2):
+        ctx.lee_richards(d_xyz.data_ptr(), d_r.data_ptr(), offs, d_out.data_ptr(), 0, probe=1.4, n_slices=n_slices)
+        runs.append(d_out.cpu().numpy().copy())
+    ctx.close()
+    assert np.max(np.abs(runs[0] - runs[1])) < 1e-11  # (the tile shape may differ between the two: same areas)
+    for k in (0, 5, len(parts) - 1):
+        sl = slice(offs[k], offs[k + 1])
+        assert np.max(np.abs(runs[1][sl] - oracle_lib.lee_richards(xyz[sl], r[sl], 1.4, n_slices))) < LR_TOL
+
+
 def test_trajectory_frames_config4_proxy(fa, oracle_lib):
     """configs[4] proxy: one system, jittered frames, radii/offsets constant across calls."""
     base, r = tools.globule(20_000, 5)
