@@ -43,7 +43,11 @@ $(LIBDIR)/select.o: $(CSRC)/select.c include/freesasa_ingest.h
 	@mkdir -p $(LIBDIR)
 	$(CC) $(CFLAGS) -Iinclude -c $< -o $@
 
-$(LIBDIR)/libfreesasa_amd.so: $(LIBDIR)/gpu_engine.o $(LIBDIR)/seam.o $(LIBDIR)/testpoints.o $(LIBDIR)/api.o $(LIBDIR)/ingest.o $(LIBDIR)/select.o
+$(LIBDIR)/ingest_cache.o: $(CSRC)/ingest_cache.c include/freesasa_ingest.h
+	@mkdir -p $(LIBDIR)
+	$(CC) $(CFLAGS) -Iinclude -c $< -o $@
+
+$(LIBDIR)/libfreesasa_amd.so: $(LIBDIR)/gpu_engine.o $(LIBDIR)/seam.o $(LIBDIR)/testpoints.o $(LIBDIR)/api.o $(LIBDIR)/ingest.o $(LIBDIR)/select.o $(LIBDIR)/ingest_cache.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
 $(LIBDIR)/libfreesasa_amd_seam.a: $(LIBDIR)/gpu_engine.o $(LIBDIR)/seam.o $(LIBDIR)/testpoints.o $(LIBDIR)/ingest.o
@@ -62,9 +66,9 @@ tests/emu/libsasa_emu.so: tests/emu/emu.cpp $(CSRC)/sasa_kernels.h $(CSRC)/lr2_k
 ASAN_SO = tests/emu/libfreesasa_amd_asan.so
 SANFLAGS = -O1 -g -std=gnu99 -fPIC -ffp-contract=off -Wall -fsanitize=address,undefined -fno-omit-frame-pointer -fno-sanitize-recover=undefined
 asan: $(ASAN_SO)
-$(ASAN_SO): $(CSRC)/api.c $(CSRC)/seam.c $(CSRC)/testpoints.c $(CSRC)/ingest.c $(CSRC)/select.c $(CSRC)/protor_table.h $(LIBDIR)/gpu_engine.o include/freesasa_amd.h include/freesasa_gpu.h include/freesasa_ingest.h
-	for f in api seam testpoints ingest select; do $(CC) $(SANFLAGS) -Iinclude -pthread -c $(CSRC)/$$f.c -o /tmp/asan_$$f.o || exit 1; done
-	$(CXX) -shared -fPIC -o $@ /tmp/asan_api.o /tmp/asan_seam.o /tmp/asan_testpoints.o /tmp/asan_ingest.o /tmp/asan_select.o $(LIBDIR)/gpu_engine.o \
+$(ASAN_SO): $(CSRC)/api.c $(CSRC)/seam.c $(CSRC)/testpoints.c $(CSRC)/ingest.c $(CSRC)/select.c $(CSRC)/ingest_cache.c $(CSRC)/protor_table.h $(LIBDIR)/gpu_engine.o include/freesasa_amd.h include/freesasa_gpu.h include/freesasa_ingest.h
+	for f in api seam testpoints ingest select ingest_cache; do $(CC) $(SANFLAGS) -Iinclude -pthread -c $(CSRC)/$$f.c -o /tmp/asan_$$f.o || exit 1; done
+	$(CXX) -shared -fPIC -o $@ /tmp/asan_api.o /tmp/asan_seam.o /tmp/asan_testpoints.o /tmp/asan_ingest.o /tmp/asan_select.o /tmp/asan_ingest_cache.o $(LIBDIR)/gpu_engine.o \
 	    -fsanitize=address,undefined -L/opt/rocm/lib -Wl,-rpath,/opt/rocm/lib -lamdhip64 -lpthread -lm
 asan-test: $(ASAN_SO)
 	LD_PRELOAD="$$($(CC) -print-file-name=libasan.so) $$($(CC) -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 \

@@ -30,9 +30,12 @@ class _CBatch(C.Structure):
 
 
 def _arr(ptr, n, dtype):
+    """numpy copy of n items behind a ctypes pointer (one memcpy; np.ctypeslib.as_array is slow on large arrays)"""
     if n == 0:
         return np.zeros(0, dtype=dtype)
-    return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+    nbytes = n * np.dtype(dtype).itemsize
+    view = (C.c_char * nbytes).from_address(C.addressof(ptr.contents))
+    return np.frombuffer(view, dtype=dtype).copy()
 
 
 class Batch:
@@ -77,7 +80,18 @@ class Batch:
         cb.offsets, cb.res_first, cb.res_offsets = ptr(self.offsets, C.c_int64), ptr(self.res_first, C.c_int64), ptr(self.res_offsets, C.c_int64)
         cb.atom_name, cb.atom_symbol = ptr(self.atom_name_raw, C.c_char), ptr(self.atom_symbol_raw, C.c_char)
         cb.res_name, cb.res_number, cb.res_chain = ptr(self.res_name_raw, C.c_char), ptr(self.res_number_raw, C.c_char), ptr(self.res_chain_raw, C.c_char)
+        self._xyz_flat = np.ascontiguousarray(self.xyz, dtype=np.float64).reshape(-1)
+        cb.xyz, cb.radii = ptr(self._xyz_flat, C.c_double), ptr(self.radii, C.c_double)
+        cb.atom_class, cb.atom_backbone = ptr(self.atom_class, C.c_uint8), ptr(self.atom_backbone, C.c_uint8)
+        cb.res_ref, cb.status = ptr(self.res_ref, C.c_int16), ptr(self.status, C.c_int32)
         return cb
+
+    def save(self, path):
+        """freesasa_ingest_save(): the batch as a binary cache file (load_cache() reads it back)."""
+        cb = self._as_c()
+        rc = _proto().freesasa_ingest_save(C.byref(cb), str(path).encode())
+        if rc:
+            raise RuntimeError(f"freesasa_ingest_save failed with code {rc}")
 
     def select(self, structure, command):
         """The reference's selection language on one structure: (name, mask[n_atoms of it], warned).
@@ -115,6 +129,8 @@ def _proto():
         L.freesasa_ingest_residue_reference_table.argtypes = [C.POINTER(C.c_double)]
         L.freesasa_ingest_is_backbone.argtypes = [C.c_char_p]
         L.freesasa_ingest_select.argtypes = [C.POINTER(_CBatch), C.c_int, C.c_char_p, C.c_char_p, C.POINTER(C.c_ubyte)]
+        L.freesasa_ingest_save.argtypes = [C.POINTER(_CBatch), C.c_char_p]
+        L.freesasa_ingest_load.argtypes = [C.c_char_p, C.POINTER(_CBatch)]
         L._ingest_ready = True
     return L
 
@@ -134,6 +150,14 @@ def load_pdb_files(paths, options=0, n_threads=0):
     arr = (C.c_char_p * len(paths))(*[str(p).encode() for p in paths])
     cb = _CBatch()
     return _finish(L, L.freesasa_ingest_pdb_files(arr, len(paths), options, n_threads, C.byref(cb)), cb)
+
+
+def load_cache(path):
+    """freesasa_ingest_load(): a Batch from the binary cache file Batch.save() wrote.  Raises RuntimeError with the
+    library's code (EIO: cannot open; EFORMAT: not a cache file, truncated, checksum or offsets wrong)."""
+    L = _proto()
+    cb = _CBatch()
+    return _finish(L, L.freesasa_ingest_load(str(path).encode(), C.byref(cb)), cb)
 
 
 def load_pdb_texts(texts, options=0, n_threads=0):

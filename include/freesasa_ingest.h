@@ -92,6 +92,16 @@ int freesasa_ingest_pdb_texts(const char *const *texts, const size_t *lens, int 
 
 void freesasa_ingest_free(freesasa_ingest_batch *batch);
 
+/* A batch on disk (the "binary cache" of SURVEY.md 8(f) N1): a sweep that is run again - another probe radius,
+ * another resolution, the other algorithm - starts from one sequential read instead of parsing and classifying
+ * every file again.  freesasa_ingest_save() writes every array of the batch (little endian, a 128-byte header
+ * with the counts and a checksum; to a temporary name, then renamed); freesasa_ingest_load() gives back an equal
+ * batch (released with freesasa_ingest_free) or refuses the file: FREESASA_INGEST_EIO if it cannot be opened or
+ * written, FREESASA_INGEST_EFORMAT if it is not a cache file of this version, is truncated, fails its checksum or
+ * holds inconsistent offsets (save: if the batch itself is inconsistent), FREESASA_INGEST_ENOMEM. */
+int freesasa_ingest_save(const freesasa_ingest_batch *batch, const char *path);
+int freesasa_ingest_load(const char *path, freesasa_ingest_batch *out);
+
 /* The reference's selection language ("name, resn ala+arg and not chain B", src/selection.c,
  * src/parser.y, src/lexer.l) on structure `structure` of a batch: mask_out[i] = 1 for the selected
  * atoms ([offsets[s+1] - offsets[s]] bytes), name_out = the selection's name.  Returns the number of

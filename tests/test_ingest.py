@@ -406,3 +406,70 @@ def test_mmcif_row_scanner_equals_the_byte_at_a_time_tokenizer():
         for f in ("xyz", "radii", "atom_class", "atom_backbone", "atom_name_raw", "atom_symbol_raw", "offsets", "res_first",
                   "res_offsets", "res_ref", "res_name_raw", "res_number_raw", "res_chain_raw", "status"):
             assert np.array_equal(getattr(a, f), getattr(b, f)), (options, f)
+
+
+BATCH_ARRAYS = ("xyz", "radii", "atom_class", "atom_backbone", "atom_name_raw", "atom_symbol_raw", "offsets", "res_first",
+                "res_offsets", "res_ref", "res_name_raw", "res_number_raw", "res_chain_raw", "status")
+
+
+def test_binary_cache_round_trip_and_refusals(tmp_path):
+    """SURVEY 8(f) N1's binary cache: a saved batch comes back array for array (failed inputs and an empty batch
+    included), and a file that is not exactly what save() wrote - truncated, extended, one flipped byte anywhere,
+    another version, another byte order, inconsistent offsets behind a valid checksum - is refused, not half-loaded."""
+    paths = [fixture("1ubq.pdb"), fixture("empty.pdb"), fixture("1ubq.cif"), "/nonexistent/x.pdb", fixture("3bkr.pdb"), fixture("1d3z.pdb")]
+    b = ingest.load_pdb_files(paths, options=ingest.INCLUDE_HETATM, n_threads=2)
+    f = tmp_path / "batch.fsab"
+    b.save(f)
+    back = ingest.load_cache(f)
+    assert (back.n_structs, back.n_atoms, back.n_residues) == (b.n_structs, b.n_atoms, b.n_residues)
+    for name in BATCH_ARRAYS:
+        x, y = getattr(b, name), getattr(back, name)
+        assert x.dtype == y.dtype and x.shape == y.shape and x.tobytes() == y.tobytes(), name
+    assert back.select(0, "s, resn ala and name ca")[1].sum() == b.select(0, "s, resn ala and name ca")[1].sum() > 0
+    assert not [p for p in os.listdir(tmp_path) if ".tmp" in p]            # written under a temporary name, renamed
+
+    empty = ingest.load_pdb_files([])
+    empty.save(tmp_path / "empty.fsab")
+    e2 = ingest.load_cache(tmp_path / "empty.fsab")
+    assert e2.n_structs == 0 and e2.n_atoms == 0 and e2.offsets.tolist() == [0]
+
+    raw = f.read_bytes()
+    assert len(raw) % 16 == 0 and raw[:8] == b"FSASABAT"
+
+    def refused(data, code):
+        g = tmp_path / "bad.fsab"
+        g.write_bytes(data)
+        with pytest.raises(RuntimeError, match=f"code {code}"):
+            ingest.load_cache(g)
+
+    refused(raw[:-16], ingest.EFORMAT)                       # truncated
+    refused(raw[:100], ingest.EFORMAT)                       # not even a header
+    refused(raw + b"\0" * 16, ingest.EFORMAT)                # extended
+    refused(b"", ingest.EFORMAT)
+    rng = np.random.default_rng(5)
+    for pos in [8, 12, 16, 24, 40, 48, 130] + rng.integers(128, len(raw), 12).tolist():
+        flipped = bytearray(raw); flipped[pos] ^= 0x40
+        refused(bytes(flipped), ingest.EFORMAT)              # version, byte-order mark, counts, checksum, payload
+    with pytest.raises(RuntimeError, match=f"code {ingest.EIO}"):
+        ingest.load_cache(tmp_path / "missing.fsab")
+    with pytest.raises(RuntimeError, match=f"code {ingest.EIO}"):
+        b.save(tmp_path / "no_such_dir" / "x.fsab")
+    # a batch whose offsets do not add up is not written at all
+    broken = ingest.load_pdb_files([fixture("1ubq.pdb")])
+    broken.offsets[1] -= 1
+    with pytest.raises(RuntimeError, match=f"code {ingest.EFORMAT}"):
+        broken.save(tmp_path / "broken.fsab")
+    assert not (tmp_path / "broken.fsab").exists()
+
+
+@pytest.mark.gpu
+def test_sweep_from_the_binary_cache_equals_the_sweep_from_the_files(tmp_path):
+    import freesasa_amd as fa
+    names = ["1ubq.pdb", "3bkr.pdb", "1ubq.cif", "2jo4.pdb"] if os.path.exists(fixture("2jo4.pdb")) else ["1ubq.pdb", "3bkr.pdb", "1ubq.cif"]
+    b = ingest.load_pdb_files([fixture(n) for n in names])
+    b.save(tmp_path / "sweep.fsab")
+    c = ingest.load_cache(tmp_path / "sweep.fsab")
+    want, _, wtot = fa.calc_batch(b.xyz, b.radii, b.offsets, fa.LEE_RICHARDS, 1.4, 20)
+    got, _, gtot = fa.calc_batch(c.xyz, c.radii, c.offsets, fa.LEE_RICHARDS, 1.4, 20)
+    assert np.array_equal(want, got) and np.array_equal(wtot, gtot)
+    assert np.array_equal(b.residue_sums(want), c.residue_sums(got))
