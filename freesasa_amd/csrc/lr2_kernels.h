@@ -271,39 +271,39 @@ SASA_D void lr2_union_step(double inf, double sup, Lr2Union &u, Arc *stk, int ds
 
 /* exposed arc length from the final components (ascending).
  * ref: src/sasa_lr.c:340-351 (arcs through the origin) and :389-408 (sweep) */
-SASA_D double lr2_sweep_step(bool wrap, double V, double ks, double ke, double &sum, double &sup, bool &covered)
+SASA_D void lr2_sweep_step(bool have, double V, double ks, double ke, double &sum, double &sup, bool &covered)
 {
-    covered = covered || (wrap && ks >= V); /* sorted behind the [V, 2pi] piece: covered, and so is everything after it */
-    if (!covered) {
-        if (sup < ks) sum += ks - sup;
-        if (ke > sup) sup = ke;
-    }
-    return sum;
+    /* straight-line: the lanes of a refill are at different depths, a branch would be taken by some of them anyway */
+    covered = covered || (have && ks >= V); /* sorted behind the [V, 2pi] piece: covered, and so is everything after it */
+    const bool live = have && !covered;
+    const double gap = ks - sup;
+    sum += live && sup < ks ? gap : 0.0;
+    sup = live && ke > sup ? ke : sup;
 }
 SASA_D double lr2_sweep(const Lr2Union &u, const Arc *stk, int ds)
 {
     const int depth = u.depth;
-    if (depth == 0) return SASA_TWOPI; /* ref: :392 */
-    const double b_s = depth == 1 ? u.ts : (depth == 2 ? u.bs : stk[0].s); /* lowest component */
-    const bool wrap = b_s < 0 || u.te > SASA_TWOPI;
-    const double Vlo = b_s < 0 ? b_s + SASA_TWOPI : SASA_TWOPI;   /* ref: :340 */
-    const double Vhi = u.te > SASA_TWOPI ? u.ts : SASA_TWOPI;     /* the piece [inf, 2pi] of an arc whose sup wraps */
-    const double V = Vlo < Vhi ? Vlo : Vhi;
-    const double W = u.te > SASA_TWOPI ? u.te - SASA_TWOPI : 0.0; /* ref: :341 */
-    const double top_e = u.te > SASA_TWOPI ? SASA_TWOPI : u.te;
+    const double b_s = depth <= 1 ? u.ts : (depth == 2 ? u.bs : stk[0].s); /* lowest component */
+    const bool lo_wraps = b_s < 0, hi_wraps = u.te > SASA_TWOPI;
+    const bool wrap = lo_wraps || hi_wraps;
+    const double Vlo = lo_wraps ? b_s + SASA_TWOPI : SASA_TWOPI;  /* ref: :340 */
+    const double Vhi = hi_wraps ? u.ts : SASA_TWOPI;              /* the piece [inf, 2pi] of an arc whose sup wraps */
+    const double Vw = Vlo < Vhi ? Vlo : Vhi;
+    const double V = wrap ? Vw : INFINITY;
+    const double W = hi_wraps ? u.te - SASA_TWOPI : 0.0;          /* ref: :341 */
+    const double top_e = hi_wraps ? SASA_TWOPI : u.te;
     double sum = 0, sup = W;
     bool covered = false;
     for (int c = 0; c < depth - 2; ++c) { /* components in the LDS column (rare: more than two) */
         const Arc k = stk[(c < ds ? c : 0) * LR2_LANES];
-        lr2_sweep_step(wrap, V, k.s, k.e, sum, sup, covered);
+        lr2_sweep_step(true, V, k.s, k.e, sum, sup, covered);
     }
-    if (depth >= 2) lr2_sweep_step(wrap, V, u.bs, u.be, sum, sup, covered); /* the two in registers: straight-line code */
-    lr2_sweep_step(wrap, V, u.ts, top_e, sum, sup, covered);
-    if (wrap) {
-        if (sup < V) sum += V - sup;
-        sup = SASA_TWOPI;
-    }
-    return sum + SASA_TWOPI - sup; /* ref: :407 */
+    lr2_sweep_step(depth >= 2, V, u.bs, u.be, sum, sup, covered); /* the two in registers */
+    lr2_sweep_step(depth >= 1, V, u.ts, top_e, sum, sup, covered);
+    sum += wrap && sup < Vw ? Vw - sup : 0.0;
+    sup = wrap ? SASA_TWOPI : sup;
+    const double r = sum + SASA_TWOPI - sup; /* ref: :407 */
+    return depth == 0 ? SASA_TWOPI : r;      /* ref: :392 */
 }
 
 /* test hook (freesasa_gpu_arc_union_dev): the exposed length of set `k`'s arcs, given sorted by their mid-points,
