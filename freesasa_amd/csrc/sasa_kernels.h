@@ -800,10 +800,12 @@ SASA_D double acos_fast(double x)
     const double u = big ? s : x;             /* asin argument */
     const double t = fma(u * z, p, u);        /* asin(u) */
     const double pio2 = 0x1.921fb54442d18p+0, pi = 0x1.921fb54442d18p+1;
-    const double t2 = t + t;   /* x > 0.5:  2 asin(sqrt zb) */
-    const double bn = t2 + pi; /* x < -0.5: pi - 2 asin(sqrt zb) = pi + 2 asin(-sqrt zb) */
-    const double sm = pio2 - t;
-    return big ? (x > 0 ? t2 : bn) : sm;
+    /* |x| <= 0.5: pi/2 - t;  x > 0.5: 2 t = 2 asin(sqrt zb);  x < -0.5: pi + 2 t = pi - 2 asin(sqrt zb).
+       One fma with selected operands (the products -1 t and 2 t are exact: the same single rounding as the sums),
+       not three results behind two branches */
+    const double m = big ? 2.0 : -1.0;
+    const double off = big ? (x > 0 ? 0.0 : pi) : pio2;
+    return fma(m, t, off);
 }
 
 /* atan2(y, x) for finite arguments: ONE division (hardware reciprocal seed + two Newton steps + a
