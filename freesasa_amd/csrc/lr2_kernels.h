@@ -681,10 +681,12 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     } while (0)
         LR2_FETCH(lane);
         for (;;) {
+            /* a refill is due when `due` lanes wait: the launch's threshold while the queue has items, all 64 after */
+            const int due = next < nq && a.refill < LR2_LANES ? a.refill : LR2_LANES;
             for (;;) { /* arc steps until a refill is due */
                 const bool act = w != 0;
                 const unsigned long long am = LR2_BALLOT(act);
-                if (am == 0 || (next < nq && LR2_LANES - LR2_POPC64(am) >= a.refill)) break;
+                if (LR2_LANES - LR2_POPC64(am) >= due) break;
                 LR2_COUNT(1, 1);
                 if (act) {
                     const Rec24 *q = R + __builtin_ctz(w);
