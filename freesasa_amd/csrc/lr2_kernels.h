@@ -465,20 +465,17 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                 }
                 for (int j = 0; j < LR2_NB_UNROLL; ++j) {
                     const unsigned long long hm = LR2_BALLOT(hit[j]);
-                    if (hm) {
-                        if (hit[j]) {
-                            const int la = la0[j] + g;
-                            const int slot = nh + LR2_RANK(hm, lane);
-                            const int sa = SASA_ATOMIC_ADD_LDS(&m.acnt[la], 1);
-                            if (slot < a.pool) {
-                                Quad hq; hq.x = dx[j]; hq.y = dy[j]; hq.z = dz[j]; hq.w = rq[j]; /* ref: src/nb.c:445-448 */
-                                m.hits[slot] = hq;
-                                m.tag[slot] = (unsigned short)((unsigned)la | ((unsigned)sa << 3)); /* la < 8, sa < 2^13 */
-                            }
-                            if (a.nb_out && sa < a.nb_cap) a.nb_out[(size_t)m.sorig[la] * a.nb_cap + sa] = a.s_orig[q[j]];
-                        }
-                        nh += LR2_POPC64(hm);
+                    if (hit[j]) {
+                        const int la = la0[j] + g;
+                        int slot = nh + LR2_RANK(hm, lane);
+                        slot = slot < a.pool ? slot : a.pool - 1; /* (a tile with more hits than the pool is redone: P2) */
+                        const int sa = SASA_ATOMIC_ADD_LDS(&m.acnt[la], 1);
+                        Quad hq; hq.x = dx[j]; hq.y = dy[j]; hq.z = dz[j]; hq.w = rq[j]; /* ref: src/nb.c:445-448 */
+                        m.hits[slot] = hq;
+                        m.tag[slot] = (unsigned short)((unsigned)la | ((unsigned)sa << 3)); /* la < 8, sa < 2^13 */
+                        if (a.nb_out && sa < a.nb_cap) a.nb_out[(size_t)m.sorig[la] * a.nb_cap + sa] = a.s_orig[q[j]];
                     }
+                    nh += LR2_POPC64(hm);
                 }
             }
         }
