@@ -546,8 +546,15 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             if (r_pos[r] < 0) continue;
             const int o = r_pos[r] & 0xffff, nn = r_pos[r] >> 16;
             const double kme = r_key[r];
-            int rank = 0;
-            for (int t = 0; t < nn; t += 2) { /* two keys per LDS read (o is even) */
+            int rank = 0, t = 0;
+            for (; t + 4 <= nn; t += 4) { /* two keys per LDS read (o is even), two reads per trip */
+                const Arc k0 = *(const Arc *)(m.keys + o + t), k1 = *(const Arc *)(m.keys + o + t + 2);
+                rank += k0.s < kme ? 1 : 0;
+                rank += k0.e < kme ? 1 : 0;
+                rank += k1.s < kme ? 1 : 0;
+                rank += k1.e < kme ? 1 : 0;
+            }
+            for (; t < nn; t += 2) { /* at most two trips (lists are padded to an even length) */
                 const Arc kk = *(const Arc *)(m.keys + o + t);
                 rank += kk.s < kme ? 1 : 0;
                 rank += kk.e < kme ? 1 : 0;
