@@ -48,6 +48,7 @@ long long wave_exchange(long long v, int src);
 #define LR2_RANK(m, lane) __builtin_popcountll((m) & ((1ull << (lane)) - 1ull))
 #define LR2_SHIFT_IN_LT1(w, c) (((w) << 1) | ((c) < 1.0 ? 1u : 0u))
 #define LR2_UNIFORM(v) (v)
+#define LR2_READLANE(v, src) LR2_SHFL((v), (src))
 namespace sasa_emu { extern long long lr2_count[16]; } /* wave-level trip counts (lane 0 counts): 0 tiles, 1 arc iterations, 2 refills, 3 P1 test rounds, 4 rank trips, 5 screening trips, 6 P3 rounds */
 #define LR2_COUNT(k, n) do { if (lane == 0) sasa_emu::lr2_count[(k)] += (n); } while (0)
 #else
@@ -70,9 +71,54 @@ namespace sasa_emu { extern long long lr2_count[16]; } /* wave-level trip counts
 /* a value every lane of the wave holds alike, moved to a scalar register: loops and branches on it become scalar
    control flow instead of exec-mask bookkeeping (the compiler cannot see that an LDS read or a shuffle is uniform) */
 #define LR2_UNIFORM(v) __builtin_amdgcn_readfirstlane(v)
+#define LR2_READLANE(v, src) __builtin_amdgcn_readlane((v), (src)) /* src wave-uniform */
 #endif
 
 namespace sasa {
+
+/* Inclusive prefix sum / running maximum over the lanes of the wave (values >= 0).  On the device: data-parallel
+ * primitives, one VALU instruction per step and no trip through the LDS crossbar (a shuffle is a ds_bpermute plus
+ * its address arithmetic): shifts by 1, 2, 4, 8 inside the rows of 16 lanes (zeros shifted in), then the last lane
+ * of row 0 / 2 into row 1 / 3 (row_bcast15) and lane 31 into the upper half (row_bcast31). */
+#ifdef SASA_EMU
+SASA_D int lr2_scan_add(int v, int lane)
+{
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = LR2_SHFL(v, lane >= d ? lane - d : lane);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+SASA_D int lr2_scan_max16(int v, int lane) /* running maximum inside each row of 16 lanes */
+{
+    for (int d = 1; d < 16; d <<= 1) {
+        const int o = LR2_SHFL(v, (lane & 15) >= d ? lane - d : lane);
+        if ((lane & 15) >= d) v = v > o ? v : o;
+    }
+    return v;
+}
+#else
+#define LR2_DPP(v, ctrl, rows) __builtin_amdgcn_update_dpp(0, (v), (ctrl), (rows), 0xf, true)
+SASA_D int lr2_scan_add(int v, int)
+{
+    v += LR2_DPP(v, 0x111, 0xf); /* row_shr:1 */
+    v += LR2_DPP(v, 0x112, 0xf); /* row_shr:2 */
+    v += LR2_DPP(v, 0x114, 0xf); /* row_shr:4 */
+    v += LR2_DPP(v, 0x118, 0xf); /* row_shr:8 */
+    v += LR2_DPP(v, 0x142, 0xa); /* row_bcast15 into rows 1 and 3 */
+    v += LR2_DPP(v, 0x143, 0xc); /* row_bcast31 into rows 2 and 3 */
+    return v;
+}
+SASA_D int lr2_scan_max16(int v, int)
+{
+    int o;
+    o = LR2_DPP(v, 0x111, 0xf); v = v > o ? v : o;
+    o = LR2_DPP(v, 0x112, 0xf); v = v > o ? v : o;
+    o = LR2_DPP(v, 0x114, 0xf); v = v > o ? v : o;
+    o = LR2_DPP(v, 0x118, 0xf); v = v > o ? v : o;
+    return v;
+}
+#endif
 
 #ifndef LR2_STOP_AFTER /* dev only (tools/build_variant.sh): return after phase k, for instruction attribution */
 #define LR2_STOP_AFTER 99
@@ -405,11 +451,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         while (la + gs < na && m.acell[la + gs] == m.acell[la]) ++gs;
         my_cnt *= (gs + LR2_P1_G - 1) / LR2_P1_G;
     }
-    int incl = my_cnt;
-    for (int d = 1; d < LR2_LANES; d <<= 1) {
-        const int v = LR2_SHFL(incl, lane >= d ? lane - d : lane);
-        if (lane >= d) incl += v;
-    }
+    const int incl = lr2_scan_add(my_cnt, lane);
     if (lane == 0) m.cpre[0] = 0;
     if (lane < 9 * TA) m.cpre[lane + 1] = incl;
     LR2_SYNC();
@@ -496,15 +538,11 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     int nn_max;
     {
         const int c = lane < TA ? m.acnt[lane] : 0, pc = (c + 1) & ~1;
-        int incl = pc, cmax = c;
-        for (int d = 1; d < 8; d <<= 1) { /* TA <= 7 */
-            const int v = LR2_SHFL(incl, lane >= d ? lane - d : lane), w = LR2_SHFL(cmax, lane >= d ? lane - d : lane);
-            if (lane >= d) { incl += v; cmax = cmax > w ? cmax : w; }
-        }
+        const int incl = lr2_scan_add(pc, lane), cmax = lr2_scan_max16(c, lane); /* (TA <= 7: the first row) */
         if (lane < TA) m.aoff[lane] = incl - pc;
         if (lane == TA - 1) m.aoff[TA] = incl;
-        const int total = LR2_SHFL(incl, TA - 1);
-        nn_max = LR2_SHFL(cmax, TA - 1);
+        const int total = LR2_READLANE(incl, TA - 1);
+        nn_max = LR2_READLANE(cmax, TA - 1);
         ovf = nn_max > 32 * mw || total > a.pool || nh > a.pool || nh > LR2_LANES * RMAX;
         if (lane == 0) {
             if (nn_max > wg_max_nn) wg_max_nn = nn_max;
@@ -640,12 +678,8 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     int nq;
     {
         const int hv = m.hist[lane];
-        int incl2 = hv;
-        for (int d = 1; d < LR2_LANES; d <<= 1) {
-            const int v = LR2_SHFL(incl2, lane >= d ? lane - d : lane);
-            if (lane >= d) incl2 += v;
-        }
-        nq = LR2_UNIFORM(LR2_SHFL(incl2, LR2_LANES - 1));
+        const int incl2 = lr2_scan_add(hv, lane);
+        nq = LR2_READLANE(incl2, LR2_LANES - 1);
         m.hist[lane] = incl2 - hv; /* first queue position of the bin */
         LR2_SYNC();
         for (int it = lane; it < items; it += LR2_LANES) {
