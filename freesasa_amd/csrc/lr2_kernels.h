@@ -705,6 +705,10 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         double t = 0, h2 = 0;
         Lr2Union u;
         lr2_union_reset(u);
+/* on to the item's next mask word with a bit set: mw - 1 straight steps (mw is 2 unless lists are long) */
+#define LR2_NEXT_WORD()                                                                            \
+    for (int k_ = 1; k_ < mw; ++k_)                                                                \
+        if (w == 0 && wleft > 0) { ++mk; R += 32; --wleft; w = *mk; }
 #define LR2_FETCH(idx)                                                                             \
     do {                                                                                           \
         const int e_ = (idx) < nq ? (int)m.queue[(idx)] : LR2_NONE;                                \
@@ -714,7 +718,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             R = m.rec + m.aoff[la]; t = m.it_tc[my];                                               \
             { const double Ri_ = m.atom[la].w; double g_; sqrt_rh(Ri_ * Ri_ - t * t, g_, h2); } /* as P4: bit for bit */ \
             mk = m.it_mask + my * mw; w = *mk; wleft = mw - 1;                                     \
-            while (w == 0 && wleft > 0) { ++mk; R += 32; --wleft; w = *mk; }                       \
+            LR2_NEXT_WORD();                                                                       \
         }                                                                                          \
     } while (0)
         LR2_FETCH(lane);
@@ -736,8 +740,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             }
             /* refill: a lane that has used up its mask word moves on to the item's next word or, when the item
                is finished, stores its area and takes the next item of the queue */
-            if (w == 0 && wleft > 0)
-                do { ++mk; R += 32; --wleft; w = *mk; } while (w == 0 && wleft > 0);
+            LR2_NEXT_WORD();
             const unsigned long long im = LR2_BALLOT(w == 0); /* finished (or without an item) */
             LR2_COUNT(2, 1);
             if (w == 0) {
@@ -749,6 +752,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             if (next - LR2_POPC64(im) >= nq && LR2_BALLOT(w != 0) == 0) break;
         }
 #undef LR2_FETCH
+#undef LR2_NEXT_WORD
     }
     LR2_SYNC();
     LR2_MARK(6);
