@@ -161,7 +161,24 @@ struct Lr2Args {
     int *nb_out;
     int nb_cap;
     int *status;
+    int hooks; /* bit 0: nn_out is set, bit 1: nb_out is set (what the tile body tests; the pointers themselves are cold) */
 };
+#include <stddef.h>
+/* Arguments only rare paths need (overflow lists, statistics, the test hooks): read from the kernel-argument
+ * segment where they are used, so that they do not hold scalar registers through the whole tile loop (the kernel is
+ * short of them: ~130 spilled to VGPR lanes, and where the reloads land decides about 3 % of its speed).  Lr2Args is
+ * the kernel's only parameter. */
+#ifdef SASA_EMU
+#define LR2_COLD(a, field) ((a).field)
+#else
+#define LR2_COLD(a, field) (*(const decltype(sasa::Lr2Args::field) *)lr2_cold_arg(offsetof(sasa::Lr2Args, field)))
+__device__ __forceinline__ const char *lr2_cold_arg(size_t off)
+{
+    auto p = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return (const char *)p + off;
+}
+#endif
 
 /* One neighbor record of P3..P6, 24 B: cos(alpha) of the arc the neighbor cuts at slice height t is
  * (b + a t) * 1/(2 Ri') (see lr2_record); beta = direction of the neighbor in the slice plane. */
@@ -371,12 +388,14 @@ SASA_D double lr2_arc_kat(const double *arcs, const int *first, int k, Arc *stk,
 /* a work item that fits no capacity of this launch, even halved */
 SASA_D void lr2_overflow(const Lr2Args &a, int p0, int na, int err_code)
 {
-    if (a.ovf_atoms) {
-        const int w = SASA_ATOMIC_ADD_GLB(a.ovf_count, na);
-        for (int k = 0; k < na; ++k) a.ovf_atoms[w + k] = p0 + k;
-    } else if (a.ovf_items) {
-        const int w = SASA_ATOMIC_ADD_GLB(a.ovf_count, 1);
-        a.ovf_items[w] = (long long)p0 | ((long long)na << 32);
+    int *const ovf_atoms = LR2_COLD(a, ovf_atoms), *const ovf_count = LR2_COLD(a, ovf_count);
+    long long *const ovf_items = LR2_COLD(a, ovf_items);
+    if (ovf_atoms) {
+        const int w = SASA_ATOMIC_ADD_GLB(ovf_count, na);
+        for (int k = 0; k < na; ++k) ovf_atoms[w + k] = p0 + k;
+    } else if (ovf_items) {
+        const int w = SASA_ATOMIC_ADD_GLB(ovf_count, 1);
+        ovf_items[w] = (long long)p0 | ((long long)na << 32);
     } else {
         SASA_ATOMIC_MAX_GLB(&a.status[ST_ERROR], err_code); /* the last launch: nothing left to hand the work to */
     }
@@ -515,7 +534,10 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                         Quad hq; hq.x = dx[j]; hq.y = dy[j]; hq.z = dz[j]; hq.w = rq[j]; /* ref: src/nb.c:445-448 */
                         m.hits[slot] = hq;
                         m.tag[slot] = (unsigned short)((unsigned)la | ((unsigned)sa << 3)); /* la < 8, sa < 2^13 */
-                        if (a.nb_out && sa < a.nb_cap) a.nb_out[(size_t)m.sorig[la] * a.nb_cap + sa] = a.s_orig[q[j]];
+                        if (a.hooks & 2) { /* (uniform) test hook: the neighbor lists themselves */
+                            const int cap = LR2_COLD(a, nb_cap);
+                            if (sa < cap) LR2_COLD(a, nb_out)[(size_t)m.sorig[la] * cap + sa] = a.s_orig[q[j]];
+                        }
                     }
                     nh += LR2_POPC64(hm);
                 }
@@ -526,8 +548,8 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
 
     LR2_STOP(1);
     LR2_MARK(1);
-    if (a.nn_out) { /* (uniform) test hook: the neighbor counts are the result */
-        if (lane < na) a.nn_out[m.sorig[lane]] = m.acnt[lane];
+    if (a.hooks & 1) { /* (uniform) test hook: the neighbor counts are the result */
+        if (lane < na) LR2_COLD(a, nn_out)[m.sorig[lane]] = m.acnt[lane];
         LR2_SYNC();
         return 0;
     }
@@ -813,7 +835,10 @@ SASA_D void lr2_wave(const Lr2Args &a, const Lr2Mem &m, int first, int stride, i
             p0 = rest0; na = rest_n; rest_n = 0;
         }
     }
-    if (lane == 0 && splits > 0 && a.split_count) SASA_ATOMIC_ADD_GLB(&a.split_count[first & 63], splits);
+    if (lane == 0 && splits > 0) {
+        int *const split_count = LR2_COLD(a, split_count);
+        if (split_count) SASA_ATOMIC_ADD_GLB(&split_count[first & 63], splits);
+    }
 }
 
 /* launch configuration (host side; shared by gpu_engine.hip and the test emulation) */
