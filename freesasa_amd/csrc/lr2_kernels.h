@@ -49,6 +49,7 @@ long long wave_exchange(long long v, int src);
 #define LR2_SHIFT_IN_LT1(w, c) (((w) << 1) | ((c) < 1.0 ? 1u : 0u))
 #define LR2_UNIFORM(v) (v)
 #define LR2_READLANE(v, src) LR2_SHFL((v), (src))
+#define LR2_MUL24(a, b) ((int)(a) * (int)(b))
 namespace sasa_emu { extern long long lr2_count[16]; } /* wave-level trip counts (lane 0 counts): 0 tiles, 1 arc iterations, 2 refills, 3 P1 test rounds, 4 rank trips, 5 screening trips, 6 P3 rounds */
 #define LR2_COUNT(k, n) do { if (lane == 0) sasa_emu::lr2_count[(k)] += (n); } while (0)
 #else
@@ -72,6 +73,9 @@ namespace sasa_emu { extern long long lr2_count[16]; } /* wave-level trip counts
    control flow instead of exec-mask bookkeeping (the compiler cannot see that an LDS read or a shuffle is uniform) */
 #define LR2_UNIFORM(v) __builtin_amdgcn_readfirstlane(v)
 #define LR2_READLANE(v, src) __builtin_amdgcn_readlane((v), (src)) /* src wave-uniform */
+/* index arithmetic on small non-negative numbers: v_mul_u32_u24 runs at full rate, the 32-bit v_mul_lo_u32 /
+   v_mul_hi at a quarter of it (what the compiler emits when it cannot see that an index is small) */
+#define LR2_MUL24(a, b) ((int)__umul24((unsigned)(a), (unsigned)(b)))
 #endif
 
 namespace sasa {
@@ -119,6 +123,9 @@ SASA_D int lr2_scan_max16(int v, int)
     return v;
 }
 #endif
+
+SASA_D int lr2_div9(int v) { return LR2_MUL24(v, 57) >> 9; }  /* v / 9 for 0 <= v < 69 */
+SASA_D int lr2_div3(int v) { return LR2_MUL24(v, 43) >> 7; }  /* v / 3 for 0 <= v < 44 */
 
 #ifndef LR2_STOP_AFTER /* dev only (tools/build_variant.sh): return after phase k, for instruction attribution */
 #define LR2_STOP_AFTER 99
@@ -431,7 +438,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     if (lane < 8) m.flags[lane] = 0;
     int my_cnt = 0; /* candidates of row `lane` (rows of atoms that do not lead a cell group count 0) */
     if (lane < 9 * TA) {
-        const int la = lane / 9, r = lane - 9 * la;
+        const int la = lr2_div9(lane), r = lane - 9 * la;
         int lo = 0, cnt = 0;
         if (la < na) { /* as tile_phase_load of sasa_kernels.h: three dependent round trips */
             const int p = p0 + la;
@@ -439,7 +446,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             const long long cf = a.s_cell[p];
             const int nx = a.grid[sid].nx, ny = a.grid[sid].ny;
             const int c = (int)(cf & 0xffffffffLL), fl = (int)(cf >> 32);
-            const int dy = (r % 3) - 1, dz = (r / 3) - 1;
+            const int dz = lr2_div3(r) - 1, dy = r - 3 * (dz + 1) - 1;
             const bool out = (dy < 0 && (fl & CELL_Y0)) || (dy > 0 && (fl & CELL_Y1)) ||
                              (dz < 0 && (fl & CELL_Z0)) || (dz > 0 && (fl & CELL_Z1));
             const int row = out ? c : c + nx * (dy + ny * dz);
@@ -465,7 +472,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     /* P1's work items: (candidate, up to LR2_P1_G atoms of the cell group the candidate belongs to); inclusive
        prefix of the item counts over the rows */
     if (my_cnt > 0) {
-        const int la = lane / 9;
+        const int la = lr2_div9(lane);
         int gs = 1;
         while (la + gs < na && m.acell[la + gs] == m.acell[la]) ++gs;
         my_cnt *= (gs + LR2_P1_G - 1) / LR2_P1_G;
@@ -499,10 +506,10 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                 q[j] = -1; la0[j] = 0; two[j] = 0;
                 if (base + j < per && fj < fend) {
                     while (fj >= m.cpre[t + 1]) ++t;
-                    const int lead = t / 9, gs = m.gsz[lead], hc = (gs + LR2_P1_G - 1) / LR2_P1_G;
+                    const int lead = lr2_div9(t), gs = m.gsz[lead], hc = lr2_div3(gs + LR2_P1_G - 1);
                     const unsigned i = (unsigned)(fj - m.cpre[t]);
-                    const unsigned c = hc == 1 ? i : (hc == 2 ? i >> 1 : (i * 0xaaabu) >> 17); /* i / hc, hc <= 3 (gs <= 7) */
-                    const int h = (int)(i - c * (unsigned)hc);
+                    const unsigned c = hc == 1 ? i : (hc == 2 ? i >> 1 : (unsigned)LR2_MUL24(i, 0xaaabu) >> 17); /* i / hc, hc <= 3 (gs <= 7); i < 2^15 */
+                    const int h = (int)i - LR2_MUL24(c, hc);
                     q[j] = m.rowlo[t] + (int)c;
                     la0[j] = lead + LR2_P1_G * h;
                     two[j] = gs - LR2_P1_G * h < LR2_P1_G ? gs - LR2_P1_G * h : LR2_P1_G; /* atoms of this item */
@@ -620,7 +627,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                 rank += kk.e < kme ? 1 : 0;
             }
             Rec24 rc; rc.a = r_a[r]; rc.b = r_b[r]; rc.beta = r_beta[r];
-            m.rec[o + rank] = rc;
+            *(Rec24 *)((char *)m.rec + LR2_MUL24(o + rank, 24)) = rc;
         }
         if (lane < TA && (m.acnt[lane] & 1)) { /* padding record: cos(alpha) huge, never an arc */
             Rec24 rc; rc.a = 0; rc.b = 1e300; rc.beta = 0;
@@ -639,12 +646,12 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         double z = zi - Ri - 0.5 * delta;
         for (int s = 0; s < ns; ++s) {
             z += delta;
-            m.it_tc[lane * ns + s] = z - zi; /* exact; |z - zi| is the reference's di (:308) */
+            m.it_tc[LR2_MUL24(lane, ns) + s] = z - zi; /* exact; |z - zi| is the reference's di (:308) */
         }
     }
     LR2_SYNC();
     for (int it = lane; it < items; it += LR2_LANES) {
-        int la = (int)(((float)it + 0.5f) * inv_ns), s = it - la * ns; /* it / ns without the integer-division sequence */
+        int la = (int)(((float)it + 0.5f) * inv_ns), s = it - LR2_MUL24(la, ns); /* it / ns without the integer-division sequence */
         if (s < 0) { --la; s += ns; } else if (s >= ns) { ++la; s -= ns; }
         const double Ri = m.atom[la].w, t = m.it_tc[it];
         const double A = Ri * Ri - t * t; /* Ri'^2, ref: src/sasa_lr.c:309 */
@@ -658,7 +665,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             for (int wi = 0; wi < mw; ++wi) {
                 unsigned w = 0;
                 const int k1 = nn - 32 * wi < 32 ? nn - 32 * wi : 32;
-                const Rec24 *R = m.rec + o + 32 * wi;
+                const Rec24 *R = (const Rec24 *)((const char *)m.rec + LR2_MUL24(o + 32 * wi, 24));
                 int k = k1 - 2; /* from the end: neighbor k lands on bit k */
                 if (k1 > 0 && (k1 & 2)) {
                     const double c0 = fma(t, R[k].a, R[k].b) * h2, c1 = fma(t, R[k + 1].a, R[k + 1].b) * h2;
@@ -677,7 +684,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                     w = LR2_SHIFT_IN_LT1(w, c1);
                     w = LR2_SHIFT_IN_LT1(w, c0);
                 }
-                m.it_mask[it * mw + wi] = w;
+                m.it_mask[LR2_MUL24(it, mw) + wi] = w;
                 cnt += LR2_POPC32(w);
             }
             if (cmin <= -1.0) cnt = 0; /* circle i inside a neighbor's: buried (ref: :327-330) */
@@ -707,7 +714,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         for (int it = lane; it < items; it += LR2_LANES) {
             const unsigned qt = m.qtmp[it];
             int la = (int)(((float)it + 0.5f) * inv_ns);
-            { const int s = it - la * ns; if (s < 0) --la; else if (s >= ns) ++la; }
+            { const int s = it - LR2_MUL24(la, ns); if (s < 0) --la; else if (s >= ns) ++la; }
             if (qt != 0xffffu) m.queue[m.hist[qt >> 10] + (qt & 1023u)] = (unsigned short)(it | (la << 10));
         }
     }
@@ -737,9 +744,9 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         my = e_ == LR2_NONE ? LR2_NONE : (e_ & 1023); w = 0; wleft = 0;                            \
         if (my != LR2_NONE) {                                                                      \
             la = e_ >> 10;                                                                         \
-            R = m.rec + m.aoff[la]; t = m.it_tc[my];                                               \
+            R = (const Rec24 *)((const char *)m.rec + LR2_MUL24(m.aoff[la], 24)); t = m.it_tc[my];  \
             { const double Ri_ = m.atom[la].w; double g_; sqrt_rh(Ri_ * Ri_ - t * t, g_, h2); } /* as P4: bit for bit */ \
-            mk = m.it_mask + my * mw; w = *mk; wleft = mw - 1;                                     \
+            mk = m.it_mask + LR2_MUL24(my, mw); w = *mk; wleft = mw - 1;                           \
             LR2_NEXT_WORD();                                                                       \
         }                                                                                          \
     } while (0)
@@ -783,7 +790,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     const bool deep = LR2_BALLOT(maxd - 2 > a.ds) != 0; /* an arc stack column was too short: the tile is redone */
     if (!deep && lane < na) {
         double s = 0;
-        for (int k = 0; k < ns; ++k) s += m.it_tc[lane * ns + k]; /* slice order, ref: :305-361 */
+        for (int k = 0; k < ns; ++k) s += m.it_tc[LR2_MUL24(lane, ns) + k]; /* slice order, ref: :305-361 */
         a.sasa[m.sorig[lane]] = s;
     }
     LR2_SYNC();
