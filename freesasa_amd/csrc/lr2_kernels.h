@@ -404,7 +404,7 @@ SASA_D void lr2_overflow(const Lr2Args &a, int p0, int na, int err_code)
         const int w = SASA_ATOMIC_ADD_GLB(ovf_count, 1);
         ovf_items[w] = (long long)p0 | ((long long)na << 32);
     } else {
-        SASA_ATOMIC_MAX_GLB(&a.status[ST_ERROR], err_code); /* the last launch: nothing left to hand the work to */
+        SASA_ATOMIC_MAX_GLB(&LR2_COLD(a, status)[ST_ERROR], err_code); /* the last launch: nothing left to hand the work to */
     }
 }
 
@@ -421,6 +421,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     LR2_COUNT(0, 1);
 
     /* ------------------------------------------------------------ P0 load */
+    const long long *const s_cell = LR2_COLD(a, s_cell); /* (P0's own pointers: read here, once per tile) */
     if (lane < TA) {
         Quad q; q.x = q.y = q.z = 0; q.w = 1;
         double del = 0;
@@ -429,8 +430,8 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             const int p = p0 + lane;
             q.x = a.sx[p]; q.y = a.sy[p]; q.z = a.sz[p]; q.w = a.sr[p];
             del = 2 * q.w / ns; /* ref: src/sasa_lr.c:304 */
-            cell = (int)(a.s_cell[p] & 0xffffffffLL);
-            so = a.s_orig[p];
+            cell = (int)(s_cell[p] & 0xffffffffLL);
+            so = LR2_COLD(a, s_orig)[p];
         }
         m.atom[lane] = q; m.adel[lane] = del; m.acell[lane] = cell; m.sorig[lane] = so;
         m.acnt[lane] = 0;
@@ -442,20 +443,22 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         int lo = 0, cnt = 0;
         if (la < na) { /* as tile_phase_load of sasa_kernels.h: three dependent round trips */
             const int p = p0 + la;
-            const int sid = a.s_struct[p];
-            const long long cf = a.s_cell[p];
-            const int nx = a.grid[sid].nx, ny = a.grid[sid].ny;
+            const int sid = LR2_COLD(a, s_struct)[p];
+            const long long cf = s_cell[p];
+            const GridS *const grid = LR2_COLD(a, grid);
+            const int nx = grid[sid].nx, ny = grid[sid].ny;
             const int c = (int)(cf & 0xffffffffLL), fl = (int)(cf >> 32);
             const int dz = lr2_div3(r) - 1, dy = r - 3 * (dz + 1) - 1;
             const bool out = (dy < 0 && (fl & CELL_Y0)) || (dy > 0 && (fl & CELL_Y1)) ||
                              (dz < 0 && (fl & CELL_Z0)) || (dz > 0 && (fl & CELL_Z1));
             const int row = out ? c : c + nx * (dy + ny * dz);
             const int x_lo = row - ((fl & CELL_X0) ? 0 : 1), x_hi = row + ((fl & CELL_X1) ? 0 : 1);
-            const int s0 = a.cell_start[x_lo], s1 = a.cell_start[x_hi + 1];
+            const int *const cell_start = LR2_COLD(a, cell_start);
+            const int s0 = cell_start[x_lo], s1 = cell_start[x_hi + 1];
             lo = out ? 0 : s0;
             cnt = out ? 0 : s1 - s0;
             /* the atoms of a tile are consecutive in cell order: atoms of one cell form a group */
-            const bool leads = la == 0 || (int)(a.s_cell[p - 1] & 0xffffffffLL) != c;
+            const bool leads = la == 0 || (int)(s_cell[p - 1] & 0xffffffffLL) != c;
             my_cnt = leads ? cnt : 0;
         }
         m.rowlo[lane] = lo;
@@ -543,7 +546,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                         m.tag[slot] = (unsigned short)((unsigned)la | ((unsigned)sa << 3)); /* la < 8, sa < 2^13 */
                         if (a.hooks & 2) { /* (uniform) test hook: the neighbor lists themselves */
                             const int cap = LR2_COLD(a, nb_cap);
-                            if (sa < cap) LR2_COLD(a, nb_out)[(size_t)m.sorig[la] * cap + sa] = a.s_orig[q[j]];
+                            if (sa < cap) LR2_COLD(a, nb_out)[(size_t)m.sorig[la] * cap + sa] = LR2_COLD(a, s_orig)[q[j]];
                         }
                     }
                     nh += LR2_POPC64(hm);
@@ -577,7 +580,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             if (nn_max > wg_max_nn) wg_max_nn = nn_max;
             if (sample) { /* demand histogram for the next batch's pool size: 1 tile in 32 of the main launch */
                 const int need = total / hist_bin_width(TA);
-                SASA_ATOMIC_ADD_GLB(&a.status[ST_HIST + (need < 63 ? need : 63)], 1);
+                SASA_ATOMIC_ADD_GLB(&LR2_COLD(a, status)[ST_HIST + (need < 63 ? need : 63)], 1);
             }
         }
     }
@@ -791,7 +794,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     if (!deep && lane < na) {
         double s = 0;
         for (int k = 0; k < ns; ++k) s += m.it_tc[LR2_MUL24(lane, ns) + k]; /* slice order, ref: :305-361 */
-        a.sasa[m.sorig[lane]] = s;
+        LR2_COLD(a, sasa)[m.sorig[lane]] = s; /* (the pointer is read here, once per tile) */
     }
     LR2_SYNC();
     LR2_MARK(7);
