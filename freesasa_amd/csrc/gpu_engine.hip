@@ -630,6 +630,7 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
     la.n_atoms = n; la.n_tiles = n_tiles; la.TA = cfg.TA; la.ns = resolution;
     la.pool = cfg.pool; la.mw = cfg.mw; la.ds = cfg.ds; la.refill = cfg.refill;
     la.sasa = d_sasa; la.status = (int *)c->status.p;
+    la.inv_ns = 1.0 / (double)resolution;
     la.ovf_items = (long long *)c->ovf_tiles.p;
     la.ovf_count = (int *)c->status.p + ST_OVF2_TILES;
     la.split_count = (int *)c->status.p + ST_SPLIT;

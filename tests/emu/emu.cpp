@@ -268,7 +268,7 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
         memset(&la, 0, sizeof la);
         la.sx = pa.sx; la.sy = pa.sy; la.sz = pa.sz; la.sr = pa.sr; la.s_orig = pa.s_orig; la.s_struct = pa.s_struct;
         la.s_cell = pa.s_cell; la.grid = pa.grid; la.cell_start = pa.cell_start; la.n_atoms = n; la.n_tiles = n_tiles2;
-        la.TA = c2.TA; la.ns = resolution; la.pool = c2.pool; la.mw = c2.mw; la.ds = c2.ds; la.refill = c2.refill;
+        la.TA = c2.TA; la.ns = resolution; la.pool = c2.pool; la.mw = c2.mw; la.ds = c2.ds; la.refill = c2.refill; la.inv_ns = 1.0 / (double)resolution;
         la.sasa = sasa; la.status = status.data();
         /* main launch: a tile that does not fit is split in place; halves that still do not fit go to the list */
         la.ovf_items = ovf2x.data(); la.ovf_count = status.data() + ST_OVF2_TILES; la.split_count = status.data() + ST_SPLIT;
