@@ -257,6 +257,8 @@ __global__ __launch_bounds__(B) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) v
 /* Second-generation L&R kernel (lr2_kernels.h): one wave per tile.  RMAX = rounds of pair records a
  * lane keeps in registers (2-4: main launch, by the pool; 6: second launch); WPE = waves per SIMD the register
  * allocation is capped for. */
+/* NOTE: Lr2Args must stay the ONLY parameter of this kernel, at offset 0 of the kernel-argument segment: the tile
+ * body reads its rarely used fields from there (LR2_COLD in lr2_kernels.h). */
 template <int RMAX, int TIER, int WPE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lr2_tile(Lr2Args a)
 {
