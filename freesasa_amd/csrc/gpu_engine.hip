@@ -339,7 +339,7 @@ struct freesasa_gpu_ctx {
     DevBuf offsets, grid, ncells, sid, cell_of, rank, cell_start, blk_sums;
     DevBuf chunk_struct, chunk_begin, chunk_len, struct_chunk0, bpart;
     int n_chunks = 0;
-    DevBuf sx, sy, sz, sr, s_orig, s_cell, s_struct;
+    DevBuf sq, s_orig, s_cell, s_struct;
     DevBuf status, ovf_tiles, ovf_tiles2, ovf_atoms, unit_pts, slab, seg;
     std::vector<int64_t> offsets_host; /* last uploaded offsets */
     std::vector<double> unit_host;     /* last uploaded S&R unit points */
@@ -455,7 +455,7 @@ extern "C" void freesasa_gpu_ctx_destroy(freesasa_gpu_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->chunk_struct, &c->chunk_begin, &c->chunk_len, &c->struct_chunk0, &c->bpart, &c->offsets, &c->grid, &c->ncells, &c->sid, &c->cell_of, &c->rank, &c->cell_start,
-                     &c->blk_sums, &c->sx, &c->sy, &c->sz, &c->sr, &c->s_orig, &c->s_cell, &c->s_struct,
+                     &c->blk_sums, &c->sq, &c->s_orig, &c->s_cell, &c->s_struct,
                      &c->status, &c->ovf_tiles, &c->ovf_tiles2, &c->ovf_atoms, &c->unit_pts, &c->slab, &c->seg,
                      &c->h_xyz, &c->h_radii, &c->h_sasa, &c->h_counts, &c->h_totals};
     for (DevBuf *b : all)
@@ -626,7 +626,7 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
 
     Lr2Args la;
     memset(&la, 0, sizeof la);
-    la.sx = pa.sx; la.sy = pa.sy; la.sz = pa.sz; la.sr = pa.sr;
+    la.sq = pa.sq;
     la.s_orig = pa.s_orig; la.s_struct = pa.s_struct; la.s_cell = pa.s_cell;
     la.grid = pa.grid; la.cell_start = pa.cell_start;
     la.n_atoms = n; la.n_tiles = n_tiles; la.TA = cfg.TA; la.ns = resolution;
@@ -673,7 +673,7 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
         if (ensure(c, c->slab, stride * SASA_FB_BLOCKS)) return -1;
         TileArgs tf;
         memset(&tf, 0, sizeof tf);
-        tf.sx = pa.sx; tf.sy = pa.sy; tf.sz = pa.sz; tf.sr = pa.sr;
+        tf.sq = pa.sq;
         tf.s_orig = pa.s_orig; tf.s_cell = pa.s_cell; tf.s_struct = pa.s_struct;
         tf.grid = pa.grid; tf.cell_start = pa.cell_start;
         tf.n_atoms = n; tf.n_tiles = n; tf.TA = 1; tf.n_res = resolution; tf.tab = fb.tab;
@@ -722,8 +722,7 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
     /* workspace */
     if (ensure(c, c->offsets, sizeof(int64_t) * ((size_t)n_structs + 1)) || ensure(c, c->grid, sizeof(GridS) * (size_t)n_structs) ||
         ensure(c, c->ncells, sizeof(long long) * ((size_t)n_structs + 1)) || ensure(c, c->sid, 4 * nb) ||
-        ensure(c, c->cell_of, 8 * nb) || ensure(c, c->rank, 4 * nb) || ensure(c, c->sx, 8 * nb) ||
-        ensure(c, c->sy, 8 * nb) || ensure(c, c->sz, 8 * nb) || ensure(c, c->sr, 8 * nb) ||
+        ensure(c, c->cell_of, 8 * nb) || ensure(c, c->rank, 4 * nb) || ensure(c, c->sq, 32 * nb) ||
         ensure(c, c->s_orig, 4 * nb) || ensure(c, c->s_cell, 8 * nb) || ensure(c, c->s_struct, 4 * nb) ||
         ensure(c, c->status, sizeof(int) * ST_WORDS))
         return -1;
@@ -767,7 +766,7 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
     pa.chunk_len = (const int *)c->chunk_len.p; pa.struct_chunk0 = (const int *)c->struct_chunk0.p; pa.bpart = (double *)c->bpart.p;
     pa.grid = (GridS *)c->grid.p; pa.ncells = (long long *)c->ncells.p;
     pa.sid = (int *)c->sid.p; pa.cell_of = (long long *)c->cell_of.p; pa.rank = (int *)c->rank.p;
-    pa.sx = (double *)c->sx.p; pa.sy = (double *)c->sy.p; pa.sz = (double *)c->sz.p; pa.sr = (double *)c->sr.p;
+    pa.sq = (Quad *)c->sq.p;
     pa.s_orig = (int *)c->s_orig.p; pa.s_cell = (long long *)c->s_cell.p; pa.s_struct = (int *)c->s_struct.p;
     pa.status = (int *)c->status.p;
     pa.occ_stride = c->hint_res[lr ? 0 : 1] == resolution ? 0 : (n / 256 > 0 ? n / 256 : 1);
@@ -850,7 +849,7 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
 
     TileArgs ta;
     memset(&ta, 0, sizeof ta);
-    ta.sx = pa.sx; ta.sy = pa.sy; ta.sz = pa.sz; ta.sr = pa.sr;
+    ta.sq = pa.sq;
     ta.s_orig = pa.s_orig; ta.s_cell = pa.s_cell; ta.s_struct = pa.s_struct;
     ta.grid = pa.grid; ta.cell_start = pa.cell_start;
     ta.n_atoms = n; ta.n_tiles = n_tiles; ta.TA = cfg.TA; ta.n_res = resolution; ta.tab = cfg.tab;

@@ -150,7 +150,7 @@ SASA_D int lr2_div3(int v) { return LR2_MUL24(v, 43) >> 7; }  /* v / 3 for 0 <= 
 #define LR2_NONE 0xffff
 
 struct Lr2Args {
-    const double *sx, *sy, *sz, *sr;
+    const Quad *sq;
     const int *s_orig, *s_struct;
     const long long *s_cell;
     const GridS *grid;
@@ -439,7 +439,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         int cell = -1 - lane, so = 0;
         if (lane < na) {
             const int p = p0 + lane;
-            q.x = a.sx[p]; q.y = a.sy[p]; q.z = a.sz[p]; q.w = a.sr[p];
+            q = a.sq[p];
             del = lr2_div_ns(2 * q.w, (double)ns, LR2_COLD(a, inv_ns)); /* = 2 Ri / ns, ref: src/sasa_lr.c:304 */
             cell = (int)(s_cell[p] & 0xffffffffLL);
             so = LR2_COLD(a, s_orig)[p];
@@ -531,7 +531,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             }
             for (int j = 0; j < LR2_NB_UNROLL; ++j) {
                 const unsigned u = (unsigned)(q[j] < 0 ? 0 : q[j]);
-                x[j] = a.sx[u]; y[j] = a.sy[u]; z[j] = a.sz[u]; rq[j] = a.sr[u];
+                { const Quad v = a.sq[u]; x[j] = v.x; y[j] = v.y; z[j] = v.z; rq[j] = v.w; }
             }
             for (int g = 0; g < LR2_P1_G; ++g) {
                 bool hit[LR2_NB_UNROLL];

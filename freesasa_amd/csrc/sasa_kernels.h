@@ -139,6 +139,7 @@ struct GridS {
 /* ------------------------------------------------------------------------------------
  * K1..K5: cell-sort pipeline
  * ---------------------------------------------------------------------------------- */
+struct __attribute__((aligned(16))) Quad { double x, y, z, w; };
 struct PipeArgs {
     const double *xyz;      /* [3*n_atoms] x1,y1,z1,...   (ref layout: src/coord.h:26-38) */
     const double *radii;    /* [n_atoms] atom radii WITHOUT probe; shared_radii: ONE structure's radii, used by every structure */
@@ -168,7 +169,8 @@ struct PipeArgs {
     int *cell_start; /* [total_cells+1]: histogram, then exclusive scan */
     int *blk_sums;   /* scan scratch */
     /* per atom, cell-sorted order */
-    double *sx, *sy, *sz, *sr; /* sr = radius + probe (ref: src/sasa_lr.c:136, sasa_sr.c:144) */
+    Quad *sq; /* (x, y, z, radius + probe) (ref: src/sasa_lr.c:136, sasa_sr.c:144): one 32-byte record per atom - two
+                 16-byte accesses where four arrays took four, one pointer where they took four */
     int *s_orig, *s_struct;
     long long *s_cell; /* cell_of of the sorted atom */
     int *status;
@@ -456,10 +458,10 @@ SASA_D void scatter_atom(const PipeArgs &a, int i)
     const long long cf = a.cell_of[i];
     const int c = (int)(cf & 0xffffffffLL);
     const int p = a.cell_start[c] + a.rank[i];
-    a.sx[p] = a.xyz[3 * i];
-    a.sy[p] = a.xyz[3 * i + 1];
-    a.sz[p] = a.xyz[3 * i + 2];
-    a.sr[p] = a.radii[a.shared_radii ? i - a.offsets[a.sid[i]] : i] + a.probe; /* ref: src/sasa_lr.c:136, src/sasa_sr.c:144 */
+    Quad v;
+    v.x = a.xyz[3 * i]; v.y = a.xyz[3 * i + 1]; v.z = a.xyz[3 * i + 2];
+    v.w = a.radii[a.shared_radii ? i - a.offsets[a.sid[i]] : i] + a.probe; /* ref: src/sasa_lr.c:136, src/sasa_sr.c:144 */
+    a.sq[p] = v;
     a.s_orig[p] = i;
     if (a.occ_stride > 0 && i % a.occ_stride == 0) { /* ~256 density samples, only while the context has no demand history */
         SASA_ATOMIC_ADD_GLB(&a.status[ST_OCC_SUM], a.cell_start[c + 1] - a.cell_start[c]);
@@ -475,7 +477,7 @@ SASA_D void scatter_atom(const PipeArgs &a, int i)
 struct Arc { double s, e; };
 
 struct TileArgs {
-    const double *sx, *sy, *sz, *sr;
+    const Quad *sq;
     const int *s_orig, *s_struct;
     const long long *s_cell;
     const GridS *grid;
@@ -510,7 +512,6 @@ struct TileArgs {
  *   S&R: x = x_j, y = y_j,                       z = z_j,       w = R_j^2
  * In the L&R pool every atom's list is padded to an even number of records with a dummy whose
  * cos(alpha) is huge (lr_padding: it never cuts an arc) so the screening loop runs 2 neighbors per trip. */
-struct __attribute__((aligned(16))) Quad { double x, y, z, w; };
 struct TileMem {
     double *ax, *ay, *az, *aR; /* [TA] tile atoms */
     int *acnt;                 /* [TA] neighbors found */
@@ -605,8 +606,8 @@ SASA_D void tile_phase_load(const TileArgs &a, TileMem &m, int tile, int tid, in
     const int na = tile_atoms(a, tile), p0 = tile_first_atom(a, tile);
     if (tid < a.TA) {
         if (tid < na) {
-            m.ax[tid] = a.sx[p0 + tid]; m.ay[tid] = a.sy[p0 + tid];
-            m.az[tid] = a.sz[p0 + tid]; m.aR[tid] = a.sr[p0 + tid];
+            const Quad v = a.sq[p0 + tid];
+            m.ax[tid] = v.x; m.ay[tid] = v.y; m.az[tid] = v.z; m.aR[tid] = v.w;
         } else {
             m.ax[tid] = m.ay[tid] = m.az[tid] = 0; m.aR[tid] = 1;
         }
@@ -687,7 +688,7 @@ SASA_D void tile_phase_neighbors(const TileArgs &a, TileMem &m, int tile, int ti
         }
         for (int j = 0; j < SASA_NB_UNROLL; ++j) {
             const unsigned u = (unsigned)q[j]; /* 32-bit offset from a uniform base: no 64-bit address per load */
-            x[j] = a.sx[u]; y[j] = a.sy[u]; z[j] = a.sz[u]; rq[j] = a.sr[u];
+            { const Quad v = a.sq[u]; x[j] = v.x; y[j] = v.y; z[j] = v.z; rq[j] = v.w; }
         }
         for (int j = 0; j < SASA_NB_UNROLL; ++j) nb_test(a, m, la, p, q[j], xi, yi, zi, ri, x[j], y[j], z[j], rq[j]);
     }
@@ -872,7 +873,7 @@ SASA_D void lr_phase_beta(const TileArgs &a, TileMem &m, int tid, int B, bool bu
         const int k = gp - m.aoff[la];
         if (k >= m.acnt[la]) { m.tb[gp] = INFINITY; continue; } /* padding slot: ranks behind everything */
         const int q = m.idx[la * a.cap_idx + k];
-        const double xd = a.sx[q] - m.ax[la], yd = a.sy[q] - m.ay[la]; /* ref: src/nb.c:445-448 */
+        const double xd = a.sq[q].x - m.ax[la], yd = a.sq[q].y - m.ay[la]; /* ref: src/nb.c:445-448 */
         const double beta = atan2_fast(yd, xd) + SASA_PI;
         m.tb[gp] = beta;
         if (bucket) SASA_ATOMIC_ADD_LDS(&m.hist[la * LR_NBUCKET + lr_bucket(beta)], 1);
@@ -903,7 +904,8 @@ SASA_D Quad lr_record_of(double xq, double yq, double zq, double rj, double xi, 
 }
 SASA_D Quad lr_record(const TileArgs &a, int q, double xi, double yi, double beta)
 {
-    return lr_record_of(a.sx[q], a.sy[q], a.sz[q], a.sr[q], xi, yi, beta);
+    const Quad v = a.sq[q];
+    return lr_record_of(v.x, v.y, v.z, v.w, xi, yi, beta);
 }
 /* padding slot of an odd-length list: a record whose c is huge, so it never cuts an arc */
 SASA_D Quad lr_padding() { Quad d; d.x = 0; d.y = 1e300; d.z = 1; d.w = 0; return d; }
@@ -937,7 +939,8 @@ SASA_D void lr_phase_rank(const TileArgs &a, TileMem &m, int tid, int B)
         if (k >= nn) { m.pq[gp] = lr_padding(); continue; }
         /* the neighbor's coordinates are requested before the ranking loop and used after it */
         const unsigned q = (unsigned)m.idx[la * a.cap_idx + k];
-        const double xq = a.sx[q], yq = a.sy[q], zq = a.sz[q], rq = a.sr[q];
+        const Quad vq = a.sq[q];
+        const double xq = vq.x, yq = vq.y, zq = vq.z, rq = vq.w;
         const double beta = m.tb[gp];
         int rank = 0;
         /* Order by (beta, list position) with ONE comparison per element: the list position replaces
@@ -1332,9 +1335,10 @@ SASA_D void sr_phase_pairs(const TileArgs &a, TileMem &m, int tid, int B)
         while (m.aoff[la + 1] <= gp) ++la;
         const int o = m.aoff[la], nn = m.aoff[la + 1] - o;
         const int q = m.idx[la * a.cap_idx + (gp - o)];
-        const double rj = a.sr[q];
+        const Quad vj = a.sq[q];
+        const double rj = vj.w;
         Quad rec;
-        rec.x = a.sx[q]; rec.y = a.sy[q]; rec.z = a.sz[q];
+        rec.x = vj.x; rec.y = vj.y; rec.z = vj.z;
         rec.w = rj * rj; /* ref: src/sasa_sr.c:146 */
         /* Neighbors whose sphere hides a large cap of atom i go to the FRONT of its list, the others
            to the back: the point test is an OR over neighbors (any order gives the same counts),
