@@ -339,7 +339,7 @@ struct freesasa_gpu_ctx {
     DevBuf offsets, grid, ncells, sid, cell_of, rank, cell_start, blk_sums;
     DevBuf chunk_struct, chunk_begin, chunk_len, struct_chunk0, bpart;
     int n_chunks = 0;
-    DevBuf sq, s_orig, s_cell, s_struct;
+    DevBuf sq, s_idx;
     DevBuf status, ovf_tiles, ovf_tiles2, ovf_atoms, unit_pts, slab, seg;
     std::vector<int64_t> offsets_host; /* last uploaded offsets */
     std::vector<double> unit_host;     /* last uploaded S&R unit points */
@@ -455,7 +455,7 @@ extern "C" void freesasa_gpu_ctx_destroy(freesasa_gpu_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->chunk_struct, &c->chunk_begin, &c->chunk_len, &c->struct_chunk0, &c->bpart, &c->offsets, &c->grid, &c->ncells, &c->sid, &c->cell_of, &c->rank, &c->cell_start,
-                     &c->blk_sums, &c->sq, &c->s_orig, &c->s_cell, &c->s_struct,
+                     &c->blk_sums, &c->sq, &c->s_idx,
                      &c->status, &c->ovf_tiles, &c->ovf_tiles2, &c->ovf_atoms, &c->unit_pts, &c->slab, &c->seg,
                      &c->h_xyz, &c->h_radii, &c->h_sasa, &c->h_counts, &c->h_totals};
     for (DevBuf *b : all)
@@ -627,7 +627,7 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
     Lr2Args la;
     memset(&la, 0, sizeof la);
     la.sq = pa.sq;
-    la.s_orig = pa.s_orig; la.s_struct = pa.s_struct; la.s_cell = pa.s_cell;
+    la.s_idx = pa.s_idx;
     la.grid = pa.grid; la.cell_start = pa.cell_start;
     la.n_atoms = n; la.n_tiles = n_tiles; la.TA = cfg.TA; la.ns = resolution;
     la.pool = cfg.pool; la.mw = cfg.mw; la.ds = cfg.ds; la.refill = cfg.refill;
@@ -674,7 +674,7 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
         TileArgs tf;
         memset(&tf, 0, sizeof tf);
         tf.sq = pa.sq;
-        tf.s_orig = pa.s_orig; tf.s_cell = pa.s_cell; tf.s_struct = pa.s_struct;
+        tf.s_idx = pa.s_idx;
         tf.grid = pa.grid; tf.cell_start = pa.cell_start;
         tf.n_atoms = n; tf.n_tiles = n; tf.TA = 1; tf.n_res = resolution; tf.tab = fb.tab;
         tf.sasa = d_sasa; tf.lr = 1; tf.status = (int *)c->status.p;
@@ -723,7 +723,7 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
     if (ensure(c, c->offsets, sizeof(int64_t) * ((size_t)n_structs + 1)) || ensure(c, c->grid, sizeof(GridS) * (size_t)n_structs) ||
         ensure(c, c->ncells, sizeof(long long) * ((size_t)n_structs + 1)) || ensure(c, c->sid, 4 * nb) ||
         ensure(c, c->cell_of, 8 * nb) || ensure(c, c->rank, 4 * nb) || ensure(c, c->sq, 32 * nb) ||
-        ensure(c, c->s_orig, 4 * nb) || ensure(c, c->s_cell, 8 * nb) || ensure(c, c->s_struct, 4 * nb) ||
+        ensure(c, c->s_idx, 16 * nb) ||
         ensure(c, c->status, sizeof(int) * ST_WORDS))
         return -1;
 
@@ -767,7 +767,7 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
     pa.grid = (GridS *)c->grid.p; pa.ncells = (long long *)c->ncells.p;
     pa.sid = (int *)c->sid.p; pa.cell_of = (long long *)c->cell_of.p; pa.rank = (int *)c->rank.p;
     pa.sq = (Quad *)c->sq.p;
-    pa.s_orig = (int *)c->s_orig.p; pa.s_cell = (long long *)c->s_cell.p; pa.s_struct = (int *)c->s_struct.p;
+    pa.s_idx = (SortIdx *)c->s_idx.p;
     pa.status = (int *)c->status.p;
     pa.occ_stride = c->hint_res[lr ? 0 : 1] == resolution ? 0 : (n / 256 > 0 ? n / 256 : 1);
 
@@ -850,7 +850,7 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
     TileArgs ta;
     memset(&ta, 0, sizeof ta);
     ta.sq = pa.sq;
-    ta.s_orig = pa.s_orig; ta.s_cell = pa.s_cell; ta.s_struct = pa.s_struct;
+    ta.s_idx = pa.s_idx;
     ta.grid = pa.grid; ta.cell_start = pa.cell_start;
     ta.n_atoms = n; ta.n_tiles = n_tiles; ta.TA = cfg.TA; ta.n_res = resolution; ta.tab = cfg.tab;
     ta.sasa = d_sasa; ta.counts = d_counts;

@@ -151,8 +151,7 @@ SASA_D int lr2_div3(int v) { return LR2_MUL24(v, 43) >> 7; }  /* v / 3 for 0 <= 
 
 struct Lr2Args {
     const Quad *sq;
-    const int *s_orig, *s_struct;
-    const long long *s_cell;
+    const SortIdx *s_idx;
     const GridS *grid;
     const int *cell_start;
     int n_atoms, n_tiles;
@@ -432,7 +431,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     LR2_COUNT(0, 1);
 
     /* ------------------------------------------------------------ P0 load */
-    const long long *const s_cell = LR2_COLD(a, s_cell); /* (P0's own pointers: read here, once per tile) */
+    const SortIdx *const s_idx = LR2_COLD(a, s_idx); /* (P0's own pointers: read here, once per tile) */
     if (lane < TA) {
         Quad q; q.x = q.y = q.z = 0; q.w = 1;
         double del = 0;
@@ -441,8 +440,9 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             const int p = p0 + lane;
             q = a.sq[p];
             del = lr2_div_ns(2 * q.w, (double)ns, LR2_COLD(a, inv_ns)); /* = 2 Ri / ns, ref: src/sasa_lr.c:304 */
-            cell = (int)(s_cell[p] & 0xffffffffLL);
-            so = LR2_COLD(a, s_orig)[p];
+            const SortIdx si = s_idx[p];
+            cell = (int)(si.cell & 0xffffffffLL);
+            so = si.orig;
         }
         m.atom[lane] = q; m.adel[lane] = del; m.acell[lane] = cell; m.sorig[lane] = so;
         m.acnt[lane] = 0;
@@ -454,8 +454,9 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         int lo = 0, cnt = 0;
         if (la < na) { /* as tile_phase_load of sasa_kernels.h: three dependent round trips */
             const int p = p0 + la;
-            const int sid = LR2_COLD(a, s_struct)[p];
-            const long long cf = s_cell[p];
+            const SortIdx si = s_idx[p];
+            const int sid = si.strct;
+            const long long cf = si.cell;
             const GridS *const grid = LR2_COLD(a, grid);
             const int nx = grid[sid].nx, ny = grid[sid].ny;
             const int c = (int)(cf & 0xffffffffLL), fl = (int)(cf >> 32);
@@ -469,7 +470,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             lo = out ? 0 : s0;
             cnt = out ? 0 : s1 - s0;
             /* the atoms of a tile are consecutive in cell order: atoms of one cell form a group */
-            const bool leads = la == 0 || (int)(s_cell[p - 1] & 0xffffffffLL) != c;
+            const bool leads = la == 0 || (int)(s_idx[p - 1].cell & 0xffffffffLL) != c;
             my_cnt = leads ? cnt : 0;
         }
         m.rowlo[lane] = lo;
@@ -557,7 +558,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                         m.tag[slot] = (unsigned short)((unsigned)la | ((unsigned)sa << 3)); /* la < 8, sa < 2^13 */
                         if (a.hooks & 2) { /* (uniform) test hook: the neighbor lists themselves */
                             const int cap = LR2_COLD(a, nb_cap);
-                            if (sa < cap) LR2_COLD(a, nb_out)[(size_t)m.sorig[la] * cap + sa] = LR2_COLD(a, s_orig)[q[j]];
+                            if (sa < cap) LR2_COLD(a, nb_out)[(size_t)m.sorig[la] * cap + sa] = LR2_COLD(a, s_idx)[q[j]].orig;
                         }
                     }
                     nh += LR2_POPC64(hm);

@@ -140,6 +140,9 @@ struct GridS {
  * K1..K5: cell-sort pipeline
  * ---------------------------------------------------------------------------------- */
 struct __attribute__((aligned(16))) Quad { double x, y, z, w; };
+/* what else a cell-sorted atom carries, one 16-byte record: its cell (batch-wide index | grid-border flags << 32,
+   as cell_of), its index in the caller's order, its structure */
+struct __attribute__((aligned(16))) SortIdx { long long cell; int orig, strct; };
 struct PipeArgs {
     const double *xyz;      /* [3*n_atoms] x1,y1,z1,...   (ref layout: src/coord.h:26-38) */
     const double *radii;    /* [n_atoms] atom radii WITHOUT probe; shared_radii: ONE structure's radii, used by every structure */
@@ -171,8 +174,7 @@ struct PipeArgs {
     /* per atom, cell-sorted order */
     Quad *sq; /* (x, y, z, radius + probe) (ref: src/sasa_lr.c:136, sasa_sr.c:144): one 32-byte record per atom - two
                  16-byte accesses where four arrays took four, one pointer where they took four */
-    int *s_orig, *s_struct;
-    long long *s_cell; /* cell_of of the sorted atom */
+    SortIdx *s_idx;
     int *status;
 };
 
@@ -462,13 +464,13 @@ SASA_D void scatter_atom(const PipeArgs &a, int i)
     v.x = a.xyz[3 * i]; v.y = a.xyz[3 * i + 1]; v.z = a.xyz[3 * i + 2];
     v.w = a.radii[a.shared_radii ? i - a.offsets[a.sid[i]] : i] + a.probe; /* ref: src/sasa_lr.c:136, src/sasa_sr.c:144 */
     a.sq[p] = v;
-    a.s_orig[p] = i;
     if (a.occ_stride > 0 && i % a.occ_stride == 0) { /* ~256 density samples, only while the context has no demand history */
         SASA_ATOMIC_ADD_GLB(&a.status[ST_OCC_SUM], a.cell_start[c + 1] - a.cell_start[c]);
         SASA_ATOMIC_ADD_GLB(&a.status[ST_OCC_N], 1);
     }
-    a.s_cell[p] = cf;
-    a.s_struct[p] = a.sid[i];
+    SortIdx si;
+    si.cell = cf; si.orig = i; si.strct = a.sid[i];
+    a.s_idx[p] = si;
 }
 
 /* ------------------------------------------------------------------------------------
@@ -478,8 +480,7 @@ struct Arc { double s, e; };
 
 struct TileArgs {
     const Quad *sq;
-    const int *s_orig, *s_struct;
-    const long long *s_cell;
+    const SortIdx *s_idx;
     const GridS *grid;
     const int *cell_start;
     int n_atoms;
@@ -624,8 +625,9 @@ SASA_D void tile_phase_load(const TileArgs &a, TileMem &m, int tile, int tid, in
             /* branch-free up to the last loads, so that s_struct and s_cell are fetched together and
                the chain is three round trips (s_struct -> grid -> cell_start), not four */
             const int p = p0 + la;
-            const int sid = a.s_struct[p];
-            const long long cf = a.s_cell[p];
+            const SortIdx si = a.s_idx[p];
+            const int sid = si.strct;
+            const long long cf = si.cell;
             const int nx = a.grid[sid].nx, ny = a.grid[sid].ny;
             const int c = (int)(cf & 0xffffffffLL), fl = (int)(cf >> 32);
             const int dy = (r % 3) - 1, dz = (r / 3) - 1;
@@ -1272,12 +1274,12 @@ SASA_D void lr_phase_store(const TileArgs &a, TileMem &m, int tile, int tid, int
         if (tid < na) {
             double s = 0;
             for (int k = 0; k < a.n_res; ++k) s += m.contrib[tid * a.n_res + k];
-            a.sasa[a.s_orig[p0 + tid]] = s;
+            a.sasa[a.s_idx[p0 + tid].orig] = s;
         }
     } else if (tid == 0) {
         double s = 0;
         for (int t = 0; t < B; ++t) s += m.contrib[t];
-        a.sasa[a.s_orig[p0]] = s;
+        a.sasa[a.s_idx[p0].orig] = s;
     }
 }
 
@@ -1447,7 +1449,7 @@ SASA_D void sr_phase_store(const TileArgs &a, TileMem &m, int tile, int tid)
     if (tid < na) {
         const double ri = m.aR[tid];
         const int n_surface = m.aexp[tid];
-        const int i = a.s_orig[p0 + tid];
+        const int i = a.s_idx[p0 + tid].orig;
         a.sasa[i] = (4.0 * SASA_PI * ri * ri * n_surface) / a.n_res; /* ref: src/sasa_sr.c:337 */
         if (a.counts) a.counts[i] = n_surface;
     }

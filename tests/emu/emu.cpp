@@ -176,8 +176,9 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
     const int PB = SASA_PIPE_B;
     std::vector<GridS> grid(n_structs);
     std::vector<long long> ncells(n_structs + 1);
-    std::vector<int> sid(n), rank(n), s_orig(n), s_struct(n), status(ST_WORDS, 0);
-    std::vector<long long> cell_of(n), s_cell(n);
+    std::vector<int> sid(n), rank(n), status(ST_WORDS, 0);
+    std::vector<long long> cell_of(n);
+    std::vector<SortIdx> s_idx(n);
     std::vector<Quad> sq(n);
 
     PipeArgs pa;
@@ -186,7 +187,7 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
     pa.probe = probe; pa.max_cells = 1LL << 28;
     pa.grid = grid.data(); pa.ncells = ncells.data(); pa.sid = sid.data(); pa.cell_of = cell_of.data();
     pa.rank = rank.data(); pa.sq = sq.data();
-    pa.s_orig = s_orig.data(); pa.s_cell = s_cell.data(); pa.s_struct = s_struct.data(); pa.status = status.data();
+    pa.s_idx = s_idx.data(); pa.status = status.data();
 
     /* chunk table, as gpu_engine.hip builds it */
     std::vector<int> cs, cl, sc0(n_structs + 1);
@@ -266,8 +267,8 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
         std::vector<int> ovf3(n + 8);
         Lr2Args la;
         memset(&la, 0, sizeof la);
-        la.sq = pa.sq; la.s_orig = pa.s_orig; la.s_struct = pa.s_struct;
-        la.s_cell = pa.s_cell; la.grid = pa.grid; la.cell_start = pa.cell_start; la.n_atoms = n; la.n_tiles = n_tiles2;
+        la.sq = pa.sq; la.s_idx = pa.s_idx;
+        la.grid = pa.grid; la.cell_start = pa.cell_start; la.n_atoms = n; la.n_tiles = n_tiles2;
         la.TA = c2.TA; la.ns = resolution; la.pool = c2.pool; la.mw = c2.mw; la.ds = c2.ds; la.refill = c2.refill; la.inv_ns = 1.0 / (double)resolution;
         la.sasa = sasa; la.status = status.data();
         /* main launch: a tile that does not fit is split in place; halves that still do not fit go to the list */
@@ -296,7 +297,7 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
             std::vector<char> slab(stride * fb_blocks + 64);
             TileArgs tf;
             memset(&tf, 0, sizeof tf);
-            tf.sq = pa.sq; tf.s_orig = pa.s_orig; tf.s_cell = pa.s_cell; tf.s_struct = pa.s_struct;
+            tf.sq = pa.sq; tf.s_idx = pa.s_idx;
             tf.grid = pa.grid; tf.cell_start = pa.cell_start; tf.n_atoms = n; tf.n_tiles = n; tf.TA = 1; tf.n_res = resolution; tf.tab = fb.tab;
             tf.sasa = sasa; tf.lr = 1; tf.status = status.data();
             tf.cap_idx = fb.cap_idx; tf.pool = fb.pool; tf.ds = fb.ds;
@@ -332,7 +333,7 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
     TileArgs ta;
     memset(&ta, 0, sizeof ta);
     ta.sq = pa.sq;
-    ta.s_orig = pa.s_orig; ta.s_cell = pa.s_cell; ta.s_struct = pa.s_struct;
+    ta.s_idx = pa.s_idx;
     ta.grid = pa.grid; ta.cell_start = pa.cell_start;
     ta.n_atoms = n; ta.n_tiles = n_tiles; ta.TA = cfg.TA; ta.n_res = resolution; ta.tab = cfg.tab;
     ta.unit_pts = unit_pts; ta.sasa = sasa; ta.counts = counts;
