@@ -486,12 +486,8 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     }
     /* P1's work items: (candidate, up to LR2_P1_G atoms of the cell group the candidate belongs to); inclusive
        prefix of the item counts over the rows */
-    if (my_cnt > 0) {
-        const int la = lr2_div9(lane);
-        int gs = 1;
-        while (la + gs < na && m.acell[la + gs] == m.acell[la]) ++gs;
-        my_cnt *= (gs + LR2_P1_G - 1) / LR2_P1_G;
-    }
+    LR2_SYNC();
+    if (my_cnt > 0) my_cnt *= lr2_div3(m.gsz[lr2_div9(lane)] + LR2_P1_G - 1); /* (rows of a group's leading atom only) */
     const int incl = lr2_scan_add(my_cnt, lane);
     if (lane == 0) m.cpre[0] = 0;
     if (lane < 9 * TA) m.cpre[lane + 1] = incl;
