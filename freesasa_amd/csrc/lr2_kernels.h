@@ -398,7 +398,7 @@ SASA_D double lr2_arc_kat(const double *arcs, const int *first, int k, Arc *stk,
 }
 
 #ifndef LR2_NB_UNROLL
-#define LR2_NB_UNROLL 2
+#define LR2_NB_UNROLL 3 /* candidates a lane has in flight per round of P1 (coils: three rounds per tile = one trip; measured 1 / 2 / 3: 3.59 / 3.63 / 3.58 ms per 3e6 atoms) */
 #endif
 #define LR2_P1_G 3 /* atoms of a cell group one work item of P1 tests its candidate against */
 
