@@ -637,11 +637,11 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
     la.ovf_count = (int *)c->status.p + ST_OVF2_TILES;
     la.split_count = (int *)c->status.p + ST_SPLIT;
 
-    int grid_main = ((n_tiles + 7) / 8) * 8;
-    if (grid_main > 147456) grid_main = 147456;
+    const int grid_all = ((n_tiles + 7) / 8) * 8;
+    int grid_main = grid_all > 147456 ? 147456 : grid_all;
     if (const char *e = getenv("FREESASA_AMD_GRID")) { /* tuning aid */
         const int g = atoi(e);
-        if (g >= 8 && g < grid_main) grid_main = (g / 8) * 8;
+        if (g >= 8) grid_main = g < grid_all ? (g / 8) * 8 : grid_all;
     }
     la.nn_out = c->dbg_nn; la.nb_out = c->dbg_nb; la.nb_cap = c->dbg_cap;
     la.hooks = (c->dbg_nn ? 1 : 0) | (c->dbg_nb ? 2 : 0);
