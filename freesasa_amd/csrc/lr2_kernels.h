@@ -356,9 +356,10 @@ SASA_D void lr2_sweep_step(bool have, double V, double ks, double ke, double &su
     /* straight-line: the lanes of a refill are at different depths, a branch would be taken by some of them anyway */
     covered = covered || (have && ks >= V); /* sorted behind the [V, 2pi] piece: covered, and so is everything after it */
     const bool live = have && !covered;
-    const double gap = ks - sup;
-    sum += live && sup < ks ? gap : 0.0;
-    sup = live && ke > sup ? ke : sup;
+    /* a component that does not count is one at -infinity: no gap in front of it, no end beyond sup */
+    const double s = live ? ks : -INFINITY, e = live ? ke : -INFINITY;
+    sum += SASA_MAX(s - sup, 0.0); /* = sup < s ? s - sup : 0 */
+    sup = SASA_MAX(sup, e);
 }
 SASA_D double lr2_sweep(const Lr2Union &u, const Arc *stk, int ds)
 {
@@ -380,7 +381,7 @@ SASA_D double lr2_sweep(const Lr2Union &u, const Arc *stk, int ds)
     }
     lr2_sweep_step(depth >= 2, V, u.bs, u.be, sum, sup, covered); /* the two in registers */
     lr2_sweep_step(depth >= 1, V, u.ts, top_e, sum, sup, covered);
-    sum += wrap && sup < Vw ? Vw - sup : 0.0;
+    sum += SASA_MAX((wrap ? Vw : -INFINITY) - sup, 0.0);
     sup = wrap ? SASA_TWOPI : sup;
     const double r = sum + SASA_TWOPI - sup; /* ref: :407 */
     return depth == 0 ? SASA_TWOPI : r;      /* ref: :392 */
