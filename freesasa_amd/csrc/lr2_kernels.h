@@ -595,6 +595,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     }
     LR2_SYNC();
     if (ovf) return 1; /* (uniform) */
+    const int mwt = (nn_max + 31) >> 5; /* mask words this tile's longest list needs (<= mw; one on most coil tiles) */
 
     LR2_STOP(2);
     LR2_MARK(2);
@@ -674,7 +675,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             sqrt_rh(A, Rip, h2); /* h2 = 1/(2 Ri') */
             const int o = m.aoff[la], nn = m.aoff[la + 1] - o;
             double cmin = 1.0;
-            for (int wi = 0; wi < mw; ++wi) {
+            for (int wi = 0; wi < mwt; ++wi) {
                 unsigned w = 0;
                 const int k1 = nn - 32 * wi < 32 ? nn - 32 * wi : 32;
                 const Rec24 *R = (const Rec24 *)((const char *)m.rec + LR2_MUL24(o + 32 * wi, 24));
@@ -748,7 +749,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         lr2_union_reset(u);
 /* on to the item's next mask word with a bit set: mw - 1 straight steps (mw is 2 unless lists are long) */
 #define LR2_NEXT_WORD()                                                                            \
-    for (int k_ = 1; k_ < mw; ++k_)                                                                \
+    for (int k_ = 1; k_ < mwt; ++k_)                                                               \
         if (w == 0 && wleft > 0) { ++mk; R += 32; --wleft; w = *mk; }
 #define LR2_FETCH(idx)                                                                             \
     do {                                                                                           \
@@ -758,7 +759,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             la = e_ >> 10;                                                                         \
             R = (const Rec24 *)((const char *)m.rec + LR2_MUL24(m.aoff[la], 24)); t = m.it_tc[my];  \
             { const double Ri_ = m.atom[la].w; double g_; sqrt_rh(Ri_ * Ri_ - t * t, g_, h2); } /* as P4: bit for bit */ \
-            mk = m.it_mask + LR2_MUL24(my, mw); w = *mk; wleft = mw - 1;                           \
+            mk = m.it_mask + LR2_MUL24(my, mw); w = *mk; wleft = mwt - 1;                          \
             LR2_NEXT_WORD();                                                                       \
         }                                                                                          \
     } while (0)
