@@ -272,7 +272,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 }
 __global__ __launch_bounds__(64) void k_lr2_arc_kat(const double *arcs, const int *first, int n_sets, double *out)
 {
-    __shared__ Arc stack[8 * 64];
+    __shared__ Arc2 stack[8 * 64];
     const int k = threadIdx.x;
     if (k < n_sets) out[k] = lr2_arc_kat(arcs, first, k, stack + k, 8);
 }

@@ -198,8 +198,12 @@ __device__ __forceinline__ const char *lr2_cold_arg(size_t off)
 #endif
 
 /* One neighbor record of P3..P6, 24 B: cos(alpha) of the arc the neighbor cuts at slice height t is
- * (b + a t) * 1/(2 Ri') (see lr2_record); beta = direction of the neighbor in the slice plane. */
-struct Rec24 { double a, b, beta; };
+ * (b + a t) * 1/(2 Ri') (see lr2_record); beta = direction of the neighbor in the slice plane.  Kept as two
+ * arrays: the coefficient pair (16 B, one ds_read_b128: 4 LDS cycles where the ds_read2_b64 a 24-byte record
+ * needs takes 8; MI355X_MICROARCH.md, LDS) and beta (8 B, read by the arc pass only). */
+struct __attribute__((aligned(16))) Ab16 { double a, b; };
+/* a component of the arc union, or two neighboring sort keys: 16 bytes at a 16-byte boundary (one ds_read_b128) */
+struct __attribute__((aligned(16))) Arc2 { double s, e; };
 
 /* LDS layout of one tile (byte offsets), shared by the host (launch size) and the device */
 struct Lr2Layout {
@@ -247,10 +251,11 @@ struct Lr2Mem {
     unsigned short *queue; /* [items] items with arcs, heaviest first: item | atom << 10 */
     unsigned short *qtmp;  /* [items] bin and arrival order of an item before the bins are laid out */
     Quad *hits;     /* [pool] (xd, yd, zd, Rj) of the neighbors found, in order of discovery */
-    Rec24 *rec;     /* [pool] records, sorted by beta inside each atom's list */
+    Ab16 *ab;       /* [pool] records, sorted by beta inside each atom's list: coefficients ... */
+    double *beta;   /* [pool] ... and direction */
     double *keys;   /* [pool] beta with the list position in its low mantissa bits */
     unsigned short *tag; /* [pool] atom (low 3 bits) and list position of a hit */
-    Arc *stack;     /* [ds][64] */
+    Arc2 *stack;     /* [ds][64] */
 };
 /* flags: 0 tile overflow, 1 stack overflow, 2 max neighbor count, 5 largest cell group */
 
@@ -268,12 +273,13 @@ SASA_D Lr2Mem lr2_carve(const Lr2Args &a, char *smem)
     m.it_mask = (unsigned *)(smem + L.o_mask);
     m.queue = (unsigned short *)(smem + L.o_queue);
     m.hits = (Quad *)(smem + L.o_rec);
-    m.rec = (Rec24 *)(smem + L.o_rec);
+    m.ab = (Ab16 *)(smem + L.o_rec);
+    m.beta = (double *)(smem + L.o_rec + 16 * a.pool); /* (the pool is even) */
     m.keys = (double *)(smem + L.o_r2);
     m.tag = (unsigned short *)(smem + L.o_tag);
     m.hist = (int *)(smem + L.o_r2);
     m.qtmp = (unsigned short *)(smem + L.o_r2 + 256);
-    m.stack = (Arc *)(smem + L.o_r2);
+    m.stack = (Arc2 *)(smem + L.o_r2);
     return m;
 }
 
@@ -321,7 +327,7 @@ SASA_D int lr2_med3(int v, int lo, int hi)
 #endif
 }
 /* maxd: the largest depth the lane has seen (a tile whose stack column was too short is redone) */
-SASA_D void lr2_union_step(double inf, double sup, Lr2Union &u, Arc *stk, int ds, int &maxd)
+SASA_D void lr2_union_step(double inf, double sup, Lr2Union &u, Arc2 *stk, int ds, int &maxd)
 {
     const bool fresh = inf > u.te; /* te = -inf while there is no component */
     const double mts = SASA_MIN(u.ts, inf), mte = SASA_MAX(u.te, sup);
@@ -329,7 +335,7 @@ SASA_D void lr2_union_step(double inf, double sup, Lr2Union &u, Arc *stk, int ds
         /* the second component goes to the LDS column, the top one becomes the second.  With fewer than
            two components the store lands in level 0, which is not in use then (it is written again,
            properly, by the push that makes a third component) */
-        Arc t; t.s = u.bs; t.e = u.be;
+        Arc2 t; t.s = u.bs; t.e = u.be;
         stk[lr2_med3(u.depth - 2, 0, ds > 0 ? ds - 1 : 0) * LR2_LANES] = t;
         u.bs = u.ts; u.be = u.te;
     }
@@ -341,7 +347,7 @@ SASA_D void lr2_union_step(double inf, double sup, Lr2Union &u, Arc *stk, int ds
         u.ts = SASA_MIN(u.ts, u.bs);
         --u.depth;
         if (u.depth >= 2) {
-            const Arc lo = stk[lr2_med3(u.depth - 2, 0, ds > 0 ? ds - 1 : 0) * LR2_LANES];
+            const Arc2 lo = stk[lr2_med3(u.depth - 2, 0, ds > 0 ? ds - 1 : 0) * LR2_LANES];
             u.bs = lo.s; u.be = lo.e;
         } else {
             u.be = -INFINITY;
@@ -361,7 +367,7 @@ SASA_D void lr2_sweep_step(bool have, double V, double ks, double ke, double &su
     sum += SASA_MAX(s - sup, 0.0); /* = sup < s ? s - sup : 0 */
     sup = SASA_MAX(sup, e);
 }
-SASA_D double lr2_sweep(const Lr2Union &u, const Arc *stk, int ds)
+SASA_D double lr2_sweep(const Lr2Union &u, const Arc2 *stk, int ds)
 {
     const int depth = u.depth;
     const double b_s = depth <= 1 ? u.ts : (depth == 2 ? u.bs : stk[0].s); /* lowest component */
@@ -376,7 +382,7 @@ SASA_D double lr2_sweep(const Lr2Union &u, const Arc *stk, int ds)
     double sum = 0, sup = W;
     bool covered = false;
     for (int c = 0; c < depth - 2; ++c) { /* components in the LDS column (rare: more than two) */
-        const Arc k = stk[(c < ds ? c : 0) * LR2_LANES];
+        const Arc2 k = stk[(c < ds ? c : 0) * LR2_LANES];
         lr2_sweep_step(true, V, k.s, k.e, sum, sup, covered);
     }
     lr2_sweep_step(depth >= 2, V, u.bs, u.be, sum, sup, covered); /* the two in registers */
@@ -389,7 +395,7 @@ SASA_D double lr2_sweep(const Lr2Union &u, const Arc *stk, int ds)
 
 /* test hook (freesasa_gpu_arc_union_dev): the exposed length of set `k`'s arcs, given sorted by their mid-points,
  * through the arc union and the sweep of the arc pass (ref KATs: src/sasa_lr.c:455-475).  One lane per set. */
-SASA_D double lr2_arc_kat(const double *arcs, const int *first, int k, Arc *stk, int ds)
+SASA_D double lr2_arc_kat(const double *arcs, const int *first, int k, Arc2 *stk, int ds)
 {
     Lr2Union u;
     lr2_union_reset(u);
@@ -628,23 +634,25 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             const double kme = r_key[r];
             int rank = 0, t = 0;
             for (; t + 4 <= nn; t += 4) { /* two keys per LDS read (o is even), two reads per trip */
-                const Arc k0 = *(const Arc *)(m.keys + o + t), k1 = *(const Arc *)(m.keys + o + t + 2);
+                const Arc2 k0 = *(const Arc2 *)(m.keys + o + t), k1 = *(const Arc2 *)(m.keys + o + t + 2);
                 rank += k0.s < kme ? 1 : 0;
                 rank += k0.e < kme ? 1 : 0;
                 rank += k1.s < kme ? 1 : 0;
                 rank += k1.e < kme ? 1 : 0;
             }
             for (; t < nn; t += 2) { /* at most two trips (lists are padded to an even length) */
-                const Arc kk = *(const Arc *)(m.keys + o + t);
+                const Arc2 kk = *(const Arc2 *)(m.keys + o + t);
                 rank += kk.s < kme ? 1 : 0;
                 rank += kk.e < kme ? 1 : 0;
             }
-            Rec24 rc; rc.a = r_a[r]; rc.b = r_b[r]; rc.beta = r_beta[r];
-            *(Rec24 *)((char *)m.rec + LR2_MUL24(o + rank, 24)) = rc;
+            Ab16 rc; rc.a = r_a[r]; rc.b = r_b[r];
+            m.ab[o + rank] = rc;
+            m.beta[o + rank] = r_beta[r];
         }
         if (lane < TA && (m.acnt[lane] & 1)) { /* padding record: cos(alpha) huge, never an arc */
-            Rec24 rc; rc.a = 0; rc.b = 1e300; rc.beta = 0;
-            m.rec[m.aoff[lane] + m.acnt[lane]] = rc;
+            Ab16 rc; rc.a = 0; rc.b = 1e300;
+            m.ab[m.aoff[lane] + m.acnt[lane]] = rc;
+            m.beta[m.aoff[lane] + m.acnt[lane]] = 0;
         }
     }
     LR2_SYNC();
@@ -678,7 +686,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             for (int wi = 0; wi < mwt; ++wi) {
                 unsigned w = 0;
                 const int k1 = nn - 32 * wi < 32 ? nn - 32 * wi : 32;
-                const Rec24 *R = (const Rec24 *)((const char *)m.rec + LR2_MUL24(o + 32 * wi, 24));
+                const Ab16 *R = m.ab + (o + 32 * wi);
                 int k = k1 - 2; /* from the end: neighbor k lands on bit k */
                 if (k1 > 0 && (k1 & 2)) {
                     const double c0 = fma(t, R[k].a, R[k].b) * h2, c1 = fma(t, R[k + 1].a, R[k + 1].b) * h2;
@@ -738,11 +746,11 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     /* ------------------------------------------------------------ P6 arc pass */
     int maxd = 0;
     {
-        Arc *stk = m.stack + lane;
+        Arc2 *stk = m.stack + lane;
         int next = LR2_LANES;
         int my = LR2_NONE, la = 0, wleft = 0;
         unsigned w = 0;
-        const Rec24 *R = m.rec;       /* record of bit 0 of the current mask word */
+        int R = 0;                    /* record of bit 0 of the current mask word */
         const unsigned *mk = m.it_mask; /* current mask word */
         double t = 0, h2 = 0;
         Lr2Union u;
@@ -757,7 +765,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         my = e_ == LR2_NONE ? LR2_NONE : (e_ & 1023); w = 0; wleft = 0;                            \
         if (my != LR2_NONE) {                                                                      \
             la = e_ >> 10;                                                                         \
-            R = (const Rec24 *)((const char *)m.rec + LR2_MUL24(m.aoff[la], 24)); t = m.it_tc[my];  \
+            R = m.aoff[la]; t = m.it_tc[my];                                                        \
             { const double Ri_ = m.atom[la].w; double g_; sqrt_rh(Ri_ * Ri_ - t * t, g_, h2); } /* as P4: bit for bit */ \
             mk = m.it_mask + LR2_MUL24(my, mw); w = *mk; wleft = mwt - 1;                          \
             LR2_NEXT_WORD();                                                                       \
@@ -773,10 +781,11 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                 if (LR2_LANES - LR2_POPC64(am) >= due) break;
                 LR2_COUNT(1, 1);
                 if (act) {
-                    const Rec24 *q = R + __builtin_ctz(w);
+                    const int q = R + __builtin_ctz(w);
                     w &= w - 1;
-                    const double bt = q->beta;
-                    const double alpha = acos_fast(fma(t, q->a, q->b) * h2); /* the screening's value, bit for bit */
+                    const Ab16 ab = m.ab[q];
+                    const double bt = m.beta[q];
+                    const double alpha = acos_fast(fma(t, ab.a, ab.b) * h2); /* the screening's value, bit for bit */
                     lr2_union_step(bt - alpha, bt + alpha, u, stk, a.ds, maxd); /* ref: :338-339 */
                 }
             }
