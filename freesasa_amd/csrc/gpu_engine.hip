@@ -631,6 +631,8 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
     la.grid = pa.grid; la.cell_start = pa.cell_start;
     la.n_atoms = n; la.n_tiles = n_tiles; la.TA = cfg.TA; la.ns = resolution;
     la.pool = cfg.pool; la.mw = cfg.mw; la.ds = cfg.ds; la.refill = cfg.refill;
+    la.cover = LR2_COVER_DENSITY;
+    if (const char *e = getenv("FREESASA_AMD_COVER")) la.cover = atoi(e); /* tuning aid: neighbor records per atom from which a tile runs the cover filter; 0: never */
     la.sasa = d_sasa; la.status = (int *)c->status.p;
     la.inv_ns = 1.0 / (double)resolution;
     la.ovf_items = (long long *)c->ovf_tiles.p;

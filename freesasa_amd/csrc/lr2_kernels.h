@@ -51,6 +51,9 @@ long long wave_exchange(long long v, int src);
 #define LR2_READLANE(v, src) LR2_SHFL((v), (src))
 #define LR2_MUL24(a, b) ((int)(a) * (int)(b))
 #define LR2_RCPF(x) (1.0f / (x))
+#define LR2_RSQF(x) (1.0f / sqrtf(x))
+#define LR2_ADD64_LDS(p, v) (*(p) += (v))
+#define LR2_OR_LDS(p, v) (*(p) |= (v))
 namespace sasa_emu { extern long long lr2_count[16]; } /* wave-level trip counts (lane 0 counts): 0 tiles, 1 arc iterations, 2 refills, 3 P1 test rounds, 4 rank trips, 5 screening trips, 6 P3 rounds */
 #define LR2_COUNT(k, n) do { if (lane == 0) sasa_emu::lr2_count[(k)] += (n); } while (0)
 #else
@@ -78,6 +81,9 @@ namespace sasa_emu { extern long long lr2_count[16]; } /* wave-level trip counts
    v_mul_hi at a quarter of it (what the compiler emits when it cannot see that an index is small) */
 #define LR2_MUL24(a, b) ((int)__umul24((unsigned)(a), (unsigned)(b)))
 #define LR2_RCPF(x) __builtin_amdgcn_rcpf(x)
+#define LR2_RSQF(x) __builtin_amdgcn_rsqf(x)
+#define LR2_ADD64_LDS(p, v) atomicAdd((p), (v))
+#define LR2_OR_LDS(p, v) atomicOr((p), (v))
 #endif
 
 namespace sasa {
@@ -161,6 +167,7 @@ struct Lr2Args {
     int mw;     /* 32-bit mask words per item: at most 32*mw neighbors per atom */
     int ds;     /* spilled levels of the arc stack */
     int refill; /* waiting lanes that trigger a refill of the arc pass */
+    int cover;  /* cover filter (see lr2_cover_*): on for tiles with at least this many neighbor records per atom; 0: off */
     double *sasa;
     /* Work that does not fit this launch's LDS capacities: the wave redoes the tile as two halves on the spot; a
        half (or a single atom's tile) that still does not fit is appended to the next launch's work list as
@@ -210,7 +217,7 @@ struct Lr2Layout {
     int o_atoms, o_ints, o_rec, o_mask, o_queue, o_tc, o_r2, o_tag, total;
 };
 SASA_HD int lr2_a16(int v) { return (v + 15) & ~15; }
-SASA_HD int lr2_n_ints(int TA) { return 6 * TA + 1 + 8; }
+SASA_HD int lr2_n_ints(int TA, int mw) { return 6 * TA + 1 + 8 + TA * mw; }
 SASA_HD int lr2_n_row_ints(int TA) { return 9 * TA + (9 * TA + 2); } /* rowlo, cpre: P0 and P1 only */
 SASA_HD Lr2Layout lr2_layout(int TA, int ns, int pool, int mw, int ds)
 {
@@ -218,7 +225,7 @@ SASA_HD Lr2Layout lr2_layout(int TA, int ns, int pool, int mw, int ds)
     const int items = TA * ns;
     int p = 0;
     L.o_atoms = p; p += 32 * TA + lr2_a16(8 * TA);
-    L.o_ints = p;  p += lr2_a16(4 * lr2_n_ints(TA));
+    L.o_ints = p;  p += lr2_a16(4 * lr2_n_ints(TA, mw));
     /* records (24 B each; P3..P6), masks and queue (P4..P6), slice heights / areas (P4..P7).  The hits of P1
        (32 B each) lie over all of them until P3 has taken every hit into registers */
     L.o_rec = p;   p += lr2_a16(24 * pool);
@@ -245,6 +252,7 @@ struct Lr2Mem {
     Quad *atom;   /* [TA] x, y, z, R + probe of the tile atoms */
     double *adel; /* [TA] 2 Ri / ns (ref: src/sasa_lr.c:304) */
     int *acell, *lead, *gsz, *acnt, *aoff, *sorig, *flags, *hist;
+    unsigned *cmask; /* [TA*mw] cover filter: the atom's neighbors with the largest caps, as bits of its (beta-sorted) list */
     int *rowlo, *cpre; /* [9 TA], [9 TA + 2]: first candidate of a row, prefix of P1's work items (over the keys until P3) */
     double *it_tc;  /* [items] slice height relative to the atom centre (z - zi) until the item's slice is done, then its area */
     unsigned *it_mask; /* [items*mw] neighbors that cut an arc */
@@ -267,7 +275,8 @@ SASA_D Lr2Mem lr2_carve(const Lr2Args &a, char *smem)
     m.atom = (Quad *)(smem + L.o_atoms); m.adel = (double *)(smem + L.o_atoms + 32 * TA);
     int *q = (int *)(smem + L.o_ints);
     m.acell = q; q += TA; m.lead = q; q += TA; m.gsz = q; q += TA; m.acnt = q; q += TA; m.aoff = q; q += TA + 1;
-    m.sorig = q; q += TA; m.flags = q;
+    m.sorig = q; q += TA; m.flags = q; q += 8;
+    m.cmask = (unsigned *)q;
     m.rowlo = (int *)(smem + L.o_r2); m.cpre = m.rowlo + 9 * TA;
     m.it_tc = (double *)(smem + L.o_tc);
     m.it_mask = (unsigned *)(smem + L.o_mask);
@@ -294,13 +303,15 @@ SASA_D Lr2Mem lr2_carve(const Lr2Args &a, char *smem)
  * line): the sign of A + D - B decides like the reference's tests; a' and b' then carry the factor
  * 2^500 instead of 1/dij (cos(alpha) = +-huge, or 0 * huge = 0 in the one case where the reference
  * divides 0 by 0; two coincident atoms of equal radius get b' = NaN: no arc, as sasa_kernels.h). */
-SASA_D void lr2_record(double xd, double yd, double zd, double rj, double ri, double &ap, double &bp)
+SASA_D void lr2_record(double xd, double yd, double zd, double rj, double ri, double &ap, double &bp, double &Kout, double &d3sq)
 {
     const double D = xd * xd + yd * yd; /* ref: src/nb.c:438 */
     double g = 0, h = 0;
     if (D > 0) sqrt_rh(D, g, h);
     const double inv = D > 0 ? 2.0 * h : 0x1p500; /* 1/dij */
-    const double K = (ri * ri - rj * rj) + (D + zd * zd);
+    d3sq = D + zd * zd;
+    const double K = (ri * ri - rj * rj) + d3sq;
+    Kout = K;
     ap = -2.0 * zd * inv;
     bp = K * inv;
     if (!(D > 0) && zd == 0 && K == 0) bp = NAN;
@@ -425,6 +436,45 @@ SASA_D void lr2_overflow(const Lr2Args &a, int p0, int na, int err_code)
     }
 }
 
+
+/* ---------------------------------------------------------------- cover filter (dense inputs)
+ * At protein density 9 of 10 arcs belong to slices whose circle ends up fully covered (area 0; tools/dev/
+ * cover_stats.cpp), and the arcs of the ~10 neighbors with the largest caps on the atom's sphere already cover 95 %
+ * of those circles.  So, on tiles that are dense enough, P4 runs a cheap CONSERVATIVE test on the arcs of these
+ * neighbors before an item is queued: half-widths from a polynomial lower bound of acos (no root; less 1e-9 rad),
+ * one running component in beta order.  A circle this proves covered is covered with room to spare, and its area is
+ * exactly 0 in the reference as well (arcs through the origin are cut at 0 and 2 pi: src/sasa_lr.c:340-351, so a
+ * covered circle sums to sum = 0, sup = 2 pi exactly, :407); everything it cannot prove goes through the exact arc
+ * pass as before.  The filter decides which slices are skipped, never what an area is.
+ * Which neighbors: cos(theta_j) = (Ri^2 - Rj^2 + d^2) / (2 Ri d), the cap neighbor j cuts out of sphere i, in
+ * 8 bins of 0.1 from 0.2 (a byte counter each, one 64-bit LDS word per atom); the bins that hold the
+ * LR2_COVER_WANT largest caps, LR2_COVER_MAX neighbors at most. */
+#define LR2_COVER_WANT 10
+#define LR2_COVER_DENSITY 30 /* neighbor records per atom of a tile from which the filter pays (coils: ~20, proteins: 40-60) */
+#define LR2_COVER_MAX 16
+SASA_D int lr2_cover_bin(double K, double d3sq, double ri)
+{
+    const float ct = (float)K * LR2_RSQF((float)d3sq) * LR2_RCPF(2.0f * (float)ri);
+    const int b = (int)fmaf(ct, 10.0f, -2.0f);
+    return b < 0 ? 0 : (b > 7 ? 7 : b);
+}
+/* the last bin needed for LR2_COVER_WANT neighbors, from the atom's byte counters */
+SASA_D int lr2_cover_last_bin(unsigned long long h)
+{
+    int cum = 0, tb = 7;
+    for (int b = 0; b < 8; ++b) {
+        cum += (int)((h >> (8 * b)) & 255u);
+        if (cum >= LR2_COVER_WANT && b < tb) tb = b;
+    }
+    return tb;
+}
+/* a lower bound of acos(c) for c <= 0.9, less a margin of 1e-9: asin x <= x + x^3/6 + 0.17 x^5 on [0, 0.9] and
+ * asin x >= x + x^3/6 + 3/40 x^5 for x >= 0 (its series has positive terms only) */
+SASA_D double lr2_acos_lower(double c)
+{
+    const double c2 = c * c, k5 = c < 0 ? 0.075 : 0.17;
+    return (1.5707963267948966 - 1e-9) - fma(c * c2, fma(k5, c2, 1.0 / 6.0), c);
+}
 
 /* The whole tile, executed by the 64 lanes of one wave.  RMAX = rounds of 64 pair records a lane
  * keeps in registers in P3 (pool <= 64 * RMAX). */
@@ -602,6 +652,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     LR2_SYNC();
     if (ovf) return 1; /* (uniform) */
     const int mwt = (nn_max + 31) >> 5; /* mask words this tile's longest list needs (<= mw; one on most coil tiles) */
+    const bool cover = a.cover > 0 && nh >= LR2_MUL24(a.cover, na); /* (uniform) dense enough for the cover filter */
 
     LR2_STOP(2);
     LR2_MARK(2);
@@ -609,25 +660,49 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     {
         double r_a[RMAX], r_b[RMAX], r_beta[RMAX], r_key[RMAX];
         int r_pos[RMAX]; /* first record of the pair's atom | list length << 16; -1: no pair */
+        int r_cb[RMAX];  /* cover filter: bin of the pair's cap | atom << 3 */
         unsigned low = 0xfffu;
         SASA_OPAQUE(low);
+        unsigned long long *const chist = (unsigned long long *)m.acell; /* [TA] over acell and lead (P0 / P1 only) */
+        if (cover) {
+            if (lane < TA) chist[lane] = 0;
+            LR2_SYNC();
+        }
         for (int r = 0; r < RMAX; ++r) {
             const int gp = lane + LR2_LANES * r;
             r_pos[r] = -1;
+            r_cb[r] = 0;
             if (gp < nh) {
                 const Quad hq = m.hits[gp];
                 const unsigned tg = m.tag[gp];
                 const int la = (int)(tg & 7u), sa = (int)(tg >> 3);
                 const int o = m.aoff[la];
+                const double ri = m.atom[la].w;
+                double Kc, d3sq;
                 r_pos[r] = o | (m.acnt[la] << 16);
-                lr2_record(hq.x, hq.y, hq.z, hq.w, m.atom[la].w, r_a[r], r_b[r]);
+                lr2_record(hq.x, hq.y, hq.z, hq.w, ri, r_a[r], r_b[r], Kc, d3sq);
                 r_beta[r] = atan2_fast(hq.y, hq.x) + SASA_PI; /* ref: src/sasa_lr.c:337 */
                 r_key[r] = lr_rank_key(r_beta[r], (unsigned)sa, low);
                 m.keys[o + sa] = r_key[r];
+                if (cover) { /* (uniform) */
+                    const int b = lr2_cover_bin(Kc, d3sq, ri);
+                    r_cb[r] = b | (la << 3);
+                    LR2_ADD64_LDS(&chist[la], 1ull << (8 * b));
+                }
             }
         }
         if (lane < TA && (m.acnt[lane] & 1)) m.keys[m.aoff[lane] + m.acnt[lane]] = INFINITY; /* never ranks below */
         LR2_SYNC(); /* every hit is in registers: R1 may now take the records */
+        if (cover) { /* per atom: the last bin of the largest caps; counters and list bits start at zero */
+            const unsigned long long h = lane < TA ? chist[lane] : 0;
+            LR2_SYNC();
+            if (lane < TA) {
+                m.gsz[lane] = lr2_cover_last_bin(h);
+                m.acell[lane] = 0;
+                for (int w = 0; w < mw; ++w) m.cmask[LR2_MUL24(lane, mw) + w] = 0;
+            }
+            LR2_SYNC();
+        }
         for (int r = 0; r < RMAX; ++r) {
             if (r_pos[r] < 0) continue;
             const int o = r_pos[r] & 0xffff, nn = r_pos[r] >> 16;
@@ -648,6 +723,11 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             Ab16 rc; rc.a = r_a[r]; rc.b = r_b[r];
             m.ab[o + rank] = rc;
             m.beta[o + rank] = r_beta[r];
+            if (cover) { /* (uniform) one of the atom's largest caps: its bit in the atom's list */
+                const int la = r_cb[r] >> 3;
+                if ((r_cb[r] & 7) <= m.gsz[la] && SASA_ATOMIC_ADD_LDS(&m.acell[la], 1) < LR2_COVER_MAX)
+                    LR2_OR_LDS(&m.cmask[LR2_MUL24(la, mw) + (rank >> 5)], 1u << (rank & 31));
+            }
         }
         if (lane < TA && (m.acnt[lane] & 1)) { /* padding record: cos(alpha) huge, never an arc */
             Ab16 rc; rc.a = 0; rc.b = 1e300;
@@ -710,6 +790,26 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             }
             if (cmin <= -1.0) cnt = 0; /* circle i inside a neighbor's: buried (ref: :327-330) */
             else if (cnt == 0) area = m.adel[la] * Ri * SASA_TWOPI; /* ref: :360 with exposed_arc_length(n = 0) */
+            if (cover) { /* (uniform) the arcs of the largest caps, in beta order: do they cover the circle? */
+                double cts = 0, cte = -INFINITY;
+                for (int wi = 0; wi < mwt; ++wi) {
+                    unsigned wc = cnt > 0 ? (m.it_mask[LR2_MUL24(it, mw) + wi] & m.cmask[LR2_MUL24(la, mw) + wi]) : 0u;
+                    const int R = o + 32 * wi;
+                    while (wc != 0) { /* (the wave runs as many trips as its busiest lane) */
+                        const int q = R + __builtin_ctz(wc);
+                        wc &= wc - 1;
+                        const Ab16 ab = m.ab[q];
+                        const double bt = m.beta[q];
+                        const double c = fma(t, ab.a, ab.b) * h2;
+                        const double al = lr2_acos_lower(c);
+                        const double inf = bt - al, sup = bt + al;
+                        const bool fresh = inf > cte;
+                        const double nts = fresh ? inf : SASA_MIN(cts, inf), nte = fresh ? sup : SASA_MAX(cte, sup);
+                        if (c <= 0.9) { cts = nts; cte = nte; }
+                    }
+                }
+                if (cte - cts >= SASA_TWOPI) cnt = 0; /* covered: area 0 */
+            }
         }
         if (cnt == 0) m.it_tc[it] = area; /* (an item with arcs keeps its slice height for the arc pass) */
         unsigned short qt = 0xffff;
@@ -785,7 +885,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                     w &= w - 1;
                     const Ab16 ab = m.ab[q];
                     const double bt = m.beta[q];
-                    const double alpha = acos_fast(fma(t, ab.a, ab.b) * h2); /* the screening's value, bit for bit */
+                    const double alpha = acos_fast2(fma(t, ab.a, ab.b) * h2); /* the screening's value, bit for bit */
                     lr2_union_step(bt - alpha, bt + alpha, u, stk, a.ds, maxd); /* ref: :338-339 */
                 }
             }

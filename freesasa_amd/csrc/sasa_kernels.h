@@ -811,6 +811,70 @@ SASA_D double acos_fast(double x)
     return fma(m, t, off);
 }
 
+/* acos on (-1,1) without a case distinction (the arc pass of lr2_kernels.h): acos|x| = 2 asin sqrt((1-|x|)/2) for
+ * every |x| < 1, reflected for x < 0.  asin u = u + u z P(z), z = u^2 = (1-|x|)/2 <= 0.5: P an interpolant at
+ * Chebyshev nodes on [0, 0.5] (fitted with mpmath), degree 14: max relative error of asin 1.5e-14 — what the
+ * two-range acos_fast reaches with degree 9 on z <= 0.25, for four more fma and eleven instructions of selecting
+ * operands less (31 -> 25 VALU instructions per arc).  ACOS2_DEG 13 / 12: 9.7e-14 / 6.3e-13, one / two fma less.
+ * The sign of x enters as the factor +-2 of (asin u - pi/4) in one fma with pi/2. */
+#ifndef ACOS2_DEG
+#define ACOS2_DEG 14
+#endif
+SASA_D double acos_fast2(double x)
+{
+    const double z = fma(fabs(x), -0.5, 0.5); /* (1 - |x|)/2, exact up to the rounding of the fma; in (0, 0.5] */
+#if ACOS2_DEG == 14
+    double p = 0x1.5983ba6d23362p-2;
+    p = SASA_FMA_K(p, z, -0x1.cda34edad75c6p-1);
+    p = SASA_FMA_K(p, z, 0x1.2a403f79f9e33p+0);
+    p = SASA_FMA_K(p, z, -0x1.c6e3b97cdbe9fp-1);
+    p = SASA_FMA_K(p, z, 0x1.dd61d178e44a1p-2);
+    p = SASA_FMA_K(p, z, -0x1.3d430158670dbp-3);
+    p = SASA_FMA_K(p, z, 0x1.a07b72b875c6fp-5);
+    p = SASA_FMA_K(p, z, 0x1.159bde5b9fe00p-8);
+    p = SASA_FMA_K(p, z, 0x1.e7736601fb531p-7);
+    p = SASA_FMA_K(p, z, 0x1.1b0b34172c6c3p-6);
+    p = SASA_FMA_K(p, z, 0x1.6e9d66a108da2p-6);
+    p = SASA_FMA_K(p, z, 0x1.f1c686ee47a13p-6);
+    p = SASA_FMA_K(p, z, 0x1.6db6dcb595fe6p-5);
+    p = SASA_FMA_K(p, z, 0x1.3333333218b17p-4);
+    p = SASA_FMA_K(p, z, 0x1.55555555557d9p-3);
+#elif ACOS2_DEG == 13
+    double p = 0x1.174d39e43815ep-2;
+    p = SASA_FMA_K(p, z, -0x1.5167956168ca9p-1);
+    p = SASA_FMA_K(p, z, 0x1.8ec93aa6263cdp-1);
+    p = SASA_FMA_K(p, z, -0x1.0f49ec92348f7p-1);
+    p = SASA_FMA_K(p, z, 0x1.037f12ba48b93p-2);
+    p = SASA_FMA_K(p, z, -0x1.10756f3cf669bp-4);
+    p = SASA_FMA_K(p, z, 0x1.ca53e50c8b27dp-6);
+    p = SASA_FMA_K(p, z, 0x1.79ec6d7065e80p-7);
+    p = SASA_FMA_K(p, z, 0x1.20458b1d083b7p-6);
+    p = SASA_FMA_K(p, z, 0x1.6e4abceb01895p-6);
+    p = SASA_FMA_K(p, z, 0x1.f1c994c2364ffp-6);
+    p = SASA_FMA_K(p, z, 0x1.6db6d52f65e8fp-5);
+    p = SASA_FMA_K(p, z, 0x1.33333339625fap-4);
+    p = SASA_FMA_K(p, z, 0x1.5555555554529p-3);
+#else
+    double p = 0x1.c70b84f2604a4p-3;
+    p = SASA_FMA_K(p, z, -0x1.eb330d405c37dp-2);
+    p = SASA_FMA_K(p, z, 0x1.084859012fcc8p-1);
+    p = SASA_FMA_K(p, z, -0x1.3a4ea43eb48adp-2);
+    p = SASA_FMA_K(p, z, 0x1.1661c4e1fecccp-3);
+    p = SASA_FMA_K(p, z, -0x1.6b69eecac872ep-6);
+    p = SASA_FMA_K(p, z, 0x1.482102e85b292p-6);
+    p = SASA_FMA_K(p, z, 0x1.1080015ff5fd3p-6);
+    p = SASA_FMA_K(p, z, 0x1.6f7002236e00bp-6);
+    p = SASA_FMA_K(p, z, 0x1.f1bcecaaa9600p-6);
+    p = SASA_FMA_K(p, z, 0x1.6db6f971a2415p-5);
+    p = SASA_FMA_K(p, z, 0x1.33333310a8a5ep-4);
+    p = SASA_FMA_K(p, z, 0x1.555555555be1fp-3);
+#endif
+    const double u = sqrt_g(z);
+    const double pio4 = 0x1.921fb54442d18p-1, pio2 = 0x1.921fb54442d18p+0;
+    const double t = fma(u * z, p, u - pio4); /* asin(u) - pi/4 (absolute error 1e-16: of no account for an angle) */
+    return SASA_FMA_K(copysign(2.0, x), t, pio2); /* x >= 0: 2 asin u;  x < 0: pi - 2 asin u */
+}
+
 /* atan2(y, x) for finite arguments: ONE division (hardware reciprocal seed + two Newton steps + a
  * residual correction) shared by both reductions — u = mn/mx, or (mn-mx)/(mn+mx) with a pi/4
  * offset when mn/mx > tan(pi/8) — then atan u = u + u s P(s), s = u^2 <= 0.1716, P a degree-10

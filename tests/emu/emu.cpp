@@ -270,6 +270,7 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
         la.sq = pa.sq; la.s_idx = pa.s_idx;
         la.grid = pa.grid; la.cell_start = pa.cell_start; la.n_atoms = n; la.n_tiles = n_tiles2;
         la.TA = c2.TA; la.ns = resolution; la.pool = c2.pool; la.mw = c2.mw; la.ds = c2.ds; la.refill = c2.refill; la.inv_ns = 1.0 / (double)resolution;
+        la.cover = getenv("EMU_LR2_COVER") ? atoi(getenv("EMU_LR2_COVER")) : LR2_COVER_DENSITY;
         la.sasa = sasa; la.status = status.data();
         /* main launch: a tile that does not fit is split in place; halves that still do not fit go to the list */
         la.ovf_items = ovf2x.data(); la.ovf_count = status.data() + ST_OVF2_TILES; la.split_count = status.data() + ST_SPLIT;
@@ -418,6 +419,10 @@ extern "C" void emu_residue_areas(const double *sasa, const unsigned char *cls, 
     for (int r = 0; r < ((n_res + 255) / 256) * 256; ++r) residue_areas(sasa, cls, bb, res_first, ref_row, ref_table, abs_out, rel_out, r, n_res);
 }
 
+extern "C" void emu_acos_fast2(const double *x, double *out, int n)
+{
+    for (int i = 0; i < n; ++i) out[i] = acos_fast2(x[i]);
+}
 extern "C" void emu_acos_fast(const double *x, double *out, int n)
 {
     for (int i = 0; i < n; ++i) out[i] = acos_fast(x[i]);
