@@ -303,12 +303,13 @@ SASA_D Lr2Mem lr2_carve(const Lr2Args &a, char *smem)
  * line): the sign of A + D - B decides like the reference's tests; a' and b' then carry the factor
  * 2^500 instead of 1/dij (cos(alpha) = +-huge, or 0 * huge = 0 in the one case where the reference
  * divides 0 by 0; two coincident atoms of equal radius get b' = NaN: no arc, as sasa_kernels.h). */
-SASA_D void lr2_record(double xd, double yd, double zd, double rj, double ri, double &ap, double &bp, double &Kout, double &d3sq)
+SASA_D void lr2_record(double xd, double yd, double zd, double rj, double ri, double &ap, double &bp, double &Kout, double &d3sq, double &inv_d)
 {
     const double D = xd * xd + yd * yd; /* ref: src/nb.c:438 */
     double g = 0, h = 0;
     if (D > 0) sqrt_rh(D, g, h);
     const double inv = D > 0 ? 2.0 * h : 0x1p500; /* 1/dij */
+    inv_d = D > 0 ? inv : 0.0;
     d3sq = D + zd * zd;
     const double K = (ri * ri - rj * rj) + d3sq;
     Kout = K;
@@ -678,10 +679,10 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                 const int la = (int)(tg & 7u), sa = (int)(tg >> 3);
                 const int o = m.aoff[la];
                 const double ri = m.atom[la].w;
-                double Kc, d3sq;
+                double Kc, d3sq, inv_d;
                 r_pos[r] = o | (m.acnt[la] << 16);
-                lr2_record(hq.x, hq.y, hq.z, hq.w, ri, r_a[r], r_b[r], Kc, d3sq);
-                r_beta[r] = atan2_fast(hq.y, hq.x) + SASA_PI; /* ref: src/sasa_lr.c:337 */
+                lr2_record(hq.x, hq.y, hq.z, hq.w, ri, r_a[r], r_b[r], Kc, d3sq, inv_d);
+                r_beta[r] = atan2_inv(hq.y, hq.x, inv_d) + SASA_PI; /* ref: src/sasa_lr.c:337 */
                 r_key[r] = lr_rank_key(r_beta[r], (unsigned)sa, low);
                 m.keys[o + sa] = r_key[r];
                 if (cover) { /* (uniform) */

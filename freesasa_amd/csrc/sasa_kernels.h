@@ -915,6 +915,39 @@ SASA_D double atan2_fast(double y, double x)
     return y < 0 ? -a : a;
 }
 
+/* beta = atan2(y, x) of a neighbor whose 1/sqrt(x^2 + y^2) = inv the pair record has already paid for (lr2_record):
+ * no division.  With mx = max(|x|, |y|), mn = min: phi = atan(mn / mx) has sin(phi) = mn inv; for phi > pi/8
+ * (mn > tan(pi/8) mx) take phi - pi/4, whose sine is (mn - mx) inv / sqrt 2.  asin s = s + s z P(z), z = s^2 <=
+ * sin^2(pi/8) = 0.1464: degree-8 interpolant at Chebyshev nodes (max relative error 6e-16, fitted with mpmath).
+ * ~3 ulp; 33 VALU instructions where atan2_fast takes 45 and a reciprocal. */
+SASA_D double atan2_inv(double y, double x, double inv)
+{
+    const double ax = fabs(x), ay = fabs(y);
+    const bool swap = ay > ax;
+    const double mx = swap ? ay : ax, mn = swap ? ax : ay;
+    if (!(mx > 0)) return 0.0;
+    const bool red = mn > 0x1.a827999fcef32p-2 * mx; /* tan(pi/8) */
+    const double num = red ? mn - mx : mn;
+    const double k = red ? inv * 0x1.6a09e667f3bcdp-1 : inv; /* 1/sqrt 2 */
+    const double s = num * k;
+    const double z = s * s;
+    double p = 0x1.22f1f7591b110p-6;
+    p = SASA_FMA_K(p, z, 0x1.2a3eff9205476p-7);
+    p = SASA_FMA_K(p, z, 0x1.d6236bde6a953p-7);
+    p = SASA_FMA_K(p, z, 0x1.1bbfea905019bp-6);
+    p = SASA_FMA_K(p, z, 0x1.6e930536f6b5fp-6);
+    p = SASA_FMA_K(p, z, 0x1.f1c6e5efcb3d9p-6);
+    p = SASA_FMA_K(p, z, 0x1.6db6dbd204301p-5);
+    p = SASA_FMA_K(p, z, 0x1.33333332ec66bp-4);
+    p = SASA_FMA_K(p, z, 0x1.55555555555d9p-3);
+    double a = fma(s * z, p, s);
+    const double pio4 = 0x1.921fb54442d18p-1, pio2 = 0x1.921fb54442d18p+0, pi = 0x1.921fb54442d18p+1;
+    a = red ? a + pio4 : a;
+    a = swap ? pio2 - a : a;
+    a = x < 0 ? pi - a : a;
+    return y < 0 ? -a : a;
+}
+
 /* ---------------------------------------------------------------- Lee & Richards */
 
 /* Angular bucket of beta in [0, 2pi]: monotone in beta, so bucket order is beta order. */

@@ -419,6 +419,14 @@ extern "C" void emu_residue_areas(const double *sasa, const unsigned char *cls, 
     for (int r = 0; r < ((n_res + 255) / 256) * 256; ++r) residue_areas(sasa, cls, bb, res_first, ref_row, ref_table, abs_out, rel_out, r, n_res);
 }
 
+extern "C" void emu_atan2_inv(const double *y, const double *x, double *out, int n)
+{
+    for (int i = 0; i < n; ++i) {
+        double g, h;
+        const double D = x[i] * x[i] + y[i] * y[i];
+        if (D > 0) { sqrt_rh(D, g, h); out[i] = atan2_inv(y[i], x[i], 2.0 * h); } else out[i] = 0;
+    }
+}
 extern "C" void emu_acos_fast2(const double *x, double *out, int n)
 {
     for (int i = 0; i < n; ++i) out[i] = acos_fast2(x[i]);
