@@ -66,6 +66,7 @@ int main(int argc, char **argv)
     double slices = 0, buried = 0, open_ = 0, full = 0, det_cap[6] = {0}, det_arc[6] = {0}, arcs_full = 0, arcs_all = 0, arcs_undet[6] = {0};
     double atoms = 0, atoms_zero = 0, atoms_det[6] = {0};
     const double taus[3] = {0.5, 0.6, 0.7}; const int Kt[3] = {8, 12, 16};
+    double cull_n[3] = {0}, cull_cont[3] = {0}, cull_tot = 0;
     double det_top = 0, det_two = 0, det_two_exact = 0;
     double det_thr[3][3] = {{0}}, undet_thr[3][3] = {{0}}, ncont_thr[3][3] = {{0}}, maxarcs_thr[3][3] = {{0}};
     FILE *dump = fopen("/tmp/cover_items.txt", "w");
@@ -104,6 +105,32 @@ int main(int argc, char **argv)
             std::sort(idx.begin(), idx.end(), [&](int a, int b) { return L[a].costheta < L[b].costheta; });
             std::vector<int> caprank(L.size());
             for (size_t k = 0; k < L.size(); ++k) caprank[idx[k]] = (int)k;
+            { /* neighbor culling with bin-selected containers: WANT largest caps by 0.1 bins of cos(theta) from 0.2, KMAX slots in discovery order */
+                for (int wi = 0; wi < 3; ++wi) {
+                    const int WANT = wi == 0 ? 3 : (wi == 1 ? 4 : 6), KMAX = wi == 0 ? 4 : (wi == 1 ? 5 : 8);
+                    int hist[8] = {0};
+                    std::vector<int> bin(L.size());
+                    for (size_t k = 0; k < L.size(); ++k) { int b = (int)(L[k].costheta * 10 - 2); b = b < 0 ? 0 : (b > 7 ? 7 : b); bin[k] = b; hist[b]++; }
+                    int cum = 0, tb = 7;
+                    for (int b = 0; b < 8; ++b) { cum += hist[b]; if (cum >= WANT && b < tb) tb = b; }
+                    std::vector<int> cont;
+                    for (size_t k = 0; k < L.size() && (int)cont.size() < KMAX; ++k) if (bin[k] <= tb) cont.push_back((int)k);
+                    int nc = 0;
+                    for (size_t j = 0; j < L.size(); ++j) {
+                        bool cul = false;
+                        const double thj = acos(std::max(-1.0, std::min(1.0, L[j].costheta)));
+                        for (int k : cont) {
+                            if (k == (int)j || !(L[k].costheta < L[j].costheta - 1e-4)) continue;
+                            const double thk = acos(std::max(-1.0, std::min(1.0, L[k].costheta)));
+                            const double cg = (L[j].xd * L[k].xd + L[j].yd * L[k].yd + L[j].zd * L[k].zd) / sqrt(L[j].d3sq * L[k].d3sq);
+                            if (acos(std::max(-1.0, std::min(1.0, cg))) + thj <= thk - 1e-6) { cul = true; break; }
+                        }
+                        if (cul) ++nc;
+                    }
+                    cull_n[wi] += nc; cull_cont[wi] += cont.size();
+                }
+                cull_tot += L.size();
+            }
             /* containers by threshold: the first K neighbors (discovery order) with cos(theta) < tau */
             std::vector<char> isc[3][3];
             for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) {
@@ -171,6 +198,7 @@ int main(int argc, char **argv)
     for (int q = 0; q < 6; ++q)
         printf("K=%2d: covered slices recognised from the K largest caps %.3f (arcs left in unrecognised ones %.3f of all arcs), from the K largest arcs of the slice %.3f; atoms with zero area %.3f, recognised (buried or covered in every slice) %.3f\n",
                Ks[q], det_cap[q] / full, arcs_undet[q] / arcs_all, det_arc[q] / full, atoms_zero / atoms, atoms_det[q] / atoms);
+    for (int wi = 0; wi < 3; ++wi) printf("culling, bin-selected containers (variant %d): %.2f containers/atom, culled %.3f of neighbors\n", wi, cull_cont[wi] / atoms, cull_n[wi] / cull_tot);
     printf("tau 0.6 K 12 with the lower bound of acos: one running component %.3f, two components %.3f (exact acos, two components %.3f)\n", det_top / full, det_two / full, det_two_exact / full);
     for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b)
         printf("tau %.1f K %2d: containers/atom %.1f, container arcs per covered slice %.1f, covered slices recognised %.3f (arcs left in unrecognised %.3f of all)\n", taus[a], Kt[b],
