@@ -127,8 +127,19 @@ static int batch_indices_ok(const freesasa_ingest_batch *b)
     if (b->offsets[0] != 0 || b->offsets[S] != b->n_atoms) return 0;
     if (b->res_offsets[0] != 0 || b->res_offsets[S] != b->n_residues) return 0;
     if (b->res_first[0] != 0 || b->res_first[b->n_residues] != b->n_atoms) return 0;
+    /* first pass: every offset inside its array BEFORE anything is indexed with it (never decreasing and ending at
+       the count is not enough: {0, 1 << 20, 2} passes both) */
     for (int32_t s = 0; s < S; ++s) {
-        if (b->offsets[s + 1] < b->offsets[s] || b->res_offsets[s + 1] < b->res_offsets[s]) return 0;
+        if (b->offsets[s + 1] < b->offsets[s] || b->offsets[s + 1] > b->n_atoms) return 0;
+        if (b->res_offsets[s + 1] < b->res_offsets[s] || b->res_offsets[s + 1] > b->n_residues) return 0;
+        if (b->status[s] < FREESASA_INGEST_OK || b->status[s] > FREESASA_INGEST_ENOMEM) return 0;
+    }
+    const int ref_rows = freesasa_ingest_residue_reference_table(NULL);
+    for (int64_t r = 0; r < b->n_residues; ++r)
+        if (b->res_ref[r] < -1 || b->res_ref[r] >= ref_rows) return 0; /* (indexes the reference table on the device) */
+    for (int64_t i = 0; i < b->n_atoms; ++i)
+        if (b->atom_class[i] > FREESASA_INGEST_UNKNOWN || b->atom_backbone[i] > 1) return 0;
+    for (int32_t s = 0; s < S; ++s) {
         if (b->res_offsets[s + 1] > b->res_offsets[s]) { /* its residues start at its first atom and end at its last */
             if (b->res_first[b->res_offsets[s]] != b->offsets[s]) return 0;
             if (b->res_first[b->res_offsets[s + 1]] != b->offsets[s + 1]) return 0;

@@ -462,6 +462,69 @@ def test_binary_cache_round_trip_and_refusals(tmp_path):
     assert not (tmp_path / "broken.fsab").exists()
 
 
+def _cache_checksum(payload_sections):
+    """The file's checksum (ingest_cache.c, mix_bytes): multiply-xorshift over every section, 8 bytes at a time."""
+    M, h = (1 << 64) - 1, 0x243F6A8885A308D3
+    for sec in payload_sections:
+        for i in range(0, len(sec), 8):
+            w = int.from_bytes(sec[i:i + 8].ljust(8, b"\0"), "little")
+            h = ((h ^ w) * 0x9E3779B97F4A7C15) & M
+            h ^= h >> 29
+        h = ((h ^ len(sec)) * 0xC2B2AE3D27D4EB4F) & M
+    return h
+
+
+def test_binary_cache_refuses_crafted_indices_behind_a_valid_checksum(tmp_path):
+    """A cache file whose index arrays were rewritten AND whose checksum was recomputed to match: offsets that point
+    outside their arrays (monotone, right end value — the validator used to index res_first with them), a residue
+    reference row or an atom class outside its table.  Refused by load() and by save(), no out-of-bounds read
+    (`make asan-test` runs this under AddressSanitizer)."""
+    import struct
+    b = ingest.load_pdb_files([fixture("1ubq.pdb"), fixture("3bkr.pdb")])
+    f = tmp_path / "good.fsab"
+    b.save(f)
+    raw = bytearray(f.read_bytes())
+    S, N, R = b.n_structs, b.n_atoms, b.n_residues
+    lens = [8 * (S + 1), 8 * (S + 1), 4 * S, 24 * N, 8 * N, N, N, 4 * N, 2 * N, 8 * (R + 1), 2 * R, 4 * R, 6 * R, 4 * R]
+    starts, pos = [], 128
+    for ln in lens:
+        starts.append(pos)
+        pos += (ln + 15) & ~15
+    assert pos == len(raw)
+
+    def crafted(section, offset, fmt, value):
+        data = bytearray(raw)
+        struct.pack_into("<" + fmt, data, starts[section] + offset, value)
+        secs = [bytes(data[st:st + ln]) for st, ln in zip(starts, lens)]
+        struct.pack_into("<Q", data, 48, _cache_checksum(secs))      # header: magic 8, version + byte-order mark 8, counts 8 + 16, payload 8, then the checksum
+        return bytes(data)
+
+    assert ingest.load_cache(_write(tmp_path / "same.fsab", crafted(3, 0, "d", float(np.asarray(b.xyz).reshape(-1)[0])))).n_atoms == N   # the recipe itself is right
+    for section, offset, fmt, value in [(1, 8, "q", 1 << 20),       # res_offsets = {0, 1 << 20, R}
+                                        (0, 8, "q", 1 << 40),       # offsets beyond the atoms
+                                        (1, 8, "q", -5),
+                                        (10, 0, "h", 30000),        # res_ref beyond the reference table
+                                        (10, 2, "h", -2),
+                                        (5, 3, "B", 7),             # atom class
+                                        (2, 0, "i", 99)]:           # status
+        g = _write(tmp_path / "crafted.fsab", crafted(section, offset, fmt, value))
+        with pytest.raises(RuntimeError, match=f"code {ingest.EFORMAT}"):
+            ingest.load_cache(g)
+    bad = ingest.load_pdb_files([fixture("1ubq.pdb"), fixture("3bkr.pdb")])
+    bad.res_offsets[1] = 1 << 20
+    with pytest.raises(RuntimeError, match=f"code {ingest.EFORMAT}"):
+        bad.save(tmp_path / "bad.fsab")
+    bad = ingest.load_pdb_files([fixture("1ubq.pdb")])
+    bad.res_ref[0] = 20000
+    with pytest.raises(RuntimeError, match=f"code {ingest.EFORMAT}"):
+        bad.save(tmp_path / "bad.fsab")
+
+
+def _write(path, data):
+    path.write_bytes(data)
+    return path
+
+
 @pytest.mark.gpu
 def test_sweep_from_the_binary_cache_equals_the_sweep_from_the_files(tmp_path):
     import freesasa_amd as fa
