@@ -438,6 +438,20 @@ SASA_D void lr2_overflow(const Lr2Args &a, int p0, int na, int err_code)
 }
 
 
+/* The order of two neighbors whose beta agree in their leading 40 bits: by 12 bits of the pair's own geometry (the
+ * low mantissa words of xd, yd, zd), not by when the neighbor was found — the order, and with it every bit of the
+ * result, is then the same whatever the tile shape (atoms per tile, halves, the second launch), which is what lets
+ * a resumed run reproduce its files byte for byte.  Two neighbors of one atom with equal keys (beta equal to 40 bits
+ * AND equal tie bits: ~1e-16 per atom) would rank alike; P3 checks that the ranks of a list are a permutation (their
+ * sum) and hands such a tile on, in the end to the slab launch, whose ranking goes by list position. */
+SASA_D unsigned lr2_tie12(double xd, double yd, double zd)
+{
+    unsigned long long a, b, c;
+    memcpy(&a, &xd, 8); memcpy(&b, &yd, 8); memcpy(&c, &zd, 8);
+    const unsigned h = (unsigned)a ^ ((unsigned)b * 0x9E3779B1u) ^ ((unsigned)c >> 7) ^ ((unsigned)c << 11);
+    return (h ^ (h >> 13)) & 0xfffu;
+}
+
 /* ---------------------------------------------------------------- cover filter (dense inputs)
  * At protein density 9 of 10 arcs belong to slices whose circle ends up fully covered (area 0; tools/dev/
  * cover_stats.cpp), and the arcs of the ~10 neighbors with the largest caps on the atom's sphere already cover 95 %
@@ -479,9 +493,10 @@ SASA_D double lr2_acos_lower(double c)
 
 /* The whole tile, executed by the 64 lanes of one wave.  RMAX = rounds of 64 pair records a lane
  * keeps in registers in P3 (pool <= 64 * RMAX). */
-/* returns 0: the atoms' areas are stored; 1: the tile does not fit this launch's capacities (nothing stored) */
+/* returns 0: the atoms' areas are stored; 1: the tile does not fit this launch's capacities (nothing stored); 2: two
+   neighbors of an atom with equal sort keys (nothing stored; see lr2_tie12): once more with tie_by_place */
 template <int RMAX>
-SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool sample, int lane, int &wg_max_nn)
+SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool sample, bool tie_by_place, int lane, int &wg_max_nn)
 {
     const int TA = a.TA, ns = a.ns, mw = a.mw;
     const int items = na * ns;
@@ -683,16 +698,18 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                 r_pos[r] = o | (m.acnt[la] << 16);
                 lr2_record(hq.x, hq.y, hq.z, hq.w, ri, r_a[r], r_b[r], Kc, d3sq, inv_d);
                 r_beta[r] = atan2_inv(hq.y, hq.x, inv_d) + SASA_PI; /* ref: src/sasa_lr.c:337 */
-                r_key[r] = lr_rank_key(r_beta[r], (unsigned)sa, low);
+                r_key[r] = lr_rank_key(r_beta[r], tie_by_place ? (unsigned)sa : lr2_tie12(hq.x, hq.y, hq.z), low);
                 m.keys[o + sa] = r_key[r];
+                r_cb[r] = la << 3;
                 if (cover) { /* (uniform) */
                     const int b = lr2_cover_bin(Kc, d3sq, ri);
-                    r_cb[r] = b | (la << 3);
+                    r_cb[r] |= b;
                     LR2_ADD64_LDS(&chist[la], 1ull << (8 * b));
                 }
             }
         }
         if (lane < TA && (m.acnt[lane] & 1)) m.keys[m.aoff[lane] + m.acnt[lane]] = INFINITY; /* never ranks below */
+        if (!cover && lane < TA) m.lead[lane] = 0; /* sum of the ranks of the atom's list */
         LR2_SYNC(); /* every hit is in registers: R1 may now take the records */
         if (cover) { /* per atom: the last bin of the largest caps; counters and list bits start at zero */
             const unsigned long long h = lane < TA ? chist[lane] : 0;
@@ -700,6 +717,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             if (lane < TA) {
                 m.gsz[lane] = lr2_cover_last_bin(h);
                 m.acell[lane] = 0;
+                m.lead[lane] = 0;
                 for (int w = 0; w < mw; ++w) m.cmask[LR2_MUL24(lane, mw) + w] = 0;
             }
             LR2_SYNC();
@@ -724,6 +742,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             Ab16 rc; rc.a = r_a[r]; rc.b = r_b[r];
             m.ab[o + rank] = rc;
             m.beta[o + rank] = r_beta[r];
+            SASA_ATOMIC_ADD_LDS(&m.lead[r_cb[r] >> 3], rank);
             if (cover) { /* (uniform) one of the atom's largest caps: its bit in the atom's list */
                 const int la = r_cb[r] >> 3;
                 if ((r_cb[r] & 7) <= m.gsz[la] && SASA_ATOMIC_ADD_LDS(&m.acell[la], 1) < LR2_COVER_MAX)
@@ -737,6 +756,13 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         }
     }
     LR2_SYNC();
+    { /* the ranks of every list are 0 .. n-1, each once?  Equal keys (see lr2_tie12: duplicate atom records, or ~1e-16
+         per atom by accident) rank alike: the tile is done once more with ties by place of discovery, as before round
+         3 (identical records may stand in any order; the accident costs that tile its shape-independence) */
+        const int nn_ = lane < TA ? m.acnt[lane] : 0;
+        const bool twice = lane < TA && m.lead[lane] != ((LR2_MUL24(nn_, nn_) - nn_) >> 1);
+        if (LR2_BALLOT(twice) != 0) return 2; /* (uniform) */
+    }
 
     LR2_STOP(3);
     LR2_MARK(3);
@@ -945,10 +971,15 @@ SASA_D void lr2_wave(const Lr2Args &a, const Lr2Mem &m, int first, int stride, i
         /* one call site (the tile is ~9000 instructions): a tile that does not fit is redone as two halves, a
            half that does not fit either goes to the next launch's list */
         int rest0 = 0, rest_n = 0;
-        bool whole = true, sample = !a.work_items && (tile & 31) == 0;
+        bool whole = true, sample = !a.work_items && (tile & 31) == 0, by_place = false;
         for (;;) {
-            const int fail = lr2_tile<RMAX>(a, m, p0, na, sample, lane, wg_max_nn);
+            int fail = lr2_tile<RMAX>(a, m, p0, na, sample, by_place, lane, wg_max_nn);
             sample = false;
+            if (fail == 2) { /* equal sort keys: once more, ties by place of discovery */
+                if (!by_place) { by_place = true; continue; }
+                fail = 1;
+            }
+            by_place = false;
             if (fail && whole && na > 1) {
                 ++splits;
                 whole = false;

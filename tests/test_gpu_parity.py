@@ -253,10 +253,35 @@ def test_lr_tile_shapes_across_slice_counts(fa, oracle_lib, n_slices):
         ctx.lee_richards(d_xyz.data_ptr(), d_r.data_ptr(), offs, d_out.data_ptr(), 0, probe=1.4, n_slices=n_slices)
         runs.append(d_out.cpu().numpy().copy())
     ctx.close()
-    assert np.max(np.abs(runs[0] - runs[1])) < 1e-11  # (the tile shape may differ between the two: same areas)
+    assert np.array_equal(runs[0], runs[1])  # (the tile shape may differ between the two: the same bits, see below)
     for k in (0, 5, len(parts) - 1):
         sl = slice(offs[k], offs[k + 1])
         assert np.max(np.abs(runs[1][sl] - oracle_lib.lee_richards(xyz[sl], r[sl], 1.4, n_slices))) < LR_TOL
+
+
+def test_lr_results_do_not_depend_on_the_tile_shape(fa, monkeypatch):
+    """What the resumable drivers' "byte-identical after a restart" rests on: the order of near-equal beta is decided
+    by the pair's own geometry (lr2_tie12), not by when a neighbor was found, so atoms per tile, pool size (tiles
+    redone as halves, the second launch), refill threshold and the cover filter change no bit of any area."""
+    import torch
+    parts = [tools.coil(4000, 300 + k) for k in range(6)] + [tools.globule(3000, 78 + k) for k in range(3)]
+    xyz = np.concatenate([p[0] for p in parts]); r = np.concatenate([p[1] for p in parts])
+    offs = np.concatenate([[0], np.cumsum([len(p[1]) for p in parts])]).astype(np.int64)
+    dev = torch.device("cuda:0")
+    d_xyz, d_r = torch.from_numpy(xyz).to(dev), torch.from_numpy(r).to(dev)
+    d_out = torch.empty(len(r), dtype=torch.float64, device=dev)
+    ref = None
+    for spec, cover in (("", ""), ("6,0,-1,0", ""), ("3,0,-1,0", "0"), ("4,96,-1,8", ""), ("2,64,1,48", "0"), ("5,200,-1,16", "1000")):
+        if spec: monkeypatch.setenv("FREESASA_AMD_LR2", spec)
+        else: monkeypatch.delenv("FREESASA_AMD_LR2", raising=False)
+        if cover: monkeypatch.setenv("FREESASA_AMD_COVER", cover)
+        else: monkeypatch.delenv("FREESASA_AMD_COVER", raising=False)
+        ctx = fa.GpuContext(0)
+        ctx.lee_richards(d_xyz.data_ptr(), d_r.data_ptr(), offs, d_out.data_ptr(), 0, probe=1.4, n_slices=20)
+        got = d_out.cpu().numpy().copy()
+        ctx.close()
+        if ref is None: ref = got
+        assert np.array_equal(got, ref), (spec, cover, float(np.max(np.abs(got - ref))))
 
 
 def test_trajectory_frames_config4_proxy(fa, oracle_lib):
