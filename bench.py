@@ -129,11 +129,110 @@ def two_streams(fa, torch, d_xyz, d_r, offs, args, dev, local_rank, steps):
                     "host gap of one pass run under the tile kernel of the other"}
 
 
+def neighbors_per_atom(fa, torch, d_xyz, d_r, offs, dev, local_rank):
+    """average number of unique neighbors per atom (the work per atom is proportional to it), counted by
+    the kernel's own neighbor phase (freesasa_gpu_lr_neighbors_dev) on a context of its own, outside every timed region."""
+    n = int(offs[-1])
+    d_nn = torch.empty(n, dtype=torch.int32, device=dev)
+    ctx = fa.GpuContext(local_rank)
+    ctx.lr_neighbors(d_xyz.data_ptr(), d_r.data_ptr(), offs, d_nn.data_ptr(), probe=1.4)
+    torch.cuda.synchronize()
+    ctx.close()
+    return float(d_nn.to(torch.float64).mean().item())
+
+
+def checker_error(alg, xyz, r, got, resolution):
+    """cpu_baseline leg (the checker, not the thing measured): largest per-atom difference to the real reference
+    (oracle/_ref) or, without it, to the oracle port, on ONE structure; for Shrake-Rupley the number of atoms whose
+    test-point count differs."""
+    import oracle
+    if alg == "lr":
+        if oracle.Reference.available():
+            want = oracle.Reference().calc_coord(xyz, r, oracle.LEE_RICHARDS, 1.4, n_slices=resolution)[0]
+        else:
+            want = oracle.Oracle().lee_richards(xyz, r, 1.4, resolution)
+        return float(np.max(np.abs(np.asarray(want) - got)))
+    want = oracle.Oracle().shrake_rupley(xyz, r, 1.4, resolution)[1]
+    return int(np.count_nonzero(np.asarray(want) != got))
+
+
+def secondary_workloads(fa, torch, tools, d_xyz, d_r, offs, xyz, r, dev, local_rank, check):
+    """The other single-GPU configurations of BASELINE.json, one short measurement each in this same process:
+    configs[2] as written (L&R 100 slices on the 1000 x 10 000 coils), protein density (10 000-atom globules, L&R 20),
+    configs[1]'s proxy (one 200 000-atom globule, Shrake-Rupley 100 points).  Each: atoms/s over whole steps (wall
+    clock around synchronous calls, inputs resident), the tile kernel's own time, average neighbors per atom and —
+    with the CPU baseline enabled — the largest difference to the checker on one structure."""
+    out = {}
+
+    def run(ctx, call, n_atoms, steps, warmup):
+        for _ in range(warmup):
+            call()
+        torch.cuda.synchronize()
+        ks, t0 = [], time.perf_counter()
+        for _ in range(steps):
+            call()
+            ks.append(ctx.stats()["ms_kernel"])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        return {"value": n_atoms / dt, "unit": "atoms/s", "ms_per_step": 1e3 * dt, "kernel_ms": float(np.mean(ks)), "steps": steps}
+
+    n = int(offs[-1])
+    d_out = torch.empty(n, dtype=torch.float64, device=dev)
+    # configs[2] as written
+    ctx = fa.GpuContext(local_rank, timing=True)
+    res = run(ctx, lambda: ctx.lee_richards(d_xyz.data_ptr(), d_r.data_ptr(), offs, d_out.data_ptr(), 0, probe=1.4, n_slices=100), n, 3, 2)
+    st = ctx.stats()
+    res.update({"workload": f"{len(offs) - 1} coils x {int(offs[1])} atoms, Lee-Richards 100 slices (BASELINE configs[2] as written)",
+                "tile_atoms": st["tile_atoms"], "max_neighbors_per_atom": st["max_neighbors"]})
+    if check:
+        res["max_abs_dsasa"] = checker_error("lr", xyz[:offs[1]], r[:offs[1]], d_out[:int(offs[1])].cpu().numpy(), 100)
+    ctx.close()
+    out["lr100_config2"] = res
+    # protein density
+    ng, na = 300, 10_000
+    parts = [tools.globule(na, 500 + k) for k in range(ng)]
+    gx = np.concatenate([p[0] for p in parts]); gr = np.concatenate([p[1] for p in parts])
+    goffs = np.arange(ng + 1, dtype=np.int64) * na
+    dgx, dgr = torch.from_numpy(gx).to(dev), torch.from_numpy(gr).to(dev)
+    dgo = torch.empty(ng * na, dtype=torch.float64, device=dev)
+    ctx = fa.GpuContext(local_rank, timing=True)
+    res = run(ctx, lambda: ctx.lee_richards(dgx.data_ptr(), dgr.data_ptr(), goffs, dgo.data_ptr(), 0, probe=1.4, n_slices=20), ng * na, 10, 3)
+    st = ctx.stats()
+    res.update({"workload": f"{ng} synthetic globules x {na} atoms (lattice spacing 2.6 A: protein density), Lee-Richards 20 slices",
+                "tile_atoms": st["tile_atoms"], "max_neighbors_per_atom": st["max_neighbors"],
+                "avg_neighbors_per_atom": neighbors_per_atom(fa, torch, dgx, dgr, goffs, dev, local_rank)})
+    if check:
+        res["max_abs_dsasa"] = checker_error("lr", gx[:na], gr[:na], dgo[:na].cpu().numpy(), 20)
+    ctx.close()
+    out["globule_lr20"] = res
+    del dgx, dgr, dgo
+    # configs[1] proxy
+    nb = 200_000
+    bx, br = tools.globule(nb, 77)
+    boffs = np.array([0, nb], dtype=np.int64)
+    dbx, dbr = torch.from_numpy(bx).to(dev), torch.from_numpy(br).to(dev)
+    dbo = torch.empty(nb, dtype=torch.float64, device=dev)
+    dbc = torch.empty(nb, dtype=torch.int32, device=dev)
+    ctx = fa.GpuContext(local_rank, timing=True)
+    res = run(ctx, lambda: ctx.shrake_rupley(dbx.data_ptr(), dbr.data_ptr(), boffs, dbo.data_ptr(), dbc.data_ptr(), 0, probe=1.4, n_points=100), nb, 20, 3)
+    st = ctx.stats()
+    res.update({"workload": "one synthetic 200 000-atom globule (BASELINE configs[1] proxy: 4V6X is not available offline), Shrake-Rupley 100 points",
+                "max_neighbors_per_atom": st["max_neighbors"],
+                "avg_neighbors_per_atom": neighbors_per_atom(fa, torch, dbx, dbr, boffs, dev, local_rank)})
+    if check:
+        res["atoms_with_a_different_count"] = checker_error("sr", bx, br, dbc.cpu().numpy(), 100)
+    ctx.close()
+    out["globule_sr100_200k"] = res
+    return out
+
+
 def profiled_traffic(args):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this same command, KB units;
-    for this kernel's 8-byte gathers FETCH_SIZE needs no x2 correction — calibrated on
-    k_scatter's known byte count).  Only valid for the default workload."""
+    (FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this same command, KB units, taken as they
+    are reported).  The kernel reads its atoms as 32-byte records, two 16-byte loads per lane; MI355X_MICROARCH.md
+    warns that FETCH_SIZE can under-count 16-byte-per-lane streams by up to 2x, and a copy kernel of known size
+    profiled in the same session (profiles/README.md, "FETCH_SIZE calibration") says by how much on this build:
+    the figure is a lower bound of the fetch side, exact on the write side.  Only valid for the default workload."""
     if (args.structs, args.atoms, args.slices) != (1000, 10000, 20):
         return None, None
     best = None
@@ -197,6 +296,10 @@ def main():
     ap.add_argument("--points", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short measurements of the other single-GPU configurations")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="TEST ONLY (tests/test_distributed.py): the rank / argument / JSON plumbing on CPU under gloo, "
+                         "with a stand-in for the engine that computes nothing; prints \"dry_run\": true")
     args = ap.parse_args()
 
     import torch
@@ -208,13 +311,24 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dry = args.dry_run
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if dry:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
 
     if args.workload == "traj_lr":
         return bench_trajectory(args, rank, world, local_rank)
@@ -239,16 +353,27 @@ def main():
         args.structs, args.atoms = len(mine), int(np.mean(sizes[mine]))
     else:
         # this rank's shard: its own independent structures (seeds are disjoint across ranks)
-        xyz, r, offs = tools.coil_batch(args.structs, args.atoms, seed0=1000 + rank * args.structs)
+        # (generated once per session: the 1 / 2 / 4 / 8-GPU runs of the driver read rank k's batch back from /tmp)
+        xyz, r, offs = tools.coil_batch(args.structs, args.atoms, seed0=1000 + rank * args.structs,
+                                        cache_dir=os.environ.get("FREESASA_AMD_BENCH_CACHE", "/tmp") if args.structs * args.atoms >= 1_000_000 else None)
     n_atoms = int(offs[-1])
     d_xyz = torch.from_numpy(xyz).to(dev)
     d_r = torch.from_numpy(r).to(dev)
     d_sasa = torch.empty(n_atoms, dtype=torch.float64, device=dev)
     d_tot = torch.empty(args.structs, dtype=torch.float64, device=dev)
-    torch.cuda.synchronize()
-    stream = torch.cuda.Stream(device=dev)      # the engine launches on this torch stream
-    torch.cuda.set_stream(stream)
-    ctx = fa.GpuContext(local_rank, stream=stream.cuda_stream, timing=True)
+    sync()
+    if dry:
+        class DryContext:                       # TEST ONLY: stands in for the engine, computes nothing
+            def lee_richards(self, *a, **k): time.sleep(0.002)
+            shrake_rupley = lee_richards
+            def stats(self): return {"ms_kernel": 0.0, "ms_prep": 0.0, "max_neighbors": 0, "fallback_tiles": 0, "tile_atoms": 0,
+                                     "block_threads": 0, "lds_bytes": 0, "n_cells": 0}
+            def close(self): pass
+        ctx = DryContext()
+    else:
+        stream = torch.cuda.Stream(device=dev)      # the engine launches on this torch stream
+        torch.cuda.set_stream(stream)
+        ctx = fa.GpuContext(local_rank, stream=stream.cuda_stream, timing=True)
 
     d_cnt = torch.empty(n_atoms, dtype=torch.int32, device=dev) if sr else None
 
@@ -261,10 +386,10 @@ def main():
                              probe=1.4, n_slices=args.slices)
 
     def barrier():
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     for _ in range(args.warmup):
         step()
@@ -337,6 +462,18 @@ def main():
                              "frac_of_issue_slots": PROFILED_VALU * CYCLES_PER_VALU / (kern_s * SIMDS * CLOCK_HZ),
                              "source": traffic_src}},
         }
+        if dry:
+            out["dry_run"] = True
+            out["atoms_all_ranks"] = atoms_all_ranks
+            print(json.dumps(out), flush=True)
+            if world > 1:
+                dist.barrier()
+                dist.destroy_process_group()
+            return
+        if not sr:
+            out["config"]["avg_neighbors_per_atom"] = neighbors_per_atom(fa, torch, d_xyz, d_r, offs, dev, local_rank)
+        if world == 1 and args.workload == "coil_lr" and not args.no_secondary and (args.structs, args.atoms, args.slices) == (1000, 10000, 20):
+            out.update(secondary_workloads(fa, torch, tools, d_xyz, d_r, offs, xyz, r, dev, local_rank, check=not args.no_cpu_baseline))
         if world == 1 and args.workload == "coil_lr" and not args.no_end_to_end:
             out["two_passes_in_flight"] = two_streams(fa, torch, d_xyz, d_r, offs, args, dev, local_rank, args.steps)
             out["end_to_end"] = end_to_end(fa, torch, xyz, r, offs, args, local_rank, d_sasa.cpu().numpy())

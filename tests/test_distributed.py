@@ -134,3 +134,33 @@ def test_contiguous_atom_balanced_cuts_of_the_single_process_multi_gpu_entry():
     assert fa.shard_cuts(np.array([0, 10, 30]), 5).tolist()[-1] == 2
     cuts = fa.shard_cuts(np.array([0, 0, 5, 5, 9]), 2)
     assert cuts[0] == 0 and cuts[-1] == 4
+
+
+def test_bench_py_two_ranks_dry_run():
+    """bench.py itself, launched the way the driver launches it for N > 1 (torch.distributed.run, one process per
+    rank), on CPU under gloo with --dry-run (a stand-in engine that computes nothing): ranks build disjoint shards,
+    the timed region is bracketed by barriers, rank 0 prints ONE JSON line whose value is the atoms of ALL ranks x
+    steps / the slowest rank's time, and every rank leaves the process group cleanly."""
+    import json
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--structs", "5", "--atoms", "400", "--dry-run"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["dry_run"] is True and res["n_gpus"] == 2 and res["steps"] == 3 and res["warmup"] == 1
+    assert res["atoms_all_ranks"] == 2 * 5 * 400 and res["scaling"] == "weak" and res["unit"] == "atoms/s"
+    assert abs(res["value"] - res["atoms_all_ranks"] * 3 / (res["ms_per_step"] * 3e-3)) < 1e-6 * res["value"]
+    assert res["ms_per_step"] >= 2.0                                   # three steps of the stand-in's 2 ms each, at least
+    for key in ("metric", "higher_is_better", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in res
+    # --gpus must agree with the launcher's world size
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--structs", "2", "--atoms", "100"],
+                         capture_output=True, text=True, timeout=120, cwd=ROOT, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK")})
+    assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr
