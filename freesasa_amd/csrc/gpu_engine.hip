@@ -259,7 +259,7 @@ __global__ __launch_bounds__(B) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) v
  * allocation is capped for. */
 /* NOTE: Lr2Args must stay the ONLY parameter of this kernel, at offset 0 of the kernel-argument segment: the tile
  * body reads its rarely used fields from there (LR2_COLD in lr2_kernels.h). */
-template <int RMAX, int TIER, int WPE>
+template <int RMAX, int TIER, int WPE, bool COVER>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lr2_tile(Lr2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     PIPE_GATE(a.status);
     Lr2Mem m = lr2_carve(a, smem);
     int wg_max_nn = 0;
-    lr2_wave<RMAX>(a, m, blockIdx.x, gridDim.x, lane, wg_max_nn);
+    lr2_wave<RMAX, COVER>(a, m, blockIdx.x, gridDim.x, lane, wg_max_nn);
     if (lane == 0 && wg_max_nn > a.status[ST_MAX_NN]) atomicMax(&a.status[ST_MAX_NN], wg_max_nn);
 }
 __global__ __launch_bounds__(64) void k_lr2_arc_kat(const double *arcs, const int *first, int n_sets, double *out)
@@ -281,7 +281,9 @@ __global__ __launch_bounds__(64) void k_lr2_arc_kat(const double *arcs, const in
  * 4 waves per SIMD (a 5-wave build spilled and was not faster) */
 static hipError_t launch_lr2_main(int rmax, int grid, size_t lds, hipStream_t st, const Lr2Args &la)
 {
-#define LR2_LAUNCH(R) hipLaunchKernelGGL((k_lr2_tile<R, 0, 4>), dim3(grid), dim3(64), lds, st, la)
+    /* (the cover filter is compiled into the launches over dense batches only: the sparse ones keep its registers) */
+#define LR2_LAUNCH(R) do { if (la.cover > 0) hipLaunchKernelGGL((k_lr2_tile<R, 0, 4, true>), dim3(grid), dim3(64), lds, st, la); \
+                           else hipLaunchKernelGGL((k_lr2_tile<R, 0, 4, false>), dim3(grid), dim3(64), lds, st, la); } while (0)
     if (rmax <= 2) LR2_LAUNCH(2); else if (rmax == 3) LR2_LAUNCH(3); else LR2_LAUNCH(4);
 #undef LR2_LAUNCH
     return hipGetLastError();
@@ -631,7 +633,8 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
     la.grid = pa.grid; la.cell_start = pa.cell_start;
     la.n_atoms = n; la.n_tiles = n_tiles; la.TA = cfg.TA; la.ns = resolution;
     la.pool = cfg.pool; la.mw = cfg.mw; la.ds = cfg.ds; la.refill = cfg.refill;
-    la.cover = LR2_COVER_DENSITY;
+    /* (hint_nn: what all but 4 % of the last batch's tiles needed per atom, or 1.25 x the density sample: coils ~30, proteins ~58) */
+    la.cover = c->hint_nn >= 1.35 * LR2_COVER_DENSITY ? LR2_COVER_DENSITY : 0;
     if (const char *e = getenv("FREESASA_AMD_COVER")) la.cover = atoi(e); /* tuning aid: neighbor records per atom from which a tile runs the cover filter; 0: never */
     la.sasa = d_sasa; la.status = (int *)c->status.p;
     la.inv_ns = 1.0 / (double)resolution;
@@ -656,6 +659,7 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
     {
         Lr2Args lm = la;
         lm.pool = cm.pool; lm.mw = cm.mw; lm.ds = cm.ds;
+        if (!getenv("FREESASA_AMD_COVER")) lm.cover = LR2_COVER_DENSITY;
         lm.work_items = (const long long *)c->ovf_tiles.p;
         lm.work_count = (const int *)c->status.p + ST_OVF2_TILES;
         lm.ovf_items = nullptr;
@@ -663,7 +667,7 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
         lm.ovf_count = (int *)c->status.p + ST_OVF3_ATOMS;
         lm.split_count = nullptr;
         const int grid_mid = n_tiles < SASA_MID_BLOCKS ? n_tiles : SASA_MID_BLOCKS;
-        hipLaunchKernelGGL((k_lr2_tile<LR2_RMAX_MID, 2, 3>), dim3(grid_mid), dim3(64), (size_t)cm.lds, st, lm);
+        hipLaunchKernelGGL((k_lr2_tile<LR2_RMAX_MID, 2, 3, true>), dim3(grid_mid), dim3(64), (size_t)cm.lds, st, lm);
         le = hipGetLastError();
         if (le != hipSuccess) return ctx_fail(c, "second tile launch failed: %s", hipGetErrorString(le));
     }

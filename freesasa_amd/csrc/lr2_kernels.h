@@ -495,7 +495,7 @@ SASA_D double lr2_acos_lower(double c)
  * keeps in registers in P3 (pool <= 64 * RMAX). */
 /* returns 0: the atoms' areas are stored; 1: the tile does not fit this launch's capacities (nothing stored); 2: two
    neighbors of an atom with equal sort keys (nothing stored; see lr2_tie12): once more with tie_by_place */
-template <int RMAX>
+template <int RMAX, bool COVER>
 SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool sample, bool tie_by_place, int lane, int &wg_max_nn)
 {
     const int TA = a.TA, ns = a.ns, mw = a.mw;
@@ -668,7 +668,8 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     LR2_SYNC();
     if (ovf) return 1; /* (uniform) */
     const int mwt = (nn_max + 31) >> 5; /* mask words this tile's longest list needs (<= mw; one on most coil tiles) */
-    const bool cover = a.cover > 0 && nh >= LR2_MUL24(a.cover, na); /* (uniform) dense enough for the cover filter */
+    const bool cover = COVER && a.cover > 0 && nh >= LR2_MUL24(a.cover, na); /* (uniform) dense enough for the cover filter; COVER: the launch
+                                                                                  was built with it (launches over sparse batches are not) */
 
     LR2_STOP(2);
     LR2_MARK(2);
@@ -950,7 +951,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
 /* The work items of one wave (items first, first + stride, ... of the launch).  A tile that does not fit is redone
  * at once as two halves (1.5 % of the 6-atom tiles of random coils at a pool of 224 records); what still does not fit
  * goes to the next launch's list. */
-template <int RMAX>
+template <int RMAX, bool COVER>
 SASA_D void lr2_wave(const Lr2Args &a, const Lr2Mem &m, int first, int stride, int lane, int &wg_max_nn)
 {
     /* all tiles (main launch, rounded up to whole XCD groups) or the items of a work list */
@@ -973,7 +974,7 @@ SASA_D void lr2_wave(const Lr2Args &a, const Lr2Mem &m, int first, int stride, i
         int rest0 = 0, rest_n = 0;
         bool whole = true, sample = !a.work_items && (tile & 31) == 0, by_place = false;
         for (;;) {
-            int fail = lr2_tile<RMAX>(a, m, p0, na, sample, by_place, lane, wg_max_nn);
+            int fail = lr2_tile<RMAX, COVER>(a, m, p0, na, sample, by_place, lane, wg_max_nn);
             sample = false;
             if (fail == 2) { /* equal sort keys: once more, ties by place of discovery */
                 if (!by_place) { by_place = true; continue; }

@@ -147,8 +147,8 @@ struct Lr2Run { const Lr2Args *a; Lr2Mem *m; int first, stride; int rmax; int *w
 static void lr2_lane_body(int lane, void *ctx)
 {
     Lr2Run *r = (Lr2Run *)ctx;
-    if (r->rmax == LR2_RMAX_MAIN) lr2_wave<LR2_RMAX_MAIN>(*r->a, *r->m, r->first, r->stride, lane, r->wg_max[lane]);
-    else lr2_wave<LR2_RMAX_MID>(*r->a, *r->m, r->first, r->stride, lane, r->wg_max[lane]);
+    if (r->rmax == LR2_RMAX_MAIN) lr2_wave<LR2_RMAX_MAIN, true>(*r->a, *r->m, r->first, r->stride, lane, r->wg_max[lane]);
+    else lr2_wave<LR2_RMAX_MID, true>(*r->a, *r->m, r->first, r->stride, lane, r->wg_max[lane]);
 }
 static void emu_lr2_kernel(const Lr2Cfg &cfg, Lr2Args a, int grid)
 {
