@@ -147,6 +147,188 @@ __global__ __launch_bounds__(SASA_PIPE_B) void k_scatter(PipeArgs a)
     scatter_atom(a, blockIdx.x * SASA_PIPE_B + threadIdx.x);
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * K3-K5 in ONE kernel for batches of small structures (round 3): one workgroup sorts one structure in LDS.
+ * The five launches it replaces (zero, count, three scan launches, scatter) stream the batch-wide cell table four
+ * times — 9 cells per atom on random coils, 0.36 GB a pass for 1e7 atoms — and hand the cell and the rank of every
+ * atom from one kernel to the next through HBM.  Here the table of a structure exists only as a bit per cell in
+ * LDS (which cells hold atoms), a count of the occupied cells before every 32-cell word, and the atom counts of
+ * the occupied cells; the first atom of any cell is  first[popcount rank of the cell]:
+ *     A  bit of every atom's cell                       (cell of the atom: ref src/nb.c:74-83,137-140)
+ *     B  occupied cells before each word                (block scan of the words' popcounts)
+ *     C  every atom takes a place in its cell           (LDS atomic on the occupied cell's 16-bit counter)
+ *     D  first atom of every occupied cell              (block scan of the counters, in place)
+ *     E  atoms to their sorted places: sq, s_idx        (what k_scatter writes)
+ *     F  the structure's part of cell_start[], once     (what the tile kernels' P0 reads: unchanged)
+ * HBM traffic: the atoms read twice (the second time from cache), 48 B per atom and 4 B per cell written once.
+ * Limits (else the batch is redone with the general pipeline, ST_RETRY = 2): SORT_ATOMS atoms and SORT_CELLS
+ * cells per structure.  The order of the atoms inside a cell is the order of arrival, as before: no result
+ * depends on it (lr2_tie12). */
+#define SORT_B 1024
+#define SORT_APT 16
+#define SORT_ATOMS (SORT_B * SORT_APT)
+#define SORT_CELLS (1 << 18) /* cells in LDS at a time (a bit each); a structure with more is done in that many passes */
+#define SORT_WORDS (SORT_CELLS / 32)
+#define SORT_CELL_BITS 26    /* cells of one structure this kernel can number (6 more bits hold the border flags) */
+__device__ __forceinline__ int sort_block_scan(int v, int *scratch, int tid) /* exclusive prefix of v over the workgroup; scratch[SORT_B / 64 + 1], the total in its last word */
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    int incl = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    __syncthreads(); /* (scratch may still be read from the previous scan) */
+    if (lane == 63) scratch[wave] = incl;
+    __syncthreads();
+    if (tid < 64) {
+        const int w = tid < SORT_B / 64 ? scratch[tid] : 0;
+        int wi = w;
+        for (int d = 1; d < SORT_B / 64; d <<= 1) {
+            const int o = __shfl_up(wi, d, 64);
+            if (tid >= d) wi += o;
+        }
+        if (tid < SORT_B / 64) scratch[tid] = wi - w;
+        if (tid == SORT_B / 64 - 1) scratch[SORT_B / 64] = wi; /* total */
+    }
+    __syncthreads();
+    return scratch[wave] + incl - v;
+}
+__global__ __launch_bounds__(SORT_B) void k_sort_struct(PipeArgs a)
+{
+    __shared__ unsigned bm[SORT_WORDS];              /* 32 KB: which cells hold atoms */
+    __shared__ unsigned short wpre[SORT_WORDS];      /* 16 KB: occupied cells before each 32-cell word */
+    __shared__ unsigned cnt[SORT_ATOMS / 2 + 2];     /* 32 KB: 16-bit counters of the occupied cells, then their first atoms (+ end) */
+    __shared__ int scratch[SORT_B / 64 + 1];
+    PIPE_GATE(a.status);
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const long long b0 = a.offsets[s];
+    const int n = (int)(a.offsets[s + 1] - b0);
+    const bool last = s == a.n_structs - 1;
+    if (n <= 0) {
+        if (last && tid == 0) a.cell_start[a.ncells[a.n_structs]] = a.n_atoms;
+        return;
+    }
+    const GridS g = a.grid[s];
+    const long long Cl = a.ncells[s];
+    if (n > SORT_ATOMS || Cl > (1LL << SORT_CELL_BITS)) { /* (uniform) not a structure for this kernel: the host redoes the batch */
+        if (tid == 0) a.status[ST_RETRY] = 2;
+        return;
+    }
+    const int C = (int)Cl;
+    /* the cell of every atom of this thread: cell | border flags << SORT_CELL_BITS */
+    unsigned cellf[SORT_APT];
+    for (int k = 0; k < SORT_APT; ++k) {
+        const int li = tid + k * SORT_B;
+        cellf[k] = 0xffffffffu;
+        if (li < n) {
+            const long long i = b0 + li;
+            int ix = cell_coord(a.xyz[3 * i], g.x0, g.d);
+            int iy = cell_coord(a.xyz[3 * i + 1], g.y0, g.d);
+            int iz = cell_coord(a.xyz[3 * i + 2], g.z0, g.d);
+            if (!(ix >= 0 && ix < g.nx && iy >= 0 && iy < g.ny && iz >= 0 && iz < g.nz)) { /* as count_phase0 */
+                if (a.status[ST_ERROR] == 0) atomicMax(&a.status[ST_ERROR], (int)ERR_BAD_COORD);
+                ix = iy = iz = 0;
+            }
+            const int c = ix + g.nx * (iy + g.ny * iz); /* ref: src/nb.c:74-83 */
+            const int fl = (ix == 0 ? CELL_X0 : 0) | (ix == g.nx - 1 ? CELL_X1 : 0) | (iy == 0 ? CELL_Y0 : 0) |
+                           (iy == g.ny - 1 ? CELL_Y1 : 0) | (iz == 0 ? CELL_Z0 : 0) | (iz == g.nz - 1 ? CELL_Z1 : 0);
+            cellf[k] = (unsigned)c | ((unsigned)fl << SORT_CELL_BITS);
+        }
+        if ((k & 3) == 3) __asm__ volatile("" ::: "memory"); /* (four atoms' loads in flight, not sixteen: the kernel has 128 registers) */
+    }
+    const unsigned cmask = (1u << SORT_CELL_BITS) - 1u;
+    int base = 0; /* atoms in the cells of the passes before this one */
+    for (int lo = 0; lo < C; lo += SORT_CELLS) { /* (once, unless the structure has more than SORT_CELLS cells) */
+        const int Cp = C - lo < SORT_CELLS ? C - lo : SORT_CELLS, W = (Cp + 31) >> 5;
+        __syncthreads();
+        for (int w = tid; w < W; w += SORT_B) bm[w] = 0;
+        for (int k = tid; k < n / 2 + 2; k += SORT_B) cnt[k] = 0;
+        __syncthreads();
+        /* A */
+        for (int k = 0; k < SORT_APT; ++k) {
+            const int cc = (int)(cellf[k] & cmask) - lo;
+            if (cellf[k] != 0xffffffffu && cc >= 0 && cc < Cp) atomicOr(&bm[cc >> 5], 1u << (cc & 31));
+        }
+        __syncthreads();
+        /* B */
+        {
+            int pc[SORT_WORDS / SORT_B], sum = 0;
+            for (int j = 0; j < SORT_WORDS / SORT_B; ++j) {
+                const int w = tid * (SORT_WORDS / SORT_B) + j;
+                pc[j] = w < W ? __popc(bm[w]) : 0;
+                sum += pc[j];
+            }
+            int run = sort_block_scan(sum, scratch, tid);
+            for (int j = 0; j < SORT_WORDS / SORT_B; ++j) {
+                const int w = tid * (SORT_WORDS / SORT_B) + j;
+                if (w < W) wpre[w] = (unsigned short)run;
+                run += pc[j];
+            }
+        }
+        __syncthreads();
+        const int occ = scratch[SORT_B / 64];
+        /* C */
+        unsigned place[SORT_APT]; /* occupied-cell number | place in the cell << 16 */
+        for (int k = 0; k < SORT_APT; ++k) {
+            place[k] = 0xffffffffu;
+            const int cc = (int)(cellf[k] & cmask) - lo;
+            if (cellf[k] != 0xffffffffu && cc >= 0 && cc < Cp) {
+                const int oc = (int)wpre[cc >> 5] + __popc(bm[cc >> 5] & ((1u << (cc & 31)) - 1u));
+                const unsigned old = atomicAdd(&cnt[oc >> 1], (oc & 1) ? 0x10000u : 1u);
+                place[k] = (unsigned)oc | (((old >> ((oc & 1) * 16)) & 0xffffu) << 16);
+            }
+        }
+        __syncthreads();
+        /* D: counters -> first atoms, in place; entry occ = atoms of this pass */
+        unsigned short *const c16 = (unsigned short *)cnt;
+        {
+            int v[SORT_APT], sum = 0;
+            for (int j = 0; j < SORT_APT; ++j) {
+                const int e = tid * SORT_APT + j;
+                v[j] = e < occ ? (int)c16[e] : 0;
+                sum += v[j];
+            }
+            int run = sort_block_scan(sum, scratch, tid);
+            for (int j = 0; j < SORT_APT; ++j) {
+                const int e = tid * SORT_APT + j;
+                if (e <= occ) c16[e] = (unsigned short)run; /* (at most 16384 atoms) */
+                run += v[j];
+            }
+        }
+        __syncthreads();
+        const int n_pass = scratch[SORT_B / 64];
+        /* E */
+        for (int k = 0; k < SORT_APT; ++k) {
+            if (place[k] == 0xffffffffu) continue;
+            const int li = tid + k * SORT_B;
+            const long long i = b0 + li;
+            const int oc = (int)(place[k] & 0xffffu);
+            const long long p = b0 + base + c16[oc] + (int)(place[k] >> 16);
+            Quad v;
+            v.x = a.xyz[3 * i]; v.y = a.xyz[3 * i + 1]; v.z = a.xyz[3 * i + 2];
+            v.w = a.radii[a.shared_radii ? (long long)li : i] + a.probe; /* ref: src/sasa_lr.c:136, src/sasa_sr.c:144 */
+            a.sq[p] = v;
+            SortIdx si;
+            si.cell = (long long)(g.cell_base + (int)(cellf[k] & cmask)) | ((long long)(cellf[k] >> SORT_CELL_BITS) << 32);
+            si.orig = (int)i; si.strct = s;
+            a.s_idx[p] = si;
+            if (a.occ_stride > 0 && i % a.occ_stride == 0) { /* density samples, as scatter_atom */
+                atomicAdd(&a.status[ST_OCC_SUM], (int)c16[oc + 1] - (int)c16[oc]);
+                atomicAdd(&a.status[ST_OCC_N], 1);
+            }
+            if ((k & 3) == 3) __asm__ volatile("" ::: "memory");
+        }
+        /* F */
+        for (int cc = tid; cc < Cp; cc += SORT_B) {
+            const int oc = (int)wpre[cc >> 5] + __popc(bm[cc >> 5] & ((1u << (cc & 31)) - 1u));
+            a.cell_start[g.cell_base + lo + cc] = (int)(b0 + base + c16[oc]);
+        }
+        base += n_pass;
+    }
+    if (last && tid == 0) a.cell_start[a.ncells[a.n_structs]] = a.n_atoms;
+}
+
 __global__ __launch_bounds__(SASA_TOT_B) void k_totals(const double *sasa, const int64_t *offsets, int n_structs, double *totals)
 {
     __shared__ double part[SASA_TOT_B];
@@ -355,6 +537,7 @@ struct freesasa_gpu_ctx {
     /* adaptive neighbor-pool size, per algorithm: (resolution, TA) it was learnt for and the value */
     int hint_res[2] = {0, 0}, hint_ta[2] = {0, 0}, hint_pool[2] = {0, 0};
     bool hint_bucket = false; /* L&R: the last batch had long neighbor lists */
+    bool sort_fused = true;   /* the per-structure cell sort (k_sort_struct) until a batch turns out not to fit it */
     double hint_nn = 0;       /* L&R (lr2): neighbor records per atom the main launch should hold */
     int hint_nn_max = 0;      /* ... and the longest neighbor list expected (mask words per item) */
     double hint_split2 = 0;   /* ... the share of its tiles above the 16-tiles-per-CU pool */
@@ -556,6 +739,10 @@ static int collect_status(freesasa_gpu_ctx *c, int n_structs, int words, long lo
     *total_cells = *total_p;
     if (status_h[ST_ERROR]) return ctx_fail(c, "%s", err_text(status_h[ST_ERROR]));
     if (*total_p <= 0 || *total_p > c->max_cells) return ctx_fail(c, "%s", err_text(ERR_GRID_TOO_BIG));
+    if (status_h[ST_RETRY] == 2) { /* a structure with more cells than k_sort_struct holds: this context sorts the general way from now on */
+        c->sort_fused = false;
+        return RC_RETRY;
+    }
     if (status_h[ST_RETRY]) {
         c->cells_hint = *total_p + *total_p / 16 + 1024;
         return RC_RETRY;
@@ -798,12 +985,19 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
     HIP_TRY(c, hipGetLastError());
 
     const int nblk_atoms = (n + SASA_PIPE_B - 1) / SASA_PIPE_B;
+    /* batches of small structures: the cell sort of a structure in one workgroup's LDS (k_sort_struct) */
+    long long biggest = 0;
+    for (int s_ = 0; s_ < n_structs; ++s_) biggest = offsets[s_ + 1] - offsets[s_] > biggest ? offsets[s_ + 1] - offsets[s_] : biggest;
+    const bool fused = c->sort_fused && biggest <= SORT_ATOMS && n_structs >= 8 && !getenv("FREESASA_AMD_NO_FUSED_SORT");
+    if (fused) hipLaunchKernelGGL(k_sort_struct, dim3(n_structs), dim3(SORT_B), 0, st, pa);
+    else {
     hipLaunchKernelGGL(k_zero_cells, dim3((unsigned)((cells_cap + 2 + 16LL * SASA_PIPE_B - 1) / (16LL * SASA_PIPE_B))), dim3(SASA_PIPE_B), 0, st, pa);
     hipLaunchKernelGGL(k_count, dim3(nblk_atoms), dim3(SASA_PIPE_B), 0, st, pa);
     hipLaunchKernelGGL(k_scan1, dim3(nblk_scan), dim3(SASA_PIPE_B), 0, st, pa);
     hipLaunchKernelGGL(k_scan2, dim3(1), dim3(SASA_PIPE_B), 0, st, pa);
     hipLaunchKernelGGL(k_scan3, dim3(nblk_scan), dim3(SASA_PIPE_B), 0, st, pa);
     hipLaunchKernelGGL(k_scatter, dim3(nblk_atoms), dim3(SASA_PIPE_B), 0, st, pa);
+    }
     HIP_TRY(c, hipGetLastError());
     if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[1], st));
 
@@ -979,7 +1173,9 @@ static int run_batch_impl(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
                      const double *unit_points, double *d_sasa, int *d_counts, double *d_totals)
 {
     int rc = run_batch_once(c, lr, d_xyz, d_radii, offsets, n_structs, probe, resolution, unit_points, d_sasa, d_counts, d_totals);
-    if (rc == RC_RETRY) /* the cell table was too small (first batch of a very sparse kind): once more, with K2's size */
+    /* once more when the cell table was too small (first batch of a very sparse kind; now with K2's size), and once more
+       when a structure did not fit the per-structure cell sort (the general pipeline from then on) */
+    for (int again = 0; rc == RC_RETRY && again < 2; ++again)
         rc = run_batch_once(c, lr, d_xyz, d_radii, offsets, n_structs, probe, resolution, unit_points, d_sasa, d_counts, d_totals);
     if (rc == RC_RETRY) return ctx_fail(c, "cell table sizing did not converge");
     return rc;
