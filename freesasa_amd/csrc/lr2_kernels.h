@@ -152,6 +152,15 @@ SASA_D int lr2_div3(int v) { return LR2_MUL24(v, 43) >> 7; }  /* v / 3 for 0 <= 
 #define LR2_MARK_BEGIN do { } while (0)
 #endif
 
+/* h = 1/(2 sqrt x) for the screening and the arc pass (the same bits in both): one coupled Goldschmidt step on
+ * the hardware seed (relative error 4e-15; -DLR2_EXACT_H2: sqrt_rh's two and a half steps, 1 ulp).  With the
+ * degree-12 acos_fast2 this spends two of the eight orders of magnitude between the reference-level 1e-12 and the
+ * 1e-4 A^2 contract: -2.5 % kernel time (round 3, measured). */
+#ifndef LR2_EXACT_H2
+#define LR2_H2(x, h) do { const double x_ = (x), y_ = SASA_RSQ(x_), g_ = x_ * y_, h_ = 0.5 * y_; (h) = fma(h_, fma(-h_, g_, 0.5), h_); } while (0)
+#else
+#define LR2_H2(x, h) do { double g_; sqrt_rh((x), g_, (h)); } while (0)
+#endif
 #define LR2_LANES 64
 #define LR2_NONE 0xffff
 
@@ -787,8 +796,8 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         double area = 0;
         int cnt = 0;
         if (A > 0) { /* ref: :310-312 */
-            double Rip, h2;
-            sqrt_rh(A, Rip, h2); /* h2 = 1/(2 Ri') */
+            double h2;
+            LR2_H2(A, h2); /* h2 = 1/(2 Ri') */
             const int o = m.aoff[la], nn = m.aoff[la + 1] - o;
             double cmin = 1.0;
             for (int wi = 0; wi < mwt; ++wi) {
@@ -894,7 +903,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         if (my != LR2_NONE) {                                                                      \
             la = e_ >> 10;                                                                         \
             R = m.aoff[la]; t = m.it_tc[my];                                                        \
-            { const double Ri_ = m.atom[la].w; double g_; sqrt_rh(Ri_ * Ri_ - t * t, g_, h2); } /* as P4: bit for bit */ \
+            { const double Ri_ = m.atom[la].w; LR2_H2(Ri_ * Ri_ - t * t, h2); } /* as P4: bit for bit */ \
             mk = m.it_mask + LR2_MUL24(my, mw); w = *mk; wleft = mwt - 1;                          \
             LR2_NEXT_WORD();                                                                       \
         }                                                                                          \

@@ -818,7 +818,7 @@ SASA_D double acos_fast(double x)
  * operands less (31 -> 25 VALU instructions per arc).  ACOS2_DEG 13 / 12: 9.7e-14 / 6.3e-13, one / two fma less.
  * The sign of x enters as the factor +-2 of (asin u - pi/4) in one fma with pi/2. */
 #ifndef ACOS2_DEG
-#define ACOS2_DEG 14
+#define ACOS2_DEG 12 /* 6.3e-13: with LR2_FAST_H2 the areas stay within ~1e-11 A^2 of the reference (measured: DESIGN.md; contract: 1e-4) */
 #endif
 SASA_D double acos_fast2(double x)
 {
