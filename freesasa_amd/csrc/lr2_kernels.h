@@ -132,6 +132,16 @@ SASA_D int lr2_scan_max16(int v, int)
 }
 #endif
 
+SASA_D double lr2_shfl_f64(double v, int src) /* v of lane src */
+{
+    unsigned long long b;
+    memcpy(&b, &v, 8);
+    const unsigned lo = (unsigned)LR2_SHFL((int)(unsigned)b, src), hi = (unsigned)LR2_SHFL((int)(unsigned)(b >> 32), src);
+    b = (unsigned long long)lo | ((unsigned long long)hi << 32);
+    memcpy(&v, &b, 8);
+    return v;
+}
+
 /* x / y, correctly rounded, from r = RN(1 / y): q = RN(x r), then one correction with the exact remainder
  * (Markstein).  Checked against the division for every y = 1 .. 1024 on 2e8 operands (tools/dev/div_by_slices_check.c):
  * identical.  Four instructions where the hardware division sequence takes about thirty. */
@@ -882,7 +892,63 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     LR2_MARK(5);
     /* ------------------------------------------------------------ P6 arc pass */
     int maxd = 0;
-    {
+    if (COVER && nq * 2 <= LR2_LANES) {
+        const int shb = nq * 4 <= LR2_LANES ? 2 : 1, share = 1 << shb; /* (uniform) 4 lanes per item, or 2 */
+        /* Few items are left (dense tiles behind the cover filter: ~9 of 60, two of them with ~27 arcs): one item
+           per lane would leave 55 lanes idle for as long as the longest item takes.  Four lanes (two, from 17 items)
+           share an item instead: each unites the arcs of its part of the atom's neighbor list (contiguous in beta), then the
+           partial unions are merged pairwise, the higher into the lower — components of the higher part arrive in
+           ascending order and each contains a mid-point beyond every mid-point of the lower part, which is all the
+           stack union asks of its input (see lr2_union_step). */
+        Arc2 *stk = m.stack + lane;
+        const int qi = lane >> shb, j = lane & (share - 1);
+        const bool valid = qi < nq;
+        int my = 0, la = 0;
+        Lr2Union u;
+        lr2_union_reset(u);
+        if (valid) {
+            const int e = (int)m.queue[qi];
+            my = e & 1023; la = e >> 10;
+            const int o = m.aoff[la], nn = m.aoff[la + 1] - o;
+            const double t = m.it_tc[my], Ri = m.atom[la].w;
+            double h2;
+            LR2_H2(Ri * Ri - t * t, h2); /* as P4: bit for bit */
+            const int lo = LR2_MUL24(nn, j) >> shb, hi = LR2_MUL24(nn, j + 1) >> shb; /* list positions of this lane */
+            for (int wi = 0; wi < mwt; ++wi) {
+                int a0 = lo - 32 * wi, a1 = hi - 32 * wi;
+                a0 = a0 < 0 ? 0 : (a0 > 32 ? 32 : a0);
+                a1 = a1 < 0 ? 0 : (a1 > 32 ? 32 : a1);
+                const unsigned below1 = a1 >= 32 ? 0xffffffffu : ((1u << a1) - 1u), below0 = a0 >= 32 ? 0xffffffffu : ((1u << a0) - 1u);
+                unsigned w = m.it_mask[LR2_MUL24(my, mw) + wi] & below1 & ~below0;
+                const int R = o + 32 * wi;
+                while (w != 0) { /* (the wave runs as many trips as its busiest lane) */
+                    const int q = R + __builtin_ctz(w);
+                    w &= w - 1;
+                    const Ab16 ab = m.ab[q];
+                    const double bt = m.beta[q];
+                    const double alpha = acos_fast2(fma(t, ab.a, ab.b) * h2);
+                    lr2_union_step(bt - alpha, bt + alpha, u, stk, a.ds, maxd); /* ref: :338-339 */
+                }
+            }
+        }
+        for (int st = 1; st < share; st <<= 1) { /* merge: lane j + st into lane j, for j a multiple of 2 st */
+            LR2_SYNC();
+            const int src = lane + st < LR2_LANES ? lane + st : lane;
+            const int d_s = LR2_SHFL(u.depth, src);
+            const double bs_s = lr2_shfl_f64(u.bs, src), be_s = lr2_shfl_f64(u.be, src);
+            const double ts_s = lr2_shfl_f64(u.ts, src), te_s = lr2_shfl_f64(u.te, src);
+            if (valid && (j & (2 * st - 1)) == 0) {
+                const Arc2 *col = m.stack + src;
+                for (int c = 0; c < d_s - 2; ++c) { /* (rare: the components below the two in registers) */
+                    const Arc2 k = col[(c < a.ds ? c : 0) * LR2_LANES];
+                    lr2_union_step(k.s, k.e, u, stk, a.ds, maxd);
+                }
+                if (d_s >= 2) lr2_union_step(bs_s, be_s, u, stk, a.ds, maxd);
+                if (d_s >= 1) lr2_union_step(ts_s, te_s, u, stk, a.ds, maxd);
+            }
+        }
+        if (valid && j == 0) m.it_tc[my] = m.adel[la] * m.atom[la].w * lr2_sweep(u, stk, a.ds); /* ref: :360 */
+    } else {
         Arc2 *stk = m.stack + lane;
         int next = LR2_LANES;
         int my = LR2_NONE, la = 0, wleft = 0;
