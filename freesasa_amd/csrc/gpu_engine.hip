@@ -536,6 +536,7 @@ struct freesasa_gpu_ctx {
     long long cells_hint = 0; /* cells the last batch needed, with a margin: the table is never sized below it */
     /* adaptive neighbor-pool size, per algorithm: (resolution, TA) it was learnt for and the value */
     int hint_res[2] = {0, 0}, hint_ta[2] = {0, 0}, hint_pool[2] = {0, 0};
+    double hint_probe = -1.0; /* the probe radius the hints were learnt with (another probe: other neighbor counts, so they start over) */
     bool hint_bucket = false; /* L&R: the last batch had long neighbor lists */
     bool sort_fused = true;   /* the per-structure cell sort (k_sort_struct) until a batch turns out not to fit it */
     double hint_nn = 0;       /* L&R (lr2): neighbor records per atom the main launch should hold */
@@ -962,14 +963,19 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
     pa.sq = (Quad *)c->sq.p;
     pa.s_idx = (SortIdx *)c->s_idx.p;
     pa.status = (int *)c->status.p;
+    if (probe != c->hint_probe) { /* launch-shape history is per (resolution, probe radius) */
+        c->hint_res[0] = c->hint_res[1] = 0;
+        c->hint_pool2 = 0;
+        c->hint_probe = probe;
+    }
     pa.occ_stride = c->hint_res[lr ? 0 : 1] == resolution ? 0 : (n / 256 > 0 ? n / 256 : 1);
 
     /* The cell table is sized WITHOUT waiting for K2's total: for what the context has seen so far, and for a
-       first batch 20 cells per atom (sparse random coils need 9, proteins 1-2) plus 2048 per structure.  K2 checks
+       first batch 10 cells per atom (sparse random coils need 9, proteins 1-2) plus 256 per structure.  K2 checks
        the real total against it on the device (ST_RETRY, see PIPE_GATE); the total itself reaches the host with
        the status words at the end of the batch. */
     int *status_h = c->pinned;
-    long long cells_cap = 20LL * n + 2048LL * n_structs;
+    long long cells_cap = 10LL * n + 256LL * n_structs; /* (0.4 GB for 1e7 atoms; a sparser batch is redone once with K2's size) */
     if (cells_cap < c->cells_hint) cells_cap = c->cells_hint;
     if (cells_cap > c->max_cells) cells_cap = c->max_cells;
     const int nblk_scan = (int)((cells_cap + 1 + (long long)SASA_PIPE_B * SASA_SCAN_ITEMS - 1) / ((long long)SASA_PIPE_B * SASA_SCAN_ITEMS));
@@ -1696,18 +1702,23 @@ static int sweep_impl(const char *const *paths, int n_paths, int ingest_options,
     std::vector<char> done((size_t)n_batches, 0);
     int fd_done = -1, fd_res = -1;
     if (done_path) {
-        unsigned long long h = 1469598103934665603ULL; /* FNV-1a over the path list: the done-list belongs to these files */
-        for (int k = 0; k < n_paths; ++k)
+        unsigned long long h = 1469598103934665603ULL; /* FNV-1a over the files' names, sizes and modification times: the done-list belongs to THESE files as they are now */
+        for (int k = 0; k < n_paths; ++k) {
             for (const char *q = paths[k] ? paths[k] : ""; ; ++q) { h = (h ^ (unsigned char)*q) * 1099511628211ULL; if (!*q) break; }
+            struct stat st;
+            long long id[3] = {-1, -1, -1};
+            if (paths[k] && stat(paths[k], &st) == 0) { id[0] = (long long)st.st_size; id[1] = (long long)st.st_mtim.tv_sec; id[2] = (long long)st.st_mtim.tv_nsec; }
+            for (size_t q = 0; q < sizeof id; ++q) h = (h ^ ((const unsigned char *)id)[q]) * 1099511628211ULL;
+        }
         char head[256];
-        snprintf(head, sizeof head, "freesasa_amd sweep done-list v1 n_files=%d batches=%d paths=%016llx options=%d alg=%d resolution=%d probe=%.17g\n",
+        snprintf(head, sizeof head, "freesasa_amd sweep done-list v2 n_files=%d batches=%d files=%016llx options=%d alg=%d resolution=%d probe=%.17g\n",
                  n_paths, n_batches, h, ingest_options, alg, resolution, probe);
         const std::string res_path = std::string(done_path) + ".bin";
         bool resume = false;
         if (FILE *fp = fopen(done_path, "r")) {
             char line[256];
             if (fgets(line, sizeof line, fp)) {
-                if (strcmp(line, head) != 0) { fclose(fp); return set_err(err_out, err_len, "the done-list belongs to a sweep with other parameters"); }
+                if (strcmp(line, head) != 0) { fclose(fp); return set_err(err_out, err_len, "the done-list belongs to a sweep with other parameters or other (changed) input files"); }
                 resume = true;
                 int b, first, count;
                 while (fgets(line, sizeof line, fp))
@@ -1976,13 +1987,13 @@ static int traj_run(TrajIO &io, const double *radii, int n_atoms, long long n_fr
                     if (io.fd_sasa >= 0 && !pwrite_all(io.fd_sasa, dst_sasa, 8 * na, 8 * (long long)n * f0)) { ctx_fail(c, "could not write the per-atom file"); break; }
                 }
                 if (io.fd_done >= 0) { /* results first, then the record: a shard is listed only when its numbers are on disk */
-                    if (io.fd_totals >= 0) (void)fdatasync(io.fd_totals);
-                    if (io.fd_sasa >= 0) (void)fdatasync(io.fd_sasa);
+                    if ((io.fd_totals >= 0 && fdatasync(io.fd_totals) != 0) || (io.fd_sasa >= 0 && fdatasync(io.fd_sasa) != 0)) {
+                        ctx_fail(c, "could not flush the result files: the shard is not listed as done"); break;
+                    }
                     char line[96];
                     const int len = snprintf(line, sizeof line, "shard %lld %lld %d\n", k, f0, nf);
                     std::lock_guard<std::mutex> lk(done_mu);
-                    if (write(io.fd_done, line, (size_t)len) != len) { ctx_fail(c, "could not append to the done-list"); break; }
-                    (void)fdatasync(io.fd_done);
+                    if (write(io.fd_done, line, (size_t)len) != len || fdatasync(io.fd_done) != 0) { ctx_fail(c, "could not append to the done-list"); break; }
                 }
                 io.done[(size_t)k] = 1;
                 rc = 0;
@@ -2069,16 +2080,20 @@ extern "C" int freesasa_gpu_trajectory_file(const char *frames_path, int frames_
         io.in_f32 = frames_f32 ? 1 : 0; io.in_header = header_bytes;
         const long long n_shards = (n_frames + frames_per_batch - 1) / frames_per_batch;
         io.done.assign((size_t)n_shards, 0);
-        char head[256];
-        snprintf(head, sizeof head, "freesasa_amd trajectory done-list v1 n_atoms=%d n_frames=%lld frames_per_batch=%d alg=%d resolution=%d probe=%.17g f32=%d\n",
-                 n_atoms, n_frames, frames_per_batch, alg, resolution, probe, io.in_f32);
+        unsigned long long hr = 1469598103934665603ULL; /* FNV-1a over the radii */
+        for (size_t q = 0; q < 8 * (size_t)n_atoms; ++q) hr = (hr ^ ((const unsigned char *)radii)[q]) * 1099511628211ULL;
+        char head[384];
+        snprintf(head, sizeof head, "freesasa_amd trajectory done-list v2 n_atoms=%d n_frames=%lld frames_per_batch=%d alg=%d resolution=%d probe=%.17g f32=%d "
+                 "header_bytes=%lld frames_size=%lld frames_mtime=%lld.%09ld radii=%016llx\n",
+                 n_atoms, n_frames, frames_per_batch, alg, resolution, probe, io.in_f32, header_bytes, (long long)st.st_size,
+                 (long long)st.st_mtim.tv_sec, (long)st.st_mtim.tv_nsec, hr);
         bool resume = false;
         if (done_path) {
             FILE *fp = fopen(done_path, "r");
             if (fp) {
-                char line[256];
+                char line[384];
                 if (fgets(line, sizeof line, fp)) {
-                    if (strcmp(line, head) != 0) { fclose(fp); set_err(err_out, err_len, "the done-list belongs to a run with other parameters"); break; }
+                    if (strcmp(line, head) != 0) { fclose(fp); set_err(err_out, err_len, "the done-list belongs to a run with other parameters, radii or frame file"); break; }
                     resume = true;
                     long long k, f0; int nf;
                     while (fgets(line, sizeof line, fp))

@@ -704,6 +704,13 @@ def test_trajectory_file_resumes_bit_for_bit(fa, tmp_path):
     assert fa.trajectory_file(f64, r, tmp_path / "t1.bin", tmp_path / "s1.bin", tmp_path / "d1.txt", frames_per_batch=3)[0]
     with pytest.raises(RuntimeError):
         fa.trajectory_file(f64, r, tmp_path / "t1.bin", None, tmp_path / "d1.txt", frames_per_batch=4)
+    # ... and so is the same run over other inputs: other radii, or a frame file that changed since (size / mtime)
+    r_other = r.copy(); r_other[7] += 0.01
+    with pytest.raises(RuntimeError, match="radii or frame file"):
+        fa.trajectory_file(f64, r_other, tmp_path / "t1.bin", tmp_path / "s1.bin", tmp_path / "d1.txt", frames_per_batch=3)
+    os.utime(f64, ns=(os.stat(f64).st_atime_ns, os.stat(f64).st_mtime_ns + 5_000_000_000))
+    with pytest.raises(RuntimeError, match="radii or frame file"):
+        fa.trajectory_file(f64, r, tmp_path / "t1.bin", tmp_path / "s1.bin", tmp_path / "d1.txt", frames_per_batch=3)
     # fp32 frames are an input format: widened on the device, same result as the widened frames in memory
     w_tot, w_sasa = fa.trajectory(frames.astype(np.float32).astype(np.float64), r, frames_per_batch=5)
     done, _ = fa.trajectory_file(f32, r, tmp_path / "t2.bin", tmp_path / "s2.bin", f32=True, frames_per_batch=5)

@@ -334,6 +334,16 @@ def test_resumable_sweep_equals_the_uninterrupted_one(tmp_path):
     assert complete and np.array_equal(totals2, want[0]) and len(done.read_text().splitlines()) == n_lines
     with pytest.raises(RuntimeError):
         fa.sweep_files_resumable(paths, done, batch_atoms=3000, resolution=21)
+    # ... and so is the same sweep over a file that changed since (the done-list names sizes and modification times)
+    import shutil
+    local = tmp_path / "copy_1ubq.pdb"
+    shutil.copy(fixture("1ubq.pdb"), local)
+    paths2, done2 = [str(local), fixture("3bkr.cif")], tmp_path / "sweep2.done"
+    assert fa.sweep_files_resumable(paths2, done2, batch_atoms=3000, n_threads=2)[0]
+    with open(local, "a") as fh:
+        fh.write("REMARK changed\n")
+    with pytest.raises(RuntimeError, match="changed"):
+        fa.sweep_files_resumable(paths2, done2, batch_atoms=3000, n_threads=2)
 
 
 def test_mmcif_row_scanner_equals_the_byte_at_a_time_tokenizer():
