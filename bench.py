@@ -227,12 +227,12 @@ def secondary_workloads(fa, torch, tools, d_xyz, d_r, offs, xyz, r, dev, local_r
 
 
 def profiled_traffic(args):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this same command, KB units, taken as they
-    are reported).  The kernel reads its atoms as 32-byte records, two 16-byte loads per lane; MI355X_MICROARCH.md
-    warns that FETCH_SIZE can under-count 16-byte-per-lane streams by up to 2x, and a copy kernel of known size
-    profiled in the same session (profiles/README.md, "FETCH_SIZE calibration") says by how much on this build:
-    the figure is a lower bound of the fetch side, exact on the write side.  Only valid for the default workload."""
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
+    collected in separate --pmc runs of this same command, KB, summed over the XCD instances of a dispatch), corrected
+    as MI355X_MICROARCH.md prescribes and as the calibration of the same session confirms: copy kernels of known
+    size (tools/dev/fetch_calib.hip: 8-byte, 16-byte and 32-byte-record accesses, streamed and gathered) report
+    FETCH_SIZE = 0.500 x and WRITE_SIZE = 1.000 x the bytes they move, so bytes = (2 FETCH_SIZE + WRITE_SIZE) x 1024
+    (profiles/README.md, "FETCH_SIZE calibration").  Only valid for the default workload."""
     if (args.structs, args.atoms, args.slices) != (1000, 10000, 20):
         return None, None
     best = None
@@ -253,7 +253,7 @@ def profiled_traffic(args):
     if best_v is not None:
         global PROFILED_VALU
         PROFILED_VALU = best_v["SQ_INSTS_VALU"]["per_launch"]
-        return (best_v["FETCH_SIZE"]["per_launch_KB"] + best_v["WRITE_SIZE"]["per_launch_KB"]) * 1024.0, "profiles/" + best
+        return (2.0 * best_v["FETCH_SIZE"]["per_launch_KB"] + best_v["WRITE_SIZE"]["per_launch_KB"]) * 1024.0, "profiles/" + best
     return None, None
 
 

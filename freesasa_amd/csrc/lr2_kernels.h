@@ -284,7 +284,7 @@ struct Lr2Mem {
     unsigned short *tag; /* [pool] atom (low 3 bits) and list position of a hit */
     Arc2 *stack;     /* [ds][64] */
 };
-/* flags: 0 tile overflow, 1 stack overflow, 2 max neighbor count, 5 largest cell group */
+/* flags: 0 tile overflow, 1 stack overflow, 2 max neighbor count, 5 largest cell group, 6 atoms with a coincident neighbor of equal radius (bits) */
 
 SASA_D Lr2Mem lr2_carve(const Lr2Args &a, char *smem)
 {
@@ -321,7 +321,8 @@ SASA_D Lr2Mem lr2_carve(const Lr2Args &a, char *smem)
  * cos(alpha) >= 1 (no arc) and cos(alpha) <= -1 (slice buried).  dij == 0 (centres on one vertical
  * line): the sign of A + D - B decides like the reference's tests; a' and b' then carry the factor
  * 2^500 instead of 1/dij (cos(alpha) = +-huge, or 0 * huge = 0 in the one case where the reference
- * divides 0 by 0; two coincident atoms of equal radius get b' = NaN: no arc, as sasa_kernels.h). */
+ * divides 0 by 0; two coincident atoms of equal radius get b' = NaN: no arc, and P7 returns NaN for the atom as
+ * the reference does — duplicate atom records do not pass for areas). */
 SASA_D void lr2_record(double xd, double yd, double zd, double rj, double ri, double &ap, double &bp, double &Kout, double &d3sq, double &inv_d)
 {
     const double D = xd * xd + yd * yd; /* ref: src/nb.c:438 */
@@ -718,6 +719,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                 r_pos[r] = o | (m.acnt[la] << 16);
                 lr2_record(hq.x, hq.y, hq.z, hq.w, ri, r_a[r], r_b[r], Kc, d3sq, inv_d);
                 r_beta[r] = atan2_inv(hq.y, hq.x, inv_d) + SASA_PI; /* ref: src/sasa_lr.c:337 */
+                if (r_b[r] != r_b[r]) LR2_OR_LDS((unsigned *)&m.flags[6], 1u << la); /* a coincident atom of equal radius: the area is NaN, as the reference's (0 / 0, src/sasa_lr.c:335) */
                 r_key[r] = lr_rank_key(r_beta[r], tie_by_place ? (unsigned)sa : lr2_tie12(hq.x, hq.y, hq.z), low);
                 m.keys[o + sa] = r_key[r];
                 r_cb[r] = la << 3;
@@ -1016,6 +1018,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     if (!deep && lane < na) {
         double s = 0;
         for (int k = 0; k < ns; ++k) s += m.it_tc[LR2_MUL24(lane, ns) + k]; /* slice order, ref: :305-361 */
+        if ((m.flags[6] >> lane) & 1) s = NAN; /* duplicate atom record (see P3) */
         LR2_COLD(a, sasa)[m.sorig[lane]] = s; /* (the pointer is read here, once per tile) */
     }
     LR2_SYNC();

@@ -99,18 +99,17 @@ def test_edge_fixtures(oracle_lib):
     assert sasa[1] == 0.0
 
 
-def test_coincident_atoms_documented_divergence(oracle_lib):
+def test_coincident_atoms_are_nan_like_the_reference(oracle_lib):
     """Duplicate atom records (same centre, same radius): the reference divides 0 by 0 in every slice and returns
-    NaN for such atoms (src/sasa_lr.c:335 with dij = 0 and equal slice radii); the kernel's record for such a
-    pair is NaN and cuts no arc, so the atoms get finite, equal areas — a deliberate, documented divergence
-    (DESIGN.md section 4); everything else in the structure is unaffected.  S&R is defined for both."""
+    NaN for such atoms (src/sasa_lr.c:335 with dij = 0 and equal slice radii).  The kernel's record for such a
+    pair is NaN and cuts no arc, and the atom's area comes back NaN as well - a duplicate record does not pass for
+    an area; everything else in the structure is unaffected.  S&R is defined for both."""
     xyz = np.array([[0.0, 0, 0], [0, 0, 0], [0, 0, 0], [9.0, 0, 0], [9.0, 2.5, 0]])
     r = np.array([1.8, 1.8, 1.8, 1.6, 1.7])
     want = oracle_lib.lee_richards(xyz, r)
     assert np.all(np.isnan(want[:3])) and np.all(np.isfinite(want[3:]))
     sasa, *_ = run_batch(True, xyz, r)
-    assert np.all(np.isfinite(sasa)) and sasa[0] == sasa[1] == sasa[2]
-    assert abs(sasa[0] - 4 * np.pi * 3.2 ** 2) < 1.0         # a free sphere of radius R + probe (20 slices)
+    assert np.all(np.isnan(sasa[:3]))
     assert close(sasa[3:], want[3:])
     _, c, _, _ = _sr(oracle_lib, xyz, r)
     assert np.array_equal(c, oracle_lib.shrake_rupley(xyz, r)[1])

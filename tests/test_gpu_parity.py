@@ -744,15 +744,15 @@ def test_trajectory_file_resumes_bit_for_bit(fa, tmp_path):
     assert killed and 0 < listed < 138, (killed, listed)   # the child really was stopped part-way
 
 
-def test_coincident_atoms_documented_divergence(fa, oracle_lib):
-    """As tests/test_emulation.py::test_coincident_atoms_documented_divergence, on the device: duplicate atoms get
-    finite equal areas where the reference returns NaN; the other atoms and S&R agree with the oracle."""
+def test_coincident_atoms_are_nan_like_the_reference(fa, oracle_lib):
+    """As tests/test_emulation.py::test_coincident_atoms_are_nan_like_the_reference, on the device: duplicate atom
+    records get NaN as in the reference; the other atoms and S&R agree with the oracle."""
     xyz = np.array([[0.0, 0, 0], [0, 0, 0], [0, 0, 0], [9.0, 0, 0], [9.0, 2.5, 0]])
     r = np.array([1.8, 1.8, 1.8, 1.6, 1.7])
     want = oracle_lib.lee_richards(xyz, r)
     assert np.all(np.isnan(want[:3]))
     sasa, _ = fa.calc_coord(xyz, r, fa.LEE_RICHARDS)
-    assert np.all(np.isfinite(sasa)) and sasa[0] == sasa[1] == sasa[2]
+    assert np.all(np.isnan(sasa[:3]))
     assert np.max(np.abs(sasa[3:] - want[3:])) <= LR_TOL
     got = fa.calc_batch(xyz, r, [0, 5], alg=fa.SHRAKE_RUPLEY, resolution=100)
     assert np.array_equal(got[1], oracle_lib.shrake_rupley(xyz, r)[1])
