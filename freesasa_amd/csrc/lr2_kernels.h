@@ -101,6 +101,14 @@ SASA_D int lr2_scan_add(int v, int lane)
     }
     return v;
 }
+SASA_D int lr2_scan_add16(int v, int lane) /* inclusive prefix sum inside each row of 16 lanes */
+{
+    for (int d = 1; d < 16; d <<= 1) {
+        const int o = LR2_SHFL(v, (lane & 15) >= d ? lane - d : lane);
+        if ((lane & 15) >= d) v += o;
+    }
+    return v;
+}
 SASA_D int lr2_scan_max16(int v, int lane) /* running maximum inside each row of 16 lanes */
 {
     for (int d = 1; d < 16; d <<= 1) {
@@ -119,6 +127,14 @@ SASA_D int lr2_scan_add(int v, int)
     v += LR2_DPP(v, 0x118, 0xf); /* row_shr:8 */
     v += LR2_DPP(v, 0x142, 0xa); /* row_bcast15 into rows 1 and 3 */
     v += LR2_DPP(v, 0x143, 0xc); /* row_bcast31 into rows 2 and 3 */
+    return v;
+}
+SASA_D int lr2_scan_add16(int v, int)
+{
+    v += LR2_DPP(v, 0x111, 0xf); /* row_shr:1 */
+    v += LR2_DPP(v, 0x112, 0xf); /* row_shr:2 */
+    v += LR2_DPP(v, 0x114, 0xf); /* row_shr:4 */
+    v += LR2_DPP(v, 0x118, 0xf); /* row_shr:8 */
     return v;
 }
 SASA_D int lr2_scan_max16(int v, int)
@@ -697,10 +713,16 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     {
         double r_a[RMAX], r_b[RMAX], r_beta[RMAX], r_key[RMAX];
         int r_pos[RMAX]; /* first record of the pair's atom | list length << 16; -1: no pair */
-        int r_cb[RMAX];  /* cover filter: bin of the pair's cap | atom << 3 */
+        int r_cb[RMAX];  /* cover filter: bin of the pair's cap | atom << 3 | bucket of its key << 6 | place in the bucket << 10 */
         unsigned low = 0xfffu;
         SASA_OPAQUE(low);
         unsigned long long *const chist = (unsigned long long *)m.acell; /* [TA] over acell and lead (P0 / P1 only) */
+        /* Long lists (dense tiles) are ranked in two levels: 16 buckets of the key per atom (counting, one LDS atomic
+           per pair), then inside the pair's own bucket - 3 keys on average where the whole list has 48.  The bucket
+           is a monotone function of the KEY, so the order is the order of the keys, exactly as below.  The bucket
+           counters lie where the item masks will be (free until P4; the hits over them are in registers by then). */
+        const bool bk = cover && ns * mw >= 16; /* (uniform) */
+        int *const bh = (int *)m.it_mask;       /* [TA][16] pairs per bucket, then first place of the bucket in the atom's list */
         if (cover) {
             if (lane < TA) chist[lane] = 0;
             LR2_SYNC();
@@ -721,7 +743,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                 r_beta[r] = atan2_inv(hq.y, hq.x, inv_d) + SASA_PI; /* ref: src/sasa_lr.c:337 */
                 if (r_b[r] != r_b[r]) LR2_OR_LDS((unsigned *)&m.flags[6], 1u << la); /* a coincident atom of equal radius: the area is NaN, as the reference's (0 / 0, src/sasa_lr.c:335) */
                 r_key[r] = lr_rank_key(r_beta[r], tie_by_place ? (unsigned)sa : lr2_tie12(hq.x, hq.y, hq.z), low);
-                m.keys[o + sa] = r_key[r];
+                if (!bk) m.keys[o + sa] = r_key[r];
                 r_cb[r] = la << 3;
                 if (cover) { /* (uniform) */
                     const int b = lr2_cover_bin(Kc, d3sq, ri);
@@ -744,11 +766,43 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             }
             LR2_SYNC();
         }
+        if (bk) {
+            for (int q = lane; q < 16 * TA; q += LR2_LANES) bh[q] = 0;
+            LR2_SYNC();
+            for (int r = 0; r < RMAX; ++r) {
+                if (r_pos[r] < 0) continue;
+                int b = (int)(r_key[r] * (16.0 / SASA_TWOPI));
+                b = b < 0 ? 0 : (b > 15 ? 15 : b);
+                const int idx = SASA_ATOMIC_ADD_LDS(&bh[((r_cb[r] >> 3) & 7) * 16 + b], 1);
+                r_cb[r] |= (b << 6) | (idx << 10);
+            }
+            LR2_SYNC();
+            for (int q0 = 0; q0 < 16 * TA; q0 += LR2_LANES) { /* counts -> first places: a prefix inside every atom's row of 16 */
+                const int q = q0 + lane, v = q < 16 * TA ? bh[q] : 0;
+                const int incl = lr2_scan_add16(v, lane);
+                LR2_SYNC();
+                if (q < 16 * TA) bh[q] = incl - v;
+            }
+            LR2_SYNC();
+            for (int r = 0; r < RMAX; ++r) {
+                if (r_pos[r] < 0) continue;
+                const int first = bh[((r_cb[r] >> 3) & 7) * 16 + ((r_cb[r] >> 6) & 15)];
+                m.keys[(r_pos[r] & 0xffff) + first + ((r_cb[r] >> 10) & 0xff)] = r_key[r];
+            }
+            LR2_SYNC();
+        }
         for (int r = 0; r < RMAX; ++r) {
             if (r_pos[r] < 0) continue;
             const int o = r_pos[r] & 0xffff, nn = r_pos[r] >> 16;
             const double kme = r_key[r];
             int rank = 0, t = 0;
+            if (bk) { /* (uniform) the keys of the pair's own bucket only */
+                const int la_ = (r_cb[r] >> 3) & 7, b = (r_cb[r] >> 6) & 15;
+                const int lo = bh[la_ * 16 + b], hi = b < 15 ? bh[la_ * 16 + b + 1] : m.acnt[la_];
+                rank = lo;
+                for (int q = lo; q < hi; ++q) rank += m.keys[o + q] < kme ? 1 : 0;
+                t = nn;
+            }
             for (; t + 4 <= nn; t += 4) { /* two keys per LDS read (o is even), two reads per trip */
                 const Arc2 k0 = *(const Arc2 *)(m.keys + o + t), k1 = *(const Arc2 *)(m.keys + o + t + 2);
                 rank += k0.s < kme ? 1 : 0;
@@ -764,9 +818,9 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             Ab16 rc; rc.a = r_a[r]; rc.b = r_b[r];
             m.ab[o + rank] = rc;
             m.beta[o + rank] = r_beta[r];
-            SASA_ATOMIC_ADD_LDS(&m.lead[r_cb[r] >> 3], rank);
+            SASA_ATOMIC_ADD_LDS(&m.lead[(r_cb[r] >> 3) & 7], rank);
             if (cover) { /* (uniform) one of the atom's largest caps: its bit in the atom's list */
-                const int la = r_cb[r] >> 3;
+                const int la = (r_cb[r] >> 3) & 7;
                 if ((r_cb[r] & 7) <= m.gsz[la] && SASA_ATOMIC_ADD_LDS(&m.acell[la], 1) < LR2_COVER_MAX)
                     LR2_OR_LDS(&m.cmask[LR2_MUL24(la, mw) + (rank >> 5)], 1u << (rank & 31));
             }
