@@ -289,7 +289,7 @@ struct Lr2Mem {
     int *acell, *lead, *gsz, *acnt, *aoff, *sorig, *flags, *hist;
     unsigned *cmask; /* [TA*mw] cover filter: the atom's neighbors with the largest caps, as bits of its (beta-sorted) list */
     int *rowlo, *cpre; /* [9 TA], [9 TA + 2]: first candidate of a row, prefix of P1's work items (over the keys until P3) */
-    double *it_tc;  /* [items] slice height relative to the atom centre (z - zi) until the item's slice is done, then its area */
+    double *it_tc;  /* [items] 1/(2 Ri') of an item with arcs until its slice is done, then (and for the others from P4 on) its area */
     unsigned *it_mask; /* [items*mw] neighbors that cut an arc */
     unsigned short *queue; /* [items] items with arcs, heaviest first: item | atom << 10 */
     unsigned short *qtmp;  /* [items] bin and arrival order of an item before the bins are laid out */
@@ -473,6 +473,14 @@ SASA_D void lr2_overflow(const Lr2Args &a, int p0, int na, int err_code)
     }
 }
 
+
+/* Height of the mid-plane of slice s above the atom's centre: (s + 1/2) delta - Ri, delta = 2 Ri / ns.  The reference
+ * walks there (z = zi - Ri - delta/2, then z += delta per slice, src/sasa_lr.c:304-307) and is off the exact plane by
+ * up to ~20 roundings of |z| (1e-13 A for coordinates of hundreds of A); this closed form (one fma) is the exact plane
+ * to half an ulp.  The two differ by less than the reference's own drift, the areas by ~1e-13 A^2 - a hundredth of what
+ * the arc pass spends on its acos - and the slice table (a 20-step dependent loop on 6 of 64 lanes) is gone, its LDS
+ * word per item free to carry 1/(2 Ri') from the screening to the arc pass. */
+SASA_D double lr2_slice_height(int s, double delta, double Ri) { return fma((double)s + 0.5, delta, -Ri); }
 
 /* The order of two neighbors whose beta agree in their leading 40 bits: by 12 bits of the pair's own geometry (the
  * low mantissa words of xd, yd, zd), not by when the neighbor was found — the order, and with it every bit of the
@@ -845,25 +853,18 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     /* ------------------------------------------------------------ P4 screening */
     const float inv_ns = LR2_RCPF((float)ns); /* index arithmetic only (one off either way is put right below) */
     m.hist[lane] = 0;
-    if (lane < na) { /* slice heights, accumulated like the reference (src/sasa_lr.c:304-307) */
-        const double zi = m.atom[lane].z, Ri = m.atom[lane].w, delta = m.adel[lane];
-        double z = zi - Ri - 0.5 * delta;
-        for (int s = 0; s < ns; ++s) {
-            z += delta;
-            m.it_tc[LR2_MUL24(lane, ns) + s] = z - zi; /* exact; |z - zi| is the reference's di (:308) */
-        }
-    }
     LR2_SYNC();
     for (int it = lane; it < items; it += LR2_LANES) {
         int la = (int)(((float)it + 0.5f) * inv_ns), s = it - LR2_MUL24(la, ns); /* it / ns without the integer-division sequence */
         if (s < 0) { --la; s += ns; } else if (s >= ns) { ++la; s -= ns; }
-        const double Ri = m.atom[la].w, t = m.it_tc[it];
+        const double Ri = m.atom[la].w, t = lr2_slice_height(s, m.adel[la], Ri);
         const double A = Ri * Ri - t * t; /* Ri'^2, ref: src/sasa_lr.c:309 */
-        double area = 0;
+        double area = 0, h2_keep = 0;
         int cnt = 0;
         if (A > 0) { /* ref: :310-312 */
             double h2;
             LR2_H2(A, h2); /* h2 = 1/(2 Ri') */
+            h2_keep = h2;
             const int o = m.aoff[la], nn = m.aoff[la + 1] - o;
             double cmin = 1.0;
             for (int wi = 0; wi < mwt; ++wi) {
@@ -914,7 +915,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                 if (cte - cts >= SASA_TWOPI) cnt = 0; /* covered: area 0 */
             }
         }
-        if (cnt == 0) m.it_tc[it] = area; /* (an item with arcs keeps its slice height for the arc pass) */
+        m.it_tc[it] = cnt == 0 ? area : h2_keep; /* (an item with arcs: 1/(2 Ri') for the arc pass, which puts the area in its place) */
         unsigned short qt = 0xffff;
         if (cnt > 0) { /* queue: heaviest first (bin 0 = 63 arcs or more); inside a bin in order of arrival */
             const int bin = 63 - (cnt < 63 ? cnt : 63);
@@ -966,9 +967,8 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             const int e = (int)m.queue[qi];
             my = e & 1023; la = e >> 10;
             const int o = m.aoff[la], nn = m.aoff[la + 1] - o;
-            const double t = m.it_tc[my], Ri = m.atom[la].w;
-            double h2;
-            LR2_H2(Ri * Ri - t * t, h2); /* as P4: bit for bit */
+            const double t = lr2_slice_height(my - LR2_MUL24(la, ns), m.adel[la], m.atom[la].w); /* as P4: bit for bit */
+            const double h2 = m.it_tc[my];
             const int lo = LR2_MUL24(nn, j) >> shb, hi = LR2_MUL24(nn, j + 1) >> shb; /* list positions of this lane */
             for (int wi = 0; wi < mwt; ++wi) {
                 int a0 = lo - 32 * wi, a1 = hi - 32 * wi;
@@ -1024,8 +1024,8 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         my = e_ == LR2_NONE ? LR2_NONE : (e_ & 1023); w = 0; wleft = 0;                            \
         if (my != LR2_NONE) {                                                                      \
             la = e_ >> 10;                                                                         \
-            R = m.aoff[la]; t = m.it_tc[my];                                                        \
-            { const double Ri_ = m.atom[la].w; LR2_H2(Ri_ * Ri_ - t * t, h2); } /* as P4: bit for bit */ \
+            R = m.aoff[la]; h2 = m.it_tc[my];                                                       \
+            t = lr2_slice_height(my - LR2_MUL24(la, ns), m.adel[la], m.atom[la].w); /* as P4: bit for bit */ \
             mk = m.it_mask + LR2_MUL24(my, mw); w = *mk; wleft = mwt - 1;                          \
             LR2_NEXT_WORD();                                                                       \
         }                                                                                          \

@@ -3,8 +3,9 @@ driven thread-by-thread by tests/emu (never shipped) in the production launch se
 compared with the oracle.  S&R must be bit-identical.  L&R shares the reference's arc-union
 result bit for bit given equal arc end points, but computes cos(alpha) with reciprocals and
 acos with its own polynomial.  Since round 3 the arc pass spends two orders of magnitude of the 1e-4 A^2
-contract on speed (degree-12 acos, 6e-13 relative; 1/(2 Ri') to 4e-15): held to LR_TOL = 1e-10 A^2 per atom
-here (observed 1.2e-11 at worst, 1.7e-12 rms); on this box only the device's v_rsq_f64 seed remains untested."""
+contract on speed (degree-12 acos, 6e-13 relative; 1/(2 Ri') to 4e-15; slice planes in closed form, where the
+reference's accumulated z drifts by ~ns ulp(z)): held to LR_TOL = 1e-9 A^2 per atom here (observed 4.5e-11 at worst
+on these inputs, 3e-12 rms; 4e-10 with coordinates near 1e4 A); on this box only the device's v_rsq_f64 seed remains untested."""
 import numpy as np
 import pytest
 
@@ -13,7 +14,7 @@ from conftest import load_golden
 import emu
 from emu import run_batch
 
-LR_TOL = 1e-10
+LR_TOL = 1e-9
 
 
 def close(a, b, tol=LR_TOL):

@@ -1,7 +1,9 @@
 """GPU parity tests (run by the driver on a real MI355X with -m gpu).  Everything goes through
 the C-ABI of libfreesasa_amd.so.  Bars: S&R bit-exact (integer counts AND the fp64 areas derived
-from them); L&R within LR_TOL of the reference (north_star allows 1e-4 A^2; the only source of
-difference is the device's acos/atan2, so the test holds the kernel to 1e-9)."""
+from them); L&R within LR_TOL of the reference.  north_star allows 1e-4 A^2; since round 3 the kernel spends part
+of that on speed (degree-12 acos, one Goldschmidt step for 1/(2 Ri'), slice planes in closed form instead of the
+reference's accumulated z): 4e-10 A^2 at worst over 7.2e5 atoms against the real reference (profiles/r03_deep_parity.json),
+a near-tangent arc can make it ~1e-7; the tests hold the kernel to 1e-8, four orders inside the contract."""
 import os
 import threading
 
@@ -13,7 +15,7 @@ from conftest import GOLDEN, load_golden, read_bfactor_pdb
 
 pytestmark = pytest.mark.gpu
 
-LR_TOL = 1e-9          # A^2 per atom, asserted
+LR_TOL = 1e-8          # A^2 per atom, asserted
 LR_TOL_NORTH_STAR = 1e-4
 STRUCTS = ["1ubq", "1a0q", "3bzd_trimmed", "1d3z", "1d3z_H"]
 
