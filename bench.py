@@ -296,6 +296,7 @@ def main():
     ap.add_argument("--points", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-neighbors", action="store_true", help="skip the neighbor count (one launch of the kernel's neighbor phase): the counter passes of tools/gpu_round.sh want the tile kernel's own launches only")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short measurements of the other single-GPU configurations")
     ap.add_argument("--dry-run", action="store_true",
                     help="TEST ONLY (tests/test_distributed.py): the rank / argument / JSON plumbing on CPU under gloo, "
@@ -470,7 +471,7 @@ def main():
                 dist.barrier()
                 dist.destroy_process_group()
             return
-        if not sr:
+        if not sr and not args.no_neighbors:
             out["config"]["avg_neighbors_per_atom"] = neighbors_per_atom(fa, torch, d_xyz, d_r, offs, dev, local_rank)
         if world == 1 and args.workload == "coil_lr" and not args.no_secondary and (args.structs, args.atoms, args.slices) == (1000, 10000, 20):
             out.update(secondary_workloads(fa, torch, tools, d_xyz, d_r, offs, xyz, r, dev, local_rank, check=not args.no_cpu_baseline))

@@ -839,6 +839,31 @@ SASA_D double acos_fast2(double x)
     p = SASA_FMA_K(p, z, 0x1.6db6dcb595fe6p-5);
     p = SASA_FMA_K(p, z, 0x1.3333333218b17p-4);
     p = SASA_FMA_K(p, z, 0x1.55555555557d9p-3);
+#elif ACOS2_DEG == 10
+    double p = 0x1.36a2e9ecec19dp-3;
+    p = SASA_FMA_K(p, z, -0x1.fd83d62a27701p-3);
+    p = SASA_FMA_K(p, z, 0x1.c42ef3b38479fp-3);
+    p = SASA_FMA_K(p, z, -0x1.67afdf6ca0003p-4);
+    p = SASA_FMA_K(p, z, 0x1.5ebf5d159b43ep-5);
+    p = SASA_FMA_K(p, z, 0x1.8ca7e177a09d9p-7);
+    p = SASA_FMA_K(p, z, 0x1.782204b9c3370p-6);
+    p = SASA_FMA_K(p, z, 0x1.f129697301e6fp-6);
+    p = SASA_FMA_K(p, z, 0x1.6db96e15f3a8ap-5);
+    p = SASA_FMA_K(p, z, 0x1.33332f0b36fd2p-4);
+    p = SASA_FMA_K(p, z, 0x1.555555566f3ffp-3);
+#elif ACOS2_DEG == 11
+    double p = 0x1.76020a8746ae9p-3;
+    p = SASA_FMA_K(p, z, -0x1.63634279a6629p-2);
+    p = SASA_FMA_K(p, z, 0x1.5b1ba556b0131p-2);
+    p = SASA_FMA_K(p, z, -0x1.5cd68bf0c924cp-3);
+    p = SASA_FMA_K(p, z, 0x1.2da9683adb436p-4);
+    p = SASA_FMA_K(p, z, 0x1.7c628cf410d04p-15);
+    p = SASA_FMA_K(p, z, 0x1.3d624404189a5p-6);
+    p = SASA_FMA_K(p, z, 0x1.6b8acd1365601p-6);
+    p = SASA_FMA_K(p, z, 0x1.f1efe6cd87ef6p-6);
+    p = SASA_FMA_K(p, z, 0x1.6db64d758973dp-5);
+    p = SASA_FMA_K(p, z, 0x1.333333f35cdcfp-4);
+    p = SASA_FMA_K(p, z, 0x1.555555552a8ffp-3);
 #elif ACOS2_DEG == 13
     double p = 0x1.174d39e43815ep-2;
     p = SASA_FMA_K(p, z, -0x1.5167956168ca9p-1);

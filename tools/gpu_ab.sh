@@ -6,8 +6,8 @@ OUT=gpurun_out/ab_$(date +%H%M%S).txt
 for rep in $(seq 1 ${REPS:-3}); do
 for lib in "$@"; do
   echo "== $lib (rep $rep)"
-  FREESASA_AMD_LIB=$PWD/$lib python tools/gpu_r2_sweep.py ${STRUCTS:-300} "0,0,-1,0" 2>&1 | grep kernel_ms | sed "s/^/coil /"
-  FREESASA_AMD_LIB=$PWD/$lib python tools/gpu_r2_sweep.py g100 "0,0,-1,0" 2>&1 | grep kernel_ms | sed "s/^/glob /"
+  FREESASA_AMD_LIB=$PWD/$lib python tools/gpu_shapes.py ${STRUCTS:-300} "0,0,-1,0" 2>&1 | grep kernel_ms | sed "s/^/coil /"
+  FREESASA_AMD_LIB=$PWD/$lib python tools/gpu_shapes.py g100 "0,0,-1,0" 2>&1 | grep kernel_ms | sed "s/^/glob /"
 done
 done 2>&1 | tee $OUT | grep -v "^coil\|^glob" > /dev/null
 python - $OUT <<'PY'

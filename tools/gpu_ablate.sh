@@ -1,12 +1,14 @@
-# A/B timing of alternative builds of the library (FREESASA_AMD_LIB) on a 300-structure batch,
-# with the two LDS counters that matter
+# DEV: wave-level VALU instructions of the L&R kernel, cumulative by phase (variant builds -DLR2_STOP_AFTER=k)
+# bash tools/gpu_r2_ablate.sh "<spec>" lib1 lib2 ...
 export PYTHONUNBUFFERED=1
+REPO=$(pwd)
+SPEC=$1; shift
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+cd /tmp
 for lib in "$@"; do
-  echo "== lib=$lib"
-  FREESASA_AMD_LIB=$lib python bench.py --steps 3 --warmup 1 --structs 300 --no-cpu-baseline 2>&1 | python -c "
-import sys, json
-for l in sys.stdin:
-    if l.startswith('{'):
-        d=json.loads(l); print('kernel_ms %.3f prep_ms %.3f value %.4g' % (d['roofline']['kernel_ms'], d['roofline']['prep_ms'], d['value']))
-"
+  tag=$(basename $lib .so)
+  FREESASA_AMD_LIB=$REPO/$lib timeout 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d $REPO/gpurun_out/abl_$tag -o pmc1 -- python $REPO/tools/gpu_shapes.py ${STRUCTS:-300} "$SPEC" > $REPO/gpurun_out/abl_$tag.log 2>&1
+  echo "== $tag: $(grep kernel_ms $REPO/gpurun_out/abl_$tag.log)"
+  python $REPO/tools/pmc_summary.py $REPO/gpurun_out/abl_$tag | grep lr2
 done

@@ -1,18 +1,21 @@
-export PYTHONUNBUFFERED=1 TMPDIR=/tmp
-REPO=$(pwd); cd /tmp
-PM="python $REPO/bench.py --steps 1 --warmup 1 --structs 300 --no-cpu-baseline"
-rocprofv3 --kernel-trace --pmc VALUBusy SALUBusy VALUUtilization --output-format csv -d $REPO/gpurun_out/prof_d -o d1 -- $PM > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc LDSBankConflict MemUnitBusy MemUnitStalled --output-format csv -d $REPO/gpurun_out/prof_d -o d2 -- $PM > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc OccupancyPercent MeanOccupancyPerCU GRBM_GUI_ACTIVE --output-format csv -d $REPO/gpurun_out/prof_d -o d3 -- $PM > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_LEVEL_WAVES SQ_ACCUM_PREV_HIRES SQ_BUSY_CU_CYCLES SQ_CYCLES --output-format csv -d $REPO/gpurun_out/prof_d -o d4 -- $PM > /dev/null 2>&1
-cd $REPO
-python - <<'PY'
-import csv, glob, collections
-for f in sorted(glob.glob('gpurun_out/prof_d/*_counter_collection.csv')):
-    agg=collections.defaultdict(lambda: collections.defaultdict(list))
+# DEV: derived hardware metrics of the L&R kernel (300-structure batch)
+export PYTHONUNBUFFERED=1
+REPO=$(pwd)
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+cd /tmp
+for set in "VALUBusy VALUUtilization SALUBusy" "LDSBankConflict SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL" "MemUnitStalled MemUnitBusy LdsUtil" "SQ_INSTS_VALU_TRANS SQ_INSTS_VALU SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU" "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU"; do
+  tag=$(echo $set | cut -d' ' -f1)
+  timeout 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $REPO/gpurun_out/der_$tag -o d -- python $REPO/tools/gpu_shapes.py ${STRUCTS:-300} "$1" > $REPO/gpurun_out/der_$tag.log 2>&1
+  python - <<PY
+import csv, collections, glob
+for f in glob.glob("$REPO/gpurun_out/der_$tag/*counter_collection.csv"):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
-        agg[r['Kernel_Name'][:40]][r['Counter_Name']].append(float(r['Counter_Value']))
-    for k,v in agg.items():
-        if 'k_lr_tile<128, false' in k:
-            print(f.split('/')[-1][:2], {c: round(sum(x)/len(x),3) for c,x in v.items()})
+        if "lr2_tile<" in r["Kernel_Name"] or "k_lr_tile<64, false, 0" in r["Kernel_Name"]:
+            agg[r["Kernel_Name"][:40]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        print(k, " ".join(f"{c}={sum(x)/len(x):.4g}" for c, x in sorted(v.items())))
 PY
+  tail -2 $REPO/gpurun_out/der_$tag.log | grep -i "error\|invalid" | head -2
+done

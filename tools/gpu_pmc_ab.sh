@@ -10,7 +10,7 @@ i=0
 for envs in "$@"; do
   i=$((i+1))
   rm -rf $REPO/gpurun_out/pmcab_$i
-  env $envs timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $REPO/gpurun_out/pmcab_$i -o pmc1 -- python $REPO/tools/gpu_r2_sweep.py $GEOM "0,0,-1,0" > $REPO/gpurun_out/pmcab_$i.log 2>&1
+  env $envs timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $REPO/gpurun_out/pmcab_$i -o pmc1 -- python $REPO/tools/gpu_shapes.py $GEOM "0,0,-1,0" > $REPO/gpurun_out/pmcab_$i.log 2>&1
   echo "== $envs: $(grep kernel_ms $REPO/gpurun_out/pmcab_$i.log)"
   python $REPO/tools/pmc_summary.py $REPO/gpurun_out/pmcab_$i | grep "lr2_tile<[234]"
 done

@@ -1,23 +1,50 @@
-# Full GPU session for a round: tests, smoke, bench, rocprof kernel trace + PMC passes.
-# Usage: bash tools/gpu_round.sh <tag>     (outputs under gpurun_out/, summaries to copy into profiles/)
-TAG=${1:-r01}
-set -x
+# Full GPU session for a round: everything profiles/ and DESIGN.md quote, in one gpurun call.
+#   bash tools/gpu_round.sh r03        (outputs under gpurun_out/<tag>_*; copy the summaries into profiles/)
+# Build the phase-ablation variants first if the per-phase instruction counts are wanted:
+#   for k in 0 1 2 3 4 5; do bash tools/build_variant.sh stop$k -DLR2_STOP_AFTER=$k; done
+TAG=${1:-r03}
 mkdir -p gpurun_out
 export PYTHONUNBUFFERED=1
 REPO=$(pwd)
-(timeout 300 python -c "import __graft_entry__ as g; g.smoke()") > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke.log
-(timeout 900 python -m pytest tests -m gpu -q --durations=5) > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
-(timeout 600 python bench.py) > gpurun_out/bench_$TAG.log 2>&1; echo "bench rc=$?" >> gpurun_out/bench_$TAG.log
+O=$REPO/gpurun_out
+(timeout 300 python -c "import __graft_entry__ as g; g.smoke()") > $O/${TAG}_smoke.log 2>&1; echo "smoke rc=$?" >> $O/${TAG}_smoke.log
+(timeout 900 python -m pytest tests -m gpu -q --durations=5) > $O/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/${TAG}_pytest_gpu.log
+(timeout 900 python bench.py) > $O/${TAG}_bench.out 2> $O/${TAG}_bench.err; echo "bench rc=$?" >> $O/${TAG}_bench.err
+grep '^{' $O/${TAG}_bench.out | tail -1 > $O/${TAG}_bench.json
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-end-to-end"
-(timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_$TAG -o trace -- $BENCH) > $REPO/gpurun_out/rocprof_trace.log 2>&1
-PM="python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-end-to-end"
-(timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU --output-format csv -d $REPO/gpurun_out/prof_$TAG -o pmc1 -- $PM) > $REPO/gpurun_out/rocprof_pmc1.log 2>&1
-(timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_VALU --output-format csv -d $REPO/gpurun_out/prof_$TAG -o pmc2 -- $PM) > $REPO/gpurun_out/rocprof_pmc2.log 2>&1
-(timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $REPO/gpurun_out/prof_$TAG -o pmc3 -- $PM) > $REPO/gpurun_out/rocprof_pmc3.log 2>&1
-(timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $REPO/gpurun_out/prof_$TAG -o pmc4 -- $PM) > $REPO/gpurun_out/rocprof_pmc4.log 2>&1
+BENCH="python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-end-to-end --no-secondary --no-neighbors"
+(timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -o trace -- $BENCH) > $O/rocprof_trace.log 2>&1
+cp $O/prof_$TAG/trace_kernel_stats.csv $O/${TAG}_kernel_stats.csv
+PM="python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-end-to-end --no-secondary --no-neighbors"
+(timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU --output-format csv -d $O/prof_$TAG -o pmc1 -- $PM) > $O/rocprof_pmc1.log 2>&1
+(timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_VALU --output-format csv -d $O/prof_$TAG -o pmc2 -- $PM) > $O/rocprof_pmc2.log 2>&1
+(timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/prof_$TAG -o pmc3 -- $PM) > $O/rocprof_pmc3.log 2>&1
+(timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/prof_$TAG -o pmc4 -- $PM) > $O/rocprof_pmc4.log 2>&1
+# FETCH_SIZE / WRITE_SIZE calibration: copy kernels of known size, same session
+for c in FETCH_SIZE WRITE_SIZE; do
+  (timeout 120 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/calib_$c -o c -- $REPO/tools/dev/fetch_calib) > /dev/null 2>&1
+  python - $O/calib_$c/c_counter_collection.csv $c <<'PY'
+import csv, sys, collections
+t = collections.defaultdict(float)
+for r in csv.DictReader(open(sys.argv[1])):
+    if r["Counter_Name"] == sys.argv[2]: t[r["Kernel_Name"].split("(")[0]] += float(r["Counter_Value"])
+for k, v in t.items():
+    if "copy" in k or "gather" in k: print("%s %-14s %9.0f KB reported = %.3f x the 262144 KB the kernel moves" % (sys.argv[2], k, v, v / 262144))
+PY
+done > $O/${TAG}_fetch_calibration.txt
 cd $REPO
-python tools/pmc_summary.py gpurun_out/prof_$TAG all | tee gpurun_out/pmc_$TAG.txt
-cat gpurun_out/prof_$TAG/trace_kernel_stats.csv
-tail -2 gpurun_out/smoke.log; tail -8 gpurun_out/pytest_gpu.log; tail -2 gpurun_out/bench_$TAG.log | cut -c1-3000
+python tools/pmc_summary.py $O/prof_$TAG all > $O/${TAG}_pmc_summary.txt
+python tools/hbm_counters.py $O/prof_$TAG > $O/${TAG}_hbm_counters.json
+# derived counters of the tile kernel (coils, then globules)
+(bash tools/gpu_derived.sh "0,0,-1,0"; echo "--- globules"; STRUCTS=g100 bash tools/gpu_derived.sh "0,0,-1,0") > $O/${TAG}_derived_counters.txt 2>&1
+# VALU instructions by phase (cumulative builds), if the variants are there
+if [ -f freesasa_amd/lib/libvar_stop0.so ]; then
+  (echo "coils (300 x 10 000 atoms, 5 launches): cumulative after P0 .. P5, then the whole kernel"
+   bash tools/gpu_ablate.sh "0,0,-1,0" freesasa_amd/lib/libvar_stop0.so freesasa_amd/lib/libvar_stop1.so freesasa_amd/lib/libvar_stop2.so freesasa_amd/lib/libvar_stop3.so freesasa_amd/lib/libvar_stop4.so freesasa_amd/lib/libvar_stop5.so freesasa_amd/lib/libfreesasa_amd.so
+   echo "globules (100 x 10 000 atoms, 5 launches)"
+   STRUCTS=g100 bash tools/gpu_ablate.sh "0,0,-1,0" freesasa_amd/lib/libvar_stop0.so freesasa_amd/lib/libvar_stop1.so freesasa_amd/lib/libvar_stop2.so freesasa_amd/lib/libvar_stop3.so freesasa_amd/lib/libvar_stop4.so freesasa_amd/lib/libvar_stop5.so freesasa_amd/lib/libfreesasa_amd.so) 2>&1 | grep "==\|coils\|globules\|lr2_tile<4" | sed "s/vgpr[^ ]* //" > $O/${TAG}_phase_valu.txt
+fi
+(timeout 600 python tools/deep_parity.py 120 24 2>/dev/null | tail -1) > $O/${TAG}_deep_parity.json
+(timeout 120 tools/dev/ubench) > $O/${TAG}_ubench.txt 2>&1
+tail -2 $O/${TAG}_smoke.log; tail -4 $O/${TAG}_pytest_gpu.log; cut -c1-400 $O/${TAG}_bench.json; cat $O/${TAG}_kernel_stats.csv | cut -d, -f1-4 | head -12; cat $O/${TAG}_fetch_calibration.txt; cat $O/${TAG}_deep_parity.json

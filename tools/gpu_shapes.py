@@ -1,5 +1,5 @@
 """DEV: one process, many launch shapes of the L&R kernel on the headline batch geometry (kernel ms per step).
-usage: python tools/gpu_r2_sweep.py [[g]structs] [spec ...]   spec = LR1 | TA,pool,ds,refill"""
+usage: python tools/gpu_shapes.py [[g]structs] [spec ...]   spec = LR1 | TA,pool,ds,refill"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
