@@ -286,6 +286,30 @@ def test_lr_results_do_not_depend_on_the_tile_shape(fa, monkeypatch):
         assert np.array_equal(got, ref), (spec, cover, float(np.max(np.abs(got - ref))))
 
 
+def test_cell_sort_in_one_kernel_equals_the_general_pipeline(fa, oracle_lib, monkeypatch):
+    """k_sort_struct (batches of structures up to 16 384 atoms: one workgroup sorts a structure in LDS) against the
+    general pipeline (zero, count, scan, scatter) and the oracle: ordinary structures, an empty one, a single atom, and
+    a sparse diagonal whose grid has more cells (~8e5) than the kernel holds bits for at a time (several passes)."""
+    parts = [tools.coil(1500, 40 + k) for k in range(5)] + [tools.globule(1200, 3)]
+    diag = np.linspace(0.0, 600.0, 240)[:, None] * np.ones((1, 3)) + np.random.default_rng(1).uniform(-0.3, 0.3, (240, 3))
+    parts += [(diag, np.full(240, 1.8)), (np.zeros((0, 3)), np.zeros(0)), (np.array([[1.0, 2.0, 3.0]]), np.array([1.7])), tools.coil(900, 77)]
+    xyz = np.concatenate([p[0] for p in parts]); r = np.concatenate([p[1] for p in parts])
+    offs = np.concatenate([[0], np.cumsum([len(p[1]) for p in parts])]).astype(np.int64)
+    monkeypatch.delenv("FREESASA_AMD_NO_FUSED_SORT", raising=False)
+    lr, _, ltot = fa.calc_batch(xyz, r, offs, fa.LEE_RICHARDS, 1.4, 20)
+    sr, cnt, _ = fa.calc_batch(xyz, r, offs, fa.SHRAKE_RUPLEY, 1.4, 100)
+    monkeypatch.setenv("FREESASA_AMD_NO_FUSED_SORT", "1")
+    lr2, _, ltot2 = fa.calc_batch(xyz, r, offs, fa.LEE_RICHARDS, 1.4, 20)
+    sr2, cnt2, _ = fa.calc_batch(xyz, r, offs, fa.SHRAKE_RUPLEY, 1.4, 100)
+    assert np.array_equal(lr, lr2) and np.array_equal(cnt, cnt2) and np.array_equal(sr, sr2) and np.array_equal(ltot, ltot2)
+    for k in range(len(parts)):
+        sl = slice(offs[k], offs[k + 1])
+        if offs[k + 1] > offs[k]:
+            assert np.max(np.abs(lr[sl] - oracle_lib.lee_richards(xyz[sl], r[sl]))) < LR_TOL
+            if offs[k + 1] - offs[k] > 1:
+                assert np.array_equal(cnt[sl], oracle_lib.shrake_rupley(xyz[sl], r[sl])[1])
+
+
 def test_trajectory_frames_config4_proxy(fa, oracle_lib):
     """configs[4] proxy: one system, jittered frames, radii/offsets constant across calls."""
     base, r = tools.globule(20_000, 5)
