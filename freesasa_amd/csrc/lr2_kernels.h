@@ -710,7 +710,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         }
     }
     LR2_SYNC();
-    if (ovf) return 1; /* (uniform) */
+    if (ovf) { LR2_COUNT(9, 1); return 1; } /* (uniform) */
     const int mwt = (nn_max + 31) >> 5; /* mask words this tile's longest list needs (<= mw; one on most coil tiles) */
     const bool cover = COVER && a.cover > 0 && nh >= LR2_MUL24(a.cover, na); /* (uniform) dense enough for the cover filter; COVER: the launch
                                                                                   was built with it (launches over sparse batches are not) */
@@ -1077,6 +1077,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     }
     LR2_SYNC();
     LR2_MARK(7);
+    if (deep) LR2_COUNT(7, 1);
     return deep ? 1 : 0;
 }
 
