@@ -161,12 +161,12 @@ __global__ __launch_bounds__(SASA_PIPE_B) void k_scatter(PipeArgs a)
  *     E  atoms to their sorted places: sq, s_idx        (what k_scatter writes)
  *     F  the structure's part of cell_start[], once     (what the tile kernels' P0 reads: unchanged)
  * HBM traffic: the atoms read twice (the second time from cache), 48 B per atom and 4 B per cell written once.
- * Limits (else the batch is redone with the general pipeline, ST_RETRY = 2): SORT_ATOMS atoms and SORT_CELLS
- * cells per structure.  The order of the atoms inside a cell is the order of arrival, as before: no result
+ * Limits (else the batch is redone with the general pipeline, ST_RETRY = 2): SORT_ATOMS atoms and 2^26 cells per
+ * structure.  The order of the atoms inside a cell is the order of arrival, as before: no result
  * depends on it (lr2_tie12). */
 #define SORT_B 1024
 #define SORT_APT 16
-#define SORT_ATOMS (SORT_B * SORT_APT)
+#define SORT_ATOMS (SORT_B * SORT_APT - 256) /* atoms of a structure (the 256 short of 16 threads' worth: two workgroups' LDS per CU) */
 #define SORT_CELLS (1 << 18) /* cells in LDS at a time (a bit each); a structure with more is done in that many passes */
 #define SORT_WORDS (SORT_CELLS / 32)
 #define SORT_CELL_BITS 26    /* cells of one structure this kernel can number (6 more bits hold the border flags) */
@@ -200,22 +200,90 @@ __global__ __launch_bounds__(SORT_B) void k_sort_struct(PipeArgs a)
     __shared__ unsigned short wpre[SORT_WORDS];      /* 16 KB: occupied cells before each 32-cell word */
     __shared__ unsigned cnt[SORT_ATOMS / 2 + 2];     /* 32 KB: 16-bit counters of the occupied cells, then their first atoms (+ end) */
     __shared__ int scratch[SORT_B / 64 + 1];
+    double (*const red)[SORT_B / 64] = (double (*)[SORT_B / 64])wpre; /* (bounds: before wpre is in use) */
+    __shared__ GridS g_sh;
+    __shared__ long long c_sh;
     PIPE_GATE(a.status);
     const int s = blockIdx.x, tid = threadIdx.x;
     const long long b0 = a.offsets[s];
     const int n = (int)(a.offsets[s + 1] - b0);
-    const bool last = s == a.n_structs - 1;
-    if (n <= 0) {
-        if (last && tid == 0) a.cell_start[a.ncells[a.n_structs]] = a.n_atoms;
+    if (n <= 0) { /* empty structure: as grid_struct */
+        if (tid == 0) { GridS e; e.x0 = e.y0 = e.z0 = 0; e.d = 1; e.nx = e.ny = e.nz = 0; e.cell_base = 0; a.grid[s] = e; a.ncells[s] = 0; }
         return;
     }
-    const GridS g = a.grid[s];
-    const long long Cl = a.ncells[s];
-    if (n > SORT_ATOMS || Cl > (1LL << SORT_CELL_BITS)) { /* (uniform) not a structure for this kernel: the host redoes the batch */
+    if (n > SORT_ATOMS) { /* (uniform) not a structure for this kernel: the host redoes the batch */
         if (tid == 0) a.status[ST_RETRY] = 2;
         return;
     }
-    const int C = (int)Cl;
+    /* K1 + K2 of the general pipeline, for this structure: bounds, grid (grid_struct), and its run of the batch-wide
+       cell numbering - taken from a counter, one cell more than it has (the entry behind its last cell is its own) */
+    {
+        double lo0 = INFINITY, lo1 = INFINITY, lo2 = INFINITY, hi0 = -INFINITY, hi1 = -INFINITY, hi2 = -INFINITY, rmax = 0; /* ref: src/nb.c:246 */
+        int bad = 0;
+        for (int li = tid; li < n; li += SORT_B) {
+            const long long i = b0 + li;
+            const double x = a.xyz[3 * i], y = a.xyz[3 * i + 1], z = a.xyz[3 * i + 2];
+            lo0 = fmin(x, lo0); hi0 = fmax(x, hi0);
+            lo1 = fmin(y, lo1); hi1 = fmax(y, hi1);
+            lo2 = fmin(z, lo2); hi2 = fmax(z, hi2);
+            const double rr = a.radii[a.shared_radii ? (long long)li : i];
+            rmax = fmax(rr + a.probe, rmax);
+            if (!(x - x == 0) || !(y - y == 0) || !(z - z == 0)) bad = ERR_BAD_COORD; /* (as bounds_phase0) */
+            if (!(rr - rr == 0)) bad = bad ? bad : ERR_BAD_RADIUS;
+        }
+        if (bad) atomicMax(&a.status[ST_ERROR], bad);
+        for (int d = 1; d < 64; d <<= 1) {
+            lo0 = fmin(lo0, __shfl_xor(lo0, d, 64)); lo1 = fmin(lo1, __shfl_xor(lo1, d, 64)); lo2 = fmin(lo2, __shfl_xor(lo2, d, 64));
+            hi0 = fmax(hi0, __shfl_xor(hi0, d, 64)); hi1 = fmax(hi1, __shfl_xor(hi1, d, 64)); hi2 = fmax(hi2, __shfl_xor(hi2, d, 64));
+            rmax = fmax(rmax, __shfl_xor(rmax, d, 64));
+        }
+        if ((tid & 63) == 0) {
+            const int w = tid >> 6;
+            red[0][w] = lo0; red[1][w] = lo1; red[2][w] = lo2; red[3][w] = hi0; red[4][w] = hi1; red[5][w] = hi2; red[6][w] = rmax;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, rm = 0;
+            for (int w = 0; w < SORT_B / 64; ++w) {
+                for (int k = 0; k < 3; ++k) { lo[k] = fmin(red[k][w], lo[k]); hi[k] = fmax(red[3 + k][w], hi[k]); }
+                rm = fmax(red[6][w], rm);
+            }
+            GridS g;
+            const double d = 2 * rm; /* ref: src/nb.c:543 */
+            int err = ERR_NONE;
+            if (!(d > 0) || !(d < INFINITY)) err = ERR_BAD_RADIUS;
+            for (int k = 0; k < 3; ++k)
+                if (!(lo[k] > -INFINITY && hi[k] < INFINITY)) err = err ? err : ERR_BAD_COORD;
+            long long nc = 0;
+            g.d = d;
+            g.x0 = lo[0] - d / 2.; g.y0 = lo[1] - d / 2.; g.z0 = lo[2] - d / 2.; /* ref: src/nb.c:61-66 */
+            g.nx = g.ny = g.nz = 0; g.cell_base = 0;
+            if (!err) {
+                const double fx = ceil((hi[0] + d / 2. - g.x0) / d); /* ref: src/nb.c:67-69 */
+                const double fy = ceil((hi[1] + d / 2. - g.y0) / d);
+                const double fz = ceil((hi[2] + d / 2. - g.z0) / d);
+                if (!(fx * fy * fz <= (double)a.max_cells) || !(fx >= 1 && fy >= 1 && fz >= 1)) err = ERR_GRID_TOO_BIG;
+                else { g.nx = (int)fx; g.ny = (int)fy; g.nz = (int)fz; nc = (long long)g.nx * g.ny * g.nz; }
+            }
+            if (err) {
+                atomicMax(&a.status[ST_ERROR], err);
+                g.nx = g.ny = g.nz = 1; g.d = 1; g.x0 = g.y0 = g.z0 = 0;
+                nc = 1; /* keep the rest of the pipeline in bounds; host discards results */
+            }
+            const long long base = (long long)atomicAdd((unsigned long long *)&a.ncells[a.n_structs], (unsigned long long)(nc + 1));
+            if (base + nc + 1 > a.max_cells) { atomicMax(&a.status[ST_ERROR], (int)ERR_GRID_TOO_BIG); nc = -1; }
+            else if (a.cells_cap > 0 && base + nc + 1 > a.cells_cap) { a.status[ST_RETRY] = 1; nc = -1; }
+            else if (nc > (1LL << SORT_CELL_BITS)) { a.status[ST_RETRY] = 2; nc = -1; }
+            g.cell_base = (int)base;
+            a.grid[s] = g;
+            a.ncells[s] = nc < 0 ? 0 : nc;
+            g_sh = g; c_sh = nc;
+        }
+        __syncthreads();
+    }
+    const GridS g = g_sh;
+    if (c_sh < 0) return; /* (uniform) no room in the cell table, or too many cells for this kernel: the host redoes the batch */
+    const int C = (int)c_sh;
     /* the cell of every atom of this thread: cell | border flags << SORT_CELL_BITS */
     unsigned cellf[SORT_APT];
     for (int k = 0; k < SORT_APT; ++k) {
@@ -326,7 +394,7 @@ __global__ __launch_bounds__(SORT_B) void k_sort_struct(PipeArgs a)
         }
         base += n_pass;
     }
-    if (last && tid == 0) a.cell_start[a.ncells[a.n_structs]] = a.n_atoms;
+    if (tid == 0) a.cell_start[g.cell_base + C] = (int)(b0 + n); /* the entry behind the structure's last cell: its end */
 }
 
 __global__ __launch_bounds__(SASA_TOT_B) void k_totals(const double *sasa, const int64_t *offsets, int n_structs, double *totals)
@@ -985,18 +1053,18 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
     pa.blk_sums = (int *)c->blk_sums.p;
     pa.cells_cap = cells_cap;
 
-    hipLaunchKernelGGL(k_bounds, dim3(c->n_chunks), dim3(SASA_PIPE_B), 0, st, pa);
-    hipLaunchKernelGGL(k_grid, dim3((n_structs + 63) / 64), dim3(64), 0, st, pa);
-    hipLaunchKernelGGL(k_cell_base, dim3(1), dim3(SASA_PIPE_B), 0, st, pa);
-    HIP_TRY(c, hipGetLastError());
-
     const int nblk_atoms = (n + SASA_PIPE_B - 1) / SASA_PIPE_B;
-    /* batches of small structures: the cell sort of a structure in one workgroup's LDS (k_sort_struct) */
+    /* batches of small structures: bounds, grid and cell sort of a structure in one workgroup (k_sort_struct) */
     long long biggest = 0;
     for (int s_ = 0; s_ < n_structs; ++s_) biggest = offsets[s_ + 1] - offsets[s_] > biggest ? offsets[s_ + 1] - offsets[s_] : biggest;
     const bool fused = c->sort_fused && biggest <= SORT_ATOMS && n_structs >= 8 && !getenv("FREESASA_AMD_NO_FUSED_SORT");
-    if (fused) hipLaunchKernelGGL(k_sort_struct, dim3(n_structs), dim3(SORT_B), 0, st, pa);
-    else {
+    if (fused) {
+        HIP_TRY(c, hipMemsetAsync((long long *)c->ncells.p + n_structs, 0, sizeof(long long), st)); /* the cell counter */
+        hipLaunchKernelGGL(k_sort_struct, dim3(n_structs), dim3(SORT_B), 0, st, pa);
+    } else {
+    hipLaunchKernelGGL(k_bounds, dim3(c->n_chunks), dim3(SASA_PIPE_B), 0, st, pa);
+    hipLaunchKernelGGL(k_grid, dim3((n_structs + 63) / 64), dim3(64), 0, st, pa);
+    hipLaunchKernelGGL(k_cell_base, dim3(1), dim3(SASA_PIPE_B), 0, st, pa);
     hipLaunchKernelGGL(k_zero_cells, dim3((unsigned)((cells_cap + 2 + 16LL * SASA_PIPE_B - 1) / (16LL * SASA_PIPE_B))), dim3(SASA_PIPE_B), 0, st, pa);
     hipLaunchKernelGGL(k_count, dim3(nblk_atoms), dim3(SASA_PIPE_B), 0, st, pa);
     hipLaunchKernelGGL(k_scan1, dim3(nblk_scan), dim3(SASA_PIPE_B), 0, st, pa);
