@@ -203,7 +203,10 @@ __global__ __launch_bounds__(SORT_B) void k_sort_struct(PipeArgs a)
     double (*const red)[SORT_B / 64] = (double (*)[SORT_B / 64])wpre; /* (bounds: before wpre is in use) */
     __shared__ GridS g_sh;
     __shared__ long long c_sh;
-    PIPE_GATE(a.status);
+    /* No PIPE_GATE here: this is the first kernel behind the status memset, so the only flags it could see are those
+       of sibling workgroups of the same launch - read per wave (a divergent barrier below), and a workgroup that left
+       early would not add its cells to the batch total the host sizes the retry with.  Every workgroup numbers its
+       cells; whether it sorts is decided uniformly through c_sh. */
     const int s = blockIdx.x, tid = threadIdx.x;
     const long long b0 = a.offsets[s];
     const int n = (int)(a.offsets[s + 1] - b0);
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(SORT_B) void k_sort_struct(PipeArgs a)
         return;
     }
     if (n > SORT_ATOMS) { /* (uniform) not a structure for this kernel: the host redoes the batch */
-        if (tid == 0) a.status[ST_RETRY] = 2;
+        if (tid == 0) atomicOr(&a.status[ST_RETRY], 2);
         return;
     }
     /* K1 + K2 of the general pipeline, for this structure: bounds, grid (grid_struct), and its run of the batch-wide
@@ -272,8 +275,9 @@ __global__ __launch_bounds__(SORT_B) void k_sort_struct(PipeArgs a)
             }
             const long long base = (long long)atomicAdd((unsigned long long *)&a.ncells[a.n_structs], (unsigned long long)(nc + 1));
             if (base + nc + 1 > a.max_cells) { atomicMax(&a.status[ST_ERROR], (int)ERR_GRID_TOO_BIG); nc = -1; }
-            else if (a.cells_cap > 0 && base + nc + 1 > a.cells_cap) { a.status[ST_RETRY] = 1; nc = -1; }
-            else if (nc > (1LL << SORT_CELL_BITS)) { a.status[ST_RETRY] = 2; nc = -1; }
+            else if (nc > (1LL << SORT_CELL_BITS)) { atomicOr(&a.status[ST_RETRY], 2); nc = -1; }
+            else if (a.cells_cap > 0 && base + nc + 1 > a.cells_cap) { atomicOr(&a.status[ST_RETRY], 1); nc = -1; }
+            else if (a.status[ST_RETRY] | a.status[ST_ERROR]) nc = -1; /* the batch is redone anyway (a sibling's flag; any order is fine: this structure's cells are counted) */
             g.cell_base = (int)base;
             a.grid[s] = g;
             a.ncells[s] = nc < 0 ? 0 : nc;
@@ -808,12 +812,11 @@ static int collect_status(freesasa_gpu_ctx *c, int n_structs, int words, long lo
     *total_cells = *total_p;
     if (status_h[ST_ERROR]) return ctx_fail(c, "%s", err_text(status_h[ST_ERROR]));
     if (*total_p <= 0 || *total_p > c->max_cells) return ctx_fail(c, "%s", err_text(ERR_GRID_TOO_BIG));
-    if (status_h[ST_RETRY] == 2) { /* a structure with more cells than k_sort_struct holds: this context sorts the general way from now on */
-        c->sort_fused = false;
-        return RC_RETRY;
-    }
-    if (status_h[ST_RETRY]) {
-        c->cells_hint = *total_p + *total_p / 16 + 1024;
+    if (status_h[ST_RETRY]) { /* bit flags (workgroups of one launch may raise both) */
+        if (status_h[ST_RETRY] & 2) c->sort_fused = false; /* a structure k_sort_struct does not hold (atoms or cells): this context sorts the general way from now on */
+        /* bit 0: the cell table was too small.  The total is every structure's demand (k_sort_struct: all but those it
+           does not hold, which the general pipeline's own count covers on the next pass) */
+        if ((status_h[ST_RETRY] & 1) && *total_p + *total_p / 16 + 1024 > c->cells_hint) c->cells_hint = *total_p + *total_p / 16 + 1024;
         return RC_RETRY;
     }
     return 0;
@@ -1249,7 +1252,7 @@ static int run_batch_impl(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
     int rc = run_batch_once(c, lr, d_xyz, d_radii, offsets, n_structs, probe, resolution, unit_points, d_sasa, d_counts, d_totals);
     /* once more when the cell table was too small (first batch of a very sparse kind; now with K2's size), and once more
        when a structure did not fit the per-structure cell sort (the general pipeline from then on) */
-    for (int again = 0; rc == RC_RETRY && again < 2; ++again)
+    for (int again = 0; rc == RC_RETRY && again < 3; ++again)
         rc = run_batch_once(c, lr, d_xyz, d_radii, offsets, n_structs, probe, resolution, unit_points, d_sasa, d_counts, d_totals);
     if (rc == RC_RETRY) return ctx_fail(c, "cell table sizing did not converge");
     return rc;

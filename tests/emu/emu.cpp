@@ -443,3 +443,11 @@ extern "C" void emu_atan2_fast(const double *y, const double *x, double *out, in
 {
     for (int i = 0; i < n; ++i) out[i] = atan2_fast(y[i], x[i]);
 }
+
+/* the arc union and sweep of the Lee-Richards kernel on sets of arcs given in the order of their mid-points
+   (what freesasa_gpu_arc_union_dev runs on the device); raw end points allowed (start < 0, end > 2 pi) */
+extern "C" void emu_arc_union(const double *arcs, const int *first, int n_sets, int ds, double *out)
+{
+    std::vector<Arc2> stack((size_t)(ds > 0 ? ds : 1) * LR2_LANES);
+    for (int k = 0; k < n_sets; ++k) out[k] = lr2_arc_kat(arcs, first, k, stack.data(), ds);
+}

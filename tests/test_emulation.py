@@ -316,3 +316,32 @@ def test_residue_area_kernel_logic():
             else:
                 expect = 100.0 * np.array(want[:5]) / table[rows[r]]
                 assert np.array_equal(R[r], expect, equal_nan=True)
+
+
+def test_closed_form_sweep_against_the_oracle(oracle_lib):
+    """lr2_sweep (round 4: closed form over the final components) through the arc union, on arcs with raw end points
+    (start < 0, end > 2 pi, half-widths up to pi, up to 13 arcs, deep stacks) against exposed_arc_length of the
+    oracle on the same arcs split at the origin the way the reference stores them (src/sasa_lr.c:340-351)."""
+    import ctypes as C
+    lib = emu._load()
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    lib.emu_arc_union.argtypes = [dp, ip, C.c_int, C.c_int, dp]
+    T = 2 * np.pi
+    rng = np.random.default_rng(7)
+    worst = 0.0
+    for trial in range(4000):
+        k = int(rng.integers(1, 14))
+        mids = np.sort(rng.uniform(0, T, k))
+        halves = np.minimum(rng.uniform(0.001, rng.choice([0.05, 0.3, 1.0, 3.1]), k), np.pi)
+        raw = np.stack([mids - halves, mids + halves], 1).ravel()
+        split = []
+        for lo, hi in zip(mids - halves, mids + halves):
+            if lo < 0 and hi > T: split += [0, T]
+            elif lo < 0: split += [0, hi, lo + T, T]
+            elif hi > T: split += [0, hi - T, lo, T]
+            else: split += [lo, hi]
+        first = np.array([0, k], dtype=np.int32)
+        out = np.zeros(1)
+        lib.emu_arc_union(raw.ctypes.data_as(dp), first.ctypes.data_as(ip), 1, 8, out.ctypes.data_as(dp))
+        worst = max(worst, abs(out[0] - oracle_lib.exposed_arc_length(split)))
+    assert worst < 1e-13

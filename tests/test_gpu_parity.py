@@ -549,7 +549,8 @@ def test_arc_union_kats_through_the_device_union(fa, oracle_lib):
     ctx = fa.GpuContext(0)
     got = ctx.arc_union(sets)
     assert np.max(np.abs(got - np.array(want))) < 1e-10          # the reference's own tolerance
-    assert [float(g) for g in got] == [oracle_lib.exposed_arc_length(s) for s in sets]   # and bit for bit the oracle's sums
+    # (until round 3 bit for bit the oracle's sums; the closed-form sweep of round 4 adds 2 pi in another place)
+    assert np.max(np.abs(got - np.array([oracle_lib.exposed_arc_length(s) for s in sets]))) < 1e-14
     # random sets, many arcs, with wrapped ones given split as the reference stores them
     rng = np.random.default_rng(5)
     rsets = []
