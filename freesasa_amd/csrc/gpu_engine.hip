@@ -382,7 +382,8 @@ __global__ __launch_bounds__(SORT_B) void k_sort_struct(PipeArgs a)
             v.w = a.radii[a.shared_radii ? (long long)li : i] + a.probe; /* ref: src/sasa_lr.c:136, src/sasa_sr.c:144 */
             a.sq[p] = v;
             SortIdx si;
-            si.cell = (long long)(g.cell_base + (int)(cellf[k] & cmask)) | ((long long)(cellf[k] >> SORT_CELL_BITS) << 32);
+            si.cell = (long long)((unsigned long long)(unsigned)(g.cell_base + (int)(cellf[k] & cmask)) |
+                                  ((unsigned long long)((cellf[k] >> SORT_CELL_BITS) | cell_pack_grid(g.nx, g.ny)) << 32));
             si.orig = (int)i; si.strct = s;
             a.s_idx[p] = si;
             if (a.occ_stride > 0 && i % a.occ_stride == 0) { /* density samples, as scatter_atom */
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(B) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) v
  * allocation is capped for. */
 /* NOTE: Lr2Args must stay the ONLY parameter of this kernel, at offset 0 of the kernel-argument segment: the tile
  * body reads its rarely used fields from there (LR2_COLD in lr2_kernels.h). */
-template <int RMAX, int TIER, int WPE, bool COVER>
+template <int RMAX, int TIER, int WPE, bool COVER, bool PAIRS = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lr2_tile(Lr2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -521,7 +522,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     PIPE_GATE(a.status);
     Lr2Mem m = lr2_carve(a, smem);
     int wg_max_nn = 0;
-    lr2_wave<RMAX, COVER>(a, m, blockIdx.x, gridDim.x, lane, wg_max_nn);
+    lr2_wave<RMAX, COVER, PAIRS>(a, m, blockIdx.x, gridDim.x, lane, wg_max_nn);
     if (lane == 0 && wg_max_nn > a.status[ST_MAX_NN]) atomicMax(&a.status[ST_MAX_NN], wg_max_nn);
 }
 __global__ __launch_bounds__(64) void k_lr2_arc_kat(const double *arcs, const int *first, int n_sets, double *out)
@@ -536,8 +537,12 @@ __global__ __launch_bounds__(64) void k_lr2_arc_kat(const double *arcs, const in
 static hipError_t launch_lr2_main(int rmax, int grid, size_t lds, hipStream_t st, const Lr2Args &la)
 {
     /* (the cover filter is compiled into the launches over dense batches only: the sparse ones keep its registers) */
-#define LR2_LAUNCH(R) do { if (la.cover > 0) hipLaunchKernelGGL((k_lr2_tile<R, 0, 4, true>), dim3(grid), dim3(64), lds, st, la); \
-                           else hipLaunchKernelGGL((k_lr2_tile<R, 0, 4, false>), dim3(grid), dim3(64), lds, st, la); } while (0)
+#define LR2_LAUNCH(R) do { \
+        if (lr2_pairs_shape(la.TA, la.ns)) { \
+            if (la.cover > 0) hipLaunchKernelGGL((k_lr2_tile<R, 0, 4, true, true>), dim3(grid), dim3(64), lds, st, la); \
+            else hipLaunchKernelGGL((k_lr2_tile<R, 0, 4, false, true>), dim3(grid), dim3(64), lds, st, la); \
+        } else if (la.cover > 0) hipLaunchKernelGGL((k_lr2_tile<R, 0, 4, true>), dim3(grid), dim3(64), lds, st, la); \
+        else hipLaunchKernelGGL((k_lr2_tile<R, 0, 4, false>), dim3(grid), dim3(64), lds, st, la); } while (0)
     if (rmax <= 2) LR2_LAUNCH(2); else if (rmax == 3) LR2_LAUNCH(3); else LR2_LAUNCH(4);
 #undef LR2_LAUNCH
     return hipGetLastError();

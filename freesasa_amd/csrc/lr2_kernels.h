@@ -54,6 +54,7 @@ long long wave_exchange(long long v, int src);
 #define LR2_RSQF(x) (1.0f / sqrtf(x))
 #define LR2_ADD64_LDS(p, v) (*(p) += (v))
 #define LR2_OR_LDS(p, v) (*(p) |= (v))
+#define LR2_INC_LDS(p) (++*(p))
 namespace sasa_emu { extern long long lr2_count[16]; } /* wave-level trip counts (lane 0 counts): 0 tiles, 1 arc iterations, 2 refills, 3 P1 test rounds, 4 rank trips, 5 screening trips, 6 P3 rounds */
 #define LR2_COUNT(k, n) do { if (lane == 0) sasa_emu::lr2_count[(k)] += (n); } while (0)
 #else
@@ -84,6 +85,7 @@ namespace sasa_emu { extern long long lr2_count[16]; } /* wave-level trip counts
 #define LR2_RSQF(x) __builtin_amdgcn_rsqf(x)
 #define LR2_ADD64_LDS(p, v) atomicAdd((p), (v))
 #define LR2_OR_LDS(p, v) atomicOr((p), (v))
+#define LR2_INC_LDS(p) ((void)__hip_atomic_fetch_add((p), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) /* result unused: ds_add_u32, nothing to wait for */
 #endif
 
 namespace sasa {
@@ -253,7 +255,7 @@ struct Lr2Layout {
 };
 SASA_HD int lr2_a16(int v) { return (v + 15) & ~15; }
 SASA_HD int lr2_n_ints(int TA, int mw) { return 6 * TA + 1 + 8 + TA * mw; }
-SASA_HD int lr2_n_row_ints(int TA) { return 9 * TA + (9 * TA + 2); } /* rowlo, cpre: P0 and P1 only */
+SASA_HD int lr2_n_row_ints(int TA) { return 9 * TA + 9 * TA + (9 * TA + 2); } /* rowlo, rinfo, cpre: P0 and P1 only */
 SASA_HD Lr2Layout lr2_layout(int TA, int ns, int pool, int mw, int ds)
 {
     Lr2Layout L;
@@ -288,8 +290,8 @@ struct Lr2Mem {
     double *adel; /* [TA] 2 Ri / ns (ref: src/sasa_lr.c:304) */
     int *acell, *lead, *gsz, *acnt, *aoff, *sorig, *flags, *hist;
     unsigned *cmask; /* [TA*mw] cover filter: the atom's neighbors with the largest caps, as bits of its (beta-sorted) list */
-    int *rowlo, *cpre; /* [9 TA], [9 TA + 2]: first candidate of a row, prefix of P1's work items (over the keys until P3) */
-    double *it_tc;  /* [items] 1/(2 Ri') of an item with arcs until its slice is done, then (and for the others from P4 on) its area */
+    int *rowlo, *rinfo, *cpre; /* [9 TA], [9 TA], [9 TA + 2]: of the rows that have work: first candidate, leading atom | group size << 4 | items per candidate << 8, prefix of P1's work items (over the keys until P3) */
+    double *it_tc;  /* [items] 1/(4 Ri') of an item with arcs until its slice is done, then (and for the others from P4 on) its area */
     unsigned *it_mask; /* [items*mw] neighbors that cut an arc */
     unsigned short *queue; /* [items] items with arcs, heaviest first: item | atom << 10 */
     unsigned short *qtmp;  /* [items] bin and arrival order of an item before the bins are laid out */
@@ -297,10 +299,10 @@ struct Lr2Mem {
     Ab16 *ab;       /* [pool] records, sorted by beta inside each atom's list: coefficients ... */
     double *beta;   /* [pool] ... and direction */
     double *keys;   /* [pool] beta with the list position in its low mantissa bits */
-    unsigned short *tag; /* [pool] atom (low 3 bits) and list position of a hit */
+    unsigned short *tag; /* [pool] atom of a hit */
     Arc2 *stack;     /* [ds][64] */
 };
-/* flags: 0 tile overflow, 1 stack overflow, 2 max neighbor count, 5 largest cell group, 6 atoms with a coincident neighbor of equal radius (bits) */
+/* flags: 0 tile overflow, 1 stack overflow, 2 max neighbor count, 6 atoms with a coincident neighbor of equal radius (bits) */
 
 SASA_D Lr2Mem lr2_carve(const Lr2Args &a, char *smem)
 {
@@ -312,7 +314,7 @@ SASA_D Lr2Mem lr2_carve(const Lr2Args &a, char *smem)
     m.acell = q; q += TA; m.lead = q; q += TA; m.gsz = q; q += TA; m.acnt = q; q += TA; m.aoff = q; q += TA + 1;
     m.sorig = q; q += TA; m.flags = q; q += 8;
     m.cmask = (unsigned *)q;
-    m.rowlo = (int *)(smem + L.o_r2); m.cpre = m.rowlo + 9 * TA;
+    m.rowlo = (int *)(smem + L.o_r2); m.rinfo = m.rowlo + 9 * TA; m.cpre = m.rinfo + 9 * TA;
     m.it_tc = (double *)(smem + L.o_tc);
     m.it_mask = (unsigned *)(smem + L.o_mask);
     m.queue = (unsigned short *)(smem + L.o_queue);
@@ -354,6 +356,17 @@ SASA_D void lr2_record(double xd, double yd, double zd, double rj, double ri, do
     if (!(D > 0) && zd == 0 && K == 0) bp = NAN;
 }
 
+/* Half-width of the arc a neighbor cuts at slice height t: acos((b' + a' t) / (2 Ri')) (lr2_record).  The arc pass gets
+ * hh = 1/(4 Ri') from the screening and forms acos_fast2's argument z = (1 - |c|)/2 = 1/2 - |b' + a' t| hh in ONE fma, the
+ * product with 1/(2 Ri') never rounded on its own (round 4: an instruction per arc less).  The screening has decided
+ * RN(|b' + a' t| / (2 Ri')) < 1, i.e. <= 1 - 2^-53, so the exact product is below 1 - 2^-54 and z > 0 after its single
+ * rounding: no arc reaches the square root with a negative argument. */
+SASA_D double lr2_arc_alpha(double t, const Ab16 &ab, double hh)
+{
+    const double v = fma(t, ab.a, ab.b);
+    return acos_fast2_z(fma(fabs(v), -hh, 0.5), v);
+}
+
 /* Arc union on raw end points (inf may be negative, sup may exceed 2 pi: every arc contains its beta
  * in [0, 2 pi], so only the lowest component can start below 0 and only the highest can end above
  * 2 pi; lr2_sweep folds them back).  Arcs arrive ordered by beta, so the disjoint components form a
@@ -377,12 +390,10 @@ SASA_D int lr2_med3(int v, int lo, int hi)
 /* maxd: the largest depth the lane has seen (a tile whose stack column was too short is redone) */
 SASA_D void lr2_union_step(double inf, double sup, Lr2Union &u, Arc2 *stk, int ds, int &maxd)
 {
+#ifdef LR2_UNION_SELECT /* (round 3's form: selects around one short branch; measured against the if / else form in round 4) */
     const bool fresh = inf > u.te; /* te = -inf while there is no component */
     const double mts = SASA_MIN(u.ts, inf), mte = SASA_MAX(u.te, sup);
     if (fresh) {
-        /* the second component goes to the LDS column, the top one becomes the second.  With fewer than
-           two components the store lands in level 0, which is not in use then (it is written again,
-           properly, by the push that makes a third component) */
         Arc2 t; t.s = u.bs; t.e = u.be;
         stk[lr2_med3(u.depth - 2, 0, ds > 0 ? ds - 1 : 0) * LR2_LANES] = t;
         u.bs = u.ts; u.be = u.te;
@@ -391,7 +402,7 @@ SASA_D void lr2_union_step(double inf, double sup, Lr2Union &u, Arc2 *stk, int d
     u.te = fresh ? sup : mte;
     u.depth += fresh ? 1 : 0;
     maxd = maxd > u.depth ? maxd : u.depth;
-    while (u.be >= u.ts) { /* the merged component reaches the one below it (never after a push: be = old te < inf) */
+    while (u.be >= u.ts) {
         u.ts = SASA_MIN(u.ts, u.bs);
         --u.depth;
         if (u.depth >= 2) {
@@ -401,6 +412,32 @@ SASA_D void lr2_union_step(double inf, double sup, Lr2Union &u, Arc2 *stk, int d
             u.be = -INFINITY;
         }
     }
+#else
+    if (inf > u.te) { /* te = -inf while there is no component */
+        /* a new component on top: the second goes to the LDS column, the top one becomes the second.  With fewer than
+           two components the store lands in level 0, which is not in use then (it is written again, properly, by
+           the push that makes a third component) */
+        Arc2 t; t.s = u.bs; t.e = u.be;
+        stk[lr2_med3(u.depth - 2, 0, ds > 0 ? ds - 1 : 0) * LR2_LANES] = t;
+        u.bs = u.ts; u.be = u.te;
+        u.ts = inf; u.te = sup;
+        ++u.depth;
+        maxd = maxd > u.depth ? maxd : u.depth;
+    } else {
+        u.ts = SASA_MIN(u.ts, inf);
+        u.te = SASA_MAX(u.te, sup);
+        while (u.be >= u.ts) { /* the merged component reaches the one below it (never after a push: be = old te < inf) */
+            u.ts = SASA_MIN(u.ts, u.bs);
+            --u.depth;
+            if (u.depth >= 2) {
+                const Arc2 lo = stk[lr2_med3(u.depth - 2, 0, ds > 0 ? ds - 1 : 0) * LR2_LANES];
+                u.bs = lo.s; u.be = lo.e;
+            } else {
+                u.be = -INFINITY;
+            }
+        }
+    }
+#endif
 }
 
 /* Exposed arc length from the final components C_0 < C_1 < ... (disjoint, ascending, raw end points).
@@ -532,12 +569,75 @@ SASA_D double lr2_acos_lower(double c)
     return (1.5707963267948966 - 1e-9) - fma(c * c2, fma(k5, c2, 1.0 / 6.0), c);
 }
 
+/* ---------------------------------------------------------------- P0's global loads, one tile ahead
+ * What P0 needs from global memory is a chain: the atom's sort record -> (its structure's grid ->) the first atoms of
+ * the cells at both ends of each of its 9 candidate rows.  Until round 3 every tile began by waiting for those round
+ * trips (P0: 9 % of a wave's life for 3 % of its instructions).  Now the chain of tile k+1 is walked while tile k
+ * computes: stage A (sort records) is issued before the queue of tile k is built, stages B (cell_start) and C (the tile's
+ * own atoms) before its areas are summed, and P0 of tile k+1 finds the values in its registers.  nx and ny of the
+ * structure's grid ride in the sort record's flag word (cell_pack_grid), so the common chain has two links, not three.
+ * A tile that was not announced (the first of a wave, halves of a split tile) walks the chain on the spot, as before. */
+struct Lr2Pre {
+    int p0;          /* first atom of the tile the values are of (-1: none) */
+    long long rcf;   /* A, row lanes: cell | (flags, nx, ny) << 32 of the row's atom */
+    int s0, s1;      /* B, row lanes: first atoms of the cells at both ends of the row's run */
+    int rfl;         /* B: bit 0 row outside the grid, bit 1 the atom leads its cell group */
+    Quad q;          /* C, lanes < TA: the atom */
+    int cell, so;    /* C: its cell and its original index */
+};
+SASA_D void lr2_pre_none(Lr2Pre &pre)
+{
+    pre.p0 = -1; pre.rcf = 0; pre.s0 = pre.s1 = 0; pre.rfl = 1; pre.cell = 0; pre.so = 0;
+    pre.q.x = pre.q.y = pre.q.z = 0; pre.q.w = 1;
+}
+/* (Loads without branches around them: a lane that has no row or no atom of the tile loads what the tile's last atom's
+ * lane loads, and P0 sorts out who is who.  A join of two paths between a load and its use makes the compiler wait for
+ * every load in flight at the join - the round trip this is here to hide.) */
+SASA_D void lr2_pre_a(const Lr2Args &a, Lr2Pre &pre, int p0, int na, int lane)
+{
+    const int la = lr2_div9(lane);
+    pre.p0 = p0;
+    pre.rcf = LR2_COLD(a, s_idx)[p0 + (la < na ? la : na - 1)].cell;
+}
+SASA_D void lr2_pre_b(const Lr2Args &a, Lr2Pre &pre, int na, int lane)
+{
+    const int la = lr2_div9(lane), r = lane - 9 * la;
+    const int c = (int)(pre.rcf & 0xffffffffLL), hw = (int)(pre.rcf >> 32);
+    const int cprev = LR2_SHFL(c, lane >= 9 ? lane - 9 : lane); /* cell of the atom before this row's atom (tile atoms are consecutive in cell order) */
+    const int fl = hw & 63;
+    int nx = (hw >> 6) & 8191, ny = (hw >> 19) & 8191;
+    if (nx == 0) { /* (rare) a grid of 8192 cells or more along x or y: two more links */
+        const GridS *const g = LR2_COLD(a, grid) + LR2_COLD(a, s_idx)[pre.p0 + (la < na ? la : na - 1)].strct;
+        nx = g->nx; ny = g->ny;
+    }
+    const int dz = lr2_div3(r < 9 ? r : 0) - 1, dy = (r < 9 ? r : 0) - 3 * (dz + 1) - 1; /* (lanes 9 TA .. 63 belong to no row) */
+    const bool out = (dy < 0 && (fl & CELL_Y0)) || (dy > 0 && (fl & CELL_Y1)) ||
+                     (dz < 0 && (fl & CELL_Z0)) || (dz > 0 && (fl & CELL_Z1));
+    const int row = out ? c : c + nx * (dy + ny * dz);
+    const int x_lo = row - ((fl & CELL_X0) ? 0 : 1), x_hi = row + ((fl & CELL_X1) ? 0 : 1);
+    const int *const cell_start = LR2_COLD(a, cell_start);
+    pre.s0 = cell_start[x_lo]; pre.s1 = cell_start[x_hi + 1];
+    /* the atoms of a tile are consecutive in cell order: atoms of one cell form a group */
+    pre.rfl = (out || la >= na ? 1 : 0) | (la == 0 || cprev != c ? 2 : 0);
+}
+SASA_D void lr2_pre_c(const Lr2Args &a, Lr2Pre &pre, int na, int lane)
+{
+    const int p = pre.p0 + (lane < na ? lane : na - 1);
+    pre.q = a.sq[p];
+    const SortIdx si = LR2_COLD(a, s_idx)[p];
+    pre.cell = lane < na ? (int)(si.cell & 0xffffffffLL) : -1 - lane;
+    pre.so = si.orig;
+}
+
 /* The whole tile, executed by the 64 lanes of one wave.  RMAX = rounds of 64 pair records a lane
  * keeps in registers in P3 (pool <= 64 * RMAX). */
 /* returns 0: the atoms' areas are stored; 1: the tile does not fit this launch's capacities (nothing stored); 2: two
    neighbors of an atom with equal sort keys (nothing stored; see lr2_tie12): once more with tie_by_place */
-template <int RMAX, bool COVER>
-SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool sample, bool tie_by_place, int lane, int &wg_max_nn)
+/* pre: what P0 loads, possibly fetched ahead by the previous call; (p0n, nan): the tile this wave does next (its
+   own again when there is none), fetched ahead by this call */
+template <int RMAX, bool COVER, bool PAIRS>
+SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool sample, bool tie_by_place, int lane, int &wg_max_nn,
+                    Lr2Pre &pre, int p0n, int nan)
 {
     const int TA = a.TA, ns = a.ns, mw = a.mw;
     const int items = na * ns;
@@ -545,82 +645,68 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     LR2_COUNT(0, 1);
 
     /* ------------------------------------------------------------ P0 load */
-    const SortIdx *const s_idx = LR2_COLD(a, s_idx); /* (P0's own pointers: read here, once per tile) */
+    if (pre.p0 != p0) { /* (uniform) not fetched ahead (a tile is announced with its own first atom and count: the halves of a split tile never find the whole tile's values): the chain, one link after the other */
+        LR2_COUNT(11, 1);
+        lr2_pre_a(a, pre, p0, na, lane);
+        lr2_pre_b(a, pre, na, lane);
+        lr2_pre_c(a, pre, na, lane);
+    }
     if (lane < TA) {
-        Quad q; q.x = q.y = q.z = 0; q.w = 1;
-        double del = 0;
-        int cell = -1 - lane, so = 0;
-        if (lane < na) {
-            const int p = p0 + lane;
-            q = a.sq[p];
-            del = lr2_div_ns(2 * q.w, (double)ns, LR2_COLD(a, inv_ns)); /* = 2 Ri / ns, ref: src/sasa_lr.c:304 */
-            const SortIdx si = s_idx[p];
-            cell = (int)(si.cell & 0xffffffffLL);
-            so = si.orig;
-        }
-        m.atom[lane] = q; m.adel[lane] = del; m.acell[lane] = cell; m.sorig[lane] = so;
+        Quad q = pre.q;
+        if (lane >= na) { q.x = q.y = q.z = 0; q.w = 1; }
+        const double del = lane < na ? lr2_div_ns(2 * q.w, (double)ns, LR2_COLD(a, inv_ns)) : 0.0; /* = 2 Ri / ns, ref: src/sasa_lr.c:304 */
+        m.atom[lane] = q; m.adel[lane] = del; m.sorig[lane] = lane < na ? pre.so : 0;
         m.acnt[lane] = 0;
+        m.gsz[lane] = 0; /* (P3's list cursors) */
     }
     if (lane < 8) m.flags[lane] = 0;
-    int my_cnt = 0; /* candidates of row `lane` (rows of atoms that do not lead a cell group count 0) */
-    if (lane < 9 * TA) {
-        const int la = lr2_div9(lane), r = lane - 9 * la;
-        int lo = 0, cnt = 0;
-        if (la < na) { /* as tile_phase_load of sasa_kernels.h: three dependent round trips */
-            const int p = p0 + la;
-            const SortIdx si = s_idx[p];
-            const int sid = si.strct;
-            const long long cf = si.cell;
-            const GridS *const grid = LR2_COLD(a, grid);
-            const int nx = grid[sid].nx, ny = grid[sid].ny;
-            const int c = (int)(cf & 0xffffffffLL), fl = (int)(cf >> 32);
-            const int dz = lr2_div3(r) - 1, dy = r - 3 * (dz + 1) - 1;
-            const bool out = (dy < 0 && (fl & CELL_Y0)) || (dy > 0 && (fl & CELL_Y1)) ||
-                             (dz < 0 && (fl & CELL_Z0)) || (dz > 0 && (fl & CELL_Z1));
-            const int row = out ? c : c + nx * (dy + ny * dz);
-            const int x_lo = row - ((fl & CELL_X0) ? 0 : 1), x_hi = row + ((fl & CELL_X1) ? 0 : 1);
-            const int *const cell_start = LR2_COLD(a, cell_start);
-            const int s0 = cell_start[x_lo], s1 = cell_start[x_hi + 1];
-            lo = out ? 0 : s0;
-            cnt = out ? 0 : s1 - s0;
-            /* the atoms of a tile are consecutive in cell order: atoms of one cell form a group */
-            const bool leads = la == 0 || (int)(s_idx[p - 1].cell & 0xffffffffLL) != c;
-            my_cnt = leads ? cnt : 0;
+    /* cell groups: the atoms of a tile are consecutive in cell order; an atom whose cell differs from its predecessor's
+       leads a group.  From one ballot every lane knows the leader and the size of any atom's group (no LDS round trip) */
+    unsigned lm;
+    {
+        const int cprev = LR2_SHFL(pre.cell, lane > 0 ? lane - 1 : 0);
+        lm = (unsigned)LR2_BALLOT(lane < na && (lane == 0 || pre.cell != cprev)); /* (bits 0 .. na-1; bit 0 is set) */
+    }
+    int lo = 0, my_cnt = 0, info = 0; /* candidates of row `lane` (rows of atoms that do not lead a cell group, rows outside the grid and empty rows count 0) */
+    {
+        const int la = lr2_div9(lane);
+        if (la < na && (pre.rfl & 3) == 2) { /* inside the grid, and its atom leads a group */
+            const unsigned above = lm >> (la + 1);
+            const int gs = (above ? la + 1 + __builtin_ctz(above) : na) - la, hc = lr2_div3(gs + LR2_P1_G - 1);
+            lo = pre.s0;
+            my_cnt = LR2_MUL24(pre.s1 - pre.s0, hc); /* P1's work items of the row: (candidate, up to LR2_P1_G atoms of the group) */
+            info = la | (gs << 4) | (hc << 8);
         }
-        m.rowlo[lane] = lo;
     }
-    LR2_SYNC();
-    if (lane < TA) {
-        const bool lead = lane < na && (lane == 0 || m.acell[lane] != m.acell[lane - 1]);
-        int gs = 0;
-        if (lead) { gs = 1; while (lane + gs < na && m.acell[lane + gs] == m.acell[lane]) ++gs; }
-        m.lead[lane] = lead ? 1 : 0;
-        m.gsz[lane] = gs;
-        if (gs > 0) SASA_ATOMIC_MAX_LDS(&m.flags[5], gs);
-    }
-    /* P1's work items: (candidate, up to LR2_P1_G atoms of the cell group the candidate belongs to); inclusive
-       prefix of the item counts over the rows */
-    LR2_SYNC();
-    if (my_cnt > 0) my_cnt *= lr2_div3(m.gsz[lr2_div9(lane)] + LR2_P1_G - 1); /* (rows of a group's leading atom only) */
+    lr2_pre_none(pre); /* (consumed: nothing of it lives through the tile) */
+    /* the rows that have work, closed up: inclusive prefix of their item counts, first candidate, group */
+    const unsigned long long rm = LR2_BALLOT(my_cnt > 0);
     const int incl = lr2_scan_add(my_cnt, lane);
+    const int nrows = LR2_POPC64(rm);
+    const int total_c = LR2_READLANE(incl, LR2_LANES - 1);
     if (lane == 0) m.cpre[0] = 0;
-    if (lane < 9 * TA) m.cpre[lane + 1] = incl;
+    if (my_cnt > 0) {
+        const int ri = LR2_RANK(rm, lane);
+        m.cpre[ri + 1] = incl; m.rowlo[ri] = lo; m.rinfo[ri] = info;
+    }
     LR2_SYNC();
 
     LR2_STOP(0);
     LR2_MARK(0);
     /* ------------------------------------------------------------ P1 neighbors */
-    const int nrows = 9 * TA;
-    const int total_c = LR2_UNIFORM(m.cpre[nrows]);
     int nh = 0; /* hits so far (wave-uniform) */
     {
         const int per = (total_c + LR2_LANES - 1) / LR2_LANES; /* consecutive work items per lane */
         const int f = lane * per;
         const int fend = f + per < total_c ? f + per : total_c;
         int t = 0;
+        /* the row of the lane's items rides in registers (items of a lane are consecutive: a row changes once in a
+           while): first item c_lo, end c_hi, first candidate rl, group */
+        int c_lo = 0, c_hi = 0, rl = 0, ri_ = 0;
         if (f < total_c) { /* row of the lane's first item: largest t with cpre[t] <= f */
             for (int step = 32; step >= 1; step >>= 1)
-                if (t + step <= nrows && m.cpre[t + step] <= f) t += step;
+                if (t + step <= nrows - 1 && m.cpre[t + step] <= f) t += step;
+            c_lo = m.cpre[t]; c_hi = m.cpre[t + 1]; rl = m.rowlo[t]; ri_ = m.rinfo[t];
         }
         LR2_COUNT(3, (per + LR2_NB_UNROLL - 1) / LR2_NB_UNROLL * LR2_NB_UNROLL * LR2_P1_G);
         for (int base = 0; base < per; base += LR2_NB_UNROLL) { /* (wave-uniform trip count) */
@@ -630,12 +716,15 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                 const int fj = f + base + j;
                 q[j] = -1; la0[j] = 0; two[j] = 0;
                 if (base + j < per && fj < fend) {
-                    while (fj >= m.cpre[t + 1]) ++t;
-                    const int lead = lr2_div9(t), gs = m.gsz[lead], hc = lr2_div3(gs + LR2_P1_G - 1);
-                    const unsigned i = (unsigned)(fj - m.cpre[t]);
+                    if (fj >= c_hi) { /* on to the next row (every row in the table has items) */
+                        ++t;
+                        c_lo = c_hi; c_hi = m.cpre[t + 1]; rl = m.rowlo[t]; ri_ = m.rinfo[t];
+                    }
+                    const int lead = ri_ & 15, gs = (ri_ >> 4) & 15, hc = ri_ >> 8;
+                    const unsigned i = (unsigned)(fj - c_lo);
                     const unsigned c = hc == 1 ? i : (hc == 2 ? i >> 1 : (unsigned)LR2_MUL24(i, 0xaaabu) >> 17); /* i / hc, hc <= 3 (gs <= 7); i < 2^15 */
                     const int h = (int)i - LR2_MUL24(c, hc);
-                    q[j] = m.rowlo[t] + (int)c;
+                    q[j] = rl + (int)c;
                     la0[j] = lead + LR2_P1_G * h;
                     two[j] = gs - LR2_P1_G * h < LR2_P1_G ? gs - LR2_P1_G * h : LR2_P1_G; /* atoms of this item */
                 }
@@ -662,11 +751,15 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                         const int la = la0[j] + g;
                         int slot = nh + LR2_RANK(hm, lane);
                         slot = slot < a.pool ? slot : a.pool - 1; /* (a tile with more hits than the pool is redone: P2) */
-                        const int sa = SASA_ATOMIC_ADD_LDS(&m.acnt[la], 1);
                         Quad hq; hq.x = dx[j]; hq.y = dy[j]; hq.z = dz[j]; hq.w = rq[j]; /* ref: src/nb.c:445-448 */
                         m.hits[slot] = hq;
-                        m.tag[slot] = (unsigned short)((unsigned)la | ((unsigned)sa << 3)); /* la < 8, sa < 2^13 */
-                        if (a.hooks & 2) { /* (uniform) test hook: the neighbor lists themselves */
+                        m.tag[slot] = (unsigned short)la;
+                        /* the atom's count only: nothing here waits for the counter's old value (the hit's place in its
+                           atom's list is handed out in P3, two round trips per tile instead of one per group of tests) */
+                        if (!(a.hooks & 2)) { /* (uniform) */
+                            LR2_INC_LDS(&m.acnt[la]);
+                        } else { /* test hook: the neighbor lists themselves */
+                            const int sa = SASA_ATOMIC_ADD_LDS(&m.acnt[la], 1);
                             const int cap = LR2_COLD(a, nb_cap);
                             if (sa < cap) LR2_COLD(a, nb_out)[(size_t)m.sorig[la] * cap + sa] = LR2_COLD(a, s_idx)[q[j]].orig;
                         }
@@ -738,8 +831,8 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             r_cb[r] = 0;
             if (gp < nh) {
                 const Quad hq = m.hits[gp];
-                const unsigned tg = m.tag[gp];
-                const int la = (int)(tg & 7u), sa = (int)(tg >> 3);
+                const int la = (int)m.tag[gp];
+                const int sa = SASA_ATOMIC_ADD_LDS(&m.gsz[la], 1); /* place in the atom's list, in order of discovery (gsz: zero since P0) */
                 const int o = m.aoff[la];
                 const double ri = m.atom[la].w;
                 double Kc, d3sq, inv_d;
@@ -851,18 +944,113 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     const float inv_ns = LR2_RCPF((float)ns); /* index arithmetic only (one off either way is put right below) */
     m.hist[lane] = 0;
     LR2_SYNC();
+    /* what is left to do for an item once its arcs are known: the cover filter (dense tiles), its word for the arc pass
+       or its area, its place in the queue */
+    auto finish_item = [&](int it, int la, double t, double h2, double Ri, int o, int cnt, bool buried, bool circle) {
+        double area = 0;
+        if (buried || !circle) cnt = 0; /* circle i inside a neighbor's: buried (ref: :327-330); no circle: ref :310-312 */
+        else if (cnt == 0) area = m.adel[la] * Ri * SASA_TWOPI; /* ref: :360 with exposed_arc_length(n = 0) */
+        if (cover && circle) { /* (uniform) the arcs of the largest caps, in beta order: do they cover the circle? */
+            double cts = 0, cte = -INFINITY;
+            for (int wi = 0; wi < mwt; ++wi) {
+                unsigned wc = cnt > 0 ? (m.it_mask[LR2_MUL24(it, mw) + wi] & m.cmask[LR2_MUL24(la, mw) + wi]) : 0u;
+                const int R = o + 32 * wi;
+                while (wc != 0) { /* (the wave runs as many trips as its busiest lane) */
+                    const int q = R + __builtin_ctz(wc);
+                    wc &= wc - 1;
+                    const Ab16 ab = m.ab[q];
+                    const double bt = m.beta[q];
+                    const double c = fma(t, ab.a, ab.b) * h2;
+                    const double al = lr2_acos_lower(c);
+                    const double inf = bt - al, sup = bt + al;
+                    const bool fresh = inf > cte;
+                    const double nts = fresh ? inf : SASA_MIN(cts, inf), nte = fresh ? sup : SASA_MAX(cte, sup);
+                    if (c <= 0.9) { cts = nts; cte = nte; }
+                }
+            }
+            if (cte - cts >= SASA_TWOPI) cnt = 0; /* covered: area 0 */
+        }
+        m.it_tc[it] = cnt == 0 ? area : 0.5 * h2; /* (an item with arcs: 1/(4 Ri') for the arc pass - see lr2_arc_alpha -, which puts the area in its place) */
+        unsigned short qt = 0xffff;
+        if (cnt > 0) { /* queue: heaviest first (bin 0 = 63 arcs or more); inside a bin in order of arrival */
+            const int bin = 63 - (cnt < 63 ? cnt : 63);
+            const int ord = SASA_ATOMIC_ADD_LDS(&m.hist[bin], 1);
+            qt = (unsigned short)((bin << 10) | ord); /* ord < items <= 512 */
+        }
+        m.qtmp[it] = qt;
+    };
+    const int hp = (ns + 1) >> 1; /* pairs of slices per atom */
+    if (PAIRS) { /* (the launch's tile shape: lr2_pairs_shape) */
+        /* More items than lanes, but no more than two per lane (6 atoms x 20 slices): a lane screens two neighboring
+           slices of one atom in ONE pass over the atom's records - every record is read once for both, the loop's
+           bookkeeping and the item's own preparations are shared - where two rounds of one item per lane walk every
+           list twice (round 4: the phase's wave instructions 450 -> ~360 per tile of coils). */
+        int ln = lane;
+        SASA_OPAQUE(ln); /* (what follows depends on the lane and the launch only: left to itself the compiler computes it once per wave and keeps - then spills - a dozen registers through every phase of every tile) */
+        if (ln < LR2_MUL24(na, hp)) {
+            int la = (int)(((float)ln + 0.5f) * LR2_RCPF((float)hp)), j = ln - LR2_MUL24(la, hp);
+            if (j < 0) { --la; j += hp; } else if (j >= hp) { ++la; j -= hp; }
+            const int sa_ = 2 * j, it0 = LR2_MUL24(la, ns) + sa_;
+            const bool second = sa_ + 1 < ns; /* (ns odd: the atom's last pair is one slice) */
+            const double Ri = m.atom[la].w, del = m.adel[la];
+            const double t0 = lr2_slice_height(sa_, del, Ri), t1 = lr2_slice_height(second ? sa_ + 1 : sa_, del, Ri);
+            const double A0 = Ri * Ri - t0 * t0, A1 = Ri * Ri - t1 * t1; /* Ri'^2, ref: src/sasa_lr.c:309 */
+            const bool circ0 = A0 > 0, circ1 = second && A1 > 0; /* ref: :310-312 */
+            double h0, h1;
+            LR2_H2(circ0 ? A0 : 1.0, h0); /* 1/(2 Ri') */
+            LR2_H2(circ1 ? A1 : 1.0, h1);
+            const int o = m.aoff[la], nn = m.aoff[la + 1] - o;
+            double cmin0 = 1.0, cmin1 = 1.0;
+            int cnt0 = 0, cnt1 = 0;
+            for (int wi = 0; wi < mwt; ++wi) {
+                unsigned w0 = 0, w1 = 0;
+                const int k1 = nn - 32 * wi < 32 ? nn - 32 * wi : 32;
+                const Ab16 *R = m.ab + (o + 32 * wi);
+                int k = k1 - 2; /* from the end: neighbor k lands on bit k */
+                if (k1 > 0 && (k1 & 2)) {
+                    const Ab16 ra = R[k], rb = R[k + 1];
+                    const double c0 = fma(t0, ra.a, ra.b) * h0, c1 = fma(t0, rb.a, rb.b) * h0;
+                    const double d0 = fma(t1, ra.a, ra.b) * h1, d1 = fma(t1, rb.a, rb.b) * h1;
+                    cmin0 = SASA_MIN(cmin0, SASA_MIN(c0, c1));
+                    cmin1 = SASA_MIN(cmin1, SASA_MIN(d0, d1));
+                    w0 = LR2_SHIFT_IN_LT1(w0, c1); w0 = LR2_SHIFT_IN_LT1(w0, c0);
+                    w1 = LR2_SHIFT_IN_LT1(w1, d1); w1 = LR2_SHIFT_IN_LT1(w1, d0);
+                    k -= 2;
+                }
+                for (; k >= 0; k -= 4) { /* four records per trip: their LDS reads are in flight together */
+                    const Ab16 r2 = R[k], r3 = R[k + 1], r0 = R[k - 2], r1 = R[k - 1];
+                    const double c2 = fma(t0, r2.a, r2.b) * h0, c3 = fma(t0, r3.a, r3.b) * h0;
+                    const double c0 = fma(t0, r0.a, r0.b) * h0, c1 = fma(t0, r1.a, r1.b) * h0;
+                    const double d2 = fma(t1, r2.a, r2.b) * h1, d3 = fma(t1, r3.a, r3.b) * h1;
+                    const double d0 = fma(t1, r0.a, r0.b) * h1, d1 = fma(t1, r1.a, r1.b) * h1;
+                    cmin0 = SASA_MIN(SASA_MIN(cmin0, c0), SASA_MIN(c1, SASA_MIN(c2, c3)));
+                    cmin1 = SASA_MIN(SASA_MIN(cmin1, d0), SASA_MIN(d1, SASA_MIN(d2, d3)));
+                    w0 = LR2_SHIFT_IN_LT1(w0, c3); w0 = LR2_SHIFT_IN_LT1(w0, c2); w0 = LR2_SHIFT_IN_LT1(w0, c1); w0 = LR2_SHIFT_IN_LT1(w0, c0);
+                    w1 = LR2_SHIFT_IN_LT1(w1, d3); w1 = LR2_SHIFT_IN_LT1(w1, d2); w1 = LR2_SHIFT_IN_LT1(w1, d1); w1 = LR2_SHIFT_IN_LT1(w1, d0);
+                }
+                m.it_mask[LR2_MUL24(it0, mw) + wi] = w0;
+                cnt0 += LR2_POPC32(w0);
+                if (second) {
+                    m.it_mask[LR2_MUL24(it0 + 1, mw) + wi] = w1;
+                    cnt1 += LR2_POPC32(w1);
+                }
+            }
+            finish_item(it0, la, t0, circ0 ? h0 : 0.0, Ri, o, cnt0, cmin0 <= -1.0, circ0);
+            if (second) finish_item(it0 + 1, la, t1, circ1 ? h1 : 0.0, Ri, o, cnt1, cmin1 <= -1.0, circ1);
+        }
+    } else
     for (int it = lane; it < items; it += LR2_LANES) {
         int la = (int)(((float)it + 0.5f) * inv_ns), s = it - LR2_MUL24(la, ns); /* it / ns without the integer-division sequence */
         if (s < 0) { --la; s += ns; } else if (s >= ns) { ++la; s -= ns; }
         const double Ri = m.atom[la].w, t = lr2_slice_height(s, m.adel[la], Ri);
         const double A = Ri * Ri - t * t; /* Ri'^2, ref: src/sasa_lr.c:309 */
-        double area = 0, h2_keep = 0;
-        int cnt = 0;
+        double h2 = 0;
+        int cnt = 0, o = 0;
+        bool buried = false;
         if (A > 0) { /* ref: :310-312 */
-            double h2;
             LR2_H2(A, h2); /* h2 = 1/(2 Ri') */
-            h2_keep = h2;
-            const int o = m.aoff[la], nn = m.aoff[la + 1] - o;
+            o = m.aoff[la];
+            const int nn = m.aoff[la + 1] - o;
             double cmin = 1.0;
             for (int wi = 0; wi < mwt; ++wi) {
                 unsigned w = 0;
@@ -889,42 +1077,15 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                 m.it_mask[LR2_MUL24(it, mw) + wi] = w;
                 cnt += LR2_POPC32(w);
             }
-            if (cmin <= -1.0) cnt = 0; /* circle i inside a neighbor's: buried (ref: :327-330) */
-            else if (cnt == 0) area = m.adel[la] * Ri * SASA_TWOPI; /* ref: :360 with exposed_arc_length(n = 0) */
-            if (cover) { /* (uniform) the arcs of the largest caps, in beta order: do they cover the circle? */
-                double cts = 0, cte = -INFINITY;
-                for (int wi = 0; wi < mwt; ++wi) {
-                    unsigned wc = cnt > 0 ? (m.it_mask[LR2_MUL24(it, mw) + wi] & m.cmask[LR2_MUL24(la, mw) + wi]) : 0u;
-                    const int R = o + 32 * wi;
-                    while (wc != 0) { /* (the wave runs as many trips as its busiest lane) */
-                        const int q = R + __builtin_ctz(wc);
-                        wc &= wc - 1;
-                        const Ab16 ab = m.ab[q];
-                        const double bt = m.beta[q];
-                        const double c = fma(t, ab.a, ab.b) * h2;
-                        const double al = lr2_acos_lower(c);
-                        const double inf = bt - al, sup = bt + al;
-                        const bool fresh = inf > cte;
-                        const double nts = fresh ? inf : SASA_MIN(cts, inf), nte = fresh ? sup : SASA_MAX(cte, sup);
-                        if (c <= 0.9) { cts = nts; cte = nte; }
-                    }
-                }
-                if (cte - cts >= SASA_TWOPI) cnt = 0; /* covered: area 0 */
-            }
+            buried = cmin <= -1.0;
         }
-        m.it_tc[it] = cnt == 0 ? area : h2_keep; /* (an item with arcs: 1/(2 Ri') for the arc pass, which puts the area in its place) */
-        unsigned short qt = 0xffff;
-        if (cnt > 0) { /* queue: heaviest first (bin 0 = 63 arcs or more); inside a bin in order of arrival */
-            const int bin = 63 - (cnt < 63 ? cnt : 63);
-            const int ord = SASA_ATOMIC_ADD_LDS(&m.hist[bin], 1);
-            qt = (unsigned short)((bin << 10) | ord); /* ord < items <= 512 */
-        }
-        m.qtmp[it] = qt;
+        finish_item(it, la, t, h2, Ri, o, cnt, buried, A > 0);
     }
     LR2_SYNC();
 
     LR2_STOP(4);
     LR2_MARK(4);
+    lr2_pre_a(a, pre, p0n, nan, lane); /* the next tile's sort records: on their way while this tile's arcs are done */
     /* ------------------------------------------------------------ P5 queue */
     int nq;
     {
@@ -965,7 +1126,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             my = e & 1023; la = e >> 10;
             const int o = m.aoff[la], nn = m.aoff[la + 1] - o;
             const double t = lr2_slice_height(my - LR2_MUL24(la, ns), m.adel[la], m.atom[la].w); /* as P4: bit for bit */
-            const double h2 = m.it_tc[my];
+            const double hh = m.it_tc[my];
             const int lo = LR2_MUL24(nn, j) >> shb, hi = LR2_MUL24(nn, j + 1) >> shb; /* list positions of this lane */
             for (int wi = 0; wi < mwt; ++wi) {
                 int a0 = lo - 32 * wi, a1 = hi - 32 * wi;
@@ -979,7 +1140,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                     w &= w - 1;
                     const Ab16 ab = m.ab[q];
                     const double bt = m.beta[q];
-                    const double alpha = acos_fast2(fma(t, ab.a, ab.b) * h2);
+                    const double alpha = lr2_arc_alpha(t, ab, hh);
                     lr2_union_step(bt - alpha, bt + alpha, u, stk, a.ds, maxd); /* ref: :338-339 */
                 }
             }
@@ -1006,28 +1167,29 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         int next = LR2_LANES;
         int my = LR2_NONE, la = 0, wleft = 0;
         unsigned w = 0;
-        int R = 0;                    /* record of bit 0 of the current mask word */
+        const Ab16 *Rab = m.ab;       /* record of bit 0 of the current mask word: its coefficients ... */
+        const double *Rbt = m.beta;   /* ... and its direction (two running addresses: one instruction each per arc, no index to add first) */
         const unsigned *mk = m.it_mask; /* current mask word */
-        double t = 0, h2 = 0;
+        double t = 0, hh = 0;
         Lr2Union u;
         lr2_union_reset(u);
 /* on to the item's next mask word with a bit set: mw - 1 straight steps (mw is 2 unless lists are long) */
 #define LR2_NEXT_WORD()                                                                            \
     for (int k_ = 1; k_ < mwt; ++k_)                                                               \
-        if (w == 0 && wleft > 0) { ++mk; R += 32; --wleft; w = *mk; }
+        if (w == 0 && wleft > 0) { ++mk; Rab += 32; Rbt += 32; --wleft; w = *mk; }
 #define LR2_FETCH(idx)                                                                             \
     do {                                                                                           \
         const int e_ = (idx) < nq ? (int)m.queue[(idx)] : LR2_NONE;                                \
         my = e_ == LR2_NONE ? LR2_NONE : (e_ & 1023); w = 0; wleft = 0;                            \
         if (my != LR2_NONE) {                                                                      \
             la = e_ >> 10;                                                                         \
-            R = m.aoff[la]; h2 = m.it_tc[my];                                                       \
+            { const int o_ = m.aoff[la]; Rab = m.ab + o_; Rbt = m.beta + o_; } hh = m.it_tc[my];     \
             t = lr2_slice_height(my - LR2_MUL24(la, ns), m.adel[la], m.atom[la].w); /* as P4: bit for bit */ \
             mk = m.it_mask + LR2_MUL24(my, mw); w = *mk; wleft = mwt - 1;                          \
             LR2_NEXT_WORD();                                                                       \
         }                                                                                          \
     } while (0)
-        LR2_FETCH(lane);
+        { int ln = lane; SASA_OPAQUE(ln); LR2_FETCH(ln); } /* (as in P4: not hoisted out of the tile loop) */
         for (;;) {
             /* a refill is due when `due` lanes wait: the launch's threshold while the queue has items, all 64 after */
             const int due = next < nq && a.refill < LR2_LANES ? a.refill : LR2_LANES;
@@ -1037,11 +1199,11 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                 if (LR2_LANES - LR2_POPC64(am) >= due) break;
                 LR2_COUNT(1, 1);
                 if (act) {
-                    const int q = R + __builtin_ctz(w);
+                    const int q = __builtin_ctz(w);
                     w &= w - 1;
-                    const Ab16 ab = m.ab[q];
-                    const double bt = m.beta[q];
-                    const double alpha = acos_fast2(fma(t, ab.a, ab.b) * h2); /* the screening's value, bit for bit */
+                    const Ab16 ab = Rab[q];
+                    const double bt = Rbt[q];
+                    const double alpha = lr2_arc_alpha(t, ab, hh);
                     lr2_union_step(bt - alpha, bt + alpha, u, stk, a.ds, maxd); /* ref: :338-339 */
                 }
             }
@@ -1063,12 +1225,20 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     }
     LR2_SYNC();
     LR2_MARK(6);
+    lr2_pre_b(a, pre, nan, lane); /* the next tile's candidate rows and its atoms: on their way while this tile's areas are summed */
+    lr2_pre_c(a, pre, nan, lane);
 
     /* ------------------------------------------------------------ P7 store */
     const bool deep = LR2_BALLOT(maxd - 2 > a.ds) != 0; /* an arc stack column was too short: the tile is redone */
     if (!deep && lane < na) {
         double s = 0;
-        for (int k = 0; k < ns; ++k) s += m.it_tc[LR2_MUL24(lane, ns) + k]; /* slice order, ref: :305-361 */
+        const double *const tc = m.it_tc + LR2_MUL24(lane, ns);
+        int k = 0;
+        for (; k + 4 <= ns; k += 4) { /* slice order, ref: :305-361; four reads in flight (one LDS round trip per four slices, not per slice) */
+            const double v0 = tc[k], v1 = tc[k + 1], v2 = tc[k + 2], v3 = tc[k + 3];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; k < ns; ++k) s += tc[k];
         if ((m.flags[6] >> lane) & 1) s = NAN; /* duplicate atom record (see P3) */
         LR2_COLD(a, sasa)[m.sorig[lane]] = s; /* (the pointer is read here, once per tile) */
     }
@@ -1081,14 +1251,17 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
 /* The work items of one wave (items first, first + stride, ... of the launch).  A tile that does not fit is redone
  * at once as two halves (1.5 % of the 6-atom tiles of random coils at a pool of 224 records); what still does not fit
  * goes to the next launch's list. */
-template <int RMAX, bool COVER>
+template <int RMAX, bool COVER, bool PAIRS>
 SASA_D void lr2_wave(const Lr2Args &a, const Lr2Mem &m, int first, int stride, int lane, int &wg_max_nn)
 {
     /* all tiles (main launch, rounded up to whole XCD groups) or the items of a work list */
     const int n_work = a.work_items ? *a.work_count : ((a.n_tiles + 7) >> 3) << 3;
     int splits = 0;
+    Lr2Pre pre;
+    lr2_pre_none(pre);
     for (int w = first; w < n_work; w += stride) {
         int p0, na, tile = 0;
+        int p0n = -1, nan = 0; /* what this wave does after this item (main launch), for P0's loads to run ahead */
         if (a.work_items) {
             const long long e = a.work_items[w];
             p0 = (int)(e & 0xffffffffLL); na = (int)(e >> 32);
@@ -1097,6 +1270,8 @@ SASA_D void lr2_wave(const Lr2Args &a, const Lr2Mem &m, int first, int stride, i
             if (tile >= a.n_tiles) continue; /* uniform per wave */
             p0 = tile * a.TA;
             na = a.n_atoms - p0 < a.TA ? a.n_atoms - p0 : a.TA;
+            const int tn = w + stride < n_work ? xcd_tile(w + stride, a.n_tiles) : a.n_tiles;
+            if (tn < a.n_tiles) { p0n = tn * a.TA; nan = a.n_atoms - p0n < a.TA ? a.n_atoms - p0n : a.TA; }
         }
         if (na <= 0) continue;
         /* one call site (the tile is ~9000 instructions): a tile that does not fit is redone as two halves, a
@@ -1104,7 +1279,10 @@ SASA_D void lr2_wave(const Lr2Args &a, const Lr2Mem &m, int first, int stride, i
         int rest0 = 0, rest_n = 0;
         bool whole = true, sample = !a.work_items && (tile & 31) == 0, by_place = false;
         for (;;) {
-            int fail = lr2_tile<RMAX, COVER>(a, m, p0, na, sample, by_place, lane, wg_max_nn);
+            /* (what comes next: the second half of a split tile, else the wave's next tile) */
+            const bool nxt = rest_n > 0 || nan > 0;
+            int fail = lr2_tile<RMAX, COVER, PAIRS>(a, m, p0, na, sample, by_place, lane, wg_max_nn, pre,
+                                             rest_n > 0 ? rest0 : (nxt ? p0n : p0), rest_n > 0 ? rest_n : (nxt ? nan : na));
             sample = false;
             if (fail == 2) { /* equal sort keys: once more, ties by place of discovery */
                 if (!by_place) { by_place = true; continue; }
@@ -1144,6 +1322,9 @@ struct Lr2Cfg {
 #define LR2_RMAX_MID 6
 
 static inline bool lr2_supported(int ns) { return ns >= 1 && ns <= LR2_NS_MAX; }
+/* tile shapes whose (atom, slice) items are more than the wave's lanes but at most two per lane (6 atoms x 20 slices:
+   120): the screening gives every lane two neighboring slices of one atom (P4) */
+static inline bool lr2_pairs_shape(int TA, int ns) { return TA * ns > LR2_LANES && TA * ((ns + 1) / 2) <= LR2_LANES; }
 
 /* nn_hint: neighbor records one atom needs (with its safety margin), 0 = unknown; nn_max_hint: the longest
  * neighbor list expected (0 = unknown): the masks of an item get ceil(nn_max / 32) words, two at least */
@@ -1187,7 +1368,7 @@ static inline Lr2Cfg lr2_choose_cfg(int ns, double nn_hint = 0, int ta_override 
     if (nn_hint > 0 && 1.45 * nn_hint > 64 && nn_max_hint > 64) c.mw = (nn_max_hint + 31) / 32;
     if (c.mw > 4) c.mw = 4;
     c.ds = 2;
-    c.refill = 32; /* (measured: 16 / 24 / 32 / 40 / 48 waiting lanes -> 4.11 / 4.09 / 4.09 / 4.09 / 4.10 ms per 3e6 coil atoms) */
+    c.refill = 16; /* (round 3, an item switch of ~100 instructions: flat from 16 to 48 waiting lanes; round 4, ~55: 19.3 / 19.5 / 20.0 / 20.6 / 21.1 / 22.6 arc iterations and 4.7 / 3.9 / 3.0 / 2.6 / 2.4 / 2.0 switches per tile at 4 / 8 / 16 / 24 / 32 / 48: least work at 12 - 24) */
     /* atoms per tile: as many as give at most ~320 items and run 16 tiles per CU with few enough split tiles */
     int ta_cap = 320 / ns;
     if (ta_cap < 1) ta_cap = 1;

@@ -50,6 +50,8 @@ inline int atomic_max(int *p, int v) { int o = *p; if (v > o) *p = v; return o; 
 #define SASA_RCP(x) (1.0 / (x))
 #define SASA_MIN(a, b) fmin((a), (b))
 #define SASA_MAX(a, b) fmax((a), (b))
+#define SASA_MIN_INTO(x, y) ((x) = fmin((x), (y)))
+#define SASA_MAX_INTO(x, y) ((x) = fmax((x), (y)))
 #define SASA_SHIFT_IN_LT1(w, c) (((w) << 1) | ((c) < 1.0 ? 1u : 0u))
 #define SASA_OPAQUE(v) ((void)0)
 #else
@@ -87,6 +89,9 @@ __device__ __forceinline__ double sasa_max(double a, double b)
 }
 #define SASA_MIN(a, b) sasa_min((a), (b))
 #define SASA_MAX(a, b) sasa_max((a), (b))
+/* x = min(x, y) / max(x, y) in x's own registers (a loop-carried value updated this way needs no copy at the loop's end) */
+#define SASA_MIN_INTO(x, y) asm("v_min_f64 %0, %0, %1" : "+v"(x) : "v"(y))
+#define SASA_MAX_INTO(x, y) asm("v_max_f64 %0, %0, %1" : "+v"(x) : "v"(y))
 /* (w << 1) | (c < 1.0): the compare leaves the per-lane result in vcc and an add-with-carry of w to
    itself shifts it in — two VALU instructions per screened neighbor instead of four */
 __device__ __forceinline__ unsigned sasa_shift_in_lt1(unsigned w, double c)
@@ -301,6 +306,10 @@ SASA_D void cellbase_phase2(const PipeArgs &a, const long long *part, int tid, i
  * divisions that would recover ix, iy, iz from the cell index) */
 enum { CELL_X0 = 1, CELL_X1 = 2, CELL_Y0 = 4, CELL_Y1 = 8, CELL_Z0 = 16, CELL_Z1 = 32 };
 SASA_D int cell_coord(double v, double v0, double d) { return (int)((v - v0) / d); } /* ref: src/nb.c:137-140 */
+/* nx and ny of the structure's grid, beside the six border flags in the high word of a sort record's cell (13 bits
+ * each; 0: a grid of 8192 cells or more along x or y, look them up in grid[]): the L&R tile kernel finds an atom's
+ * candidate rows from the record alone, one dependent load less at the start of every tile (lr2_pre_b) */
+SASA_HD unsigned cell_pack_grid(int nx, int ny) { return (nx < 8192 && ny < 8192) ? ((unsigned)nx << 6) | ((unsigned)ny << 19) : 0u; }
 
 /* K3: one thread per atom (original order): its cell, and its rank among the atoms of that cell.
  * Consecutive atoms of a chain mostly share a cell, so a RUN of equal cells inside the workgroup
@@ -321,7 +330,7 @@ SASA_D void count_phase0(const PipeArgs &a, int *cells, int i, int tid)
     const int c = g.cell_base + ix + g.nx * (iy + g.ny * iz); /* ref: src/nb.c:74-83 */
     const int fl = (ix == 0 ? CELL_X0 : 0) | (ix == g.nx - 1 ? CELL_X1 : 0) | (iy == 0 ? CELL_Y0 : 0) |
                    (iy == g.ny - 1 ? CELL_Y1 : 0) | (iz == 0 ? CELL_Z0 : 0) | (iz == g.nz - 1 ? CELL_Z1 : 0);
-    a.cell_of[i] = (long long)c | ((long long)fl << 32);
+    a.cell_of[i] = (long long)((unsigned long long)(unsigned)c | ((unsigned long long)((unsigned)fl | cell_pack_grid(g.nx, g.ny)) << 32));
     cells[tid] = c;
 }
 SASA_D void count_phase1(const PipeArgs &a, const int *cells, int *base, int tid, int B)
@@ -820,9 +829,9 @@ SASA_D double acos_fast(double x)
 #ifndef ACOS2_DEG
 #define ACOS2_DEG 12 /* 6.3e-13: with LR2_FAST_H2 the areas stay within ~1e-11 A^2 of the reference (measured: DESIGN.md; contract: 1e-4) */
 #endif
-SASA_D double acos_fast2(double x)
+/* z = (1 - |x|)/2 in (0, 0.5] and any number with the sign of x */
+SASA_D double acos_fast2_z(double z, double x)
 {
-    const double z = fma(fabs(x), -0.5, 0.5); /* (1 - |x|)/2, exact up to the rounding of the fma; in (0, 0.5] */
 #if ACOS2_DEG == 14
     double p = 0x1.5983ba6d23362p-2;
     p = SASA_FMA_K(p, z, -0x1.cda34edad75c6p-1);
@@ -879,7 +888,7 @@ SASA_D double acos_fast2(double x)
     p = SASA_FMA_K(p, z, 0x1.6db6d52f65e8fp-5);
     p = SASA_FMA_K(p, z, 0x1.33333339625fap-4);
     p = SASA_FMA_K(p, z, 0x1.5555555554529p-3);
-#else
+#elif defined(ACOS2_HORNER)
     double p = 0x1.c70b84f2604a4p-3;
     p = SASA_FMA_K(p, z, -0x1.eb330d405c37dp-2);
     p = SASA_FMA_K(p, z, 0x1.084859012fcc8p-1);
@@ -893,11 +902,35 @@ SASA_D double acos_fast2(double x)
     p = SASA_FMA_K(p, z, 0x1.6db6f971a2415p-5);
     p = SASA_FMA_K(p, z, 0x1.33333310a8a5ep-4);
     p = SASA_FMA_K(p, z, 0x1.555555555be1fp-3);
+#else
+    /* the same degree-12 polynomial, even and odd powers apart: two chains of six and five fma that run side by side
+       where Horner's rule is one chain of twelve (a dependent fp64 instruction waits two issue slots for its operand,
+       profiles/r03_ubench.txt: the arc pass is as much a matter of a wave's own critical path as of instruction count
+       once fewer than all four waves of a SIMD are in it); one multiplication and one fma more */
+    const double w = z * z;
+    double pe = 0x1.c70b84f2604a4p-3, po = -0x1.eb330d405c37dp-2;
+    pe = SASA_FMA_K(pe, w, 0x1.084859012fcc8p-1);  po = SASA_FMA_K(po, w, -0x1.3a4ea43eb48adp-2);
+    pe = SASA_FMA_K(pe, w, 0x1.1661c4e1fecccp-3);  po = SASA_FMA_K(po, w, -0x1.6b69eecac872ep-6);
+    pe = SASA_FMA_K(pe, w, 0x1.482102e85b292p-6);  po = SASA_FMA_K(po, w, 0x1.1080015ff5fd3p-6);
+    pe = SASA_FMA_K(pe, w, 0x1.6f7002236e00bp-6);  po = SASA_FMA_K(po, w, 0x1.f1bcecaaa9600p-6);
+    pe = SASA_FMA_K(pe, w, 0x1.6db6f971a2415p-5);  po = SASA_FMA_K(po, w, 0x1.33333310a8a5ep-4);
+    pe = SASA_FMA_K(pe, w, 0x1.555555555be1fp-3);
+    const double p = fma(po, z, pe);
 #endif
-    const double u = sqrt_g(z);
+    /* asin u = u (1 + z P(z)) with u = sqrt z from the seed's coupled Goldschmidt step (sqrt_g): u = g (1 + e), so
+       asin u - pi/4 = g ((1 + e) q) - pi/4, q = 1 + z P: seven instructions behind the polynomial where forming u and
+       u z first took eight (round 4; the two differ by a rounding or two of 1e-16) */
+    const double q = fma(z, p, 1.0);
+    const double y = SASA_RSQ(z);
+    const double g = z * y, h = 0.5 * y;
+    const double e = fma(-h, g, 0.5);
     const double pio4 = 0x1.921fb54442d18p-1, pio2 = 0x1.921fb54442d18p+0;
-    const double t = fma(u * z, p, u - pio4); /* asin(u) - pi/4 (absolute error 1e-16: of no account for an angle) */
+    const double t = SASA_FMA_K(g, fma(e, q, q), -pio4); /* asin(u) - pi/4 (absolute error 1e-16: of no account for an angle) */
     return SASA_FMA_K(copysign(2.0, x), t, pio2); /* x >= 0: 2 asin u;  x < 0: pi - 2 asin u */
+}
+SASA_D double acos_fast2(double x)
+{
+    return acos_fast2_z(fma(fabs(x), -0.5, 0.5), x); /* (1 - |x|)/2, exact up to the rounding of the fma */
 }
 
 /* atan2(y, x) for finite arguments: ONE division (hardware reciprocal seed + two Newton steps + a

@@ -147,8 +147,10 @@ struct Lr2Run { const Lr2Args *a; Lr2Mem *m; int first, stride; int rmax; int *w
 static void lr2_lane_body(int lane, void *ctx)
 {
     Lr2Run *r = (Lr2Run *)ctx;
-    if (r->rmax == LR2_RMAX_MAIN) lr2_wave<LR2_RMAX_MAIN, true>(*r->a, *r->m, r->first, r->stride, lane, r->wg_max[lane]);
-    else lr2_wave<LR2_RMAX_MID, true>(*r->a, *r->m, r->first, r->stride, lane, r->wg_max[lane]);
+    const bool pairs = r->rmax == LR2_RMAX_MAIN && lr2_pairs_shape(r->a->TA, r->a->ns); /* (as launch_lr2_main) */
+    if (r->rmax == LR2_RMAX_MAIN && pairs) lr2_wave<LR2_RMAX_MAIN, true, true>(*r->a, *r->m, r->first, r->stride, lane, r->wg_max[lane]);
+    else if (r->rmax == LR2_RMAX_MAIN) lr2_wave<LR2_RMAX_MAIN, true, false>(*r->a, *r->m, r->first, r->stride, lane, r->wg_max[lane]);
+    else lr2_wave<LR2_RMAX_MID, true, false>(*r->a, *r->m, r->first, r->stride, lane, r->wg_max[lane]);
 }
 static void emu_lr2_kernel(const Lr2Cfg &cfg, Lr2Args a, int grid)
 {

@@ -2,5 +2,4 @@
 mkdir -p gpurun_out
 export PYTHONUNBUFFERED=1
 L=freesasa_amd/lib
-(bash tools/gpu_ablate.sh "0,0,-1,0" $L/libvar_base_stop2.so $L/libvar_s32_stop2.so $L/libvar_base_stop3.so $L/libvar_s32_stop3.so $L/libvar_base_stop4.so $L/libvar_s32_stop4.so) 2>&1 | grep "==\|lr2_tile<4" | sed "s/vgpr[^)]*) //" > gpurun_out/s3_pmc.log 2>&1
-cat gpurun_out/s3_pmc.log
+REPS=5 bash tools/gpu_ab.sh $L/libvar_pre4.so $L/libvar_pre6.so $L/libvar_pre6sel.so $L/libvar_pre6selh.so $L/libvar_pre6h.so 2>&1 | tee gpurun_out/s14_ab.log
