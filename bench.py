@@ -294,6 +294,7 @@ def main():
                          "ONE 200k-atom globule per GPU, Shrake-Rupley 100 points (secondary line).  sweep_lr: configs[3] proxy, "
                          "structures of log-uniform size 500..50 000 atoms dealt to the ranks by LPT on atom count")
     ap.add_argument("--points", type=int, default=100)
+    ap.add_argument("--sync-entry", action="store_true", help="time freesasa_gpu_lr_batch_dev (one synchronous call per step) instead of the asynchronous batch entry")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-neighbors", action="store_true", help="skip the neighbor count (one launch of the kernel's neighbor phase): the counter passes of tools/gpu_round.sh want the tile kernel's own launches only")
@@ -378,13 +379,26 @@ def main():
 
     d_cnt = torch.empty(n_atoms, dtype=torch.int32, device=dev) if sr else None
 
+    # Lee-Richards steps go through the asynchronous batch entry (freesasa_gpu_lr_batch_dev_async): a step is enqueued
+    # while the one before it runs, up to two in flight, and everything is collected (ctx.wait) inside the timed region.
+    # Same kernels, bit-identical outputs (checked below against one synchronous step); --sync-entry times the
+    # synchronous entry instead.
+    use_async = not sr and not dry and not args.sync_entry
+
     def step():
         if sr:
             ctx.shrake_rupley(d_xyz.data_ptr(), d_r.data_ptr(), offs, d_sasa.data_ptr(), d_cnt.data_ptr(),
                               d_tot.data_ptr(), probe=1.4, n_points=args.points)
+        elif use_async:
+            ctx.lee_richards_async(d_xyz.data_ptr(), d_r.data_ptr(), offs, d_sasa.data_ptr(), d_tot.data_ptr(),
+                                   probe=1.4, n_slices=args.slices)
         else:
             ctx.lee_richards(d_xyz.data_ptr(), d_r.data_ptr(), offs, d_sasa.data_ptr(), d_tot.data_ptr(),
                              probe=1.4, n_slices=args.slices)
+
+    def drain():
+        if use_async:
+            ctx.wait()
 
     def barrier():
         sync()
@@ -394,16 +408,22 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     barrier()
     k_ms, prep_ms = [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        st = ctx.stats()
+        st = ctx.stats()                    # (asynchronous entry: of the step collected last, two calls back)
         k_ms.append(st["ms_kernel"])
         prep_ms.append(st["ms_prep"])
+    drain()
     barrier()
     elapsed = time.perf_counter() - t0
+    if use_async:
+        st = ctx.stats()
+        k_ms = k_ms[2:] + [st["ms_kernel"]] if len(k_ms) > 2 else [st["ms_kernel"]]
+        prep_ms = prep_ms[2:] + [st["ms_prep"]] if len(prep_ms) > 2 else [st["ms_prep"]]
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -445,6 +465,8 @@ def main():
                        "structures_per_gpu": args.structs, "atoms_per_structure": args.atoms,
                        "n_slices": args.slices, "probe_radius": 1.4,
                        "parallelism": f"{world} x independent structure shards (no collective)",
+                       "entry": ("freesasa_gpu_lr_batch_dev_async: steps enqueued back to back, at most two in flight, all collected inside the timed region"
+                                 if use_async else "synchronous batch entry, one call per step"),
                        "max_neighbors_per_atom": st["max_neighbors"], "fallback_tiles": st["fallback_tiles"],
                        "tile_atoms": st["tile_atoms"], "block_threads": st["block_threads"],
                        "lds_bytes_per_block": st["lds_bytes"], "cells": st["n_cells"]},
@@ -473,6 +495,16 @@ def main():
             return
         if not sr and not args.no_neighbors:
             out["config"]["avg_neighbors_per_atom"] = neighbors_per_atom(fa, torch, d_xyz, d_r, offs, dev, local_rank)
+        if use_async and world == 1:
+            # the synchronous entry on the same context: the same bits, and its rate for comparison
+            got_async = d_sasa.clone()
+            ts = time.perf_counter()
+            for _ in range(max(3, args.steps // 4)):
+                ctx.lee_richards(d_xyz.data_ptr(), d_r.data_ptr(), offs, d_sasa.data_ptr(), d_tot.data_ptr(), probe=1.4, n_slices=args.slices)
+            torch.cuda.synchronize()
+            dts = (time.perf_counter() - ts) / max(3, args.steps // 4)
+            out["synchronous_entry"] = {"value": n_atoms / dts, "unit": "atoms/s", "ms_per_step": 1e3 * dts,
+                                        "identical_outputs": bool(torch.equal(got_async, d_sasa))}
         if world == 1 and args.workload == "coil_lr" and not args.no_secondary and (args.structs, args.atoms, args.slices) == (1000, 10000, 20):
             out.update(secondary_workloads(fa, torch, tools, d_xyz, d_r, offs, xyz, r, dev, local_rank, check=not args.no_cpu_baseline))
         if world == 1 and args.workload == "coil_lr" and not args.no_end_to_end:

@@ -108,6 +108,8 @@ def lib():
         L.freesasa_gpu_ctx_last_error.restype = C.c_char_p
         L.freesasa_gpu_lr_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, _lp, C.c_int,
                                                 C.c_double, C.c_int, C.c_void_p, C.c_void_p]
+        L.freesasa_gpu_lr_batch_dev_async.argtypes = L.freesasa_gpu_lr_batch_dev.argtypes
+        L.freesasa_gpu_wait.argtypes = [C.c_void_p]
         L.freesasa_gpu_sr_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, _lp, C.c_int,
                                                 C.c_double, C.c_int, _dp, C.c_void_p, C.c_void_p,
                                                 C.c_void_p]
@@ -350,6 +352,17 @@ class GpuContext:
                                               d_totals or None)
         if ret:
             raise RuntimeError("freesasa_gpu_lr_batch_dev: " + self.error())
+
+    def lee_richards_async(self, d_xyz, d_radii, offsets, d_sasa, d_totals=0, probe=1.4, n_slices=20):
+        """Enqueue the batch and return (freesasa_gpu_lr_batch_dev_async): up to two in flight; wait() collects them."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        if lib().freesasa_gpu_lr_batch_dev_async(self._h, d_xyz, d_radii, offsets.ctypes.data_as(_lp),
+                                                 offsets.size - 1, probe, n_slices, d_sasa, d_totals or None):
+            raise RuntimeError("freesasa_gpu_lr_batch_dev_async: " + self.error())
+
+    def wait(self):
+        if lib().freesasa_gpu_wait(self._h):
+            raise RuntimeError("freesasa_gpu_wait: " + self.error())
 
     def lr_neighbors(self, d_xyz, d_radii, offsets, d_nn, d_nb=0, nb_cap=0, probe=1.4):
         """Test hook: the neighbor sets the L&R kernel finds (counts, optionally the first nb_cap neighbors per atom)."""

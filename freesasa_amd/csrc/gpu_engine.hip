@@ -514,15 +514,15 @@ __global__ __launch_bounds__(B) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) v
  * allocation is capped for. */
 /* NOTE: Lr2Args must stay the ONLY parameter of this kernel, at offset 0 of the kernel-argument segment: the tile
  * body reads its rarely used fields from there (LR2_COLD in lr2_kernels.h). */
-template <int RMAX, int TIER, int WPE, bool COVER, bool PAIRS = false>
+template <int RMAX, int TIER, int WPE, bool COVER, bool PAIRS = false, int SHAPE = 0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lr2_tile(Lr2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     PIPE_GATE(a.status);
-    Lr2Mem m = lr2_carve(a, smem);
+    Lr2Mem m = lr2_carve<SHAPE>(a, smem);
     int wg_max_nn = 0;
-    lr2_wave<RMAX, COVER, PAIRS>(a, m, blockIdx.x, gridDim.x, lane, wg_max_nn);
+    lr2_wave<RMAX, COVER, PAIRS, SHAPE>(a, m, blockIdx.x, gridDim.x, lane, wg_max_nn);
     if (lane == 0 && wg_max_nn > a.status[ST_MAX_NN]) atomicMax(&a.status[ST_MAX_NN], wg_max_nn);
 }
 __global__ __launch_bounds__(64) void k_lr2_arc_kat(const double *arcs, const int *first, int n_sets, double *out)
@@ -540,6 +540,7 @@ static hipError_t launch_lr2_main(int rmax, int grid, size_t lds, hipStream_t st
 #define LR2_LAUNCH(R) do { \
         if (lr2_pairs_shape(la.TA, la.ns)) { \
             if (la.cover > 0) hipLaunchKernelGGL((k_lr2_tile<R, 0, 4, true, true>), dim3(grid), dim3(64), lds, st, la); \
+            else if (lr2_default_shape(la.TA, la.ns, la.mw, la.ds) && !getenv("FREESASA_AMD_NO_SHAPE")) hipLaunchKernelGGL((k_lr2_tile<R, 0, 4, false, true, 1>), dim3(grid), dim3(64), lds, st, la); \
             else hipLaunchKernelGGL((k_lr2_tile<R, 0, 4, false, true>), dim3(grid), dim3(64), lds, st, la); \
         } else if (la.cover > 0) hipLaunchKernelGGL((k_lr2_tile<R, 0, 4, true>), dim3(grid), dim3(64), lds, st, la); \
         else hipLaunchKernelGGL((k_lr2_tile<R, 0, 4, false>), dim3(grid), dim3(64), lds, st, la); } while (0)
@@ -595,7 +596,25 @@ struct freesasa_gpu_ctx {
     bool shared_radii = false; /* d_radii holds ONE structure's radii (trajectory frames) */
     char err[512] = {0};
     freesasa_gpu_stats stats = {};
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    /* Two sets of what the HOST reads of a batch (page-locked status words, stage events, end-of-batch event): a batch
+       submitted with freesasa_gpu_lr_batch_dev_async leaves its set behind until it is collected, while the next one
+       is enqueued with the other set.  The device side needs no second copy: the copies into a set are enqueued at
+       the end of their batch, in stream order before the next batch resets the device words. */
+    int slot = 0;
+    hipEvent_t evs[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    struct Pend {
+        bool active = false;
+        /* the call, for the rare batch that has to be redone (cell table sizing, see RC_RETRY) */
+        const double *d_xyz = nullptr, *d_radii = nullptr;
+        std::vector<int64_t> offsets;
+        int n_structs = 0, resolution = 0;
+        double probe = 0;
+        double *d_sasa = nullptr, *d_totals = nullptr;
+        /* what completing it needs */
+        int n = 0, TA = 0, mw = 0, ds = 0, lds = 0;
+    } pend[2];
+    int pend_err = 0; /* a batch collected on the way (to make room, before a reallocation) failed: reported by the next wait */
     /* workspace */
     DevBuf offsets, grid, ncells, sid, cell_of, rank, cell_start, blk_sums;
     DevBuf chunk_struct, chunk_begin, chunk_len, struct_chunk0, bpart;
@@ -608,7 +627,7 @@ struct freesasa_gpu_ctx {
     DevBuf h_xyz, h_radii, h_sasa, h_counts, h_totals;
     void *stage_in = nullptr, *stage_out = nullptr; /* page-locked host staging of freesasa_gpu_calc_batch_pipelined */
     size_t stage_in_cap = 0, stage_out_cap = 0;
-    int *pinned = nullptr; /* page-locked host words for the small device->host readbacks */
+    int *pinned = nullptr; /* page-locked host words for the small device->host readbacks: two sets of ST_WORDS + 4 */
     long long max_cells = 1LL << 30;
     long long cells_hint = 0; /* cells the last batch needed, with a margin: the table is never sized below it */
     /* adaptive neighbor-pool size, per algorithm: (resolution, TA) it was learnt for and the value */
@@ -640,6 +659,10 @@ static int ctx_fail(freesasa_gpu_ctx *c, const char *fmt, ...)
             return ctx_fail((c), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+static inline int *ctx_status_h(freesasa_gpu_ctx *c) { return c->pinned + c->slot * (ST_WORDS + 4); }
+static inline hipEvent_t *ctx_ev(freesasa_gpu_ctx *c) { return c->evs[c->slot]; }
+static int drain_pending(freesasa_gpu_ctx *c);
+
 /* Test hook (include/freesasa_gpu.h, freesasa_gpu_test_fail_after): the n-th device / page-locked allocation from
  * now on fails, like the reference's interposed malloc (tests/tools.c:10-48) makes its n-th malloc fail. */
 static std::atomic<int> g_fail_after(0);
@@ -666,6 +689,7 @@ static hipError_t host_malloc(void **p, size_t bytes)
 static int ensure(freesasa_gpu_ctx *c, DevBuf &b, size_t bytes)
 {
     if (bytes <= b.cap) return 0;
+    if (drain_pending(c)) c->pend_err = 1; /* (batches in flight may be using the buffer about to be freed) */
     if (b.p) HIP_TRY(c, hipFree(b.p));
     b.p = nullptr;
     b.cap = 0;
@@ -700,12 +724,18 @@ extern "C" freesasa_gpu_ctx *freesasa_gpu_ctx_create(int device, void *stream)
         }
         c->own_stream = true;
     }
-    for (int k = 0; k < 4; ++k)
-        if (hipEventCreate(&c->ev[k]) != hipSuccess) {
+    for (int s_ = 0; s_ < 2; ++s_) {
+        for (int k = 0; k < 4; ++k)
+            if (hipEventCreate(&c->evs[s_][k]) != hipSuccess) {
+                freesasa_gpu_ctx_destroy(c);
+                return nullptr;
+            }
+        if (hipEventCreateWithFlags(&c->done[s_], hipEventDisableTiming) != hipSuccess) {
             freesasa_gpu_ctx_destroy(c);
             return nullptr;
         }
-    if (host_malloc((void **)&c->pinned, sizeof(int) * (ST_WORDS + 4)) != hipSuccess) {
+    }
+    if (host_malloc((void **)&c->pinned, sizeof(int) * 2 * (ST_WORDS + 4)) != hipSuccess) {
         freesasa_gpu_ctx_destroy(c);
         return nullptr;
     }
@@ -723,8 +753,11 @@ extern "C" void freesasa_gpu_ctx_destroy(freesasa_gpu_ctx *c)
                      &c->h_xyz, &c->h_radii, &c->h_sasa, &c->h_counts, &c->h_totals};
     for (DevBuf *b : all)
         if (b->p) (void)hipFree(b->p);
-    for (int k = 0; k < 4; ++k)
-        if (c->ev[k]) (void)hipEventDestroy(c->ev[k]);
+    for (int s_ = 0; s_ < 2; ++s_) {
+        for (int k = 0; k < 4; ++k)
+            if (c->evs[s_][k]) (void)hipEventDestroy(c->evs[s_][k]);
+        if (c->done[s_]) (void)hipEventDestroy(c->done[s_]);
+    }
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->stage_in) (void)hipHostFree(c->stage_in);
     if (c->stage_out) (void)hipHostFree(c->stage_out);
@@ -804,16 +837,24 @@ static void dump_phase_clocks()
 /* run_batch_once's third outcome: the cell table was too small, redo the batch (c->cells_hint has the size) */
 #define RC_RETRY 2
 
+static int judge_status(freesasa_gpu_ctx *c, const int *status_h, long long *total_cells);
 /* Status words [0, words) and K2's cell total, read back behind everything enqueued so far.  Returns 0, RC_RETRY,
  * or -1 with the batch's error text set. */
 static int collect_status(freesasa_gpu_ctx *c, int n_structs, int words, long long *total_cells)
 {
     hipStream_t st = c->stream;
-    int *status_h = c->pinned;
-    long long *total_p = (long long *)(c->pinned + ST_WORDS + 2);
+    int *status_h = ctx_status_h(c);
+    long long *total_p = (long long *)(status_h + ST_WORDS + 2);
     HIP_TRY(c, hipMemcpyAsync(total_p, (long long *)c->ncells.p + n_structs, sizeof(long long), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(status_h, c->status.p, sizeof(int) * (size_t)words, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
+    return judge_status(c, status_h, total_cells);
+}
+
+/* the verdict of a batch's status words (already in host memory) */
+static int judge_status(freesasa_gpu_ctx *c, const int *status_h, long long *total_cells)
+{
+    const long long *total_p = (const long long *)(status_h + ST_WORDS + 2);
     *total_cells = *total_p;
     if (status_h[ST_ERROR]) return ctx_fail(c, "%s", err_text(status_h[ST_ERROR]));
     if (*total_p <= 0 || *total_p > c->max_cells) return ctx_fail(c, "%s", err_text(ERR_GRID_TOO_BIG));
@@ -827,8 +868,9 @@ static int collect_status(freesasa_gpu_ctx *c, int n_structs, int words, long lo
     return 0;
 }
 
-static int finish_batch(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs, double *d_sasa,
-                        double *d_totals, int tile_atoms, int block_threads, int lds, int *status_h)
+/* The tail of a batch on the stream: per-structure totals, then the status words and the cell total into the
+ * current set of page-locked host words, then the set's end-of-batch event.  Nothing is waited for. */
+static int enqueue_tail(freesasa_gpu_ctx *c, const PipeArgs &pa, int n_structs, double *d_sasa, double *d_totals)
 {
     hipStream_t st = c->stream;
     if (d_totals) {
@@ -837,9 +879,21 @@ static int finish_batch(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_st
         hipLaunchKernelGGL(k_totals_structs, dim3((n_structs + 255) / 256), dim3(256), 0, st, pa, (const double *)c->bpart.p, d_totals);
         HIP_TRY(c, hipGetLastError());
     }
-    if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[3], st));
+    if (c->timing) HIP_TRY(c, hipEventRecord(ctx_ev(c)[3], st));
+    int *status_h = ctx_status_h(c);
+    HIP_TRY(c, hipMemcpyAsync(status_h + ST_WORDS + 2, (long long *)c->ncells.p + n_structs, sizeof(long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(status_h, c->status.p, sizeof(int) * (size_t)ST_WORDS, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipEventRecord(c->done[c->slot], st));
+    return 0;
+}
+
+/* Wait for the batch whose tail went into the current set, and read its verdict and statistics there. */
+static int complete_batch(freesasa_gpu_ctx *c, int n, int n_structs, int tile_atoms, int block_threads, int lds)
+{
+    HIP_TRY(c, hipEventSynchronize(c->done[c->slot]));
+    const int *status_h = ctx_status_h(c);
     long long total_cells = 0;
-    const int rcs = collect_status(c, n_structs, ST_WORDS, &total_cells);
+    const int rcs = judge_status(c, status_h, &total_cells);
     freesasa_gpu_stats &S = c->stats;
     S.n_atoms = n; S.n_cells = total_cells; S.n_structs = n_structs;
     S.max_neighbors = status_h[ST_MAX_NN]; S.fallback_tiles = status_h[ST_OVF_TILES];
@@ -848,9 +902,9 @@ static int finish_batch(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_st
     S.ms_prep = S.ms_kernel = S.ms_total = 0;
     if (c->timing) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) S.ms_prep = ms;
-        if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) S.ms_kernel = ms;
-        if (hipEventElapsedTime(&ms, c->ev[0], c->ev[3]) == hipSuccess) S.ms_total = ms;
+        if (hipEventElapsedTime(&ms, ctx_ev(c)[0], ctx_ev(c)[1]) == hipSuccess) S.ms_prep = ms;
+        if (hipEventElapsedTime(&ms, ctx_ev(c)[1], ctx_ev(c)[2]) == hipSuccess) S.ms_kernel = ms;
+        if (hipEventElapsedTime(&ms, ctx_ev(c)[0], ctx_ev(c)[3]) == hipSuccess) S.ms_total = ms;
     }
     if (rcs) return rcs;
     if (total_cells + total_cells / 32 > c->cells_hint) c->cells_hint = total_cells + total_cells / 32;
@@ -858,11 +912,29 @@ static int finish_batch(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_st
     return 0;
 }
 
+static int finish_batch(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs, double *d_sasa,
+                        double *d_totals, int tile_atoms, int block_threads, int lds, int *)
+{
+    if (enqueue_tail(c, pa, n_structs, d_sasa, d_totals)) return -1;
+    return complete_batch(c, n, n_structs, tile_atoms, block_threads, lds);
+}
+
+/* what a completed Lee-Richards batch teaches the context about the next one of its kind (trajectory frames, sweeps) */
+static void lr2_learn(freesasa_gpu_ctx *c, const int *status_h, int TA, int ns, int mw, int ds)
+{
+    const int learnt = lr2_need_from_hist(status_h + ST_HIST, TA);
+    if (learnt > 0) c->hint_nn = (double)(learnt - 8) / TA;
+    c->hint_pool2 = lr2_pool_from_hist(status_h + ST_HIST, TA, ns, mw, ds, &c->hint_split2); /* (see there: pool vs occupancy) */
+    c->hint_ta2 = TA; c->hint_mw2 = mw;
+    c->hint_nn_max = status_h[ST_MAX_NN] + 4; /* the longest list of this batch, a little room */
+}
+
+/* defer: enqueue only (freesasa_gpu_lr_batch_dev_async); the caller completes the batch later (complete_pending) */
 static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs, int resolution, double *d_sasa,
-                   double *d_totals)
+                   double *d_totals, bool defer)
 {
     hipStream_t st = c->stream;
-    int *status_h = c->pinned;
+    int *status_h = ctx_status_h(c);
     int ta_env = 0, pool_env = 0, ds_env = -1, refill_env = 0;
     if (const char *e = getenv("FREESASA_AMD_LR2")) (void)sscanf(e, "%d,%d,%d,%d", &ta_env, &pool_env, &ds_env, &refill_env); /* tuning aid: "TA,pool,ds,refill" */
     if (c->hint_res[0] != resolution) {
@@ -916,7 +988,7 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
     la.hooks = (c->dbg_nn ? 1 : 0) | (c->dbg_nb ? 2 : 0);
     hipError_t le = launch_lr2_main(cfg.rmax, grid_main, (size_t)cfg.lds, st, la);
     if (le != hipSuccess) return ctx_fail(c, "tile kernel launch failed: %s", hipGetErrorString(le));
-    if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[2], st));
+    if (c->timing) HIP_TRY(c, hipEventRecord(ctx_ev(c)[2], st));
     if (c->dbg_nn) return finish_batch(c, pa, n, n_structs, d_sasa, nullptr, cfg.TA, 64, cfg.lds, status_h);
     /* second launch: halves that did not fit either: larger LDS lists, more registers */
     const Lr2Cfg cm = lr2_mid_cfg(cfg);
@@ -956,14 +1028,13 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
         le = launch_lr<true, 2>(fb, tf, SASA_FB_BLOCKS, fb.lds, st);
         if (le != hipSuccess) return ctx_fail(c, "fallback kernel launch failed: %s", hipGetErrorString(le));
     }
-    const int rc = finish_batch(c, pa, n, n_structs, d_sasa, d_totals, cfg.TA, 64, cfg.lds, status_h);
+    if (enqueue_tail(c, pa, n_structs, d_sasa, d_totals)) return -1;
+    freesasa_gpu_ctx::Pend &P = c->pend[c->slot];
+    P.n = n; P.TA = cfg.TA; P.mw = cfg.mw; P.ds = cfg.ds; P.lds = cfg.lds; P.n_structs = n_structs; P.resolution = resolution;
+    if (defer) return 0;
+    const int rc = complete_batch(c, n, n_structs, cfg.TA, 64, cfg.lds);
     if (rc) return rc;
-    /* learn the pool size for the next batch of this kind (trajectory frames, sweeps) */
-    const int learnt = lr2_need_from_hist(status_h + ST_HIST, cfg.TA);
-    if (learnt > 0) c->hint_nn = (double)(learnt - 8) / cfg.TA;
-    c->hint_pool2 = lr2_pool_from_hist(status_h + ST_HIST, cfg.TA, cfg.ns, cfg.mw, cfg.ds, &c->hint_split2); /* (see there: pool vs occupancy) */
-    c->hint_ta2 = cfg.TA; c->hint_mw2 = cfg.mw;
-    c->hint_nn_max = status_h[ST_MAX_NN] + 4; /* the longest list of this batch, a little room */
+    lr2_learn(c, status_h, cfg.TA, cfg.ns, cfg.mw, cfg.ds);
     return 0;
 }
 
@@ -971,9 +1042,10 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
 
 static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, const double *d_radii,
                      const int64_t *offsets, int n_structs, double probe, int resolution,
-                     const double *unit_points, double *d_sasa, int *d_counts, double *d_totals)
+                     const double *unit_points, double *d_sasa, int *d_counts, double *d_totals, bool defer = false, bool *deferred = nullptr)
 {
     c->err[0] = 0;
+    if (deferred) *deferred = false;
     if (!d_xyz || !d_radii || !offsets || !d_sasa) return ctx_fail(c, "null argument");
     if (n_structs <= 0) return ctx_fail(c, "n_structs must be > 0");
     if (resolution <= 0) return ctx_fail(c, "resolution must be > 0");
@@ -1001,6 +1073,7 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
        (trajectory frames and repeated batches reuse them) */
     if ((int)c->offsets_host.size() != n_structs + 1 ||
         memcmp(c->offsets_host.data(), offsets, sizeof(int64_t) * ((size_t)n_structs + 1)) != 0) {
+        if (drain_pending(c)) c->pend_err = 1; /* (batches in flight read the tables about to be overwritten) */
         c->offsets_host.clear(); /* (set again below, once the tables derived from it are on the device) */
         std::vector<int> cs, cl, sc0((size_t)n_structs + 1);
         std::vector<int64_t> cb;
@@ -1025,7 +1098,7 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
         c->offsets_host.assign(offsets, offsets + n_structs + 1);
     }
     HIP_TRY(c, hipMemsetAsync(c->status.p, 0, sizeof(int) * ST_WORDS, st));
-    if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[0], st));
+    if (c->timing) HIP_TRY(c, hipEventRecord(ctx_ev(c)[0], st));
 
     PipeArgs pa;
     memset(&pa, 0, sizeof pa);
@@ -1050,7 +1123,7 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
        first batch 10 cells per atom (sparse random coils need 9, proteins 1-2) plus 256 per structure.  K2 checks
        the real total against it on the device (ST_RETRY, see PIPE_GATE); the total itself reaches the host with
        the status words at the end of the batch. */
-    int *status_h = c->pinned;
+    int *status_h = ctx_status_h(c);
     long long cells_cap = 10LL * n + 256LL * n_structs; /* (0.4 GB for 1e7 atoms; a sparser batch is redone once with K2's size) */
     if (cells_cap < c->cells_hint) cells_cap = c->cells_hint;
     if (cells_cap > c->max_cells) cells_cap = c->max_cells;
@@ -1081,11 +1154,14 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
     hipLaunchKernelGGL(k_scatter, dim3(nblk_atoms), dim3(SASA_PIPE_B), 0, st, pa);
     }
     HIP_TRY(c, hipGetLastError());
-    if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[1], st));
+    if (c->timing) HIP_TRY(c, hipEventRecord(ctx_ev(c)[1], st));
 
     /* Lee & Richards at ordinary resolutions: the second-generation kernel (lr2_kernels.h) */
-    if (lr && lr2_supported(resolution) && !getenv("FREESASA_AMD_LR1"))
-        return run_lr2(c, pa, n, n_structs, resolution, d_sasa, d_totals);
+    if (lr && lr2_supported(resolution) && !getenv("FREESASA_AMD_LR1")) {
+        const int rc2 = run_lr2(c, pa, n, n_structs, resolution, d_sasa, d_totals, defer && !c->dbg_nn);
+        if (rc2 == 0 && defer && !c->dbg_nn && deferred) *deferred = true;
+        return rc2;
+    }
 
     /* fused tile kernel */
     const int hi = lr ? 0 : 1;
@@ -1184,7 +1260,7 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
     const bool bucket = lr && c->hint_bucket && c->hint_res[0] == resolution;
     le = lr ? launch_lr<false, 0>(cfg, ta, grid_main, cfg.lds, st, bucket) : launch_sr<false, 0>(cfg, ta, grid_main, cfg.lds, st);
     if (le != hipSuccess) return ctx_fail(c, "tile kernel launch failed: %s", hipGetErrorString(le));
-    if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[2], st));
+    if (c->timing) HIP_TRY(c, hipEventRecord(ctx_ev(c)[2], st));
 
     /* second launch: the tiles whose lists did not fit the small LDS capacities (the blocks read
        the count on the device; normally a fraction of a percent of the tiles) */
@@ -1223,7 +1299,7 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
         hipLaunchKernelGGL(k_totals_structs, dim3((n_structs + 255) / 256), dim3(256), 0, st, pa, (const double *)c->bpart.p, d_totals);
         HIP_TRY(c, hipGetLastError());
     }
-    if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[3], st));
+    if (c->timing) HIP_TRY(c, hipEventRecord(ctx_ev(c)[3], st));
 
     long long total_cells = 0;
     const int rcs = collect_status(c, n_structs, ST_WORDS, &total_cells);
@@ -1235,9 +1311,9 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
     S.ms_prep = S.ms_kernel = S.ms_total = 0;
     if (c->timing) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) S.ms_prep = ms;
-        if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) S.ms_kernel = ms;
-        if (hipEventElapsedTime(&ms, c->ev[0], c->ev[3]) == hipSuccess) S.ms_total = ms;
+        if (hipEventElapsedTime(&ms, ctx_ev(c)[0], ctx_ev(c)[1]) == hipSuccess) S.ms_prep = ms;
+        if (hipEventElapsedTime(&ms, ctx_ev(c)[1], ctx_ev(c)[2]) == hipSuccess) S.ms_kernel = ms;
+        if (hipEventElapsedTime(&ms, ctx_ev(c)[0], ctx_ev(c)[3]) == hipSuccess) S.ms_total = ms;
     }
     if (rcs) return rcs;
     if (total_cells + total_cells / 32 > c->cells_hint) c->cells_hint = total_cells + total_cells / 32;
@@ -1275,11 +1351,83 @@ static int run_batch(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, const do
     return rc;
 }
 
+/* ------------------------------------------------------------------ asynchronous batches
+ * freesasa_gpu_lr_batch_dev_async enqueues a batch and returns; up to two may be in flight on a context.  Each leaves
+ * its host-side set (status words, events) behind; complete_pending waits for its end-of-batch event and reads the
+ * verdict there.  The rare batch whose cell table was too small (RC_RETRY) is redone synchronously, with everything
+ * else on the stream drained first. */
+static int complete_pending(freesasa_gpu_ctx *c, int slot)
+{
+    freesasa_gpu_ctx::Pend &P = c->pend[slot];
+    if (!P.active) return 0;
+    const int keep = c->slot;
+    c->slot = slot;
+    int rc = complete_batch(c, P.n, P.n_structs, P.TA, 64, P.lds);
+    if (rc == 0) lr2_learn(c, ctx_status_h(c), P.TA, P.resolution, P.mw, P.ds);
+    c->slot = keep;
+    P.active = false;
+    if (rc == RC_RETRY) {
+        /* redo it the synchronous way (which sizes the table from this pass's count); the other batch in flight, if
+           any, ran into the same table and is redone when it is collected */
+        (void)hipStreamSynchronize(c->stream);
+        std::vector<int64_t> offs;
+        offs.swap(P.offsets);
+        rc = run_batch(c, true, P.d_xyz, P.d_radii, offs.data(), P.n_structs, P.probe, P.resolution, nullptr, P.d_sasa, nullptr, P.d_totals);
+    }
+    return rc;
+}
+/* collect every batch in flight, oldest first; -1 if any failed (the context's error text is the last failure's) */
+static int drain_pending(freesasa_gpu_ctx *c)
+{
+    int rc = 0;
+    for (int k = 0; k < 2; ++k) {
+        const int slot = (c->slot + k) & 1; /* c->slot is the set the next batch takes: the older one of two in flight */
+        if (c->pend[slot].active && complete_pending(c, slot)) rc = -1;
+    }
+    return rc;
+}
+
+extern "C" int freesasa_gpu_wait(freesasa_gpu_ctx *c)
+{
+    if (!c) return -1;
+    if (hipSetDevice(c->device) != hipSuccess) return ctx_fail(c, "hipSetDevice failed");
+    int rc = drain_pending(c);
+    if (c->pend_err) { rc = -1; c->pend_err = 0; }
+    return rc;
+}
+
+extern "C" int freesasa_gpu_lr_batch_dev_async(freesasa_gpu_ctx *c, const double *d_xyz, const double *d_radii,
+                                               const int64_t *offsets, int n_structs, double probe, int n_slices,
+                                               double *d_sasa, double *d_totals)
+{
+    if (!c) return -1;
+    if (hipSetDevice(c->device) != hipSuccess) return ctx_fail(c, "hipSetDevice failed");
+    /* the set this batch takes may still belong to the batch submitted two calls ago: collect that one first */
+    if (c->pend[c->slot].active && complete_pending(c, c->slot)) return -1;
+    if (c->pend_err) { c->pend_err = 0; return -1; } /* (an older batch failed while making room: its error text stands) */
+    bool deferred = false;
+    int rc = run_batch_once(c, true, d_xyz, d_radii, offsets, n_structs, probe, n_slices, nullptr, d_sasa, nullptr, d_totals, true, &deferred);
+    if (rc == RC_RETRY || (rc == 0 && !deferred)) {
+        /* a first batch of its kind (its density is read back before the tile kernel is shaped) that has to be
+           redone, or a path without a deferred tail: finish it the synchronous way */
+        if (rc == RC_RETRY) rc = run_batch(c, true, d_xyz, d_radii, offsets, n_structs, probe, n_slices, nullptr, d_sasa, nullptr, d_totals);
+        return rc;
+    }
+    if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
+    freesasa_gpu_ctx::Pend &P = c->pend[c->slot];
+    P.active = true;
+    P.d_xyz = d_xyz; P.d_radii = d_radii; P.offsets.assign(offsets, offsets + n_structs + 1);
+    P.probe = probe; P.d_sasa = d_sasa; P.d_totals = d_totals;
+    c->slot ^= 1;
+    return 0;
+}
+
 extern "C" int freesasa_gpu_lr_batch_dev(freesasa_gpu_ctx *c, const double *d_xyz, const double *d_radii,
                                          const int64_t *offsets, int n_structs, double probe, int n_slices,
                                          double *d_sasa, double *d_totals)
 {
     if (!c) return -1;
+    if (freesasa_gpu_wait(c)) return -1; /* (batches submitted asynchronously come first) */
     return run_batch(c, true, d_xyz, d_radii, offsets, n_structs, probe, n_slices, nullptr, d_sasa, nullptr, d_totals);
 }
 
@@ -1288,6 +1436,7 @@ extern "C" int freesasa_gpu_sr_batch_dev(freesasa_gpu_ctx *c, const double *d_xy
                                          const double *unit_points, double *d_sasa, int *d_counts, double *d_totals)
 {
     if (!c) return -1;
+    if (freesasa_gpu_wait(c)) return -1;
     return run_batch(c, false, d_xyz, d_radii, offsets, n_structs, probe, n_points, unit_points, d_sasa, d_counts, d_totals);
 }
 

@@ -190,6 +190,19 @@ SASA_D int lr2_div3(int v) { return LR2_MUL24(v, 43) >> 7; }  /* v / 3 for 0 <= 
 #define LR2_H2(x, h) do { double g_; sqrt_rh((x), g_, (h)); } while (0)
 #endif
 #define LR2_LANES 64
+/* The tile shape of the library's default parameters on sparse input - 6 atoms x 20 slices, two mask words, two
+   spilled stack levels (what lr2_choose_cfg gives coils and most proteins at 20 slices) - has a build of its own in
+   which these four are compile-time constants (template parameter SHAPE = 1): LDS addresses become immediates, the
+   index arithmetic folds, and the kernel spills 44 scalar registers instead of 104 (round 4: wave instructions -4 %,
+   kernel -1 %).  SHAPE = 0 reads them from the arguments. */
+#define LR2_SHAPE_TA 6
+#define LR2_SHAPE_NS 20
+#define LR2_SHAPE_MW 2
+#define LR2_SHAPE_DS 2
+#define LR2_A_TA(a) (SHAPE ? LR2_SHAPE_TA : (a).TA)
+#define LR2_A_NS(a) (SHAPE ? LR2_SHAPE_NS : (a).ns)
+#define LR2_A_MW(a) (SHAPE ? LR2_SHAPE_MW : (a).mw)
+#define LR2_A_DS(a) (SHAPE ? LR2_SHAPE_DS : (a).ds)
 #define LR2_NONE 0xffff
 
 struct Lr2Args {
@@ -304,10 +317,11 @@ struct Lr2Mem {
 };
 /* flags: 0 tile overflow, 1 stack overflow, 2 max neighbor count, 6 atoms with a coincident neighbor of equal radius (bits) */
 
+template <int SHAPE = 0>
 SASA_D Lr2Mem lr2_carve(const Lr2Args &a, char *smem)
 {
-    const Lr2Layout L = lr2_layout(a.TA, a.ns, a.pool, a.mw, a.ds);
-    const int TA = a.TA;
+    const Lr2Layout L = lr2_layout(LR2_A_TA(a), LR2_A_NS(a), a.pool, LR2_A_MW(a), LR2_A_DS(a));
+    const int TA = LR2_A_TA(a);
     Lr2Mem m;
     m.atom = (Quad *)(smem + L.o_atoms); m.adel = (double *)(smem + L.o_atoms + 32 * TA);
     int *q = (int *)(smem + L.o_ints);
@@ -635,11 +649,18 @@ SASA_D void lr2_pre_c(const Lr2Args &a, Lr2Pre &pre, int na, int lane)
    neighbors of an atom with equal sort keys (nothing stored; see lr2_tie12): once more with tie_by_place */
 /* pre: what P0 loads, possibly fetched ahead by the previous call; (p0n, nan): the tile this wave does next (its
    own again when there is none), fetched ahead by this call */
-template <int RMAX, bool COVER, bool PAIRS>
-SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool sample, bool tie_by_place, int lane, int &wg_max_nn,
+template <int RMAX, bool COVER, bool PAIRS, int SHAPE>
+SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool sample, bool tie_by_place, int lane_of_wave, int &wg_max_nn,
                     Lr2Pre &pre, int p0n, int nan)
 {
-    const int TA = a.TA, ns = a.ns, mw = a.mw;
+    /* Whatever depends on the lane and the launch alone (row and atom of the lane, its LDS addresses, its item) the
+       compiler computes once per wave, outside the tile loop, and holds in registers through every phase of every
+       tile.  The sparse kernel has the room (126 of 128 registers, nothing in scratch) and is 1.7 % faster for it;
+       the builds with the cover filter do not (8 registers in scratch): there the lane number is made something the
+       compiler cannot see through, and those values are computed where they are used (117-119 registers). */
+    int lane = lane_of_wave;
+    if (COVER) SASA_OPAQUE(lane);
+    const int TA = LR2_A_TA(a), ns = LR2_A_NS(a), mw = LR2_A_MW(a);
     const int items = na * ns;
     LR2_MARK_BEGIN;
     LR2_COUNT(0, 1);
@@ -1141,7 +1162,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                     const Ab16 ab = m.ab[q];
                     const double bt = m.beta[q];
                     const double alpha = lr2_arc_alpha(t, ab, hh);
-                    lr2_union_step(bt - alpha, bt + alpha, u, stk, a.ds, maxd); /* ref: :338-339 */
+                    lr2_union_step(bt - alpha, bt + alpha, u, stk, LR2_A_DS(a), maxd); /* ref: :338-339 */
                 }
             }
         }
@@ -1154,14 +1175,14 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             if (valid && (j & (2 * st - 1)) == 0) {
                 const Arc2 *col = m.stack + src;
                 for (int c = 0; c < d_s - 2; ++c) { /* (rare: the components below the two in registers) */
-                    const Arc2 k = col[(c < a.ds ? c : 0) * LR2_LANES];
-                    lr2_union_step(k.s, k.e, u, stk, a.ds, maxd);
+                    const Arc2 k = col[(c < LR2_A_DS(a) ? c : 0) * LR2_LANES];
+                    lr2_union_step(k.s, k.e, u, stk, LR2_A_DS(a), maxd);
                 }
-                if (d_s >= 2) lr2_union_step(bs_s, be_s, u, stk, a.ds, maxd);
-                if (d_s >= 1) lr2_union_step(ts_s, te_s, u, stk, a.ds, maxd);
+                if (d_s >= 2) lr2_union_step(bs_s, be_s, u, stk, LR2_A_DS(a), maxd);
+                if (d_s >= 1) lr2_union_step(ts_s, te_s, u, stk, LR2_A_DS(a), maxd);
             }
         }
-        if (valid && j == 0) m.it_tc[my] = m.adel[la] * m.atom[la].w * lr2_sweep(u, stk, a.ds); /* ref: :360 */
+        if (valid && j == 0) m.it_tc[my] = m.adel[la] * m.atom[la].w * lr2_sweep(u, stk, LR2_A_DS(a)); /* ref: :360 */
     } else {
         Arc2 *stk = m.stack + lane;
         int next = LR2_LANES;
@@ -1204,7 +1225,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                     const Ab16 ab = Rab[q];
                     const double bt = Rbt[q];
                     const double alpha = lr2_arc_alpha(t, ab, hh);
-                    lr2_union_step(bt - alpha, bt + alpha, u, stk, a.ds, maxd); /* ref: :338-339 */
+                    lr2_union_step(bt - alpha, bt + alpha, u, stk, LR2_A_DS(a), maxd); /* ref: :338-339 */
                 }
             }
             /* refill: a lane that has used up its mask word moves on to the item's next word or, when the item
@@ -1213,7 +1234,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             const unsigned long long im = LR2_BALLOT(w == 0); /* finished (or without an item) */
             LR2_COUNT(2, 1);
             if (w == 0) {
-                if (my != LR2_NONE) m.it_tc[my] = m.adel[la] * m.atom[la].w * lr2_sweep(u, stk, a.ds); /* ref: :360 */
+                if (my != LR2_NONE) m.it_tc[my] = m.adel[la] * m.atom[la].w * lr2_sweep(u, stk, LR2_A_DS(a)); /* ref: :360 */
                 lr2_union_reset(u);
                 LR2_FETCH(next + LR2_RANK(im, lane));
             }
@@ -1229,7 +1250,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     lr2_pre_c(a, pre, nan, lane);
 
     /* ------------------------------------------------------------ P7 store */
-    const bool deep = LR2_BALLOT(maxd - 2 > a.ds) != 0; /* an arc stack column was too short: the tile is redone */
+    const bool deep = LR2_BALLOT(maxd - 2 > LR2_A_DS(a)) != 0; /* an arc stack column was too short: the tile is redone */
     if (!deep && lane < na) {
         double s = 0;
         const double *const tc = m.it_tc + LR2_MUL24(lane, ns);
@@ -1251,7 +1272,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
 /* The work items of one wave (items first, first + stride, ... of the launch).  A tile that does not fit is redone
  * at once as two halves (1.5 % of the 6-atom tiles of random coils at a pool of 224 records); what still does not fit
  * goes to the next launch's list. */
-template <int RMAX, bool COVER, bool PAIRS>
+template <int RMAX, bool COVER, bool PAIRS, int SHAPE = 0>
 SASA_D void lr2_wave(const Lr2Args &a, const Lr2Mem &m, int first, int stride, int lane, int &wg_max_nn)
 {
     /* all tiles (main launch, rounded up to whole XCD groups) or the items of a work list */
@@ -1268,10 +1289,10 @@ SASA_D void lr2_wave(const Lr2Args &a, const Lr2Mem &m, int first, int stride, i
         } else {
             tile = xcd_tile(w, a.n_tiles);
             if (tile >= a.n_tiles) continue; /* uniform per wave */
-            p0 = tile * a.TA;
-            na = a.n_atoms - p0 < a.TA ? a.n_atoms - p0 : a.TA;
+            p0 = tile * LR2_A_TA(a);
+            na = a.n_atoms - p0 < LR2_A_TA(a) ? a.n_atoms - p0 : LR2_A_TA(a);
             const int tn = w + stride < n_work ? xcd_tile(w + stride, a.n_tiles) : a.n_tiles;
-            if (tn < a.n_tiles) { p0n = tn * a.TA; nan = a.n_atoms - p0n < a.TA ? a.n_atoms - p0n : a.TA; }
+            if (tn < a.n_tiles) { p0n = tn * LR2_A_TA(a); nan = a.n_atoms - p0n < LR2_A_TA(a) ? a.n_atoms - p0n : LR2_A_TA(a); }
         }
         if (na <= 0) continue;
         /* one call site (the tile is ~9000 instructions): a tile that does not fit is redone as two halves, a
@@ -1281,7 +1302,7 @@ SASA_D void lr2_wave(const Lr2Args &a, const Lr2Mem &m, int first, int stride, i
         for (;;) {
             /* (what comes next: the second half of a split tile, else the wave's next tile) */
             const bool nxt = rest_n > 0 || nan > 0;
-            int fail = lr2_tile<RMAX, COVER, PAIRS>(a, m, p0, na, sample, by_place, lane, wg_max_nn, pre,
+            int fail = lr2_tile<RMAX, COVER, PAIRS, SHAPE>(a, m, p0, na, sample, by_place, lane, wg_max_nn, pre,
                                              rest_n > 0 ? rest0 : (nxt ? p0n : p0), rest_n > 0 ? rest_n : (nxt ? nan : na));
             sample = false;
             if (fail == 2) { /* equal sort keys: once more, ties by place of discovery */
@@ -1325,6 +1346,7 @@ static inline bool lr2_supported(int ns) { return ns >= 1 && ns <= LR2_NS_MAX; }
 /* tile shapes whose (atom, slice) items are more than the wave's lanes but at most two per lane (6 atoms x 20 slices:
    120): the screening gives every lane two neighboring slices of one atom (P4) */
 static inline bool lr2_pairs_shape(int TA, int ns) { return TA * ns > LR2_LANES && TA * ((ns + 1) / 2) <= LR2_LANES; }
+static inline bool lr2_default_shape(int TA, int ns, int mw, int ds) { return TA == LR2_SHAPE_TA && ns == LR2_SHAPE_NS && mw == LR2_SHAPE_MW && ds == LR2_SHAPE_DS; }
 
 /* nn_hint: neighbor records one atom needs (with its safety margin), 0 = unknown; nn_max_hint: the longest
  * neighbor list expected (0 = unknown): the masks of an item get ceil(nn_max / 32) words, two at least */

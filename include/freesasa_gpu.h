@@ -59,6 +59,19 @@ const char *freesasa_gpu_ctx_last_error(const freesasa_gpu_ctx *ctx);
 int freesasa_gpu_lr_batch_dev(freesasa_gpu_ctx *ctx, const double *d_xyz, const double *d_radii,
                               const int64_t *offsets, int n_structs, double probe_radius,
                               int n_slices, double *d_sasa, double *d_totals);
+/* The same batch, enqueued only: the call returns as soon as the batch is on the context's stream, so that the host
+   side of the next batch (argument checks, launches; and on the device its cell sort) follows the tile kernel of
+   this one without a gap.  Up to two batches may be in flight on a context; a third call first collects the oldest.
+   The inputs of a batch and its offsets' VALUES must stay valid, and its outputs are complete, only after
+   freesasa_gpu_wait (or the call that collects it) has returned 0; a failed batch is reported there, with the
+   context's error text.  A batch whose cell table turns out too small (a first, very sparse batch) is redone by the
+   collecting call, synchronously.  Results are bit-identical to freesasa_gpu_lr_batch_dev's.  Every synchronous
+   entry point of the context collects what is in flight first.  Returns 0 (enqueued) / -1. */
+int freesasa_gpu_lr_batch_dev_async(freesasa_gpu_ctx *ctx, const double *d_xyz, const double *d_radii,
+                                    const int64_t *offsets, int n_structs, double probe_radius,
+                                    int n_slices, double *d_sasa, double *d_totals);
+/* Collect every batch in flight on the context.  Returns 0, or -1 if one of them failed. */
+int freesasa_gpu_wait(freesasa_gpu_ctx *ctx);
 /* unit_points: HOST array [3*n_points] of unit test points (generate with
    freesasa_gpu_test_points for bit-exact parity with the reference).  d_counts [n_atoms]
    exposed points per atom (may be NULL). */

@@ -156,7 +156,7 @@ static void emu_lr2_kernel(const Lr2Cfg &cfg, Lr2Args a, int grid)
 {
     std::vector<char> smem(cfg.lds + 64);
     for (int blk = 0; blk < grid; ++blk) {
-        Lr2Mem m = lr2_carve(a, smem.data());
+        Lr2Mem m = lr2_carve<0>(a, smem.data());
         std::vector<int> wg_max(64, 0);
         Lr2Run run = {&a, &m, blk, grid, cfg.rmax, wg_max.data()};
         sasa_emu::run_wave(lr2_lane_body, &run);

@@ -286,6 +286,64 @@ def test_lr_results_do_not_depend_on_the_tile_shape(fa, monkeypatch):
         assert np.array_equal(got, ref), (spec, cover, float(np.max(np.abs(got - ref))))
 
 
+def test_asynchronous_batches_match_the_synchronous_ones(fa, oracle_lib):
+    """freesasa_gpu_lr_batch_dev_async: batches enqueued back to back (two in flight, a third call collects the oldest),
+    different inputs and output buffers per batch, offsets that change between batches (the tables of the batches in
+    flight are not overwritten under them), a first, very sparse batch whose cell table is too small (redone by the call
+    that collects it), a failing batch in the middle (reported by wait, the context usable afterwards): every result
+    equals the synchronous entry's bit for bit."""
+    import torch
+    dev = torch.device("cuda:0")
+    def batch(parts):
+        xyz = np.concatenate([p[0] for p in parts]); r = np.concatenate([p[1] for p in parts])
+        offs = np.concatenate([[0], np.cumsum([len(p[1]) for p in parts])]).astype(np.int64)
+        return (torch.from_numpy(np.ascontiguousarray(xyz)).to(dev), torch.from_numpy(np.ascontiguousarray(r)).to(dev), offs,
+                torch.empty(len(r), dtype=torch.float64, device=dev), torch.empty(len(parts), dtype=torch.float64, device=dev), xyz, r)
+    # a sparse first batch: diagonal rods, ~30 x the cells the first table has room for
+    rods = []
+    for k in range(12):
+        d = np.linspace(0.0, 900.0, 300)[:, None] * np.ones((1, 3)) + np.random.default_rng(k).uniform(-0.3, 0.3, (300, 3))
+        rods.append((d, np.full(300, 1.8)))
+    batches = [batch(rods),
+               batch([tools.coil(3000, 900 + k) for k in range(8)]),
+               batch([tools.coil(3000, 900 + k) for k in range(8)]),            # same offsets as the one before
+               batch([tools.globule(2500, 40 + k) for k in range(9)]),          # other offsets, dense
+               batch([tools.coil(1200, 950 + k) for k in range(10)] + [tools.coil(40, 3)])]
+    ref = []
+    ctx = fa.GpuContext(0)
+    for dx, dr, offs, out, tot, *_ in batches:
+        ctx.lee_richards(dx.data_ptr(), dr.data_ptr(), offs, out.data_ptr(), tot.data_ptr(), probe=1.4, n_slices=20)
+        ref.append((out.cpu().numpy().copy(), tot.cpu().numpy().copy()))
+        out.zero_(); tot.zero_()
+    ctx.close()
+    ctx = fa.GpuContext(0)                       # a fresh context: the first batch meets the small first table again
+    for rep in range(2):
+        for dx, dr, offs, out, tot, *_ in batches:
+            ctx.lee_richards_async(dx.data_ptr(), dr.data_ptr(), offs, out.data_ptr(), tot.data_ptr(), probe=1.4, n_slices=20)
+        ctx.wait()
+        for (out_ref, tot_ref), (_, _, _, out, tot, *_) in zip(ref, batches):
+            assert np.array_equal(out.cpu().numpy(), out_ref) and np.array_equal(tot.cpu().numpy(), tot_ref)
+            out.zero_(); tot.zero_()
+    # against the checker, one structure
+    dx, dr, offs, out, tot, xyz, r = batches[1]
+    ctx.lee_richards_async(dx.data_ptr(), dr.data_ptr(), offs, out.data_ptr(), tot.data_ptr(), probe=1.4, n_slices=20)
+    ctx.wait()
+    sl = slice(offs[2], offs[3])
+    assert np.max(np.abs(out.cpu().numpy()[sl] - oracle_lib.lee_richards(xyz[sl], r[sl], 1.4, 20))) < LR_TOL
+    # a failing batch between two good ones: a non-finite coordinate
+    bad = batches[1][0].clone(); bad[7] = float("nan")
+    good = batches[4]
+    ctx.lee_richards_async(good[0].data_ptr(), good[1].data_ptr(), good[2], good[3].data_ptr(), good[4].data_ptr(), probe=1.4, n_slices=20)
+    ctx.lee_richards_async(bad.data_ptr(), dr.data_ptr(), offs, out.data_ptr(), tot.data_ptr(), probe=1.4, n_slices=20)
+    with pytest.raises(RuntimeError):
+        ctx.lee_richards_async(good[0].data_ptr(), good[1].data_ptr(), good[2], good[3].data_ptr(), good[4].data_ptr(), probe=1.4, n_slices=20)
+        ctx.wait()
+    ctx.wait()                                    # nothing left in flight, the failure was reported once
+    ctx.lee_richards(good[0].data_ptr(), good[1].data_ptr(), good[2], good[3].data_ptr(), good[4].data_ptr(), probe=1.4, n_slices=20)
+    assert np.array_equal(good[3].cpu().numpy(), ref[4][0])
+    ctx.close()
+
+
 def test_cell_sort_in_one_kernel_equals_the_general_pipeline(fa, oracle_lib, monkeypatch):
     """k_sort_struct (batches of structures up to 16 384 atoms: one workgroup sorts a structure in LDS) against the
     general pipeline (zero, count, scan, scatter) and the oracle: ordinary structures, an empty one, a single atom, and
