@@ -206,6 +206,36 @@ def secondary_workloads(fa, torch, tools, d_xyz, d_r, offs, xyz, r, dev, local_r
     ctx.close()
     out["globule_lr20"] = res
     del dgx, dgr, dgo
+    # real proteins: the reference's own test entries, ProtOr radii through the batched reader, replicated to >= 3e6 atoms
+    try:
+        from freesasa_amd import ingest
+        pdb_dir = os.path.join(ROOT, "tests", "golden", "pdb")
+        names = ["1a0q", "3gnn", "5dx9", "2jo4", "3bkr", "1d3z", "1ubq"]
+        b = ingest.load_pdb_files([os.path.join(pdb_dir, nm + ".pdb") for nm in names])
+        per = [int(b.offsets[k + 1] - b.offsets[k]) for k in range(b.n_structs)]
+        reps = max(1, -(-3_000_000 // int(b.n_atoms)))
+        px = np.ascontiguousarray(np.tile(b.xyz.reshape(-1), reps)); pr = np.ascontiguousarray(np.tile(b.radii, reps))
+        poffs = np.concatenate([[0], np.cumsum(np.tile(per, reps))]).astype(np.int64)
+        dpx, dpr = torch.from_numpy(px).to(dev), torch.from_numpy(pr).to(dev)
+        dpo = torch.empty(len(pr), dtype=torch.float64, device=dev)
+        ctx = fa.GpuContext(local_rank, timing=True)
+        res = run(ctx, lambda: ctx.lee_richards(dpx.data_ptr(), dpr.data_ptr(), poffs, dpo.data_ptr(), 0, probe=1.4, n_slices=20), len(pr), 10, 3)
+        st = ctx.stats()
+        res.update({"workload": f"{reps} x the PDB entries {', '.join(names)} of the reference's test data ({', '.join(str(v) for v in per)} atoms after its "
+                                f"default filters; ProtOr radii, include/freesasa_ingest.h), {len(poffs) - 1} structures, {len(pr)} atoms, Lee-Richards 20 slices: "
+                                "the offline stand-in for BASELINE configs[1] / [3] that is not a lattice",
+                    "tile_atoms": st["tile_atoms"], "max_neighbors_per_atom": st["max_neighbors"],
+                    "avg_neighbors_per_atom": neighbors_per_atom(fa, torch, dpx, dpr, poffs, dev, local_rank)})
+        if check:
+            k = names.index("1a0q")
+            sl = slice(int(poffs[k]), int(poffs[k + 1]))
+            res["max_abs_dsasa"] = checker_error("lr", px.reshape(-1, 3)[sl].reshape(-1), pr[sl], dpo[sl].cpu().numpy(), 20)
+            res["checked_entry"] = "1a0q"
+        ctx.close()
+        out["real_pdb_lr20"] = res
+        del dpx, dpr, dpo
+    except Exception as exc:        # (a secondary line must not take the headline down)
+        out["real_pdb_lr20"] = {"error": repr(exc)}
     # configs[1] proxy
     nb = 200_000
     bx, br = tools.globule(nb, 77)
@@ -226,6 +256,55 @@ def secondary_workloads(fa, torch, tools, d_xyz, d_r, offs, xyz, r, dev, local_r
     return out
 
 
+def live_counters(args, timeout_s=120):
+    """HBM bytes and wave-level VALU instructions per launch of the dominant kernel, measured NOW: one extra run of this
+    script (one timed step, synchronous entry, nothing secondary) under rocprofv3 per counter - FETCH_SIZE, WRITE_SIZE
+    and SQ_INSTS_VALU in separate --pmc passes, as MI355X_MICROARCH.md prescribes - when rocprofv3 is on PATH.  Values
+    of one dispatch are summed over its XCD instances; the main launch of the tile kernel is the k_lr2_tile /
+    k_sr_tile instantiation with the most VALU instructions.  Returns (traffic_bytes, valu_per_launch, note) or None."""
+    import csv
+    import collections
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe or args.no_live_counters or os.environ.get("FREESASA_AMD_BENCH_CHILD"):
+        return None
+    per = {}
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+            for counter in ("SQ_INSTS_VALU", "FETCH_SIZE", "WRITE_SIZE"):
+                cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", os.path.join(tmp, counter), "-o", "c", "--",
+                       sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--structs", str(args.structs), "--atoms", str(args.atoms),
+                       "--slices", str(args.slices), "--workload", args.workload, "--points", str(args.points), "--sync-entry",
+                       "--no-cpu-baseline", "--no-end-to-end", "--no-secondary", "--no-neighbors", "--no-live-counters"]
+                env = dict(os.environ, FREESASA_AMD_BENCH_CHILD="1", TMPDIR="/tmp")
+                res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd="/tmp", env=env)
+                if res.returncode != 0:
+                    return None
+                total, launches = collections.defaultdict(float), collections.defaultdict(set)
+                for root, _, files in os.walk(os.path.join(tmp, counter)):
+                    for f in files:
+                        if f.endswith("counter_collection.csv"):
+                            for r in csv.DictReader(open(os.path.join(root, f))):
+                                if r["Counter_Name"] == counter:
+                                    total[r["Kernel_Name"]] += float(r["Counter_Value"])
+                                    launches[r["Kernel_Name"]].add(r["Dispatch_Id"])
+                per[counter] = {k: v / len(launches[k]) for k, v in total.items()}
+    except (OSError, subprocess.SubprocessError, KeyError, ValueError):
+        return None
+    tiles = {k: v for k, v in per.get("SQ_INSTS_VALU", {}).items() if "k_lr2_tile<" in k or "k_sr_tile<" in k or "k_lr_tile<" in k}
+    if not tiles:
+        return None
+    main = max(tiles, key=tiles.get)
+    if main not in per.get("FETCH_SIZE", {}) or main not in per.get("WRITE_SIZE", {}):
+        return None
+    # both counters are in KB; on gfx950 FETCH_SIZE reports 0.500 x the bytes moved and WRITE_SIZE 1.000 x (copy kernels of known
+    # size, profiles/r0N_fetch_calibration.txt: re-checked every round by tools/gpu_round.sh)
+    traffic = (2.0 * per["FETCH_SIZE"][main] + per["WRITE_SIZE"][main]) * 1024.0
+    return traffic, tiles[main], f"live: rocprofv3 --pmc passes of this run ({main.split('(')[0]})"
+
+
 def profiled_traffic(args):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
     collected in separate --pmc runs of this same command, KB, summed over the XCD instances of a dispatch), corrected
@@ -235,10 +314,12 @@ def profiled_traffic(args):
     (profiles/README.md, "FETCH_SIZE calibration").  Only valid for the default workload."""
     if (args.structs, args.atoms, args.slices) != (1000, 10000, 20):
         return None, None
-    best = None
-    for name in sorted(os.listdir(os.path.join(ROOT, "profiles"))) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
-        if name.endswith("_hbm_counters.json"):
-            best = name
+    import re
+    best, best_round = None, -1
+    for name in os.listdir(os.path.join(ROOT, "profiles")) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
+        m = re.match(r"r(\d+)_hbm_counters\.json$", name)
+        if m and int(m.group(1)) > best_round:                 # (by round NUMBER: r10 comes after r9)
+            best, best_round = name, int(m.group(1))
     if not best:
         return None, None
     with open(os.path.join(ROOT, "profiles", best)) as fh:
@@ -295,6 +376,7 @@ def main():
                          "structures of log-uniform size 500..50 000 atoms dealt to the ranks by LPT on atom count")
     ap.add_argument("--points", type=int, default=100)
     ap.add_argument("--sync-entry", action="store_true", help="time freesasa_gpu_lr_batch_dev (one synchronous call per step) instead of the asynchronous batch entry")
+    ap.add_argument("--no-live-counters", action="store_true", help="do not re-run under rocprofv3 for roofline.traffic / valu_issue (the committed profile is quoted instead)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-neighbors", action="store_true", help="skip the neighbor count (one launch of the kernel's neighbor phase): the counter passes of tools/gpu_round.sh want the tile kernel's own launches only")
@@ -439,7 +521,11 @@ def main():
         value = total_atoms / elapsed
         kern_s = float(np.mean(k_ms)) * 1e-3
         achieved = ALGO_BYTES_PER_ATOM * n_atoms / kern_s / 1e9 if kern_s > 0 else None
-        traffic, traffic_src = profiled_traffic(args)
+        traffic, traffic_src = profiled_traffic(args)          # the committed profile of the last round ...
+        live = live_counters(args) if (world == 1 and not dry) else None
+        if live:                                               # ... unless the counters can be read now
+            global PROFILED_VALU
+            traffic, PROFILED_VALU, traffic_src = live
         if sr:
             traffic = None
             metric = f"atoms/sec SASA (S&R {args.points} points)"

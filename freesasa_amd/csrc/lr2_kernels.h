@@ -1390,7 +1390,7 @@ static inline Lr2Cfg lr2_choose_cfg(int ns, double nn_hint = 0, int ta_override 
     if (nn_hint > 0 && 1.45 * nn_hint > 64 && nn_max_hint > 64) c.mw = (nn_max_hint + 31) / 32;
     if (c.mw > 4) c.mw = 4;
     c.ds = 2;
-    c.refill = 16; /* (round 3, an item switch of ~100 instructions: flat from 16 to 48 waiting lanes; round 4, ~55: 19.3 / 19.5 / 20.0 / 20.6 / 21.1 / 22.6 arc iterations and 4.7 / 3.9 / 3.0 / 2.6 / 2.4 / 2.0 switches per tile at 4 / 8 / 16 / 24 / 32 / 48: least work at 12 - 24) */
+    c.refill = 24; /* waiting lanes that trigger an item switch.  Emulation, coils: 19.3 / 19.5 / 20.0 / 20.6 / 21.1 / 22.6 arc iterations and 4.7 / 3.9 / 3.0 / 2.6 / 2.4 / 2.0 switches per tile at 4 / 8 / 16 / 24 / 32 / 48; with ~50 instructions per arc step and ~105 per switch the work is least at 16-32, and the MI355X agrees (round 4, 1e7 atoms: 9.57 / 9.56 / 9.58 ms at 16 / 24 / 32; round 3, with a switch of ~165: flat from 16 to 48) */
     /* atoms per tile: as many as give at most ~320 items and run 16 tiles per CU with few enough split tiles */
     int ta_cap = 320 / ns;
     if (ta_cap < 1) ta_cap = 1;

@@ -164,3 +164,30 @@ def test_bench_py_two_ranks_dry_run():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--structs", "2", "--atoms", "100"],
                          capture_output=True, text=True, timeout=120, cwd=ROOT, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK")})
     assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr
+
+
+def test_bench_py_eight_ranks_dry_run_share_the_cpus_and_the_cache(tmp_path):
+    """The driver's 8-GPU launch of bench.py, on CPU under gloo with --dry-run: eight ranks generate their (disjoint)
+    shards at the same time - each with its share of the CPUs the cgroup grants -, write them to one cache directory
+    (private name, then rename) and a second launch reads them back: one JSON line, the atoms of all eight ranks."""
+    import json
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    res = []
+    for attempt in range(2):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FREESASA_AMD_BENCH_CACHE=str(cache))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+               "--structs", "250", "--atoms", "4000", "--dry-run"]
+        out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        res.append(json.loads(lines[0]))
+        files = sorted(os.listdir(cache))
+        assert len(files) == 8 and all(f.endswith(".npy") and ".tmp." not in f for f in files), files   # one per rank, no leftovers
+    for r in res:
+        assert r["dry_run"] is True and r["n_gpus"] == 8 and r["atoms_all_ranks"] == 8 * 250 * 4000 and r["scaling"] == "weak"
