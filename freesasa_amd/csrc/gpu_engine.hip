@@ -273,7 +273,9 @@ __global__ __launch_bounds__(SORT_B) void k_sort_struct(PipeArgs a)
                 g.nx = g.ny = g.nz = 1; g.d = 1; g.x0 = g.y0 = g.z0 = 0;
                 nc = 1; /* keep the rest of the pipeline in bounds; host discards results */
             }
-            const long long base = (long long)atomicAdd((unsigned long long *)&a.ncells[a.n_structs], (unsigned long long)(nc + 1));
+            /* (compact cell table: a structure's cells start at a multiple of 32, its table words are its own) */
+            const long long take = a.cell_tbl ? ((nc + 1 + 31) & ~31LL) : nc + 1;
+            const long long base = (long long)atomicAdd((unsigned long long *)&a.ncells[a.n_structs], (unsigned long long)take);
             if (base + nc + 1 > a.max_cells) { atomicMax(&a.status[ST_ERROR], (int)ERR_GRID_TOO_BIG); nc = -1; }
             else if (nc > (1LL << SORT_CELL_BITS)) { atomicOr(&a.status[ST_RETRY], 2); nc = -1; }
             else if (a.cells_cap > 0 && base + nc + 1 > a.cells_cap) { atomicOr(&a.status[ST_RETRY], 1); nc = -1; }
@@ -311,6 +313,8 @@ __global__ __launch_bounds__(SORT_B) void k_sort_struct(PipeArgs a)
     }
     const unsigned cmask = (1u << SORT_CELL_BITS) - 1u;
     int base = 0; /* atoms in the cells of the passes before this one */
+    int occ_done = 0; /* occupied cells of the passes before this one */
+    const long long occ_base = b0 + s; /* this structure's entries of cell_first: one per occupied cell (<= n) and one behind them */
     for (int lo = 0; lo < C; lo += SORT_CELLS) { /* (once, unless the structure has more than SORT_CELLS cells) */
         const int Cp = C - lo < SORT_CELLS ? C - lo : SORT_CELLS, W = (Cp + 31) >> 5;
         __syncthreads();
@@ -393,13 +397,27 @@ __global__ __launch_bounds__(SORT_B) void k_sort_struct(PipeArgs a)
             if ((k & 3) == 3) __asm__ volatile("" ::: "memory");
         }
         /* F */
-        for (int cc = tid; cc < Cp; cc += SORT_B) {
-            const int oc = (int)wpre[cc >> 5] + __popc(bm[cc >> 5] & ((1u << (cc & 31)) - 1u));
-            a.cell_start[g.cell_base + lo + cc] = (int)(b0 + base + c16[oc]);
+        if (a.cell_tbl) { /* (uniform) compact: the words of this pass, the first atoms of its occupied cells */
+            unsigned long long *const tbl = a.cell_tbl + (((long long)g.cell_base + lo) >> 5);
+            for (int w = tid; w < W; w += SORT_B) tbl[w] = (unsigned long long)bm[w] | ((unsigned long long)(unsigned)(occ_base + occ_done + wpre[w]) << 32);
+            for (int e = tid; e < occ; e += SORT_B) a.cell_first[occ_base + occ_done + e] = (int)(b0 + base + c16[e]);
+        } else {
+            for (int cc = tid; cc < Cp; cc += SORT_B) {
+                const int oc = (int)wpre[cc >> 5] + __popc(bm[cc >> 5] & ((1u << (cc & 31)) - 1u));
+                a.cell_start[g.cell_base + lo + cc] = (int)(b0 + base + c16[oc]);
+            }
         }
         base += n_pass;
+        occ_done += occ;
     }
-    if (tid == 0) a.cell_start[g.cell_base + C] = (int)(b0 + n); /* the entry behind the structure's last cell: its end */
+    if (tid == 0) { /* the entry behind the structure's last cell: its end */
+        if (a.cell_tbl) {
+            a.cell_first[occ_base + occ_done] = (int)(b0 + n);
+            if ((C & 31) == 0) a.cell_tbl[((long long)g.cell_base + C) >> 5] = (unsigned long long)(unsigned)(occ_base + occ_done) << 32; /* (cell C opens a word of its own: no cell of it holds atoms) */
+        } else {
+            a.cell_start[g.cell_base + C] = (int)(b0 + n);
+        }
+    }
 }
 
 __global__ __launch_bounds__(SASA_TOT_B) void k_totals(const double *sasa, const int64_t *offsets, int n_structs, double *totals)
@@ -616,7 +634,7 @@ struct freesasa_gpu_ctx {
     } pend[2];
     int pend_err = 0; /* a batch collected on the way (to make room, before a reallocation) failed: reported by the next wait */
     /* workspace */
-    DevBuf offsets, grid, ncells, sid, cell_of, rank, cell_start, blk_sums;
+    DevBuf offsets, grid, ncells, sid, cell_of, rank, cell_start, blk_sums, cell_tbl, cell_first;
     DevBuf chunk_struct, chunk_begin, chunk_len, struct_chunk0, bpart;
     int n_chunks = 0;
     DevBuf sq, s_idx;
@@ -748,7 +766,7 @@ extern "C" void freesasa_gpu_ctx_destroy(freesasa_gpu_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->chunk_struct, &c->chunk_begin, &c->chunk_len, &c->struct_chunk0, &c->bpart, &c->offsets, &c->grid, &c->ncells, &c->sid, &c->cell_of, &c->rank, &c->cell_start,
-                     &c->blk_sums, &c->sq, &c->s_idx,
+                     &c->blk_sums, &c->cell_tbl, &c->cell_first, &c->sq, &c->s_idx,
                      &c->status, &c->ovf_tiles, &c->ovf_tiles2, &c->ovf_atoms, &c->unit_pts, &c->slab, &c->seg,
                      &c->h_xyz, &c->h_radii, &c->h_sasa, &c->h_counts, &c->h_totals};
     for (DevBuf *b : all)
@@ -966,7 +984,7 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
     memset(&la, 0, sizeof la);
     la.sq = pa.sq;
     la.s_idx = pa.s_idx;
-    la.grid = pa.grid; la.cell_start = pa.cell_start;
+    la.grid = pa.grid; la.cell_start = pa.cell_start; la.cell_tbl = pa.cell_tbl; la.cell_first = pa.cell_first;
     la.n_atoms = n; la.n_tiles = n_tiles; la.TA = cfg.TA; la.ns = resolution;
     la.pool = cfg.pool; la.mw = cfg.mw; la.ds = cfg.ds; la.refill = cfg.refill;
     /* (hint_nn: what all but 4 % of the last batch's tiles needed per atom, or 1.25 x the density sample: coils ~30, proteins ~58) */
@@ -983,6 +1001,12 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
     if (const char *e = getenv("FREESASA_AMD_GRID")) { /* tuning aid */
         const int g = atoi(e);
         if (g >= 8) grid_main = g < grid_all ? (g / 8) * 8 : grid_all;
+    }
+    /* the last quarter of a full-size launch's workgroups takes two tiles each, the others share the rest (Lr2Args::seg_grid) */
+    la.seg_grid = 0; la.seg_tiles = 0;
+    if (grid_main == 147456 && !getenv("FREESASA_AMD_ONE_PART")) {
+        const int g2 = grid_main / 4, t2 = 2 * g2;
+        if (n_tiles >= 8 * t2) { la.seg_grid = grid_main - g2; la.seg_tiles = ((n_tiles - t2) / 8) * 8; }
     }
     la.nn_out = c->dbg_nn; la.nb_out = c->dbg_nb; la.nb_cap = c->dbg_cap;
     la.hooks = (c->dbg_nn ? 1 : 0) | (c->dbg_nb ? 2 : 0);
@@ -1017,7 +1041,7 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
         memset(&tf, 0, sizeof tf);
         tf.sq = pa.sq;
         tf.s_idx = pa.s_idx;
-        tf.grid = pa.grid; tf.cell_start = pa.cell_start;
+        tf.grid = pa.grid; tf.cell_start = pa.cell_start; tf.cell_tbl = pa.cell_tbl; tf.cell_first = pa.cell_first;
         tf.n_atoms = n; tf.n_tiles = n; tf.TA = 1; tf.n_res = resolution; tf.tab = fb.tab;
         tf.sasa = d_sasa; tf.lr = 1; tf.status = (int *)c->status.p;
         tf.cap_idx = fb.cap_idx; tf.pool = fb.pool; tf.ds = fb.ds;
@@ -1128,17 +1152,25 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
     if (cells_cap < c->cells_hint) cells_cap = c->cells_hint;
     if (cells_cap > c->max_cells) cells_cap = c->max_cells;
     const int nblk_scan = (int)((cells_cap + 1 + (long long)SASA_PIPE_B * SASA_SCAN_ITEMS - 1) / ((long long)SASA_PIPE_B * SASA_SCAN_ITEMS));
-    if (ensure(c, c->cell_start, sizeof(int) * ((size_t)cells_cap + 2)) || ensure(c, c->blk_sums, sizeof(int) * ((size_t)nblk_scan + 1)))
-        return -1;
-    pa.cell_start = (int *)c->cell_start.p;
-    pa.blk_sums = (int *)c->blk_sums.p;
-    pa.cells_cap = cells_cap;
-
     const int nblk_atoms = (n + SASA_PIPE_B - 1) / SASA_PIPE_B;
     /* batches of small structures: bounds, grid and cell sort of a structure in one workgroup (k_sort_struct) */
     long long biggest = 0;
     for (int s_ = 0; s_ < n_structs; ++s_) biggest = offsets[s_ + 1] - offsets[s_] > biggest ? offsets[s_ + 1] - offsets[s_] : biggest;
     const bool fused = c->sort_fused && biggest <= SORT_ATOMS && n_structs >= 8 && !getenv("FREESASA_AMD_NO_FUSED_SORT");
+    /* ... which writes the cell table in its compact form for the Lee-Richards tile kernel (PipeArgs::cell_tbl) */
+    const bool compact = fused && lr && lr2_supported(resolution) && !getenv("FREESASA_AMD_LR1") && !getenv("FREESASA_AMD_DENSE_CELLS");
+    if (compact) {
+        if (ensure(c, c->cell_tbl, sizeof(unsigned long long) * ((size_t)(cells_cap >> 5) + 2)) || ensure(c, c->cell_first, sizeof(int) * (nb + (size_t)n_structs + 2)))
+            return -1;
+        pa.cell_tbl = (unsigned long long *)c->cell_tbl.p;
+        pa.cell_first = (int *)c->cell_first.p;
+    } else if (ensure(c, c->cell_start, sizeof(int) * ((size_t)cells_cap + 2)) || ensure(c, c->blk_sums, sizeof(int) * ((size_t)nblk_scan + 1))) {
+        return -1;
+    }
+    pa.cell_start = (int *)c->cell_start.p;
+    pa.blk_sums = (int *)c->blk_sums.p;
+    pa.cells_cap = cells_cap;
+
     if (fused) {
         HIP_TRY(c, hipMemsetAsync((long long *)c->ncells.p + n_structs, 0, sizeof(long long), st)); /* the cell counter */
         hipLaunchKernelGGL(k_sort_struct, dim3(n_structs), dim3(SORT_B), 0, st, pa);

@@ -210,6 +210,8 @@ struct Lr2Args {
     const SortIdx *s_idx;
     const GridS *grid;
     const int *cell_start;
+    const unsigned long long *cell_tbl; /* compact cell table (sasa_kernels.h, PipeArgs), or null */
+    const int *cell_first;
     int n_atoms, n_tiles;
     int TA;     /* atoms per tile, 9*TA <= 64 */
     int ns;     /* slices per atom */
@@ -235,6 +237,12 @@ struct Lr2Args {
     int nb_cap;
     int *status;
     double inv_ns; /* 1.0 / ns, correctly rounded (host division): lr2_div_ns */
+    /* The main launch in two parts, so that its last workgroups are short ones: workgroups [0, seg_grid) share the tiles
+       [0, seg_tiles) (a dozen each), the others share the rest (two or three each).  Workgroups start in the order of
+       their numbers; those that start last decide how ragged the end of the launch is: a third of a workgroup's
+       duration on average (measured: kernel time = 9.45 ms + 0.34 x that duration over grids of 4 096 .. 147 456
+       workgroups, 1e7 atoms).  seg_grid 0: one part (work lists, small launches). */
+    int seg_grid, seg_tiles;
     int hooks; /* bit 0: nn_out is set, bit 1: nb_out is set (what the tile body tests; the pointers themselves are cold) */
 };
 #include <stddef.h>
@@ -287,7 +295,7 @@ SASA_HD Lr2Layout lr2_layout(int TA, int ns, int pool, int mw, int ds)
        scratch (P4, P5), then the arc stack (P6) */
     int r2k = lr2_a16(8 * pool);
     if (r2k < lr2_a16(4 * lr2_n_row_ints(TA))) r2k = lr2_a16(4 * lr2_n_row_ints(TA));
-    int r2 = r2k + lr2_a16(2 * pool);
+    int r2 = r2k + lr2_a16(pool); /* (a byte per hit: its atom) */
     const int r2q = lr2_a16(2 * items) + 256, r2s = 16 * LR2_LANES * (ds > 0 ? ds : 1); /* (one column level even when ds == 0: see lr2_union_step) */
     if (r2q > r2) r2 = r2q;
     if (r2s > r2) r2 = r2s;
@@ -312,7 +320,7 @@ struct Lr2Mem {
     Ab16 *ab;       /* [pool] records, sorted by beta inside each atom's list: coefficients ... */
     double *beta;   /* [pool] ... and direction */
     double *keys;   /* [pool] beta with the list position in its low mantissa bits */
-    unsigned short *tag; /* [pool] atom of a hit */
+    unsigned char *tag; /* [pool] atom of a hit */
     Arc2 *stack;     /* [ds][64] */
 };
 /* flags: 0 tile overflow, 1 stack overflow, 2 max neighbor count, 6 atoms with a coincident neighbor of equal radius (bits) */
@@ -336,7 +344,7 @@ SASA_D Lr2Mem lr2_carve(const Lr2Args &a, char *smem)
     m.ab = (Ab16 *)(smem + L.o_rec);
     m.beta = (double *)(smem + L.o_rec + 16 * a.pool); /* (the pool is even) */
     m.keys = (double *)(smem + L.o_r2);
-    m.tag = (unsigned short *)(smem + L.o_tag);
+    m.tag = (unsigned char *)(smem + L.o_tag);
     m.hist = (int *)(smem + L.o_r2);
     m.qtmp = (unsigned short *)(smem + L.o_r2 + 256);
     m.stack = (Arc2 *)(smem + L.o_r2);
@@ -587,21 +595,23 @@ SASA_D double lr2_acos_lower(double c)
  * What P0 needs from global memory is a chain: the atom's sort record -> (its structure's grid ->) the first atoms of
  * the cells at both ends of each of its 9 candidate rows.  Until round 3 every tile began by waiting for those round
  * trips (P0: 9 % of a wave's life for 3 % of its instructions).  Now the chain of tile k+1 is walked while tile k
- * computes: stage A (sort records) is issued before the queue of tile k is built, stages B (cell_start) and C (the tile's
- * own atoms) before its areas are summed, and P0 of tile k+1 finds the values in its registers.  nx and ny of the
+ * computes: stage A (sort records) is issued before tile k is screened, stage B (cell table) before its queue is built,
+ * stages B2 (compact cell table: first atoms of the cells) and C (the tile's own atoms) before its areas are summed,
+ * and P0 of tile k+1 finds the values in its registers.  nx and ny of the
  * structure's grid ride in the sort record's flag word (cell_pack_grid), so the common chain has two links, not three.
  * A tile that was not announced (the first of a wave, halves of a split tile) walks the chain on the spot, as before. */
 struct Lr2Pre {
     int p0;          /* first atom of the tile the values are of (-1: none) */
     long long rcf;   /* A, row lanes: cell | (flags, nx, ny) << 32 of the row's atom */
-    int s0, s1;      /* B, row lanes: first atoms of the cells at both ends of the row's run */
+    int s0, s1;      /* B, row lanes: first atoms of the cells at both ends of the row's run (compact cell table: the cells themselves until B2) */
+    unsigned long long w0, w1; /* B1, compact cell table: the table words of the two cells */
     int rfl;         /* B: bit 0 row outside the grid, bit 1 the atom leads its cell group */
     Quad q;          /* C, lanes < TA: the atom */
     int cell, so;    /* C: its cell and its original index */
 };
 SASA_D void lr2_pre_none(Lr2Pre &pre)
 {
-    pre.p0 = -1; pre.rcf = 0; pre.s0 = pre.s1 = 0; pre.rfl = 1; pre.cell = 0; pre.so = 0;
+    pre.p0 = -1; pre.rcf = 0; pre.s0 = pre.s1 = 0; pre.w0 = pre.w1 = 0; pre.rfl = 1; pre.cell = 0; pre.so = 0;
     pre.q.x = pre.q.y = pre.q.z = 0; pre.q.w = 1;
 }
 /* (Loads without branches around them: a lane that has no row or no atom of the tile loads what the tile's last atom's
@@ -629,10 +639,24 @@ SASA_D void lr2_pre_b(const Lr2Args &a, Lr2Pre &pre, int na, int lane)
                      (dz < 0 && (fl & CELL_Z0)) || (dz > 0 && (fl & CELL_Z1));
     const int row = out ? c : c + nx * (dy + ny * dz);
     const int x_lo = row - ((fl & CELL_X0) ? 0 : 1), x_hi = row + ((fl & CELL_X1) ? 0 : 1);
-    const int *const cell_start = LR2_COLD(a, cell_start);
-    pre.s0 = cell_start[x_lo]; pre.s1 = cell_start[x_hi + 1];
+    const unsigned long long *const tbl = LR2_COLD(a, cell_tbl);
+    if (tbl) { /* (uniform) compact table: the words now, the first atoms in lr2_pre_b2 */
+        pre.s0 = x_lo; pre.s1 = x_hi + 1;
+        pre.w0 = tbl[x_lo >> 5]; pre.w1 = tbl[(x_hi + 1) >> 5];
+    } else {
+        const int *const cell_start = LR2_COLD(a, cell_start);
+        pre.s0 = cell_start[x_lo]; pre.s1 = cell_start[x_hi + 1];
+    }
     /* the atoms of a tile are consecutive in cell order: atoms of one cell form a group */
     pre.rfl = (out || la >= na ? 1 : 0) | (la == 0 || cprev != c ? 2 : 0);
+}
+/* the last link with the compact cell table: occupied-cell ranks of the two cells -> first atoms */
+SASA_D void lr2_pre_b2(const Lr2Args &a, Lr2Pre &pre)
+{
+    if (!LR2_COLD(a, cell_tbl)) return; /* (uniform) */
+    const int *const first = LR2_COLD(a, cell_first);
+    const int r0 = cell_rank(pre.w0, pre.s0), r1 = cell_rank(pre.w1, pre.s1);
+    pre.s0 = first[r0]; pre.s1 = first[r1];
 }
 SASA_D void lr2_pre_c(const Lr2Args &a, Lr2Pre &pre, int na, int lane)
 {
@@ -670,6 +694,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         LR2_COUNT(11, 1);
         lr2_pre_a(a, pre, p0, na, lane);
         lr2_pre_b(a, pre, na, lane);
+        lr2_pre_b2(a, pre);
         lr2_pre_c(a, pre, na, lane);
     }
     if (lane < TA) {
@@ -774,7 +799,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                         slot = slot < a.pool ? slot : a.pool - 1; /* (a tile with more hits than the pool is redone: P2) */
                         Quad hq; hq.x = dx[j]; hq.y = dy[j]; hq.z = dz[j]; hq.w = rq[j]; /* ref: src/nb.c:445-448 */
                         m.hits[slot] = hq;
-                        m.tag[slot] = (unsigned short)la;
+                        m.tag[slot] = (unsigned char)la;
                         /* the atom's count only: nothing here waits for the counter's old value (the hit's place in its
                            atom's list is handed out in P3, two round trips per tile instead of one per group of tests) */
                         if (!(a.hooks & 2)) { /* (uniform) */
@@ -961,6 +986,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
 
     LR2_STOP(3);
     LR2_MARK(3);
+    lr2_pre_a(a, pre, p0n, nan, lane); /* the next tile's sort records: on their way while this tile is screened */
     /* ------------------------------------------------------------ P4 screening */
     const float inv_ns = LR2_RCPF((float)ns); /* index arithmetic only (one off either way is put right below) */
     m.hist[lane] = 0;
@@ -1106,7 +1132,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
 
     LR2_STOP(4);
     LR2_MARK(4);
-    lr2_pre_a(a, pre, p0n, nan, lane); /* the next tile's sort records: on their way while this tile's arcs are done */
+    lr2_pre_b(a, pre, nan, lane); /* the next tile's candidate rows (compact cell table: their table words): on their way while this tile's arcs are done */
     /* ------------------------------------------------------------ P5 queue */
     int nq;
     {
@@ -1246,7 +1272,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     }
     LR2_SYNC();
     LR2_MARK(6);
-    lr2_pre_b(a, pre, nan, lane); /* the next tile's candidate rows and its atoms: on their way while this tile's areas are summed */
+    lr2_pre_b2(a, pre);           /* the next tile's candidate rows (compact cell table: the last link) and its atoms: on their way while this tile's areas are summed */
     lr2_pre_c(a, pre, nan, lane);
 
     /* ------------------------------------------------------------ P7 store */
@@ -1276,7 +1302,13 @@ template <int RMAX, bool COVER, bool PAIRS, int SHAPE = 0>
 SASA_D void lr2_wave(const Lr2Args &a, const Lr2Mem &m, int first, int stride, int lane, int &wg_max_nn)
 {
     /* all tiles (main launch, rounded up to whole XCD groups) or the items of a work list */
-    const int n_work = a.work_items ? *a.work_count : ((a.n_tiles + 7) >> 3) << 3;
+    int n_work = a.work_items ? *a.work_count : ((a.n_tiles + 7) >> 3) << 3;
+    int tile0 = 0, n_seg = a.n_tiles; /* the part of the launch this workgroup belongs to: its first tile, its tiles */
+    if (!a.work_items && a.seg_grid > 0) {
+        if (first < a.seg_grid) { n_seg = a.seg_tiles; stride = a.seg_grid; }
+        else { tile0 = a.seg_tiles; n_seg = a.n_tiles - a.seg_tiles; first -= a.seg_grid; stride -= a.seg_grid; }
+        n_work = ((n_seg + 7) >> 3) << 3;
+    }
     int splits = 0;
     Lr2Pre pre;
     lr2_pre_none(pre);
@@ -1287,12 +1319,13 @@ SASA_D void lr2_wave(const Lr2Args &a, const Lr2Mem &m, int first, int stride, i
             const long long e = a.work_items[w];
             p0 = (int)(e & 0xffffffffLL); na = (int)(e >> 32);
         } else {
-            tile = xcd_tile(w, a.n_tiles);
-            if (tile >= a.n_tiles) continue; /* uniform per wave */
+            tile = xcd_tile(w, n_seg);
+            if (tile >= n_seg) continue; /* uniform per wave */
+            tile += tile0;
             p0 = tile * LR2_A_TA(a);
             na = a.n_atoms - p0 < LR2_A_TA(a) ? a.n_atoms - p0 : LR2_A_TA(a);
-            const int tn = w + stride < n_work ? xcd_tile(w + stride, a.n_tiles) : a.n_tiles;
-            if (tn < a.n_tiles) { p0n = tn * LR2_A_TA(a); nan = a.n_atoms - p0n < LR2_A_TA(a) ? a.n_atoms - p0n : LR2_A_TA(a); }
+            const int tn = w + stride < n_work ? xcd_tile(w + stride, n_seg) : n_seg;
+            if (tn < n_seg) { p0n = (tile0 + tn) * LR2_A_TA(a); nan = a.n_atoms - p0n < LR2_A_TA(a) ? a.n_atoms - p0n : LR2_A_TA(a); }
         }
         if (na <= 0) continue;
         /* one call site (the tile is ~9000 instructions): a tile that does not fit is redone as two halves, a

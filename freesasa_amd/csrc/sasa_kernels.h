@@ -175,6 +175,12 @@ struct PipeArgs {
     int *rank;    /* arrival rank within the cell */
     /* per cell */
     int *cell_start; /* [total_cells+1]: histogram, then exclusive scan */
+    /* The cell table in its compact form (k_sort_struct for the Lee-Richards tile kernel, round 4): per 32 cells one
+       word {which of them hold atoms, occupied cells before them}, and the first atom of every OCCUPIED cell - 2 + 1.3
+       bytes per atom on random coils where the dense table is 36 (9 cells per atom, 4 bytes each), written once and
+       gathered from by every tile.  null: the dense table. */
+    unsigned long long *cell_tbl; /* [total cells / 32 + 1] bits | occupied cells before the word << 32; a structure's cells start at a multiple of 32 */
+    int *cell_first;              /* [n_atoms + n_structs] first atom of an occupied cell; structure s uses entries offsets[s] + s ...; behind its last: its end */
     int *blk_sums;   /* scan scratch */
     /* per atom, cell-sorted order */
     Quad *sq; /* (x, y, z, radius + probe) (ref: src/sasa_lr.c:136, sasa_sr.c:144): one 32-byte record per atom - two
@@ -306,6 +312,20 @@ SASA_D void cellbase_phase2(const PipeArgs &a, const long long *part, int tid, i
  * divisions that would recover ix, iy, iz from the cell index) */
 enum { CELL_X0 = 1, CELL_X1 = 2, CELL_Y0 = 4, CELL_Y1 = 8, CELL_Z0 = 16, CELL_Z1 = 32 };
 SASA_D int cell_coord(double v, double v0, double d) { return (int)((v - v0) / d); } /* ref: src/nb.c:137-140 */
+/* first cell-sorted atom of the first occupied cell >= x: what cell_start[x] holds in the dense table */
+SASA_D int cell_rank(unsigned long long w, int x)
+{
+#ifdef SASA_EMU
+    return (int)(w >> 32) + __builtin_popcount((unsigned)w & ((1u << (x & 31)) - 1u));
+#else
+    return (int)(w >> 32) + __popc((unsigned)w & ((1u << (x & 31)) - 1u));
+#endif
+}
+SASA_D int cell_first_atom(const int *cell_start, const unsigned long long *tbl, const int *first, int x)
+{
+    if (!tbl) return cell_start[x];
+    return first[cell_rank(tbl[x >> 5], x)];
+}
 /* nx and ny of the structure's grid, beside the six border flags in the high word of a sort record's cell (13 bits
  * each; 0: a grid of 8192 cells or more along x or y, look them up in grid[]): the L&R tile kernel finds an atom's
  * candidate rows from the record alone, one dependent load less at the start of every tile (lr2_pre_b) */
@@ -492,6 +512,8 @@ struct TileArgs {
     const SortIdx *s_idx;
     const GridS *grid;
     const int *cell_start;
+    const unsigned long long *cell_tbl; /* compact cell table (see PipeArgs), or null */
+    const int *cell_first;
     int n_atoms;
     int n_tiles;
     int TA;      /* atoms per tile */
@@ -644,7 +666,7 @@ SASA_D void tile_phase_load(const TileArgs &a, TileMem &m, int tile, int tid, in
                              (dz < 0 && (fl & CELL_Z0)) || (dz > 0 && (fl & CELL_Z1));
             const int row = out ? c : c + nx * (dy + ny * dz); /* same ix, neighbouring (iy, iz) */
             const int x_lo = row - ((fl & CELL_X0) ? 0 : 1), x_hi = row + ((fl & CELL_X1) ? 0 : 1);
-            const int s0 = a.cell_start[x_lo], s1 = a.cell_start[x_hi + 1];
+            const int s0 = cell_first_atom(a.cell_start, a.cell_tbl, a.cell_first, x_lo), s1 = cell_first_atom(a.cell_start, a.cell_tbl, a.cell_first, x_hi + 1);
             lo = out ? 0 : s0;
             cnt = out ? 0 : s1 - s0;
         }
