@@ -252,8 +252,13 @@ struct Lr2Args {
  * the kernel's only parameter. */
 #ifdef SASA_EMU
 #define LR2_COLD(a, field) ((a).field)
+#define LR2_WARM(a, field) ((a).field)
 #else
 #define LR2_COLD(a, field) (*(const decltype(sasa::Lr2Args::field) *)lr2_cold_arg(offsetof(sasa::Lr2Args, field)))
+/* (P0's pointers and the result pointer, used once or twice per tile, stay cold in the build for the default tile shape
+   too, although it has scalar registers to spare: as ordinary arguments they cost 32 more spilled scalar registers and
+   0.7 % of the kernel's time - round 4, measured) */
+#define LR2_WARM(a, field) LR2_COLD(a, field)
 __device__ __forceinline__ const char *lr2_cold_arg(size_t off)
 {
     auto p = __builtin_amdgcn_kernarg_segment_ptr();
@@ -617,12 +622,14 @@ SASA_D void lr2_pre_none(Lr2Pre &pre)
 /* (Loads without branches around them: a lane that has no row or no atom of the tile loads what the tile's last atom's
  * lane loads, and P0 sorts out who is who.  A join of two paths between a load and its use makes the compiler wait for
  * every load in flight at the join - the round trip this is here to hide.) */
+template <int SHAPE>
 SASA_D void lr2_pre_a(const Lr2Args &a, Lr2Pre &pre, int p0, int na, int lane)
 {
     const int la = lr2_div9(lane);
     pre.p0 = p0;
-    pre.rcf = LR2_COLD(a, s_idx)[p0 + (la < na ? la : na - 1)].cell;
+    pre.rcf = LR2_WARM(a, s_idx)[p0 + (la < na ? la : na - 1)].cell;
 }
+template <int SHAPE>
 SASA_D void lr2_pre_b(const Lr2Args &a, Lr2Pre &pre, int na, int lane)
 {
     const int la = lr2_div9(lane), r = lane - 9 * la;
@@ -639,7 +646,7 @@ SASA_D void lr2_pre_b(const Lr2Args &a, Lr2Pre &pre, int na, int lane)
                      (dz < 0 && (fl & CELL_Z0)) || (dz > 0 && (fl & CELL_Z1));
     const int row = out ? c : c + nx * (dy + ny * dz);
     const int x_lo = row - ((fl & CELL_X0) ? 0 : 1), x_hi = row + ((fl & CELL_X1) ? 0 : 1);
-    const unsigned long long *const tbl = LR2_COLD(a, cell_tbl);
+    const unsigned long long *const tbl = LR2_WARM(a, cell_tbl);
     if (tbl) { /* (uniform) compact table: the words now, the first atoms in lr2_pre_b2 */
         pre.s0 = x_lo; pre.s1 = x_hi + 1;
         pre.w0 = tbl[x_lo >> 5]; pre.w1 = tbl[(x_hi + 1) >> 5];
@@ -651,18 +658,20 @@ SASA_D void lr2_pre_b(const Lr2Args &a, Lr2Pre &pre, int na, int lane)
     pre.rfl = (out || la >= na ? 1 : 0) | (la == 0 || cprev != c ? 2 : 0);
 }
 /* the last link with the compact cell table: occupied-cell ranks of the two cells -> first atoms */
+template <int SHAPE>
 SASA_D void lr2_pre_b2(const Lr2Args &a, Lr2Pre &pre)
 {
-    if (!LR2_COLD(a, cell_tbl)) return; /* (uniform) */
-    const int *const first = LR2_COLD(a, cell_first);
+    if (!LR2_WARM(a, cell_tbl)) return; /* (uniform) */
+    const int *const first = LR2_WARM(a, cell_first);
     const int r0 = cell_rank(pre.w0, pre.s0), r1 = cell_rank(pre.w1, pre.s1);
     pre.s0 = first[r0]; pre.s1 = first[r1];
 }
+template <int SHAPE>
 SASA_D void lr2_pre_c(const Lr2Args &a, Lr2Pre &pre, int na, int lane)
 {
     const int p = pre.p0 + (lane < na ? lane : na - 1);
     pre.q = a.sq[p];
-    const SortIdx si = LR2_COLD(a, s_idx)[p];
+    const SortIdx si = LR2_WARM(a, s_idx)[p];
     pre.cell = lane < na ? (int)(si.cell & 0xffffffffLL) : -1 - lane;
     pre.so = si.orig;
 }
@@ -692,15 +701,15 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     /* ------------------------------------------------------------ P0 load */
     if (pre.p0 != p0) { /* (uniform) not fetched ahead (a tile is announced with its own first atom and count: the halves of a split tile never find the whole tile's values): the chain, one link after the other */
         LR2_COUNT(11, 1);
-        lr2_pre_a(a, pre, p0, na, lane);
-        lr2_pre_b(a, pre, na, lane);
-        lr2_pre_b2(a, pre);
-        lr2_pre_c(a, pre, na, lane);
+        lr2_pre_a<SHAPE>(a, pre, p0, na, lane);
+        lr2_pre_b<SHAPE>(a, pre, na, lane);
+        lr2_pre_b2<SHAPE>(a, pre);
+        lr2_pre_c<SHAPE>(a, pre, na, lane);
     }
     if (lane < TA) {
         Quad q = pre.q;
         if (lane >= na) { q.x = q.y = q.z = 0; q.w = 1; }
-        const double del = lane < na ? lr2_div_ns(2 * q.w, (double)ns, LR2_COLD(a, inv_ns)) : 0.0; /* = 2 Ri / ns, ref: src/sasa_lr.c:304 */
+        const double del = lane < na ? lr2_div_ns(2 * q.w, (double)ns, LR2_WARM(a, inv_ns)) : 0.0; /* = 2 Ri / ns, ref: src/sasa_lr.c:304 */
         m.atom[lane] = q; m.adel[lane] = del; m.sorig[lane] = lane < na ? pre.so : 0;
         m.acnt[lane] = 0;
         m.gsz[lane] = 0; /* (P3's list cursors) */
@@ -892,7 +901,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                 if (cover) { /* (uniform) */
                     const int b = lr2_cover_bin(Kc, d3sq, ri);
                     r_cb[r] |= b;
-                    LR2_ADD64_LDS(&chist[la], 1ull << (8 * b));
+                    LR2_ADD64_LDS(&chist[la], 1ull << (8 * b)); /* (a byte per bin: a bin of 256 neighbors or more would carry into the next one - an atom with that many does not fit this launch's lists (32 mw <= 128), and the bins only choose which neighbors the filter looks at, never an area) */
                 }
             }
         }
@@ -986,7 +995,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
 
     LR2_STOP(3);
     LR2_MARK(3);
-    lr2_pre_a(a, pre, p0n, nan, lane); /* the next tile's sort records: on their way while this tile is screened */
+    lr2_pre_a<SHAPE>(a, pre, p0n, nan, lane); /* the next tile's sort records: on their way while this tile is screened */
     /* ------------------------------------------------------------ P4 screening */
     const float inv_ns = LR2_RCPF((float)ns); /* index arithmetic only (one off either way is put right below) */
     m.hist[lane] = 0;
@@ -1132,7 +1141,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
 
     LR2_STOP(4);
     LR2_MARK(4);
-    lr2_pre_b(a, pre, nan, lane); /* the next tile's candidate rows (compact cell table: their table words): on their way while this tile's arcs are done */
+    lr2_pre_b<SHAPE>(a, pre, nan, lane); /* the next tile's candidate rows (compact cell table: their table words): on their way while this tile's arcs are done */
     /* ------------------------------------------------------------ P5 queue */
     int nq;
     {
@@ -1272,8 +1281,8 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     }
     LR2_SYNC();
     LR2_MARK(6);
-    lr2_pre_b2(a, pre);           /* the next tile's candidate rows (compact cell table: the last link) and its atoms: on their way while this tile's areas are summed */
-    lr2_pre_c(a, pre, nan, lane);
+    lr2_pre_b2<SHAPE>(a, pre);           /* the next tile's candidate rows (compact cell table: the last link) and its atoms: on their way while this tile's areas are summed */
+    lr2_pre_c<SHAPE>(a, pre, nan, lane);
 
     /* ------------------------------------------------------------ P7 store */
     const bool deep = LR2_BALLOT(maxd - 2 > LR2_A_DS(a)) != 0; /* an arc stack column was too short: the tile is redone */
@@ -1287,7 +1296,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         }
         for (; k < ns; ++k) s += tc[k];
         if ((m.flags[6] >> lane) & 1) s = NAN; /* duplicate atom record (see P3) */
-        LR2_COLD(a, sasa)[m.sorig[lane]] = s; /* (the pointer is read here, once per tile) */
+        LR2_WARM(a, sasa)[m.sorig[lane]] = s; /* (generic build: the pointer is read here, once per tile) */
     }
     LR2_SYNC();
     LR2_MARK(7);

@@ -1,22 +1,23 @@
 # Full GPU session for a round: everything profiles/ and DESIGN.md quote, in one gpurun call.
-#   bash tools/gpu_round.sh r03        (outputs under gpurun_out/<tag>_*; copy the summaries into profiles/)
+#   bash tools/gpu_round.sh r04        (outputs under gpurun_out/<tag>_*; copy the summaries into profiles/)
 # Build the phase-ablation variants first if the per-phase instruction counts are wanted:
-#   for k in 0 1 2 3 4 5; do bash tools/build_variant.sh stop$k -DLR2_STOP_AFTER=$k; done
-TAG=${1:-r03}
+#   for k in 0 1 2 3 4 5; do bash tools/build_variant.sh stop$k -DLR2_STOP_AFTER=$k; done; bash tools/build_variant.sh pt -DSASA_PHASE_TIMING
+TAG=${1:-r04}
 mkdir -p gpurun_out
 export PYTHONUNBUFFERED=1
 REPO=$(pwd)
 O=$REPO/gpurun_out
 (timeout 300 python -c "import __graft_entry__ as g; g.smoke()") > $O/${TAG}_smoke.log 2>&1; echo "smoke rc=$?" >> $O/${TAG}_smoke.log
-(timeout 900 python -m pytest tests -m gpu -q --durations=5) > $O/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/${TAG}_pytest_gpu.log
+(timeout 900 python -m pytest tests -m gpu -q -s --durations=5) > $O/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/${TAG}_pytest_gpu.log
+grep "adversarial" $O/${TAG}_pytest_gpu.log > $O/${TAG}_adversarial.txt
 (timeout 900 python bench.py) > $O/${TAG}_bench.out 2> $O/${TAG}_bench.err; echo "bench rc=$?" >> $O/${TAG}_bench.err
 grep '^{' $O/${TAG}_bench.out | tail -1 > $O/${TAG}_bench.json
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-end-to-end --no-secondary --no-neighbors"
+BENCH="python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-end-to-end --no-secondary --no-neighbors --no-live-counters"
 (timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -o trace -- $BENCH) > $O/rocprof_trace.log 2>&1
 cp $O/prof_$TAG/trace_kernel_stats.csv $O/${TAG}_kernel_stats.csv
-PM="python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-end-to-end --no-secondary --no-neighbors"
+PM="python $REPO/bench.py --steps 1 --warmup 1 --sync-entry --no-cpu-baseline --no-end-to-end --no-secondary --no-neighbors --no-live-counters"
 (timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU --output-format csv -d $O/prof_$TAG -o pmc1 -- $PM) > $O/rocprof_pmc1.log 2>&1
 (timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_VALU --output-format csv -d $O/prof_$TAG -o pmc2 -- $PM) > $O/rocprof_pmc2.log 2>&1
 (timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/prof_$TAG -o pmc3 -- $PM) > $O/rocprof_pmc3.log 2>&1
@@ -44,6 +45,16 @@ if [ -f freesasa_amd/lib/libvar_stop0.so ]; then
    bash tools/gpu_ablate.sh "0,0,-1,0" freesasa_amd/lib/libvar_stop0.so freesasa_amd/lib/libvar_stop1.so freesasa_amd/lib/libvar_stop2.so freesasa_amd/lib/libvar_stop3.so freesasa_amd/lib/libvar_stop4.so freesasa_amd/lib/libvar_stop5.so freesasa_amd/lib/libfreesasa_amd.so
    echo "globules (100 x 10 000 atoms, 5 launches)"
    STRUCTS=g100 bash tools/gpu_ablate.sh "0,0,-1,0" freesasa_amd/lib/libvar_stop0.so freesasa_amd/lib/libvar_stop1.so freesasa_amd/lib/libvar_stop2.so freesasa_amd/lib/libvar_stop3.so freesasa_amd/lib/libvar_stop4.so freesasa_amd/lib/libvar_stop5.so freesasa_amd/lib/libfreesasa_amd.so) 2>&1 | grep "==\|coils\|globules\|lr2_tile<4" | sed "s/vgpr[^ ]* //" > $O/${TAG}_phase_valu.txt
+fi
+# wall clock of a wave by phase (variant built with -DSASA_PHASE_TIMING)
+if [ -f freesasa_amd/lib/libvar_pt.so ]; then
+  (echo "coils (300 x 10 000 atoms)"; FREESASA_AMD_LIB=$REPO/freesasa_amd/lib/libvar_pt.so python tools/gpu_shapes.py 300 "0,0,-1,0" 2>&1 | grep "phase clocks" | tail -1
+   echo "globules (100 x 10 000 atoms)"; FREESASA_AMD_LIB=$REPO/freesasa_amd/lib/libvar_pt.so python tools/gpu_shapes.py g100 "0,0,-1,0" 2>&1 | grep "phase clocks" | tail -1) > $O/${TAG}_phase_clock.txt 2>&1
+fi
+# configs[2] as written (L&R 100 slices, TA 3): VALU instructions by phase
+if [ -f freesasa_amd/lib/libvar_stop0.so ]; then
+  (echo "coils, Lee-Richards 100 slices (100 x 10 000 atoms, 5 launches): cumulative after P0 .. P5, then the whole kernel"
+   SLICES=100 STRUCTS=100 bash tools/gpu_ablate.sh "0,0,-1,0" freesasa_amd/lib/libvar_stop0.so freesasa_amd/lib/libvar_stop1.so freesasa_amd/lib/libvar_stop2.so freesasa_amd/lib/libvar_stop3.so freesasa_amd/lib/libvar_stop4.so freesasa_amd/lib/libvar_stop5.so freesasa_amd/lib/libfreesasa_amd.so) 2>&1 | grep "==\|coils\|lr2_tile<" | sed "s/vgpr[^ ]* //" > $O/${TAG}_lr100_phase_valu.txt
 fi
 (timeout 600 python tools/deep_parity.py 120 24 2>/dev/null | tail -1) > $O/${TAG}_deep_parity.json
 (timeout 120 tools/dev/ubench) > $O/${TAG}_ubench.txt 2>&1

@@ -33,7 +33,7 @@ for spec in specs:
     ks = []
     for i in range(5):
         t0 = time.perf_counter()
-        ctx.lee_richards(dx.data_ptr(), dr.data_ptr(), offs, out.data_ptr(), tot.data_ptr(), probe=1.4, n_slices=20)
+        ctx.lee_richards(dx.data_ptr(), dr.data_ptr(), offs, out.data_ptr(), tot.data_ptr(), probe=1.4, n_slices=int(os.environ.get("SLICES", "20")))
         dt = time.perf_counter() - t0
         st = ctx.stats()
         ks.append((st["ms_kernel"], st["ms_total"], dt * 1e3))
