@@ -414,6 +414,13 @@ SASA_D int lr2_med3(int v, int lo, int hi)
     return r;
 #endif
 }
+/* the level of the lane's LDS column that holds component (depth - 2) from below, kept inside the column: level 0 for
+   fewer than two components, the last level beyond the column's end (maxd tells).  The "- 2" is folded into the
+   column's address (one clamp and one shift-add per push or pop) */
+SASA_D Arc2 &lr2_level(Arc2 *stk, int depth, int ds)
+{
+    return (stk - 2 * LR2_LANES)[lr2_med3(depth, 2, ds > 0 ? ds + 1 : 2) * LR2_LANES];
+}
 /* maxd: the largest depth the lane has seen (a tile whose stack column was too short is redone) */
 SASA_D void lr2_union_step(double inf, double sup, Lr2Union &u, Arc2 *stk, int ds, int &maxd)
 {
@@ -422,7 +429,7 @@ SASA_D void lr2_union_step(double inf, double sup, Lr2Union &u, Arc2 *stk, int d
     const double mts = SASA_MIN(u.ts, inf), mte = SASA_MAX(u.te, sup);
     if (fresh) {
         Arc2 t; t.s = u.bs; t.e = u.be;
-        stk[lr2_med3(u.depth - 2, 0, ds > 0 ? ds - 1 : 0) * LR2_LANES] = t;
+        lr2_level(stk, u.depth, ds) = t;
         u.bs = u.ts; u.be = u.te;
     }
     u.ts = fresh ? inf : mts;
@@ -433,7 +440,7 @@ SASA_D void lr2_union_step(double inf, double sup, Lr2Union &u, Arc2 *stk, int d
         u.ts = SASA_MIN(u.ts, u.bs);
         --u.depth;
         if (u.depth >= 2) {
-            const Arc2 lo = stk[lr2_med3(u.depth - 2, 0, ds > 0 ? ds - 1 : 0) * LR2_LANES];
+            const Arc2 lo = lr2_level(stk, u.depth, ds);
             u.bs = lo.s; u.be = lo.e;
         } else {
             u.be = -INFINITY;
@@ -445,7 +452,7 @@ SASA_D void lr2_union_step(double inf, double sup, Lr2Union &u, Arc2 *stk, int d
            two components the store lands in level 0, which is not in use then (it is written again, properly, by
            the push that makes a third component) */
         Arc2 t; t.s = u.bs; t.e = u.be;
-        stk[lr2_med3(u.depth - 2, 0, ds > 0 ? ds - 1 : 0) * LR2_LANES] = t;
+        lr2_level(stk, u.depth, ds) = t;
         u.bs = u.ts; u.be = u.te;
         u.ts = inf; u.te = sup;
         ++u.depth;
@@ -457,7 +464,7 @@ SASA_D void lr2_union_step(double inf, double sup, Lr2Union &u, Arc2 *stk, int d
             u.ts = SASA_MIN(u.ts, u.bs);
             --u.depth;
             if (u.depth >= 2) {
-                const Arc2 lo = stk[lr2_med3(u.depth - 2, 0, ds > 0 ? ds - 1 : 0) * LR2_LANES];
+                const Arc2 lo = lr2_level(stk, u.depth, ds);
                 u.bs = lo.s; u.be = lo.e;
             } else {
                 u.be = -INFINITY;
