@@ -256,7 +256,7 @@ def secondary_workloads(fa, torch, tools, d_xyz, d_r, offs, xyz, r, dev, local_r
     return out
 
 
-def live_counters(args, timeout_s=120):
+def live_counters(args, timeout_s=75):
     """HBM bytes and wave-level VALU instructions per launch of the dominant kernel, measured NOW: one extra run of this
     script (one timed step, synchronous entry, nothing secondary) under rocprofv3 per counter - FETCH_SIZE, WRITE_SIZE
     and SQ_INSTS_VALU in separate --pmc passes, as MI355X_MICROARCH.md prescribes - when rocprofv3 is on PATH.  Values

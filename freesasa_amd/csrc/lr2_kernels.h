@@ -174,7 +174,7 @@ SASA_D int lr2_div3(int v) { return LR2_MUL24(v, 43) >> 7; }  /* v / 3 for 0 <= 
 #ifndef LR2_STOP_AFTER /* dev only (tools/build_variant.sh): return after phase k, for instruction attribution */
 #define LR2_STOP_AFTER 99
 #endif
-#define LR2_STOP(k) do { if (LR2_STOP_AFTER == (k)) return 0; } while (0)
+#define LR2_STOP(k) do { if (LR2_STOP_AFTER == (k)) { lr2_pre_none(pre); return 0; } } while (0) /* (whatever was fetched ahead for the next tile is incomplete: it walks its chain itself) */
 #ifndef LR2_MARK /* dev only (-DSASA_PHASE_TIMING in gpu_engine.hip): wall clock of lane 0 at the phase boundaries */
 #define LR2_MARK(k) do { } while (0)
 #define LR2_MARK_BEGIN do { } while (0)
