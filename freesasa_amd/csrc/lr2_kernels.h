@@ -986,9 +986,10 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             }
         }
         if (lane < TA && (m.acnt[lane] & 1)) { /* padding record: cos(alpha) huge, never an arc */
-            Ab16 rc; rc.a = 0; rc.b = 1e300;
+            int zero = 0; SASA_OPAQUE(zero); /* (made here: as a hoisted 64-bit constant it was kept in scratch) */
+            Ab16 rc; rc.a = (double)zero; rc.b = 1e300;
             m.ab[m.aoff[lane] + m.acnt[lane]] = rc;
-            m.beta[m.aoff[lane] + m.acnt[lane]] = 0;
+            m.beta[m.aoff[lane] + m.acnt[lane]] = rc.a;
         }
     }
     LR2_SYNC();

@@ -1,4 +1,4 @@
-"""Adversarial accuracy of the Lee-Richards path on the GPU (round-3 verdict, item 3): inputs built to sit ON the
+"""Adversarial accuracy of the Lee-Richards path on the GPU: inputs built to sit ON the
 decisions of the reference's slice loop, where a last-bit difference in cos(alpha) flips a branch -
 
 * a neighbor's circle tangent to the atom's circle at a slice plane from outside (dij = Ri' + Rj' +- k ulp: an arc of
@@ -12,10 +12,10 @@ decisions of the reference's slice loop, where a last-bit difference in cos(alph
 each against the real reference (oracle/_ref) when it is there, else the oracle.  What is asserted, and what the MI355X
 gave in round 4 (pytest -s prints the maxima):
 
-    family                                              asserted     measured
-    ordinary inputs, any coordinates / radii / slices   1e-6 A^2     < 3e-9
-    circles tangent to k ulp, atom at the origin        1e-6         ~3e-7   (an arc of width sqrt(2 eps) exists or not)
-    circles tangent to k ulp, coordinates ~5e3, ~1.6e4  1e-4         4e-6, 2e-5  (plane drift 1e-11 A -> sqrt -> 1e-5 rad)
+    family                                              asserted     measured (profiles/r04_adversarial.txt)
+    ordinary inputs, any coordinates / radii / slices   1e-6 A^2     3.2e-9 (shifted by 1e4 A), < 5e-11 otherwise
+    circles tangent to k ulp, atom at the origin        1e-6         1.7e-7  (an arc of width sqrt(2 eps) exists or not)
+    circles tangent to k ulp, coordinates ~5e3, ~1.6e4  1e-4         2.4e-5, 2.9e-5  (plane drift 1e-11 A -> sqrt -> 1e-5 rad)
 
 north_star's contract is 1e-4 A^2 per atom everywhere.  One kind of input is NOT held to the reference's value at the
 same input: circles tangent to the last few bits.  The reference's three comparisons (:324-333) and its acos argument
