@@ -529,7 +529,8 @@ __global__ __launch_bounds__(B) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) v
 
 /* Second-generation L&R kernel (lr2_kernels.h): one wave per tile.  RMAX = rounds of pair records a
  * lane keeps in registers (2-4: main launch, by the pool; 6: second launch); WPE = waves per SIMD the register
- * allocation is capped for. */
+ * allocation is capped for; TIER: 0 main launch, 2 second launch, 4 the main launch of the neighbor test hooks
+ * (freesasa_gpu_lr_neighbors_dev: the only build that carries their code). */
 /* NOTE: Lr2Args must stay the ONLY parameter of this kernel, at offset 0 of the kernel-argument segment: the tile
  * body reads its rarely used fields from there (LR2_COLD in lr2_kernels.h). */
 template <int RMAX, int TIER, int WPE, bool COVER, bool PAIRS = false, int SHAPE = 0>
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     PIPE_GATE(a.status);
     Lr2Mem m = lr2_carve<SHAPE>(a, smem);
     int wg_max_nn = 0;
-    lr2_wave<RMAX, COVER, PAIRS, SHAPE>(a, m, blockIdx.x, gridDim.x, lane, wg_max_nn);
+    lr2_wave<RMAX, COVER, PAIRS, SHAPE, (TIER & 4) != 0>(a, m, blockIdx.x, gridDim.x, lane, wg_max_nn);
     if (lane == 0 && wg_max_nn > a.status[ST_MAX_NN]) atomicMax(&a.status[ST_MAX_NN], wg_max_nn);
 }
 __global__ __launch_bounds__(64) void k_lr2_arc_kat(const double *arcs, const int *first, int n_sets, double *out)
@@ -556,7 +557,8 @@ static hipError_t launch_lr2_main(int rmax, int grid, size_t lds, hipStream_t st
 {
     /* (the cover filter is compiled into the launches over dense batches only: the sparse ones keep its registers) */
 #define LR2_LAUNCH(R) do { \
-        if (lr2_pairs_shape(la.TA, la.ns)) { \
+        if (la.hooks) hipLaunchKernelGGL((k_lr2_tile<R, 4, 4, false>), dim3(grid), dim3(64), lds, st, la); \
+        else if (lr2_pairs_shape(la.TA, la.ns)) { \
             if (la.cover > 0) hipLaunchKernelGGL((k_lr2_tile<R, 0, 4, true, true>), dim3(grid), dim3(64), lds, st, la); \
             else if (lr2_default_shape(la.TA, la.ns, la.mw, la.ds) && !getenv("FREESASA_AMD_NO_SHAPE")) hipLaunchKernelGGL((k_lr2_tile<R, 0, 4, false, true, 1>), dim3(grid), dim3(64), lds, st, la); \
             else hipLaunchKernelGGL((k_lr2_tile<R, 0, 4, false, true>), dim3(grid), dim3(64), lds, st, la); \

@@ -50,6 +50,7 @@ long long wave_exchange(long long v, int src);
 #define LR2_UNIFORM(v) (v)
 #define LR2_READLANE(v, src) LR2_SHFL((v), (src))
 #define LR2_MUL24(a, b) ((int)(a) * (int)(b))
+#define LR2_UMUL24(a, b) ((unsigned)(a) * (unsigned)(b))
 #define LR2_RCPF(x) (1.0f / (x))
 #define LR2_RSQF(x) (1.0f / sqrtf(x))
 #define LR2_ADD64_LDS(p, v) (*(p) += (v))
@@ -81,6 +82,7 @@ namespace sasa_emu { extern long long lr2_count[16]; } /* wave-level trip counts
 /* index arithmetic on small non-negative numbers: v_mul_u32_u24 runs at full rate, the 32-bit v_mul_lo_u32 /
    v_mul_hi at a quarter of it (what the compiler emits when it cannot see that an index is small) */
 #define LR2_MUL24(a, b) ((int)__umul24((unsigned)(a), (unsigned)(b)))
+#define LR2_UMUL24(a, b) __umul24((unsigned)(a), (unsigned)(b)) /* (the product's low 32 bits, unsigned) */
 #define LR2_RCPF(x) __builtin_amdgcn_rcpf(x)
 #define LR2_RSQF(x) __builtin_amdgcn_rsqf(x)
 #define LR2_ADD64_LDS(p, v) atomicAdd((p), (v))
@@ -689,7 +691,7 @@ SASA_D void lr2_pre_c(const Lr2Args &a, Lr2Pre &pre, int na, int lane)
    neighbors of an atom with equal sort keys (nothing stored; see lr2_tie12): once more with tie_by_place */
 /* pre: what P0 loads, possibly fetched ahead by the previous call; (p0n, nan): the tile this wave does next (its
    own again when there is none), fetched ahead by this call */
-template <int RMAX, bool COVER, bool PAIRS, int SHAPE>
+template <int RMAX, bool COVER, bool PAIRS, int SHAPE, bool HOOKS>
 SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool sample, bool tie_by_place, int lane_of_wave, int &wg_max_nn,
                     Lr2Pre &pre, int p0n, int nan)
 {
@@ -737,7 +739,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             const int gs = (above ? la + 1 + __builtin_ctz(above) : na) - la, hc = lr2_div3(gs + LR2_P1_G - 1);
             lo = pre.s0;
             my_cnt = LR2_MUL24(pre.s1 - pre.s0, hc); /* P1's work items of the row: (candidate, up to LR2_P1_G atoms of the group) */
-            info = la | (gs << 4) | (hc << 8);
+            info = la | (gs << 4) | (hc << 8) | ((hc == 1 ? 0x20000 : (hc == 2 ? 0x10000 : 0xaaab)) << 10); /* (bits 10..27: 2^17 / hc, rounded up) */
         }
     }
     lr2_pre_none(pre); /* (consumed: nothing of it lives through the tile) */
@@ -775,21 +777,22 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             int q[LR2_NB_UNROLL], la0[LR2_NB_UNROLL], two[LR2_NB_UNROLL];
             double x[LR2_NB_UNROLL], y[LR2_NB_UNROLL], z[LR2_NB_UNROLL], rq[LR2_NB_UNROLL];
             for (int j = 0; j < LR2_NB_UNROLL; ++j) {
+                /* no branch but the one around the row table's reads: an item that does not exist (the lane's run is
+                   over) decodes to something harmless and is switched off by selects */
                 const int fj = f + base + j;
-                q[j] = -1; la0[j] = 0; two[j] = 0;
-                if (base + j < per && fj < fend) {
-                    if (fj >= c_hi) { /* on to the next row (every row in the table has items) */
-                        ++t;
-                        c_lo = c_hi; c_hi = m.cpre[t + 1]; rl = m.rowlo[t]; ri_ = m.rinfo[t];
-                    }
-                    const int lead = ri_ & 15, gs = (ri_ >> 4) & 15, hc = ri_ >> 8;
-                    const unsigned i = (unsigned)(fj - c_lo);
-                    const unsigned c = hc == 1 ? i : (hc == 2 ? i >> 1 : (unsigned)LR2_MUL24(i, 0xaaabu) >> 17); /* i / hc, hc <= 3 (gs <= 7); i < 2^15 */
-                    const int h = (int)i - LR2_MUL24(c, hc);
-                    q[j] = rl + (int)c;
-                    la0[j] = lead + LR2_P1_G * h;
-                    two[j] = gs - LR2_P1_G * h < LR2_P1_G ? gs - LR2_P1_G * h : LR2_P1_G; /* atoms of this item */
+                const bool live = fj < fend; /* (fend <= f + per) */
+                if (live && fj >= c_hi) { /* on to the next row (every row in the table has items) */
+                    ++t;
+                    c_lo = c_hi; c_hi = m.cpre[t + 1]; rl = m.rowlo[t]; ri_ = m.rinfo[t];
                 }
+                const int lead = ri_ & 15, gs = (ri_ >> 4) & 15, hc = (ri_ >> 8) & 3;
+                const unsigned i = (unsigned)(fj - c_lo) & 0x7fffu;
+                const unsigned c = LR2_UMUL24(i, (unsigned)ri_ >> 10) >> 17; /* i / hc (hc <= 3: gs <= 7; i < 2^15) */
+                const int h = (int)i - LR2_MUL24(c, hc);
+                const int left = gs - LR2_P1_G * h; /* atoms of this item */
+                q[j] = live ? rl + (int)c : -1;
+                la0[j] = live ? lead + LR2_P1_G * h : 0;
+                two[j] = live ? (left < LR2_P1_G ? left : LR2_P1_G) : 0;
             }
             for (int j = 0; j < LR2_NB_UNROLL; ++j) {
                 const unsigned u = (unsigned)(q[j] < 0 ? 0 : q[j]);
@@ -804,8 +807,8 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                     /* the reference's contact test, operand for operand (src/nb.c:483-492) */
                     const double cut2 = (ai[j].w + rq[j]) * (ai[j].w + rq[j]);
                     dx[j] = x[j] - ai[j].x; dy[j] = y[j] - ai[j].y; dz[j] = z[j] - ai[j].z;
-                    hit[j] = q[j] >= 0 && g < two[j] && q[j] != p0 + la0[j] + g &&
-                             dx[j] * dx[j] + dy[j] * dy[j] + dz[j] * dz[j] < cut2;
+                    const double d2 = dx[j] * dx[j] + dy[j] * dy[j] + dz[j] * dz[j];
+                    hit[j] = (g < two[j]) & (q[j] != p0 + la0[j] + g) & (d2 < cut2); /* (two > 0 only for q >= 0; every lane computes: no branch around ten instructions) */
                 }
                 for (int j = 0; j < LR2_NB_UNROLL; ++j) {
                     const unsigned long long hm = LR2_BALLOT(hit[j]);
@@ -818,7 +821,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                         m.tag[slot] = (unsigned char)la;
                         /* the atom's count only: nothing here waits for the counter's old value (the hit's place in its
                            atom's list is handed out in P3, two round trips per tile instead of one per group of tests) */
-                        if (!(a.hooks & 2)) { /* (uniform) */
+                        if (!(HOOKS && (a.hooks & 2))) { /* (uniform; HOOKS: the build the neighbor hooks are launched with - the others carry none of this) */
                             LR2_INC_LDS(&m.acnt[la]);
                         } else { /* test hook: the neighbor lists themselves */
                             const int sa = SASA_ATOMIC_ADD_LDS(&m.acnt[la], 1);
@@ -835,7 +838,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
 
     LR2_STOP(1);
     LR2_MARK(1);
-    if (a.hooks & 1) { /* (uniform) test hook: the neighbor counts are the result */
+    if (HOOKS && (a.hooks & 1)) { /* (uniform) test hook: the neighbor counts are the result */
         if (lane < na) LR2_COLD(a, nn_out)[m.sorig[lane]] = m.acnt[lane];
         LR2_SYNC();
         return 0;
@@ -1315,7 +1318,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
 /* The work items of one wave (items first, first + stride, ... of the launch).  A tile that does not fit is redone
  * at once as two halves (1.5 % of the 6-atom tiles of random coils at a pool of 224 records); what still does not fit
  * goes to the next launch's list. */
-template <int RMAX, bool COVER, bool PAIRS, int SHAPE = 0>
+template <int RMAX, bool COVER, bool PAIRS, int SHAPE = 0, bool HOOKS = false>
 SASA_D void lr2_wave(const Lr2Args &a, const Lr2Mem &m, int first, int stride, int lane, int &wg_max_nn)
 {
     /* all tiles (main launch, rounded up to whole XCD groups) or the items of a work list */
@@ -1352,7 +1355,7 @@ SASA_D void lr2_wave(const Lr2Args &a, const Lr2Mem &m, int first, int stride, i
         for (;;) {
             /* (what comes next: the second half of a split tile, else the wave's next tile) */
             const bool nxt = rest_n > 0 || nan > 0;
-            int fail = lr2_tile<RMAX, COVER, PAIRS, SHAPE>(a, m, p0, na, sample, by_place, lane, wg_max_nn, pre,
+            int fail = lr2_tile<RMAX, COVER, PAIRS, SHAPE, HOOKS>(a, m, p0, na, sample, by_place, lane, wg_max_nn, pre,
                                              rest_n > 0 ? rest0 : (nxt ? p0n : p0), rest_n > 0 ? rest_n : (nxt ? nan : na));
             sample = false;
             if (fail == 2) { /* equal sort keys: once more, ties by place of discovery */
