@@ -47,6 +47,7 @@ long long wave_exchange(long long v, int src);
 #define LR2_POPC32(m) __builtin_popcount(m)
 #define LR2_RANK(m, lane) __builtin_popcountll((m) & ((1ull << (lane)) - 1ull))
 #define LR2_SHIFT_IN_LT1(w, c) (((w) << 1) | ((c) < 1.0 ? 1u : 0u))
+#define LR2_SHIFT_IN_LT(w, v, lim) (((w) << 1) | ((v) < (lim) ? 1u : 0u))
 #define LR2_UNIFORM(v) (v)
 #define LR2_READLANE(v, src) LR2_SHFL((v), (src))
 #define LR2_MUL24(a, b) ((int)(a) * (int)(b))
@@ -75,6 +76,7 @@ namespace sasa_emu { extern long long lr2_count[16]; } /* wave-level trip counts
 #define LR2_POPC32(m) __popc(m)
 #define LR2_RANK(m, lane) ((int)__builtin_amdgcn_mbcnt_hi((unsigned)((m) >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)(m), 0u)))
 #define LR2_SHIFT_IN_LT1(w, c) sasa_shift_in_lt1((w), (c))
+#define LR2_SHIFT_IN_LT(w, v, lim) sasa_shift_in_lt((w), (v), (lim))
 /* a value every lane of the wave holds alike, moved to a scalar register: loops and branches on it become scalar
    control flow instead of exec-mask bookkeeping (the compiler cannot see that an LDS read or a shuffle is uniform) */
 #define LR2_UNIFORM(v) __builtin_amdgcn_readfirstlane(v)
@@ -191,6 +193,18 @@ SASA_D int lr2_div3(int v) { return LR2_MUL24(v, 43) >> 7; }  /* v / 3 for 0 <= 
 #else
 #define LR2_H2(x, h) do { double g_; sqrt_rh((x), g_, (h)); } while (0)
 #endif
+/* The screening's limit for v = b' + a' t (lr2_record): a neighbor cuts an arc when |v| h < 1, h = 1/(2 Ri') as LR2_H2
+   made it.  Comparing v with T = (1 - 2^-49) / h spares the product per (neighbor, slice); T from 4 A h (= 1/h up to
+   h's own 4e-15) and one Newton step (T h = 1 to 2^-52), so |v| < T guarantees |v| h < 1 - 2^-50: the arc pass never
+   takes the root of a negative number (lr2_arc_alpha), and the two passes agree on what an arc is because both read
+   the mask.  Against the exact rule (|v| / (2 Ri') < 1) a decision can differ only where cos(alpha) is within 2e-15 of
+   +-1: an arc of half-width < 6e-8 rad, or one that leaves that much of its circle (tests/test_adversarial.py). */
+SASA_D double lr2_arc_limit(double A, double h)
+{
+    const double T0 = (4.0 * A) * h;
+    const double T1 = fma(T0, fma(-T0, h, 1.0), T0);
+    return T1 * (1.0 - 0x1p-49);
+}
 #define LR2_LANES 64
 /* The tile shape of the library's default parameters on sparse input - 6 atoms x 20 slices, two mask words, two
    spilled stack levels (what lr2_choose_cfg gives coils and most proteins at 20 slices) - has a build of its own in
@@ -1066,8 +1080,9 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             double h0, h1;
             LR2_H2(circ0 ? A0 : 1.0, h0); /* 1/(2 Ri') */
             LR2_H2(circ1 ? A1 : 1.0, h1);
+            const double T0 = lr2_arc_limit(circ0 ? A0 : 1.0, h0), T1 = lr2_arc_limit(circ1 ? A1 : 1.0, h1);
             const int o = m.aoff[la], nn = m.aoff[la + 1] - o;
-            double cmin0 = 1.0, cmin1 = 1.0;
+            double vmin0 = 0.0, vmin1 = 0.0; /* least b' + a' t of the slice: at or below -T the circle lies inside a neighbor's */
             int cnt0 = 0, cnt1 = 0;
             for (int wi = 0; wi < mwt; ++wi) {
                 unsigned w0 = 0, w1 = 0;
@@ -1076,24 +1091,24 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                 int k = k1 - 2; /* from the end: neighbor k lands on bit k */
                 if (k1 > 0 && (k1 & 2)) {
                     const Ab16 ra = R[k], rb = R[k + 1];
-                    const double c0 = fma(t0, ra.a, ra.b) * h0, c1 = fma(t0, rb.a, rb.b) * h0;
-                    const double d0 = fma(t1, ra.a, ra.b) * h1, d1 = fma(t1, rb.a, rb.b) * h1;
-                    cmin0 = SASA_MIN(cmin0, SASA_MIN(c0, c1));
-                    cmin1 = SASA_MIN(cmin1, SASA_MIN(d0, d1));
-                    w0 = LR2_SHIFT_IN_LT1(w0, c1); w0 = LR2_SHIFT_IN_LT1(w0, c0);
-                    w1 = LR2_SHIFT_IN_LT1(w1, d1); w1 = LR2_SHIFT_IN_LT1(w1, d0);
+                    const double c0 = fma(t0, ra.a, ra.b), c1 = fma(t0, rb.a, rb.b);
+                    const double d0 = fma(t1, ra.a, ra.b), d1 = fma(t1, rb.a, rb.b);
+                    vmin0 = SASA_MIN(vmin0, SASA_MIN(c0, c1));
+                    vmin1 = SASA_MIN(vmin1, SASA_MIN(d0, d1));
+                    w0 = LR2_SHIFT_IN_LT(w0, c1, T0); w0 = LR2_SHIFT_IN_LT(w0, c0, T0);
+                    w1 = LR2_SHIFT_IN_LT(w1, d1, T1); w1 = LR2_SHIFT_IN_LT(w1, d0, T1);
                     k -= 2;
                 }
                 for (; k >= 0; k -= 4) { /* four records per trip: their LDS reads are in flight together */
                     const Ab16 r2 = R[k], r3 = R[k + 1], r0 = R[k - 2], r1 = R[k - 1];
-                    const double c2 = fma(t0, r2.a, r2.b) * h0, c3 = fma(t0, r3.a, r3.b) * h0;
-                    const double c0 = fma(t0, r0.a, r0.b) * h0, c1 = fma(t0, r1.a, r1.b) * h0;
-                    const double d2 = fma(t1, r2.a, r2.b) * h1, d3 = fma(t1, r3.a, r3.b) * h1;
-                    const double d0 = fma(t1, r0.a, r0.b) * h1, d1 = fma(t1, r1.a, r1.b) * h1;
-                    cmin0 = SASA_MIN(SASA_MIN(cmin0, c0), SASA_MIN(c1, SASA_MIN(c2, c3)));
-                    cmin1 = SASA_MIN(SASA_MIN(cmin1, d0), SASA_MIN(d1, SASA_MIN(d2, d3)));
-                    w0 = LR2_SHIFT_IN_LT1(w0, c3); w0 = LR2_SHIFT_IN_LT1(w0, c2); w0 = LR2_SHIFT_IN_LT1(w0, c1); w0 = LR2_SHIFT_IN_LT1(w0, c0);
-                    w1 = LR2_SHIFT_IN_LT1(w1, d3); w1 = LR2_SHIFT_IN_LT1(w1, d2); w1 = LR2_SHIFT_IN_LT1(w1, d1); w1 = LR2_SHIFT_IN_LT1(w1, d0);
+                    const double c2 = fma(t0, r2.a, r2.b), c3 = fma(t0, r3.a, r3.b);
+                    const double c0 = fma(t0, r0.a, r0.b), c1 = fma(t0, r1.a, r1.b);
+                    const double d2 = fma(t1, r2.a, r2.b), d3 = fma(t1, r3.a, r3.b);
+                    const double d0 = fma(t1, r0.a, r0.b), d1 = fma(t1, r1.a, r1.b);
+                    vmin0 = SASA_MIN(SASA_MIN(vmin0, c0), SASA_MIN(c1, SASA_MIN(c2, c3)));
+                    vmin1 = SASA_MIN(SASA_MIN(vmin1, d0), SASA_MIN(d1, SASA_MIN(d2, d3)));
+                    w0 = LR2_SHIFT_IN_LT(w0, c3, T0); w0 = LR2_SHIFT_IN_LT(w0, c2, T0); w0 = LR2_SHIFT_IN_LT(w0, c1, T0); w0 = LR2_SHIFT_IN_LT(w0, c0, T0);
+                    w1 = LR2_SHIFT_IN_LT(w1, d3, T1); w1 = LR2_SHIFT_IN_LT(w1, d2, T1); w1 = LR2_SHIFT_IN_LT(w1, d1, T1); w1 = LR2_SHIFT_IN_LT(w1, d0, T1);
                 }
                 m.it_mask[LR2_MUL24(it0, mw) + wi] = w0;
                 cnt0 += LR2_POPC32(w0);
@@ -1102,8 +1117,8 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                     cnt1 += LR2_POPC32(w1);
                 }
             }
-            finish_item(it0, la, t0, circ0 ? h0 : 0.0, Ri, o, cnt0, cmin0 <= -1.0, circ0);
-            if (second) finish_item(it0 + 1, la, t1, circ1 ? h1 : 0.0, Ri, o, cnt1, cmin1 <= -1.0, circ1);
+            finish_item(it0, la, t0, circ0 ? h0 : 0.0, Ri, o, cnt0, vmin0 <= -T0, circ0);
+            if (second) finish_item(it0 + 1, la, t1, circ1 ? h1 : 0.0, Ri, o, cnt1, vmin1 <= -T1, circ1);
         }
     } else
     for (int it = lane; it < items; it += LR2_LANES) {
@@ -1116,35 +1131,36 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         bool buried = false;
         if (A > 0) { /* ref: :310-312 */
             LR2_H2(A, h2); /* h2 = 1/(2 Ri') */
+            const double T = lr2_arc_limit(A, h2);
             o = m.aoff[la];
             const int nn = m.aoff[la + 1] - o;
-            double cmin = 1.0;
+            double vmin = 0.0;
             for (int wi = 0; wi < mwt; ++wi) {
                 unsigned w = 0;
                 const int k1 = nn - 32 * wi < 32 ? nn - 32 * wi : 32;
                 const Ab16 *R = m.ab + (o + 32 * wi);
                 int k = k1 - 2; /* from the end: neighbor k lands on bit k */
                 if (k1 > 0 && (k1 & 2)) {
-                    const double c0 = fma(t, R[k].a, R[k].b) * h2, c1 = fma(t, R[k + 1].a, R[k + 1].b) * h2;
-                    cmin = SASA_MIN(cmin, c0);
-                    cmin = SASA_MIN(cmin, c1);
-                    w = LR2_SHIFT_IN_LT1(w, c1);
-                    w = LR2_SHIFT_IN_LT1(w, c0);
+                    const double c0 = fma(t, R[k].a, R[k].b), c1 = fma(t, R[k + 1].a, R[k + 1].b);
+                    vmin = SASA_MIN(vmin, c0);
+                    vmin = SASA_MIN(vmin, c1);
+                    w = LR2_SHIFT_IN_LT(w, c1, T);
+                    w = LR2_SHIFT_IN_LT(w, c0, T);
                     k -= 2;
                 }
                 for (; k >= 0; k -= 4) { /* four records per trip: their LDS reads are in flight together */
-                    const double c2 = fma(t, R[k].a, R[k].b) * h2, c3 = fma(t, R[k + 1].a, R[k + 1].b) * h2;
-                    const double c0 = fma(t, R[k - 2].a, R[k - 2].b) * h2, c1 = fma(t, R[k - 1].a, R[k - 1].b) * h2;
-                    cmin = SASA_MIN(SASA_MIN(cmin, c0), SASA_MIN(c1, SASA_MIN(c2, c3)));
-                    w = LR2_SHIFT_IN_LT1(w, c3);
-                    w = LR2_SHIFT_IN_LT1(w, c2);
-                    w = LR2_SHIFT_IN_LT1(w, c1);
-                    w = LR2_SHIFT_IN_LT1(w, c0);
+                    const double c2 = fma(t, R[k].a, R[k].b), c3 = fma(t, R[k + 1].a, R[k + 1].b);
+                    const double c0 = fma(t, R[k - 2].a, R[k - 2].b), c1 = fma(t, R[k - 1].a, R[k - 1].b);
+                    vmin = SASA_MIN(SASA_MIN(vmin, c0), SASA_MIN(c1, SASA_MIN(c2, c3)));
+                    w = LR2_SHIFT_IN_LT(w, c3, T);
+                    w = LR2_SHIFT_IN_LT(w, c2, T);
+                    w = LR2_SHIFT_IN_LT(w, c1, T);
+                    w = LR2_SHIFT_IN_LT(w, c0, T);
                 }
                 m.it_mask[LR2_MUL24(it, mw) + wi] = w;
                 cnt += LR2_POPC32(w);
             }
-            buried = cmin <= -1.0;
+            buried = vmin <= -T;
         }
         finish_item(it, la, t, h2, Ri, o, cnt, buried, A > 0);
     }

@@ -101,6 +101,13 @@ __device__ __forceinline__ unsigned sasa_shift_in_lt1(unsigned w, double c)
     return r;
 }
 #define SASA_SHIFT_IN_LT1(w, c) sasa_shift_in_lt1((w), (c))
+/* (w << 1) | (v < lim) */
+__device__ __forceinline__ unsigned sasa_shift_in_lt(unsigned w, double v, double lim)
+{
+    unsigned r;
+    asm("v_cmp_gt_f64 vcc, %3, %1\n\tv_addc_co_u32 %0, vcc, %2, %2, vcc" : "=v"(r) : "v"(v), "v"(w), "v"(lim) : "vcc");
+    return r;
+}
 /* keeps a constant in a VGPR the optimizer cannot fold */
 #define SASA_OPAQUE(v) asm("" : "+v"(v))
 #endif
