@@ -387,8 +387,8 @@ SASA_D Lr2Mem lr2_carve(const Lr2Args &a, char *smem)
 SASA_D void lr2_record(double xd, double yd, double zd, double rj, double ri, double &ap, double &bp, double &Kout, double &d3sq, double &inv_d)
 {
     const double D = xd * xd + yd * yd; /* ref: src/nb.c:438 */
-    double g = 0, h = 0;
-    if (D > 0) sqrt_rh(D, g, h);
+    double h;
+    LR2_H2(D, h); /* 1/(2 dij) to 4e-15, as the slices' 1/(2 Ri'); every lane computes (D == 0: not a number, replaced below) */
     const double inv = D > 0 ? 2.0 * h : 0x1p500; /* 1/dij */
     inv_d = D > 0 ? inv : 0.0;
     d3sq = D + zd * zd;

@@ -1012,7 +1012,7 @@ SASA_D double atan2_inv(double y, double x, double inv)
     const double ax = fabs(x), ay = fabs(y);
     const bool swap = ay > ax;
     const double mx = swap ? ay : ax, mn = swap ? ax : ay;
-    if (!(mx > 0)) return 0.0;
+    /* (x = y = 0 comes with inv = 0: s = 0 and every select below leaves 0, as atan2(0, 0) - no branch for it) */
     const bool red = mn > 0x1.a827999fcef32p-2 * mx; /* tan(pi/8) */
     const double num = red ? mn - mx : mn;
     const double k = red ? inv * 0x1.6a09e667f3bcdp-1 : inv; /* 1/sqrt 2 */
