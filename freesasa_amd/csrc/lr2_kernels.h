@@ -663,6 +663,7 @@ SASA_D void lr2_pre_b(const Lr2Args &a, Lr2Pre &pre, int na, int lane)
     if (nx == 0) { /* (rare) a grid of 8192 cells or more along x or y: two more links */
         const GridS *const g = LR2_COLD(a, grid) + LR2_COLD(a, s_idx)[pre.p0 + (la < na ? la : na - 1)].strct;
         nx = g->nx; ny = g->ny;
+        SASA_OPAQUE(nx); SASA_OPAQUE(ny); /* (waited for HERE: left in flight, these two loads make the compiler wait for every load - the ones below included - where the registers are next written, in the middle of P5) */
     }
     const int dz = lr2_div3(r < 9 ? r : 0) - 1, dy = (r < 9 ? r : 0) - 3 * (dz + 1) - 1; /* (lanes 9 TA .. 63 belong to no row) */
     const bool out = (dy < 0 && (fl & CELL_Y0)) || (dy > 0 && (fl & CELL_Y1)) ||
