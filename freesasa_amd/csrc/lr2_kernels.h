@@ -537,6 +537,9 @@ SASA_D double lr2_arc_kat(const double *arcs, const int *first, int k, Arc2 *stk
 }
 
 #ifndef LR2_NB_UNROLL
+#ifndef LR2_ARC_STEPS
+#define LR2_ARC_STEPS 2 /* arc steps between two looks at how many lanes wait for a refill */
+#endif
 #define LR2_NB_UNROLL 3 /* candidates a lane has in flight per round of P1 (coils: three rounds per tile = one trip; measured 1 / 2 / 3: 3.59 / 3.63 / 3.58 ms per 3e6 atoms) */
 #endif
 #define LR2_P1_G 3 /* atoms of a cell group one work item of P1 tests its candidate against */
@@ -1290,6 +1293,15 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                     const double alpha = lr2_arc_alpha(t, ab, hh);
                     lr2_union_step(bt - alpha, bt + alpha, u, stk, LR2_A_DS(a), maxd); /* ref: :338-339 */
                 }
+                for (int more = 1; more < LR2_ARC_STEPS; ++more) /* further steps before the waiting lanes are counted again */
+                    if (w != 0) {
+                        const int q = __builtin_ctz(w);
+                        w &= w - 1;
+                        const Ab16 ab = Rab[q];
+                        const double bt = Rbt[q];
+                        const double alpha = lr2_arc_alpha(t, ab, hh);
+                        lr2_union_step(bt - alpha, bt + alpha, u, stk, LR2_A_DS(a), maxd);
+                    }
             }
             /* refill: a lane that has used up its mask word moves on to the item's next word or, when the item
                is finished, stores its area and takes the next item of the queue */
