@@ -1181,6 +1181,17 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         nq = LR2_READLANE(incl2, LR2_LANES - 1);
         m.hist[lane] = incl2 - hv; /* first queue position of the bin */
         LR2_SYNC();
+        if (items <= 2 * LR2_LANES) { /* (uniform; the default shape: 120) both rounds' reads in flight together: two LDS round trips, not four */
+            const int it1 = lane + LR2_LANES;
+            const unsigned q0 = m.qtmp[lane < items ? lane : 0], q1 = m.qtmp[it1 < items ? it1 : 0];
+            const bool on0 = lane < items && q0 != 0xffffu, on1 = it1 < items && q1 != 0xffffu;
+            const int h0 = m.hist[on0 ? q0 >> 10 : 0], h1 = m.hist[on1 ? q1 >> 10 : 0];
+            int la0 = (int)(((float)lane + 0.5f) * inv_ns), la1 = (int)(((float)it1 + 0.5f) * inv_ns);
+            { const int s = lane - LR2_MUL24(la0, ns); if (s < 0) --la0; else if (s >= ns) ++la0; }
+            { const int s = it1 - LR2_MUL24(la1, ns); if (s < 0) --la1; else if (s >= ns) ++la1; }
+            if (on0) m.queue[h0 + (q0 & 1023u)] = (unsigned short)(lane | (la0 << 10));
+            if (on1) m.queue[h1 + (q1 & 1023u)] = (unsigned short)(it1 | (la1 << 10));
+        } else
         for (int it = lane; it < items; it += LR2_LANES) {
             const unsigned qt = m.qtmp[it];
             int la = (int)(((float)it + 0.5f) * inv_ns);
@@ -1330,7 +1341,12 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         double s = 0;
         const double *const tc = m.it_tc + LR2_MUL24(lane, ns);
         int k = 0;
-        for (; k + 4 <= ns; k += 4) { /* slice order, ref: :305-361; four reads in flight (one LDS round trip per four slices, not per slice) */
+        for (; k + 10 <= ns; k += 10) { /* slice order, ref: :305-361; ten reads in flight (20 slices: two LDS round trips) */
+            const double v0 = tc[k], v1 = tc[k + 1], v2 = tc[k + 2], v3 = tc[k + 3], v4 = tc[k + 4];
+            const double v5 = tc[k + 5], v6 = tc[k + 6], v7 = tc[k + 7], v8 = tc[k + 8], v9 = tc[k + 9];
+            s += v0; s += v1; s += v2; s += v3; s += v4; s += v5; s += v6; s += v7; s += v8; s += v9;
+        }
+        for (; k + 4 <= ns; k += 4) { /* four reads in flight */
             const double v0 = tc[k], v1 = tc[k + 1], v2 = tc[k + 2], v3 = tc[k + 3];
             s += v0; s += v1; s += v2; s += v3;
         }
