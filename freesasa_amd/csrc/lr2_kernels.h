@@ -627,7 +627,7 @@ SASA_D double lr2_acos_lower(double c)
  * the cells at both ends of each of its 9 candidate rows.  Until round 3 every tile began by waiting for those round
  * trips (P0: 9 % of a wave's life for 3 % of its instructions).  Now the chain of tile k+1 is walked while tile k
  * computes: stage A (sort records) is issued before tile k is screened, stage B (cell table) before its queue is built,
- * stages B2 (compact cell table: first atoms of the cells) and C (the tile's own atoms) before its areas are summed,
+ * stages B2 (compact cell table: first atoms of the cells) and C (the tile's own atoms) before its arcs are united,
  * and P0 of tile k+1 finds the values in its registers.  nx and ny of the
  * structure's grid ride in the sort record's flag word (cell_pack_grid), so the common chain has two links, not three.
  * A tile that was not announced (the first of a wave, halves of a split tile) walks the chain on the spot, as before. */
@@ -1203,6 +1203,8 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
 
     LR2_STOP(5);
     LR2_MARK(5);
+    lr2_pre_b2<SHAPE>(a, pre);           /* the next tile's candidate rows (compact cell table: the last link) and its atoms: on their way while this tile's arcs are united */
+    lr2_pre_c<SHAPE>(a, pre, nan, lane); /* (until round 4's last session these two went out behind the arc pass and P0 waited for them: -1.5 %) */
     /* ------------------------------------------------------------ P6 arc pass */
     int maxd = 0;
     if (COVER && nq * 2 <= LR2_LANES) {
@@ -1332,8 +1334,6 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     }
     LR2_SYNC();
     LR2_MARK(6);
-    lr2_pre_b2<SHAPE>(a, pre);           /* the next tile's candidate rows (compact cell table: the last link) and its atoms: on their way while this tile's areas are summed */
-    lr2_pre_c<SHAPE>(a, pre, nan, lane);
 
     /* ------------------------------------------------------------ P7 store */
     const bool deep = LR2_BALLOT(maxd - 2 > LR2_A_DS(a)) != 0; /* an arc stack column was too short: the tile is redone */
