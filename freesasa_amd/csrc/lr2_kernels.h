@@ -728,10 +728,11 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     /* ------------------------------------------------------------ P0 load */
     if (pre.p0 != p0) { /* (uniform) not fetched ahead (a tile is announced with its own first atom and count: the halves of a split tile never find the whole tile's values): the chain, one link after the other */
         LR2_COUNT(11, 1);
+        pre.p0 = p0;
+        lr2_pre_c<SHAPE>(a, pre, na, lane); /* (first: it hangs on nothing, and travels with the first link of the chain) */
         lr2_pre_a<SHAPE>(a, pre, p0, na, lane);
         lr2_pre_b<SHAPE>(a, pre, na, lane);
         lr2_pre_b2<SHAPE>(a, pre);
-        lr2_pre_c<SHAPE>(a, pre, na, lane);
     }
     if (lane < TA) {
         Quad q = pre.q;
