@@ -7,7 +7,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-_SO = os.path.join(HERE, "libsasa_emu.so")
+_SO = os.environ.get("SASA_EMU_SO") or os.path.join(HERE, "libsasa_emu.so")  # (SASA_EMU_SO: a variant build, see test_emulation.py)
 _dp, _ip, _lp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int64)
 _lib = None
 
@@ -15,7 +15,8 @@ _lib = None
 def _load():
     global _lib
     if _lib is None:
-        subprocess.run(["make", "-C", ROOT, "emu"], check=True, stdout=subprocess.DEVNULL)
+        if not os.environ.get("SASA_EMU_SO"):
+            subprocess.run(["make", "-C", ROOT, "emu"], check=True, stdout=subprocess.DEVNULL)
         _lib = C.CDLL(_SO)
         _lib.emu_run_batch.argtypes = [C.c_int, _dp, _dp, _lp, C.c_int, C.c_double, C.c_int, _dp,
                                        _dp, _ip, _dp, C.POINTER(C.c_longlong)] + [C.c_int] * 9

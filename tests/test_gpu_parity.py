@@ -138,6 +138,29 @@ def test_sparse_batch_outgrows_the_first_cell_table_and_is_redone(fa, oracle_lib
     assert np.array_equal(lr2, lr)
 
 
+def test_many_sparse_structures_size_the_retry_from_the_whole_batch(fa, oracle_lib):
+    """2500 structures, each a dozen atoms spread over ~100 A: about nine times the cells the first table has room for,
+    and far more workgroups than the device runs at once - so most of them start AFTER a sibling has found the table
+    too small.  Every workgroup still counts its cells (round-3 advisor finding: a workgroup that left at the gate did
+    not, and the retry was sized from a fraction of the demand), so ONE retry fits the batch; a fresh context each
+    time, both algorithms, a sample of the structures against the oracle."""
+    rng = np.random.default_rng(2024)
+    n_s, per = 2500, 12
+    xyz = rng.uniform(0, 100, (n_s * per, 3)) + np.repeat(rng.uniform(-500, 500, (n_s, 3)), per, axis=0)
+    r = rng.uniform(1.2, 1.9, n_s * per)
+    offsets = np.arange(n_s + 1, dtype=np.int64) * per
+    lr, _, ltot = fa.calc_batch(xyz, r, offsets, fa.LEE_RICHARDS, 1.4, 20)
+    sr, cnt, _ = fa.calc_batch(xyz, r, offsets, fa.SHRAKE_RUPLEY, 1.4, 100)
+    assert np.all(np.isfinite(lr)) and np.all(np.isfinite(ltot))
+    for k in list(range(0, n_s, 97)) + [n_s - 1]:
+        sl = slice(offsets[k], offsets[k + 1])
+        assert np.max(np.abs(lr[sl] - oracle_lib.lee_richards(xyz[sl], r[sl]))) < LR_TOL
+        ws, wc = oracle_lib.shrake_rupley(xyz[sl], r[sl])
+        assert np.array_equal(cnt[sl], wc) and np.array_equal(sr[sl], ws)
+    lr2, _, _ = fa.calc_batch(xyz, r, offsets, fa.LEE_RICHARDS, 1.4, 20)   # (the pooled context has learnt the size: no retry now; same bits)
+    assert np.array_equal(lr2, lr)
+
+
 def test_ragged_batch_matches_oracle(fa, oracle_lib):
     parts = [tools.coil(1500, 21), tools.globule(777, 22), (np.zeros((0, 3)), np.zeros(0)),
              (np.array([[5.0, 5.0, 5.0]]), np.array([1.7])), tools.coil(33, 23),
