@@ -259,7 +259,7 @@ def test_lr100_batch_config2(fa, oracle_lib):
         assert np.max(np.abs(lr[sl] - oracle_lib.lee_richards(xyz[sl], r[sl], 1.4, 100))) < LR_TOL
 
 
-@pytest.mark.parametrize("n_slices", [30, 40, 60, 200, 256, 300])
+@pytest.mark.parametrize("n_slices", [7, 21, 30, 33, 40, 60, 101, 200, 256, 300])  # (odd counts: an atom's last pair of slices is one slice)
 def test_lr_tile_shapes_across_slice_counts(fa, oracle_lib, n_slices):
     """The launch shape of the L&R kernel follows the slice count (6 ... 1 atoms per tile, 16 tiles per CU, a few %
     of the tiles split in place; above 256 slices the first-generation kernel): every shape against the oracle, on
