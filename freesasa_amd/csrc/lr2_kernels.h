@@ -1095,8 +1095,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
            list twice (round 4: the phase's wave instructions 450 -> ~360 per tile of coils). */
         int ln = lane;
         SASA_OPAQUE(ln); /* (what follows depends on the lane and the launch only: left to itself the compiler computes it once per wave and keeps - then spills - a dozen registers through every phase of every tile) */
-        /* (the default shape has 60 pairs: one trip, known when it is compiled; 100 slices: 150 pairs of 3 atoms, three trips) */
-        for (; ln < LR2_MUL24(na, hp); ln += SHAPE ? (1 << 20) : LR2_LANES) {
+        if (ln < LR2_MUL24(na, hp)) {
             int la = (int)(((float)ln + 0.5f) * LR2_RCPF((float)hp)), j = ln - LR2_MUL24(la, hp);
             if (j < 0) { --la; j += hp; } else if (j >= hp) { ++la; j -= hp; }
             const int sa_ = 2 * j, it0 = LR2_MUL24(la, ns) + sa_;
@@ -1465,9 +1464,9 @@ struct Lr2Cfg {
 #define LR2_RMAX_MID 6
 
 static inline bool lr2_supported(int ns) { return ns >= 1 && ns <= LR2_NS_MAX; }
-/* tile shapes with more (atom, slice) items than the wave has lanes (6 atoms x 20 slices: 120; 3 x 100: 300): the
-   screening gives a lane two neighboring slices of one atom at a time (P4) */
-static inline bool lr2_pairs_shape(int TA, int ns) { return TA * ns > LR2_LANES; }
+/* tile shapes whose (atom, slice) items are more than the wave's lanes but at most two per lane (6 atoms x 20 slices:
+   120): the screening gives every lane two neighboring slices of one atom (P4) */
+static inline bool lr2_pairs_shape(int TA, int ns) { return TA * ns > LR2_LANES && TA * ((ns + 1) / 2) <= LR2_LANES; }
 static inline bool lr2_default_shape(int TA, int ns, int mw, int ds) { return TA == LR2_SHAPE_TA && ns == LR2_SHAPE_NS && mw == LR2_SHAPE_MW && ds == LR2_SHAPE_DS; }
 
 /* nn_hint: neighbor records one atom needs (with its safety margin), 0 = unknown; nn_max_hint: the longest
