@@ -564,6 +564,13 @@ static hipError_t launch_lr2_main(int rmax, int grid, size_t lds, hipStream_t st
             else hipLaunchKernelGGL((k_lr2_tile<R, 0, 4, false, true>), dim3(grid), dim3(64), lds, st, la); \
         } else if (la.cover > 0) hipLaunchKernelGGL((k_lr2_tile<R, 0, 4, true>), dim3(grid), dim3(64), lds, st, la); \
         else hipLaunchKernelGGL((k_lr2_tile<R, 0, 4, false>), dim3(grid), dim3(64), lds, st, la); } while (0)
+    /* shapes 2-4 (lr2_shape_id), each with the pair-record rounds its workload asks for; any other combination: the generic builds below */
+    if (!la.hooks && !getenv("FREESASA_AMD_NO_SHAPE")) {
+        const int sid = lr2_shape_id(la.TA, la.ns, la.mw, la.ds);
+        if (sid == 2 && rmax <= 2 && la.cover == 0) { hipLaunchKernelGGL((k_lr2_tile<2, 0, 4, false, false, 2>), dim3(grid), dim3(64), lds, st, la); return hipGetLastError(); }
+        if (sid == 3 && rmax == 4 && la.cover > 0) { hipLaunchKernelGGL((k_lr2_tile<4, 0, 4, true, false, 3>), dim3(grid), dim3(64), lds, st, la); return hipGetLastError(); }
+        if (sid == 4 && rmax == 4 && la.cover > 0) { hipLaunchKernelGGL((k_lr2_tile<4, 0, 4, true, true, 4>), dim3(grid), dim3(64), lds, st, la); return hipGetLastError(); }
+    }
     if (rmax <= 2) LR2_LAUNCH(2); else if (rmax == 3) LR2_LAUNCH(3); else LR2_LAUNCH(4);
 #undef LR2_LAUNCH
     return hipGetLastError();
@@ -978,6 +985,7 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
     if (ds_env >= 0) cfg.ds = ds_env;
     if (refill_env > 0) cfg.refill = refill_env;
     cfg.lds = lr2_layout(cfg.TA, cfg.ns, cfg.pool, cfg.mw, cfg.ds).total;
+    if (getenv("FREESASA_AMD_SHOW_SHAPE")) fprintf(stderr, "lr2 shape: TA %d ns %d pool %d mw %d ds %d refill %d rmax %d lds %d cover %d\n", cfg.TA, cfg.ns, cfg.pool, cfg.mw, cfg.ds, cfg.refill, cfg.rmax, cfg.lds, c->hint_nn >= 1.35 * LR2_COVER_DENSITY ? 1 : 0); /* (dev aid) */
     const int n_tiles = (n + cfg.TA - 1) / cfg.TA;
     if (ensure(c, c->ovf_tiles, sizeof(long long) * (2 * (size_t)n_tiles + 2)) || ensure(c, c->ovf_atoms, sizeof(int) * ((size_t)n + 8)))
         return -1;

@@ -215,10 +215,18 @@ SASA_D double lr2_arc_limit(double A, double h)
 #define LR2_SHAPE_NS 20
 #define LR2_SHAPE_MW 2
 #define LR2_SHAPE_DS 2
-#define LR2_A_TA(a) (SHAPE ? LR2_SHAPE_TA : (a).TA)
-#define LR2_A_NS(a) (SHAPE ? LR2_SHAPE_NS : (a).ns)
-#define LR2_A_MW(a) (SHAPE ? LR2_SHAPE_MW : (a).mw)
-#define LR2_A_DS(a) (SHAPE ? LR2_SHAPE_DS : (a).ds)
+/* Three more shapes have builds of their own since the end of round 4, when the kernel had become bound by its
+   instruction count alone: 2 = 3 atoms x 100 slices, two mask words (coils at 100 slices: BASELINE
+   configs[2] as written), 3 = 3 x 20 with three mask words (protein density on a lattice), 4 = 4 x 20 with three
+   (the reference's PDB entries); all with two spilled stack levels. */
+SASA_HD constexpr int lr2_shape_ta(int s) { return s == 1 ? LR2_SHAPE_TA : (s == 4 ? 4 : 3); }
+SASA_HD constexpr int lr2_shape_ns(int s) { return s == 2 ? 100 : LR2_SHAPE_NS; }
+SASA_HD constexpr int lr2_shape_mw(int s) { return s <= 2 ? 2 : 3; }
+SASA_HD constexpr int lr2_shape_ds(int s) { return (void)s, LR2_SHAPE_DS; }
+#define LR2_A_TA(a) (SHAPE ? lr2_shape_ta(SHAPE) : (a).TA)
+#define LR2_A_NS(a) (SHAPE ? lr2_shape_ns(SHAPE) : (a).ns)
+#define LR2_A_MW(a) (SHAPE ? lr2_shape_mw(SHAPE) : (a).mw)
+#define LR2_A_DS(a) (SHAPE ? lr2_shape_ds(SHAPE) : (a).ds)
 #define LR2_NONE 0xffff
 
 struct Lr2Args {
@@ -1468,6 +1476,13 @@ static inline bool lr2_supported(int ns) { return ns >= 1 && ns <= LR2_NS_MAX; }
    120): the screening gives every lane two neighboring slices of one atom (P4) */
 static inline bool lr2_pairs_shape(int TA, int ns) { return TA * ns > LR2_LANES && TA * ((ns + 1) / 2) <= LR2_LANES; }
 static inline bool lr2_default_shape(int TA, int ns, int mw, int ds) { return TA == LR2_SHAPE_TA && ns == LR2_SHAPE_NS && mw == LR2_SHAPE_MW && ds == LR2_SHAPE_DS; }
+/* the build (template parameter SHAPE) a tile shape has, 0: none */
+static inline int lr2_shape_id(int TA, int ns, int mw, int ds)
+{
+    for (int s = 1; s <= 4; ++s)
+        if (TA == lr2_shape_ta(s) && ns == lr2_shape_ns(s) && mw == lr2_shape_mw(s) && ds == lr2_shape_ds(s)) return s;
+    return 0;
+}
 
 /* nn_hint: neighbor records one atom needs (with its safety margin), 0 = unknown; nn_max_hint: the longest
  * neighbor list expected (0 = unknown): the masks of an item get ceil(nn_max / 32) words, two at least */
