@@ -837,28 +837,6 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                     const double d2 = dx[j] * dx[j] + dy[j] * dy[j] + dz[j] * dz[j];
                     hit[j] = (g < two[j]) & (q[j] != p0 + la0[j] + g) & (d2 < cut2); /* (two > 0 only for q >= 0; every lane computes: no branch around ten instructions) */
                 }
-                if (COVER) { /* (the builds for dense input, where most rounds have hits for every candidate: -0.5 % on globules, 6 of 8 interleaved runs; sparse builds: no gain, and their registers do not have the room) the three candidates' hits of this atom take their places together: lane by lane, a lane's own in the order of its candidates */
-                    unsigned long long hm[LR2_NB_UNROLL];
-                    int slot = nh;
-                    for (int j = 0; j < LR2_NB_UNROLL; ++j) { hm[j] = LR2_BALLOT(hit[j]); slot += LR2_RANK(hm[j], lane); nh += LR2_POPC64(hm[j]); }
-                    for (int j = 0; j < LR2_NB_UNROLL; ++j) {
-                        if (hit[j]) {
-                            const int la = la0[j] + g;
-                            const int sl = slot < a.pool ? slot : a.pool - 1; /* (a tile with more hits than the pool is redone: P2) */
-                            Quad hq; hq.x = dx[j]; hq.y = dy[j]; hq.z = dz[j]; hq.w = rq[j]; /* ref: src/nb.c:445-448 */
-                            m.hits[sl] = hq;
-                            m.tag[sl] = (unsigned char)la;
-                            if (!(HOOKS && (a.hooks & 2))) {
-                                LR2_INC_LDS(&m.acnt[la]);
-                            } else { /* test hook: the neighbor lists themselves */
-                                const int sa = SASA_ATOMIC_ADD_LDS(&m.acnt[la], 1);
-                                const int cap = LR2_COLD(a, nb_cap);
-                                if (sa < cap) LR2_COLD(a, nb_out)[(size_t)m.sorig[la] * cap + sa] = LR2_COLD(a, s_idx)[q[j]].orig;
-                            }
-                            ++slot;
-                        }
-                    }
-                } else
                 for (int j = 0; j < LR2_NB_UNROLL; ++j) {
                     const unsigned long long hm = LR2_BALLOT(hit[j]);
                     if (hit[j]) {
