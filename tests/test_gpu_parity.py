@@ -309,6 +309,39 @@ def test_lr_results_do_not_depend_on_the_tile_shape(fa, monkeypatch):
         assert np.array_equal(got, ref), (spec, cover, float(np.max(np.abs(got - ref))))
 
 
+def test_shape_builds_give_the_generic_builds_bits(fa, monkeypatch):
+    """The tile shapes with builds of their own (compile-time atoms per tile, slices, mask words, stack levels: coils at 20
+    and at 100 slices, protein density at 3 and at 4 atoms per tile) against the generic builds of the same shapes
+    (FREESASA_AMD_NO_SHAPE): the same arithmetic in the same order, so every bit; FREESASA_AMD_SHOW_SHAPE on, so the log
+    of a failing run says which shapes ran."""
+    import torch
+    from conftest import load_golden
+    dev = torch.device("cuda:0")
+    g = load_golden("1ubq")
+    prot = (g["xyz"].reshape(-1, 3), g["radii"])
+    sets = {"coils, 20 slices": ([tools.coil(5000, 410 + k) for k in range(8)], 20),
+            "coils, 100 slices": ([tools.coil(5000, 420 + k) for k in range(4)], 100),
+            "globules": ([tools.globule(10000, 430 + k) for k in range(3)], 20),
+            "protein copies": ([(prot[0] + 40.0 * k, prot[1]) for k in range(40)], 20)}
+    monkeypatch.setenv("FREESASA_AMD_SHOW_SHAPE", "1")
+    for name, (parts, ns) in sets.items():
+        xyz = np.concatenate([np.asarray(p[0]).reshape(-1, 3) for p in parts]); r = np.concatenate([p[1] for p in parts])
+        offs = np.concatenate([[0], np.cumsum([len(p[1]) for p in parts])]).astype(np.int64)
+        d_xyz, d_r = torch.from_numpy(np.ascontiguousarray(xyz)).to(dev), torch.from_numpy(np.ascontiguousarray(r)).to(dev)
+        d_out = torch.empty(len(r), dtype=torch.float64, device=dev)
+        got = {}
+        for generic in (False, True):
+            if generic: monkeypatch.setenv("FREESASA_AMD_NO_SHAPE", "1")
+            else: monkeypatch.delenv("FREESASA_AMD_NO_SHAPE", raising=False)
+            ctx = fa.GpuContext(0)
+            for _ in range(2):  # (the second batch runs with the shape learnt from the first one's demand)
+                ctx.lee_richards(d_xyz.data_ptr(), d_r.data_ptr(), offs, d_out.data_ptr(), 0, probe=1.4, n_slices=ns)
+            got[generic] = d_out.cpu().numpy().copy()
+            ctx.close()
+        assert np.array_equal(got[False], got[True]), (name, float(np.nanmax(np.abs(got[False] - got[True]))))
+    monkeypatch.delenv("FREESASA_AMD_NO_SHAPE", raising=False)
+
+
 def test_asynchronous_batches_match_the_synchronous_ones(fa, oracle_lib):
     """freesasa_gpu_lr_batch_dev_async: batches enqueued back to back (two in flight, a third call collects the oldest),
     different inputs and output buffers per batch, offsets that change between batches (the tables of the batches in
