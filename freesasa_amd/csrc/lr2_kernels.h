@@ -603,9 +603,13 @@ SASA_D unsigned lr2_tie12(double xd, double yd, double zd)
  * Which neighbors: cos(theta_j) = (Ri^2 - Rj^2 + d^2) / (2 Ri d), the cap neighbor j cuts out of sphere i, in
  * 8 bins of 0.1 from 0.2 (a byte counter each, one 64-bit LDS word per atom); the bins that hold the
  * LR2_COVER_WANT largest caps, LR2_COVER_MAX neighbors at most. */
-#define LR2_COVER_WANT 10
+#ifndef LR2_COVER_WANT
+#define LR2_COVER_WANT 12 /* (round 4, by the instruction counter on globules: 8 / 10 / 12 / 14 / 16 wanted with caps of 12 ... 32: 12 of at most 20 is the least, 2 % under round 3's 10 of 16) */
+#endif
 #define LR2_COVER_DENSITY 30 /* neighbor records per atom of a tile from which the filter pays (coils: ~20, proteins: 40-60) */
-#define LR2_COVER_MAX 16
+#ifndef LR2_COVER_MAX
+#define LR2_COVER_MAX 20
+#endif
 SASA_D int lr2_cover_bin(double K, double d3sq, double ri)
 {
     const float ct = (float)K * LR2_RSQF((float)d3sq) * LR2_RCPF(2.0f * (float)ri);
