@@ -641,7 +641,6 @@ struct freesasa_gpu_ctx {
         /* what completing it needs */
         int n = 0, TA = 0, mw = 0, ds = 0, lds = 0;
     } pend[2];
-    int pend_err = 0; /* a batch collected on the way (to make room, before a reallocation) failed: reported by the next wait */
     /* workspace */
     DevBuf offsets, grid, ncells, sid, cell_of, rank, cell_start, blk_sums, cell_tbl, cell_first;
     DevBuf chunk_struct, chunk_begin, chunk_len, struct_chunk0, bpart;
@@ -716,7 +715,11 @@ static hipError_t host_malloc(void **p, size_t bytes)
 static int ensure(freesasa_gpu_ctx *c, DevBuf &b, size_t bytes)
 {
     if (bytes <= b.cap) return 0;
-    if (drain_pending(c)) c->pend_err = 1; /* (batches in flight may be using the buffer about to be freed) */
+    /* Batches in flight may be using the buffer about to be freed: wait for the stream, nothing more.  Their verdicts
+       are already on their way into their own sets of page-locked words (enqueue_tail) and are read when they are
+       collected; collecting them HERE - in the middle of another batch's set-up - could redo one of them through
+       run_batch and leave this batch with status words, arguments and buffers that are no longer its own. */
+    if (b.p && (c->pend[0].active || c->pend[1].active)) HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (b.p) HIP_TRY(c, hipFree(b.p));
     b.p = nullptr;
     b.cap = 0;
@@ -1107,7 +1110,7 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
        (trajectory frames and repeated batches reuse them) */
     if ((int)c->offsets_host.size() != n_structs + 1 ||
         memcmp(c->offsets_host.data(), offsets, sizeof(int64_t) * ((size_t)n_structs + 1)) != 0) {
-        if (drain_pending(c)) c->pend_err = 1; /* (batches in flight read the tables about to be overwritten) */
+        if (c->pend[0].active || c->pend[1].active) HIP_TRY(c, hipStreamSynchronize(st)); /* (batches in flight read the tables about to be overwritten; they are collected later, from their own sets of host words: see ensure) */
         c->offsets_host.clear(); /* (set again below, once the tables derived from it are on the device) */
         std::vector<int> cs, cl, sc0((size_t)n_structs + 1);
         std::vector<int64_t> cb;
@@ -1405,7 +1408,9 @@ static int complete_pending(freesasa_gpu_ctx *c, int slot)
     const int keep = c->slot;
     c->slot = slot;
     int rc = complete_batch(c, P.n, P.n_structs, P.TA, 64, P.lds);
-    if (rc == 0) lr2_learn(c, ctx_status_h(c), P.TA, P.resolution, P.mw, P.ds);
+    /* (what it teaches is keyed to the resolution and probe the hints stand for NOW: a later batch of another kind may
+       have reset them since this one was enqueued) */
+    if (rc == 0 && P.resolution == c->hint_res[0] && P.probe == c->hint_probe) lr2_learn(c, ctx_status_h(c), P.TA, P.resolution, P.mw, P.ds);
     c->slot = keep;
     P.active = false;
     if (rc == RC_RETRY) {
@@ -1433,9 +1438,7 @@ extern "C" int freesasa_gpu_wait(freesasa_gpu_ctx *c)
 {
     if (!c) return -1;
     if (hipSetDevice(c->device) != hipSuccess) return ctx_fail(c, "hipSetDevice failed");
-    int rc = drain_pending(c);
-    if (c->pend_err) { rc = -1; c->pend_err = 0; }
-    return rc;
+    return drain_pending(c);
 }
 
 extern "C" int freesasa_gpu_lr_batch_dev_async(freesasa_gpu_ctx *c, const double *d_xyz, const double *d_radii,
@@ -1446,7 +1449,6 @@ extern "C" int freesasa_gpu_lr_batch_dev_async(freesasa_gpu_ctx *c, const double
     if (hipSetDevice(c->device) != hipSuccess) return ctx_fail(c, "hipSetDevice failed");
     /* the set this batch takes may still belong to the batch submitted two calls ago: collect that one first */
     if (c->pend[c->slot].active && complete_pending(c, c->slot)) return -1;
-    if (c->pend_err) { c->pend_err = 0; return -1; } /* (an older batch failed while making room: its error text stands) */
     bool deferred = false;
     int rc = run_batch_once(c, true, d_xyz, d_radii, offsets, n_structs, probe, n_slices, nullptr, d_sasa, nullptr, d_totals, true, &deferred);
     if (rc == RC_RETRY || (rc == 0 && !deferred)) {
@@ -1565,6 +1567,7 @@ extern "C" int freesasa_gpu_lr_neighbors_dev(freesasa_gpu_ctx *c, const double *
     if (!d_nn || (d_nb && nb_cap <= 0)) return ctx_fail(c, "bad argument");
     const int64_t n = offsets && n_structs > 0 ? offsets[n_structs] : 0;
     if (n <= 0) return ctx_fail(c, "empty batch");
+    if (freesasa_gpu_wait(c)) return -1; /* (batches submitted asynchronously come first, as for every synchronous entry) */
     if (hipSetDevice(c->device) != hipSuccess || ensure(c, c->h_sasa, 8 * (size_t)n)) return -1;
     c->dbg_nn = d_nn; c->dbg_nb = d_nb; c->dbg_cap = nb_cap;
     const int rc = run_batch(c, true, d_xyz, d_radii, offsets, n_structs, probe, 20, nullptr,

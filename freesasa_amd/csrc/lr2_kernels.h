@@ -551,6 +551,9 @@ SASA_D double lr2_arc_kat(const double *arcs, const int *first, int k, Arc2 *stk
 #define LR2_NB_UNROLL 3 /* candidates a lane has in flight per round of P1 (coils: three rounds per tile = one trip; measured 1 / 2 / 3: 3.59 / 3.63 / 3.58 ms per 3e6 atoms) */
 #endif
 #define LR2_P1_G 3 /* atoms of a cell group one work item of P1 tests its candidate against */
+#ifndef LR2_P1_ITEMS_MAX
+#define LR2_P1_ITEMS_MAX 0x8000 /* P1's work items per tile, exclusive: the decode of an item's place in its row is exact below 2^15 (tests build with less to walk the hand-on path) */
+#endif
 
 /* a work item that fits no capacity of this launch, even halved */
 SASA_D void lr2_overflow(const Lr2Args &a, int p0, int na, int err_code)
@@ -785,6 +788,12 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         m.cpre[ri + 1] = incl; m.rowlo[ri] = lo; m.rinfo[ri] = info;
     }
     LR2_SYNC();
+    /* P1 decodes a work item's place in its row with a 15-bit index and a 24-bit multiplication (i / hc as
+       i * (2^17 / hc) >> 17: exact for i < 2^15 only).  The rows' counts sum to total_c, so total_c < 2^15 bounds every
+       one of them; a tile beyond that (a giant radius that puts tens of thousands of small atoms into one cell) does not
+       fit this kernel at any tile shape and is handed on like a tile whose lists do not fit: halves, then atom by atom to
+       the slab launch, which walks its candidates one by one. */
+    if (total_c >= LR2_P1_ITEMS_MAX) { LR2_COUNT(9, 1); return 1; } /* (uniform) */
 
     LR2_STOP(0);
     LR2_MARK(0);

@@ -159,3 +159,19 @@ def test_probe_zero_extreme_radii_and_slice_counts(fa, checker):
     worst["probe 5"] = _run(fa, checker, coils[:2], 5.0, 20)
     print("\n[adversarial] " + ", ".join(f"{k}: {v:.3g}" for k, v in worst.items()))
     assert max(worst.values()) < TOL
+
+
+def test_a_giant_radius_that_puts_tens_of_thousands_of_atoms_into_one_cell(fa, checker):
+    """Round-4 advisor (high): one atom of radius 30 A makes cells of 62.8 A, and 20 000 small atoms then share two of
+    them: a candidate row of the tile kernel holds 20 000 candidates, and a tile of six atoms of one cell 40 000 work
+    items - more than the 15 bits P1 decodes an item's place in its row with.  Round 4 wrapped there (candidates tested
+    twice, others never: wrong areas, no error); now such a tile is handed on (halves, the second launch, the slab
+    launch that walks its candidates one by one).  Sparse enough (39 neighbors per atom on average) that the tile
+    kernel would otherwise keep most of these tiles: the areas of ALL atoms are compared."""
+    rng = np.random.default_rng(3)
+    n = 20000
+    xyz = np.vstack([rng.uniform([0, 0, 0], [60, 31, 31], size=(n, 3)), [[260.0, 15.0, 15.0]]])
+    r = np.append(np.full(n, 0.1), 30.0)
+    worst = _run(fa, checker, [(xyz, r)], 1.4, 20)
+    print(f"\n[adversarial] 20 000 atoms in two cells (one giant radius): max |dSASA| {worst:.3g} A^2")
+    assert worst < TOL

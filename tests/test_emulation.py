@@ -371,3 +371,32 @@ def test_exact_arithmetic_build_holds_a_tighter_bar(tmp_path):
     worst = float(out.split("WORST")[1])
     print(f"\n[exact build] max |dSASA| vs the golden areas: {worst:.3g}")
     assert worst < 5e-11
+
+
+def test_tiles_with_too_many_candidate_items_are_handed_on(tmp_path):
+    """Round-4 advisor (high): P1 decodes a work item's place in its row with a 15-bit index, so a tile whose candidate
+    rows hold 2^15 work items or more (a giant radius that puts tens of thousands of small atoms into one cell) must
+    not be decoded at all - it is handed on like a tile whose lists do not fit (halves, the second launch, then atom by
+    atom to the slab launch, which walks its candidates one by one).  The limit itself needs > 16 000 atoms in a cell
+    (a GPU test: tests/test_adversarial.py); here the same sources are built with a limit of 300 / 40 items, so that
+    many / nearly all atoms of an ordinary structure take the hand-on path down to the slab launch (whose first-generation
+    arithmetic differs from the tile kernel's in the last bits: both are held to LR_TOL against the reference's areas)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for limit in (0, 300, 40):
+        so = str(tmp_path / f"libsasa_emu_lim{limit}.so")
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-DSASA_EMU"] +
+                       ([f"-DLR2_P1_ITEMS_MAX={limit}"] if limit else []) +
+                       ["-shared", "-o", so, os.path.join(root, "tests", "emu", "emu.cpp"), "-lm"], check=True)
+        code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+                "from conftest import load_golden; from emu import run_batch\n"
+                "g = load_golden('1ubq'); s, _, _, st = run_batch(True, g['xyz'], g['radii'], resolution=20)\n"
+                "print('ERR', float(np.max(np.abs(s - g['lr20']))), 'FB', st['fallback_tiles'], 'SLAB', st['slab_tiles'])\n"
+                ) % (os.path.join(root, "tests"), root)
+        out = subprocess.run([sys.executable, "-c", code], check=True, capture_output=True, text=True,
+                             env=dict(os.environ, SASA_EMU_SO=so)).stdout.split()
+        outs[limit] = dict(err=float(out[1]), fb=int(out[3]), slab=int(out[5]))
+    assert outs[0]["err"] < LR_TOL and outs[0]["slab"] == 0
+    assert outs[300]["fb"] > outs[0]["fb"] and 0 < outs[300]["slab"] < 100 and outs[300]["err"] < LR_TOL  # halves, second launch, a few atoms to the slab
+    assert outs[40]["slab"] > 500 and outs[40]["err"] < LR_TOL                                            # nearly every atom through the slab launch
