@@ -16,12 +16,18 @@ CFLAGS   = -O2 -std=gnu99 -fPIC -ffp-contract=off -Wall
 
 all: $(LIBDIR)/libfreesasa_amd.so $(LIBDIR)/libfreesasa_amd_seam.a
 
-# the compiler's per-kernel resource report (registers, scratch, LDS) is kept next to the object:
-# tests/test_capi.py checks that the hot kernels do not spill
-$(LIBDIR)/gpu_engine.o: $(CSRC)/gpu_engine.hip $(CSRC)/sasa_kernels.h $(CSRC)/lr2_kernels.h include/freesasa_gpu.h include/freesasa_ingest.h
+# Device code lives in ONE translation unit (gpu_kernels.hip); the compiler's per-kernel resource report (registers,
+# scratch, LDS) is kept next to its object: tests/test_capi.py checks that the hot kernels do not spill.  The other
+# .hip files are host code over the HIP runtime (engine_internal.h says who holds what).
+ENGINE_HDRS = $(CSRC)/engine_internal.h $(CSRC)/sasa_kernels.h $(CSRC)/lr2_kernels.h include/freesasa_gpu.h include/freesasa_ingest.h
+$(LIBDIR)/gpu_kernels.o: $(CSRC)/gpu_kernels.hip $(ENGINE_HDRS)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(LIBDIR)/kernel_resources.txt; rc=$$?; \
 	grep -v "remark:" $(LIBDIR)/kernel_resources.txt >&2; exit $$rc
+$(LIBDIR)/gpu_%.o: $(CSRC)/gpu_%.hip $(ENGINE_HDRS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+GPU_OBJS = $(LIBDIR)/gpu_kernels.o $(LIBDIR)/gpu_engine.o $(LIBDIR)/gpu_ops.o $(LIBDIR)/gpu_hostbatch.o $(LIBDIR)/gpu_drivers.o
 
 $(LIBDIR)/seam.o: $(CSRC)/seam.c include/freesasa_amd.h include/freesasa_gpu.h
 	@mkdir -p $(LIBDIR)
@@ -45,13 +51,13 @@ $(LIBDIR)/select.o: $(CSRC)/select.c include/freesasa_ingest.h
 
 $(LIBDIR)/ingest_cache.o: $(CSRC)/ingest_cache.c include/freesasa_ingest.h
 	@mkdir -p $(LIBDIR)
-	$(CC) $(CFLAGS) -Iinclude -c $< -o $@
+	$(CC) $(CFLAGS) -Iinclude -pthread -c $< -o $@
 
-$(LIBDIR)/libfreesasa_amd.so: $(LIBDIR)/gpu_engine.o $(LIBDIR)/seam.o $(LIBDIR)/testpoints.o $(LIBDIR)/api.o $(LIBDIR)/ingest.o $(LIBDIR)/select.o $(LIBDIR)/ingest_cache.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
+$(LIBDIR)/libfreesasa_amd.so: $(GPU_OBJS) $(LIBDIR)/seam.o $(LIBDIR)/testpoints.o $(LIBDIR)/api.o $(LIBDIR)/ingest.o $(LIBDIR)/select.o $(LIBDIR)/ingest_cache.o $(CSRC)/exports.map
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -Wl,--version-script=$(CSRC)/exports.map -o $@ $(filter %.o,$^)
 
-$(LIBDIR)/libfreesasa_amd_seam.a: $(LIBDIR)/gpu_engine.o $(LIBDIR)/seam.o $(LIBDIR)/testpoints.o $(LIBDIR)/ingest.o
-	ar rcs $@ $^
+$(LIBDIR)/libfreesasa_amd_seam.a: $(GPU_OBJS) $(LIBDIR)/seam.o $(LIBDIR)/testpoints.o $(LIBDIR)/ingest.o $(LIBDIR)/ingest_cache.o
+	rm -f $@; ar rcs $@ $^
 
 emu: tests/emu/libsasa_emu.so tests/emu/libingest_scalar.so
 # the loader with its byte-at-a-time mmCIF tokenizer only: the differential twin of the SSE2 row scanner
@@ -66,9 +72,9 @@ tests/emu/libsasa_emu.so: tests/emu/emu.cpp $(CSRC)/sasa_kernels.h $(CSRC)/lr2_k
 ASAN_SO = tests/emu/libfreesasa_amd_asan.so
 SANFLAGS = -O1 -g -std=gnu99 -fPIC -ffp-contract=off -Wall -fsanitize=address,undefined -fno-omit-frame-pointer -fno-sanitize-recover=undefined
 asan: $(ASAN_SO)
-$(ASAN_SO): $(CSRC)/api.c $(CSRC)/seam.c $(CSRC)/testpoints.c $(CSRC)/ingest.c $(CSRC)/select.c $(CSRC)/ingest_cache.c $(CSRC)/protor_table.h $(LIBDIR)/gpu_engine.o include/freesasa_amd.h include/freesasa_gpu.h include/freesasa_ingest.h
+$(ASAN_SO): $(CSRC)/api.c $(CSRC)/seam.c $(CSRC)/testpoints.c $(CSRC)/ingest.c $(CSRC)/select.c $(CSRC)/ingest_cache.c $(CSRC)/protor_table.h $(GPU_OBJS) include/freesasa_amd.h include/freesasa_gpu.h include/freesasa_ingest.h
 	for f in api seam testpoints ingest select ingest_cache; do $(CC) $(SANFLAGS) -Iinclude -pthread -c $(CSRC)/$$f.c -o /tmp/asan_$$f.o || exit 1; done
-	$(CXX) -shared -fPIC -o $@ /tmp/asan_api.o /tmp/asan_seam.o /tmp/asan_testpoints.o /tmp/asan_ingest.o /tmp/asan_select.o /tmp/asan_ingest_cache.o $(LIBDIR)/gpu_engine.o \
+	$(CXX) -shared -fPIC -o $@ /tmp/asan_api.o /tmp/asan_seam.o /tmp/asan_testpoints.o /tmp/asan_ingest.o /tmp/asan_select.o /tmp/asan_ingest_cache.o $(GPU_OBJS) \
 	    -fsanitize=address,undefined -L/opt/rocm/lib -Wl,-rpath,/opt/rocm/lib -lamdhip64 -lpthread -lm
 asan-test: $(ASAN_SO)
 	LD_PRELOAD="$$($(CC) -print-file-name=libasan.so) $$($(CC) -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 \

@@ -142,8 +142,23 @@ def lib():
         L.freesasa_gpu_trajectory_file.argtypes = [C.c_char_p, C.c_int, C.c_longlong, _dp, C.c_int, C.c_longlong, C.c_int, C.c_double,
                                                    C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_longlong, C.c_int,
                                                    C.POINTER(C.c_longlong), C.c_char_p, C.c_int]
+        L.freesasa_gpu_sweep_files_devices.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
+                                                       C.c_longlong, _dp, _dp, _lp, _ip, C.c_char_p, C.c_longlong, _ip, C.c_int, C.c_char_p, C.c_int]
+        L.freesasa_gpu_sweep_cache_devices.argtypes = [C.c_char_p, C.c_int, C.c_double, C.c_int, C.c_longlong, _dp, _dp, _lp, _ip, C.c_int,
+                                                       _ip, C.c_int, C.c_int, C.c_char_p, C.c_int]
+        L.freesasa_gpu_trajectory_devices.argtypes = [_dp, _dp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
+                                                      C.c_int, _dp, _dp, _ip, C.c_int, C.c_char_p, C.c_int]
+        L.freesasa_gpu_trajectory_file_devices.argtypes = [C.c_char_p, C.c_int, C.c_longlong, _dp, C.c_int, C.c_longlong, C.c_int, C.c_double,
+                                                           C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_longlong, _ip, C.c_int,
+                                                           C.POINTER(C.c_longlong), C.c_char_p, C.c_int]
         _lib = L
     return _lib
+
+
+def _devs(devices, device):
+    """the device list of a driver call: `devices` (a list; entries may repeat) or the single `device`"""
+    d = np.ascontiguousarray([device] if devices is None else list(devices), dtype=np.int32)
+    return d, d.ctypes.data_as(_ip), int(d.size)
 
 
 def device_count():
@@ -238,24 +253,31 @@ def shard_cuts(offsets, n_parts):
 
 
 def sweep_files(paths, alg=LEE_RICHARDS, probe=1.4, resolution=20, ingest_options=0, n_threads=0, batch_atoms=0,
-                class_sums=True, device=-1):
-    """freesasa_gpu_sweep_files(): PDB / mmCIF files -> (totals[n], class_sums[n,3] or None, n_atoms[n], status[n]);
-    loading of the next batch overlaps the GPU work on the current one."""
+                class_sums=True, device=-1, devices=None):
+    """freesasa_gpu_sweep_files[_devices](): PDB / mmCIF files -> (totals[n], class_sums[n,3] or None, n_atoms[n],
+    status[n]); loading of the next batch overlaps the GPU work on the current one.  devices: a list of devices
+    (entries may repeat) that share the batches, largest first."""
     n = len(paths)
     arr = (C.c_char_p * n)(*[str(p).encode() for p in paths])
     totals, atoms, status = np.zeros(n), np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int32)
     cls = np.zeros((n, 3)) if class_sums else None
     err = C.create_string_buffer(512)
-    ret = lib().freesasa_gpu_sweep_files(arr, n, ingest_options, n_threads, alg, probe, resolution, batch_atoms,
-                                         totals.ctypes.data_as(_dp), cls.ctypes.data_as(_dp) if cls is not None else None,
-                                         atoms.ctypes.data_as(_lp), status.ctypes.data_as(_ip), device, err, 512)
+    if devices is None:
+        ret = lib().freesasa_gpu_sweep_files(arr, n, ingest_options, n_threads, alg, probe, resolution, batch_atoms,
+                                             totals.ctypes.data_as(_dp), cls.ctypes.data_as(_dp) if cls is not None else None,
+                                             atoms.ctypes.data_as(_lp), status.ctypes.data_as(_ip), device, err, 512)
+    else:
+        keep, dp_, nd = _devs(devices, device)
+        ret = lib().freesasa_gpu_sweep_files_devices(arr, n, ingest_options, n_threads, alg, probe, resolution, batch_atoms,
+                                                     totals.ctypes.data_as(_dp), cls.ctypes.data_as(_dp) if cls is not None else None,
+                                                     atoms.ctypes.data_as(_lp), status.ctypes.data_as(_ip), None, 0, dp_, nd, err, 512)
     if ret:
         raise RuntimeError("freesasa_gpu_sweep_files: " + err.value.decode())
     return totals, cls, atoms, status
 
 
 def sweep_files_resumable(paths, done_path, alg=LEE_RICHARDS, probe=1.4, resolution=20, ingest_options=0, n_threads=0,
-                          batch_atoms=0, max_new_batches=0, device=-1):
+                          batch_atoms=0, max_new_batches=0, device=-1, devices=None):
     """freesasa_gpu_sweep_files_resumable(): like sweep_files with a done-list at done_path (+ done_path.bin):
     returns (complete, totals, class_sums, n_atoms, status); batches listed there are not computed again."""
     n = len(paths)
@@ -263,16 +285,43 @@ def sweep_files_resumable(paths, done_path, alg=LEE_RICHARDS, probe=1.4, resolut
     totals, atoms, status = np.zeros(n), np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int32)
     cls = np.zeros((n, 3))
     err = C.create_string_buffer(512)
-    ret = lib().freesasa_gpu_sweep_files_resumable(arr, n, ingest_options, n_threads, alg, probe, resolution, batch_atoms,
-                                                   totals.ctypes.data_as(_dp), cls.ctypes.data_as(_dp), atoms.ctypes.data_as(_lp),
-                                                   status.ctypes.data_as(_ip), str(done_path).encode(), max_new_batches, device, err, 512)
+    if devices is None:
+        ret = lib().freesasa_gpu_sweep_files_resumable(arr, n, ingest_options, n_threads, alg, probe, resolution, batch_atoms,
+                                                       totals.ctypes.data_as(_dp), cls.ctypes.data_as(_dp), atoms.ctypes.data_as(_lp),
+                                                       status.ctypes.data_as(_ip), str(done_path).encode(), max_new_batches, device, err, 512)
+    else:
+        keep, dp_, nd = _devs(devices, device)
+        ret = lib().freesasa_gpu_sweep_files_devices(arr, n, ingest_options, n_threads, alg, probe, resolution, batch_atoms,
+                                                     totals.ctypes.data_as(_dp), cls.ctypes.data_as(_dp), atoms.ctypes.data_as(_lp),
+                                                     status.ctypes.data_as(_ip), str(done_path).encode(), max_new_batches, dp_, nd, err, 512)
     if ret < 0:
         raise RuntimeError("freesasa_gpu_sweep_files_resumable: " + err.value.decode())
     return ret == 0, totals, cls, atoms, status
 
 
+def sweep_cache(cache_path, alg=LEE_RICHARDS, probe=1.4, resolution=20, batch_atoms=0, class_sums=True, device=-1, devices=None,
+                lanes_per_device=0):
+    """freesasa_gpu_sweep_cache_devices(): the sweep of a binary cache file (ingest.Batch.save) -> (totals[n],
+    class_sums[n,3] or None, n_atoms[n], status[n]): only coordinates, radii and classes are read, verified piece by
+    piece, by a few lanes per device."""
+    from . import ingest
+    c = ingest.Cache(cache_path)
+    n = c.n_structs
+    c.close()
+    totals, atoms, status = np.zeros(n), np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int32)
+    cls = np.zeros((n, 3)) if class_sums else None
+    err = C.create_string_buffer(512)
+    keep, dp_, nd = _devs(devices, device)
+    ret = lib().freesasa_gpu_sweep_cache_devices(str(cache_path).encode(), alg, probe, resolution, batch_atoms, totals.ctypes.data_as(_dp),
+                                                 cls.ctypes.data_as(_dp) if cls is not None else None, atoms.ctypes.data_as(_lp),
+                                                 status.ctypes.data_as(_ip), n, dp_, nd, lanes_per_device, err, 512)
+    if ret:
+        raise RuntimeError("freesasa_gpu_sweep_cache_devices: " + err.value.decode())
+    return totals, cls, atoms, status
+
+
 def trajectory(xyz_frames, radii, alg=LEE_RICHARDS, probe=1.4, resolution=20, frames_per_batch=0,
-               per_atom=True, device=-1):
+               per_atom=True, device=-1, devices=None):
     """freesasa_gpu_trajectory() on host arrays: xyz_frames [n_frames, n_atoms, 3] -> (totals
     [n_frames], per-atom [n_frames, n_atoms] or None)."""
     xyz_frames = np.ascontiguousarray(xyz_frames, dtype=np.float64)
@@ -282,27 +331,40 @@ def trajectory(xyz_frames, radii, alg=LEE_RICHARDS, probe=1.4, resolution=20, fr
     totals = np.empty(n_frames)
     sasa = np.empty((n_frames, n_atoms)) if per_atom else None
     err = C.create_string_buffer(512)
-    ret = lib().freesasa_gpu_trajectory(xyz_frames.ctypes.data_as(_dp), radii.ctypes.data_as(_dp), n_atoms,
-                                        n_frames, alg, probe, resolution, frames_per_batch,
-                                        totals.ctypes.data_as(_dp),
-                                        sasa.ctypes.data_as(_dp) if sasa is not None else None,
-                                        device, err, 512)
+    if devices is None:
+        ret = lib().freesasa_gpu_trajectory(xyz_frames.ctypes.data_as(_dp), radii.ctypes.data_as(_dp), n_atoms,
+                                            n_frames, alg, probe, resolution, frames_per_batch,
+                                            totals.ctypes.data_as(_dp),
+                                            sasa.ctypes.data_as(_dp) if sasa is not None else None,
+                                            device, err, 512)
+    else:
+        keep, dp_, nd = _devs(devices, device)
+        ret = lib().freesasa_gpu_trajectory_devices(xyz_frames.ctypes.data_as(_dp), radii.ctypes.data_as(_dp), n_atoms,
+                                                    n_frames, alg, probe, resolution, frames_per_batch, totals.ctypes.data_as(_dp),
+                                                    sasa.ctypes.data_as(_dp) if sasa is not None else None, dp_, nd, err, 512)
     if ret:
         raise RuntimeError("freesasa_gpu_trajectory: " + err.value.decode())
     return totals, sasa
 
 
 def trajectory_file(frames_path, radii, totals_path, sasa_path=None, done_path=None, f32=False, header_bytes=0,
-                    n_frames=0, alg=LEE_RICHARDS, probe=1.4, resolution=20, frames_per_batch=0, max_new_shards=0, device=-1):
+                    n_frames=0, alg=LEE_RICHARDS, probe=1.4, resolution=20, frames_per_batch=0, max_new_shards=0, device=-1,
+                    devices=None):
     """freesasa_gpu_trajectory_file(): raw frame file -> totals file (+ per-atom file), resumable through the
     done-list at done_path.  Returns (complete, n_frames): complete is False when max_new_shards stopped the run."""
     radii = _f64(radii)
     err = C.create_string_buffer(512)
     total = C.c_longlong(0)
     enc = lambda p: None if p is None else str(p).encode()
-    ret = lib().freesasa_gpu_trajectory_file(enc(frames_path), 1 if f32 else 0, header_bytes, radii.ctypes.data_as(_dp), radii.size,
-                                             n_frames, alg, probe, resolution, frames_per_batch, enc(totals_path), enc(sasa_path),
-                                             enc(done_path), max_new_shards, device, C.byref(total), err, 512)
+    if devices is None:
+        ret = lib().freesasa_gpu_trajectory_file(enc(frames_path), 1 if f32 else 0, header_bytes, radii.ctypes.data_as(_dp), radii.size,
+                                                 n_frames, alg, probe, resolution, frames_per_batch, enc(totals_path), enc(sasa_path),
+                                                 enc(done_path), max_new_shards, device, C.byref(total), err, 512)
+    else:
+        keep, dp_, nd = _devs(devices, device)
+        ret = lib().freesasa_gpu_trajectory_file_devices(enc(frames_path), 1 if f32 else 0, header_bytes, radii.ctypes.data_as(_dp), radii.size,
+                                                         n_frames, alg, probe, resolution, frames_per_batch, enc(totals_path), enc(sasa_path),
+                                                         enc(done_path), max_new_shards, dp_, nd, C.byref(total), err, 512)
     if ret < 0:
         raise RuntimeError("freesasa_gpu_trajectory_file: " + err.value.decode())
     return ret == 0, int(total.value)

@@ -1,0 +1,715 @@
+/*
+ * gpu_drivers.hip — the drivers for BASELINE configs[3] and configs[4] (include/freesasa_gpu.h): the structure sweep
+ * over PDB / mmCIF files, the same sweep from a binary cache, and the trajectory drivers — each over ONE device or a
+ * LIST of devices of the node.  Host code; kernels in gpu_kernels.hip.
+ *
+ * What replaces what: the reference reads one file per run of its CLI (src/main.cc:763-779) and spreads ONE structure
+ * over <= 16 pthreads (src/sasa_lr.c:219-253).  Here the unit of parallel work is a batch of whole structures (a
+ * shard of whole frames), and the units are independent: there is no exchange between devices, only a shared list of
+ * work.  One worker (sweep) or a few lanes (trajectory, cache sweep) per entry of devices[] take the next unit from a
+ * shared counter — largest first for the file sweep (LPT on the file sizes: atoms are proportional to bytes) — so
+ * that a device that finishes early takes more; every result lands at its own place of the caller's arrays / the
+ * result files (pwrite at the unit's offset), and ONE done-list, appended to under a mutex after a unit's results
+ * are on disk, serves all devices.  The host CPUs THE CGROUP GRANTS (freesasa_ingest_usable_cpus: a GPU box shows 256
+ * and grants 16) are divided among the devices' loaders.  A device may appear in the list more than once (its units
+ * then overlap their copies and kernels; the tests run device lists [0, 0, 0] and [0] * 8 on a one-GPU box).
+ * Results are bit-identical to the single-device drivers': a unit's numbers do not depend on who computed it.
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <fcntl.h>
+#include <mutex>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <sys/stat.h>
+#include <thread>
+#include <unistd.h>
+#include <vector>
+
+#include "engine_internal.h"
+
+namespace {
+
+bool pread_all(int fd, void *buf, size_t bytes, long long off)
+{
+    char *p = (char *)buf;
+    while (bytes) {
+        const ssize_t r = pread(fd, p, bytes, (off_t)off);
+        if (r <= 0) return false;
+        p += r; off += r; bytes -= (size_t)r;
+    }
+    return true;
+}
+bool pwrite_all(int fd, const void *buf, size_t bytes, long long off)
+{
+    const char *p = (const char *)buf;
+    while (bytes) {
+        const ssize_t r = pwrite(fd, p, bytes, (off_t)off);
+        if (r <= 0) return false;
+        p += r; off += r; bytes -= (size_t)r;
+    }
+    return true;
+}
+
+/* the device list of a call: every entry an existing device (entries may repeat) */
+int check_devices(const int *devices, int n_devices, char *err_out, int err_len)
+{
+    const int n_dev = freesasa_gpu_device_count();
+    if (n_dev <= 0) return set_err(err_out, err_len, "no HIP device available: libfreesasa_amd has no CPU path");
+    if (!devices || n_devices <= 0 || n_devices > 64) return set_err(err_out, err_len, "bad device list (1 .. 64 entries)");
+    for (int k = 0; k < n_devices; ++k)
+        if (devices[k] < -1 || devices[k] >= n_dev) return set_err(err_out, err_len, "device index out of range");
+    return 0;
+}
+
+/* host threads of one of n_workers loaders: the caller's total (or, <= 0, the CPUs the cgroup grants) divided among them */
+int threads_per_worker(int n_threads, int n_workers)
+{
+    int total = n_threads > 0 ? n_threads : freesasa_ingest_usable_cpus();
+    if (const char *lws = getenv("LOCAL_WORLD_SIZE")) { /* one process per GPU: the ranks of a node share its CPUs */
+        const int ranks = atoi(lws);
+        if (n_threads <= 0 && ranks > 1) total /= ranks;
+    }
+    const int per = total / (n_workers > 0 ? n_workers : 1);
+    return per < 1 ? 1 : per;
+}
+
+/* first failure of a set of workers wins; the others stop taking work */
+struct FirstError {
+    std::mutex mu;
+    std::atomic<int> failed{0};
+    char text[256] = {0};
+    void set(const char *msg)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!failed.load()) snprintf(text, sizeof text, "%s", msg && msg[0] ? msg : "GPU driver failed");
+        failed = 1;
+    }
+};
+
+/* ------------------------------------------------------------------ structure sweep: files */
+
+struct SweepRec { double total, cls[3]; long long atoms; int status, pad; };
+static_assert(sizeof(SweepRec) == 48, "result record");
+
+/* Files -> per-structure totals.  Every worker owns a pooled context of its device and a loader: while batch k is on
+ * the GPU the loader's threads (include/freesasa_ingest.h) read the batch the worker took next.  Inputs that fail to
+ * load get total 0 and their loader status; the call only fails for GPU errors.
+ * done_path (may be NULL): the sweep's done-list — a first line with the run's parameters, then "shard <batch> <first
+ * file> <files>" per finished batch — next to a result file <done_path>.bin that holds, per file, total | class sums
+ * (3) | atoms | status (fixed 48-byte records), written before the batch is listed.  A call that finds the done-list of
+ * the same run takes the listed batches' results from the result file and only computes the others.
+ * Returns 0 done, 1 stopped after max_new_batches, -1 error. */
+int sweep_impl(const char *const *paths, int n_paths, int ingest_options, int n_threads,
+               int alg, double probe, int resolution, long long batch_atoms,
+               double *totals_out, double *class_sums_out, long long *atoms_out, int *status_out,
+               const char *done_path, long long max_new_batches, const int *devices, int n_devices, char *err_out, int err_len)
+{
+    if (err_out && err_len > 0) err_out[0] = 0;
+    if (!paths || n_paths < 0 || !totals_out || !status_out) return set_err(err_out, err_len, "null argument");
+    if (alg != 0 && alg != 1) return set_err(err_out, err_len, "unknown algorithm");
+    if (check_devices(devices, n_devices, err_out, err_len)) return -1;
+    if (n_paths == 0) return 0;
+    if (batch_atoms <= 0) batch_atoms = 2000000;
+    /* batches of roughly batch_atoms atoms, estimated from the file sizes (~81 bytes per ATOM line) */
+    std::vector<int> cut(1, 0);
+    std::vector<long long> batch_bytes;
+    {
+        long long bytes = 0;
+        for (int k = 0; k < n_paths; ++k) {
+            struct stat st;
+            bytes += (paths[k] && stat(paths[k], &st) == 0) ? (long long)st.st_size : 0;
+            if (bytes >= batch_atoms * 81 && k + 1 < n_paths) { cut.push_back(k + 1); batch_bytes.push_back(bytes); bytes = 0; }
+        }
+        cut.push_back(n_paths);
+        batch_bytes.push_back(bytes);
+    }
+    const int n_batches = (int)cut.size() - 1;
+    /* done-list and result file */
+    std::vector<char> done((size_t)n_batches, 0);
+    int fd_done = -1, fd_res = -1;
+    if (done_path) {
+        unsigned long long h = 1469598103934665603ULL; /* FNV-1a over the files' names, sizes and modification times: the done-list belongs to THESE files as they are now */
+        for (int k = 0; k < n_paths; ++k) {
+            for (const char *q = paths[k] ? paths[k] : ""; ; ++q) { h = (h ^ (unsigned char)*q) * 1099511628211ULL; if (!*q) break; }
+            struct stat st;
+            long long id[3] = {-1, -1, -1};
+            if (paths[k] && stat(paths[k], &st) == 0) { id[0] = (long long)st.st_size; id[1] = (long long)st.st_mtim.tv_sec; id[2] = (long long)st.st_mtim.tv_nsec; }
+            for (size_t q = 0; q < sizeof id; ++q) h = (h ^ ((const unsigned char *)id)[q]) * 1099511628211ULL;
+        }
+        char head[256];
+        snprintf(head, sizeof head, "freesasa_amd sweep done-list v2 n_files=%d batches=%d files=%016llx options=%d alg=%d resolution=%d probe=%.17g\n",
+                 n_paths, n_batches, h, ingest_options, alg, resolution, probe);
+        const std::string res_path = std::string(done_path) + ".bin";
+        bool resume = false;
+        if (FILE *fp = fopen(done_path, "r")) {
+            char line[256];
+            if (fgets(line, sizeof line, fp)) {
+                if (strcmp(line, head) != 0) { fclose(fp); return set_err(err_out, err_len, "the done-list belongs to a sweep with other parameters or other (changed) input files"); }
+                resume = true;
+                int b, first, count;
+                while (fgets(line, sizeof line, fp))
+                    if (sscanf(line, "shard %d %d %d", &b, &first, &count) == 3 && b >= 0 && b < n_batches && first == cut[b] &&
+                        count == cut[b + 1] - cut[b] && line[strlen(line) - 1] == '\n')
+                        done[(size_t)b] = 1;
+            }
+            fclose(fp);
+        }
+        fd_res = open(res_path.c_str(), resume ? O_RDWR | O_CREAT : O_RDWR | O_CREAT | O_TRUNC, 0644);
+        fd_done = open(done_path, resume ? O_WRONLY | O_APPEND : O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (fd_res < 0 || fd_done < 0 || (!resume && write(fd_done, head, strlen(head)) != (ssize_t)strlen(head))) {
+            if (fd_res >= 0) close(fd_res);
+            if (fd_done >= 0) close(fd_done);
+            return set_err(err_out, err_len, "cannot open the done-list or its result file");
+        }
+        for (int b = 0; b < n_batches; ++b) { /* results of the batches already done */
+            if (!done[(size_t)b]) continue;
+            std::vector<SweepRec> recs((size_t)(cut[b + 1] - cut[b]));
+            if (!pread_all(fd_res, recs.data(), sizeof(SweepRec) * recs.size(), (long long)sizeof(SweepRec) * cut[b])) { done[(size_t)b] = 0; continue; }
+            for (size_t k = 0; k < recs.size(); ++k) {
+                const int f = cut[b] + (int)k;
+                totals_out[f] = recs[k].total; status_out[f] = recs[k].status;
+                if (atoms_out) atoms_out[f] = recs[k].atoms;
+                if (class_sums_out) for (int q = 0; q < 3; ++q) class_sums_out[3 * f + q] = recs[k].cls[q];
+            }
+        }
+    }
+    std::vector<int> todo;
+    for (int b = 0; b < n_batches; ++b)
+        if (!done[(size_t)b]) todo.push_back(b);
+    bool stopped = false;
+    if (max_new_batches > 0 && (long long)todo.size() > max_new_batches) { todo.resize((size_t)max_new_batches); stopped = true; }
+    auto close_files = [&] { if (fd_res >= 0) close(fd_res); if (fd_done >= 0) close(fd_done); };
+    if (todo.empty()) { close_files(); return stopped ? 1 : 0; }
+    /* largest first (LPT): whoever is free takes the largest batch left */
+    std::stable_sort(todo.begin(), todo.end(), [&](int x, int y) { return batch_bytes[(size_t)x] > batch_bytes[(size_t)y]; });
+    int n_workers = n_devices < (int)todo.size() ? n_devices : (int)todo.size();
+    const int loader_threads = threads_per_worker(n_threads, n_workers);
+    const bool want_cls = class_sums_out != nullptr || done_path != nullptr;
+    std::vector<double> tp;
+    if (alg == 1) { tp.resize(3 * (size_t)(resolution > 0 ? resolution : 1)); if (resolution > 0) freesasa_gpu_test_points(resolution, tp.data()); }
+    std::atomic<size_t> next(0);
+    std::mutex done_mu;
+    FirstError fe;
+
+    auto worker = [&](int w) {
+        freesasa_gpu_ctx *c = pool_get(devices[w]);
+        if (!c) { fe.set("could not create a GPU context"); return; }
+        std::vector<double> cls_tmp;
+        freesasa_ingest_batch cur, nxt;
+        int cur_rc = 0, nxt_rc = 0;
+        memset(&cur, 0, sizeof cur);
+        memset(&nxt, 0, sizeof nxt);
+        auto load = [&](int b, freesasa_ingest_batch *out, int *rc) {
+            *rc = freesasa_ingest_pdb_files(paths + cut[b], cut[b + 1] - cut[b], ingest_options, loader_threads, out);
+        };
+        size_t ti = next.fetch_add(1);
+        if (ti < todo.size()) load(todo[ti], &cur, &cur_rc);
+        while (ti < todo.size() && !fe.failed.load()) {
+            const int b = todo[ti];
+            const size_t tn = next.fetch_add(1); /* the batch this worker does next: read while this one computes */
+            std::thread loader;
+            if (tn < todo.size()) loader = std::thread(load, todo[tn], &nxt, &nxt_rc);
+            const int first = cut[b], ns = cut[b + 1] - cut[b];
+            int ret = 0;
+            do {
+                if (cur_rc) { ctx_fail(c, "loader failed with code %d", cur_rc); ret = -1; break; }
+                for (int k = 0; k < ns; ++k) {
+                    status_out[first + k] = cur.status[k];
+                    totals_out[first + k] = 0;
+                    if (atoms_out) atoms_out[first + k] = cur.offsets[k + 1] - cur.offsets[k];
+                    if (class_sums_out) class_sums_out[3 * (first + k)] = class_sums_out[3 * (first + k) + 1] = class_sums_out[3 * (first + k) + 2] = 0;
+                }
+                const size_t n = (size_t)cur.n_atoms;
+                if (n == 0) break;
+                ret = -1;
+                if (hipSetDevice(c->device) != hipSuccess) { ctx_fail(c, "hipSetDevice failed"); break; }
+                if (ensure(c, c->h_xyz, 24 * n) || ensure(c, c->h_radii, 8 * n) || ensure(c, c->h_sasa, 8 * n) ||
+                    ensure(c, c->h_counts, n) || ensure(c, c->h_totals, 8 * 4 * (size_t)ns))
+                    break;
+                if (hipMemcpyAsync(c->h_xyz.p, cur.xyz, 24 * n, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                    hipMemcpyAsync(c->h_radii.p, cur.radii, 8 * n, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+                    ctx_fail(c, "host-to-device copy failed");
+                    break;
+                }
+                double *d_tot = (double *)c->h_totals.p, *d_cls = d_tot + ns;
+                if (run_batch(c, alg == 0, (double *)c->h_xyz.p, (double *)c->h_radii.p, cur.offsets, ns, probe, resolution,
+                              alg == 1 ? tp.data() : nullptr, (double *)c->h_sasa.p, nullptr, d_tot))
+                    break;
+                double *cls_dst = class_sums_out ? class_sums_out + 3 * (size_t)first : nullptr;
+                if (want_cls) {
+                    if (!cls_dst) { cls_tmp.resize(3 * (size_t)ns); cls_dst = cls_tmp.data(); }
+                    if (hipMemcpyAsync(c->h_counts.p, cur.atom_class, n, hipMemcpyHostToDevice, c->stream) != hipSuccess) { ctx_fail(c, "host-to-device copy failed"); break; }
+                    if (freesasa_gpu_class_sums_dev(c, (double *)c->h_sasa.p, (const unsigned char *)c->h_counts.p, cur.offsets, ns, d_cls)) break;
+                    if (hipMemcpyAsync(cls_dst, d_cls, 8 * 3 * (size_t)ns, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { ctx_fail(c, "device-to-host copy failed"); break; }
+                }
+                if (hipMemcpyAsync(totals_out + first, d_tot, 8 * (size_t)ns, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { ctx_fail(c, "device-to-host copy failed"); break; }
+                if (hipStreamSynchronize(c->stream) != hipSuccess) { ctx_fail(c, "stream synchronize failed"); break; }
+                ret = 0;
+            } while (0);
+            if (ret) (void)hipStreamSynchronize(c->stream); /* no copy may still read the batch when it is freed */
+            if (!ret && fd_done >= 0) { /* the batch's results to the result file, then its line in the done-list */
+                std::vector<SweepRec> recs((size_t)ns);
+                const bool have_cls = cur.n_atoms > 0;
+                const double *cls_src = class_sums_out ? class_sums_out + 3 * (size_t)first : (have_cls ? cls_tmp.data() : nullptr);
+                for (int k = 0; k < ns; ++k) {
+                    SweepRec &r = recs[(size_t)k];
+                    memset(&r, 0, sizeof r);
+                    r.total = totals_out[first + k]; r.status = status_out[first + k];
+                    r.atoms = cur.offsets ? cur.offsets[k + 1] - cur.offsets[k] : 0;
+                    if (cls_src) for (int q = 0; q < 3; ++q) r.cls[q] = cls_src[3 * k + q];
+                }
+                char line[96];
+                const int len = snprintf(line, sizeof line, "shard %d %d %d\n", b, first, ns);
+                std::lock_guard<std::mutex> lk(done_mu); /* (the records of a batch lie at their own offset; the list is appended to by one worker at a time) */
+                if (!pwrite_all(fd_res, recs.data(), sizeof(SweepRec) * recs.size(), (long long)sizeof(SweepRec) * first) || fdatasync(fd_res) != 0 ||
+                    write(fd_done, line, (size_t)len) != len || fdatasync(fd_done) != 0) {
+                    ctx_fail(c, "could not record the finished batch in the done-list");
+                    ret = -1;
+                }
+            }
+            if (ret) fe.set(c->err[0] ? c->err : "GPU sweep failed");
+            if (loader.joinable()) loader.join();
+            freesasa_ingest_free(&cur);
+            cur = nxt;
+            cur_rc = nxt_rc;
+            memset(&nxt, 0, sizeof nxt);
+            ti = tn;
+        }
+        freesasa_ingest_free(&cur);
+        pool_put(c);
+    };
+    std::vector<std::thread> th;
+    for (int w = 1; w < n_workers; ++w) th.emplace_back(worker, w);
+    worker(0);
+    for (auto &t : th) t.join();
+    close_files();
+    if (fe.failed.load()) return set_err(err_out, err_len, fe.text);
+    return stopped ? 1 : 0;
+}
+
+/* ------------------------------------------------------------------ structure sweep: from a binary cache */
+
+/* The sweep of a cache file (freesasa_ingest_save): no parsing, no classification — what is left on the host is to get
+ * 33 bytes per atom (coordinates, radius, class) from the file into page-locked memory, which one thread does at
+ * ~1e8 atoms/s (pread from the page cache + checksum) against 4.5e8 atoms/s of one GPU at protein density.  So every
+ * device gets several lanes (threads), each with its own pooled context and page-locked staging: a lane takes the
+ * next batch of structures from the shared counter, reads and verifies exactly its run of atoms
+ * (freesasa_ingest_cache_read_atoms: piece checksums) into its staging buffer, copies it to the device and computes,
+ * while the other lanes are in another stage. */
+int sweep_cache_impl(const char *cache_path, int alg, double probe, int resolution, long long batch_atoms,
+                     double *totals_out, double *class_sums_out, long long *atoms_out, int *status_out, int n_out,
+                     const int *devices, int n_devices, int lanes_per_device, char *err_out, int err_len)
+{
+    if (err_out && err_len > 0) err_out[0] = 0;
+    if (!cache_path || !totals_out) return set_err(err_out, err_len, "null argument");
+    if (alg != 0 && alg != 1) return set_err(err_out, err_len, "unknown algorithm");
+    if (resolution <= 0) return set_err(err_out, err_len, "resolution must be > 0");
+    if (check_devices(devices, n_devices, err_out, err_len)) return -1;
+    freesasa_ingest_cache *cache = nullptr;
+    const int orc = freesasa_ingest_cache_open(cache_path, &cache);
+    if (orc) {
+        char msg[96];
+        snprintf(msg, sizeof msg, "cannot open the cache file (freesasa_ingest code %d)", orc);
+        return set_err(err_out, err_len, msg);
+    }
+    const int S = freesasa_ingest_cache_n_structs(cache);
+    const int64_t *offs = freesasa_ingest_cache_offsets(cache);
+    const int32_t *stat = freesasa_ingest_cache_status(cache);
+    if (n_out < S) { freesasa_ingest_cache_close(cache); return set_err(err_out, err_len, "the output arrays are shorter than the cache's structure count"); }
+    if (batch_atoms <= 0) batch_atoms = 2000000;
+    if (batch_atoms > (1LL << 30)) batch_atoms = 1LL << 30;
+    std::vector<int> cut(1, 0);
+    for (int s = 0; s < S; ++s) {
+        if (offs[s + 1] - offs[s] > (1LL << 30)) { freesasa_ingest_cache_close(cache); return set_err(err_out, err_len, "a structure of the cache is too large for one batch"); }
+        if (offs[s + 1] - offs[cut.back()] > batch_atoms && s > cut.back()) cut.push_back(s); /* (a batch never exceeds batch_atoms unless one structure does) */
+    }
+    cut.push_back(S);
+    const int n_batches = (int)cut.size() - 1;
+    for (int s = 0; s < S; ++s) {
+        totals_out[s] = 0;
+        if (status_out) status_out[s] = stat[s];
+        if (atoms_out) atoms_out[s] = offs[s + 1] - offs[s];
+        if (class_sums_out) class_sums_out[3 * s] = class_sums_out[3 * s + 1] = class_sums_out[3 * s + 2] = 0;
+    }
+    if (lanes_per_device <= 0) {
+        lanes_per_device = freesasa_ingest_usable_cpus() / n_devices;
+        if (lanes_per_device > 4) lanes_per_device = 4;
+        if (lanes_per_device < 2) lanes_per_device = 2; /* (one lane reads while the other computes, at least) */
+    }
+    if (lanes_per_device > 8) lanes_per_device = 8;
+    int n_lanes = lanes_per_device * n_devices;
+    if (n_lanes > n_batches) n_lanes = n_batches;
+    std::vector<double> tp;
+    if (alg == 1) { tp.resize(3 * (size_t)resolution); freesasa_gpu_test_points(resolution, tp.data()); }
+    std::atomic<int> next(0);
+    FirstError fe;
+    auto lane = [&](int id) {
+        freesasa_gpu_ctx *c = pool_get(devices[id % n_devices]);
+        if (!c) { fe.set("could not create a GPU context"); return; }
+        std::vector<int64_t> off;
+        for (;;) {
+            const int b = next.fetch_add(1);
+            if (b >= n_batches || fe.failed.load()) break;
+            const int s0 = cut[b], ns = cut[b + 1] - cut[b];
+            const int64_t a0 = offs[s0];
+            const size_t n = (size_t)(offs[s0 + ns] - a0);
+            if (n == 0) continue;
+            off.resize((size_t)ns + 1);
+            for (int i = 0; i <= ns; ++i) off[i] = offs[s0 + i] - a0;
+            int rc = -1;
+            do {
+                if (hipSetDevice(c->device) != hipSuccess) { ctx_fail(c, "hipSetDevice failed"); break; }
+                if (ensure(c, c->h_xyz, 24 * n) || ensure(c, c->h_radii, 8 * n) || ensure(c, c->h_sasa, 8 * n) ||
+                    ensure(c, c->h_counts, n) || ensure(c, c->h_totals, 8 * 4 * (size_t)ns))
+                    break;
+                if (ensure_pinned(c, &c->stage_in, &c->stage_in_cap, 33 * n + 64) || ensure_pinned(c, &c->stage_out, &c->stage_out_cap, 8 * 4 * (size_t)ns)) break;
+                double *h_xyz = (double *)c->stage_in, *h_r = h_xyz + 3 * n;
+                uint8_t *h_cls = (uint8_t *)(h_r + n);
+                const int rrc = freesasa_ingest_cache_read_atoms(cache, a0, a0 + (int64_t)n, h_xyz, h_r, class_sums_out ? h_cls : nullptr);
+                if (rrc) { ctx_fail(c, "the cache file failed its checksum or could not be read (freesasa_ingest code %d)", rrc); break; }
+                if (hipMemcpyAsync(c->h_xyz.p, h_xyz, 24 * n, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                    hipMemcpyAsync(c->h_radii.p, h_r, 8 * n, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                    (class_sums_out && hipMemcpyAsync(c->h_counts.p, h_cls, n, hipMemcpyHostToDevice, c->stream) != hipSuccess)) {
+                    ctx_fail(c, "host-to-device copy failed");
+                    break;
+                }
+                double *d_tot = (double *)c->h_totals.p, *d_cls = d_tot + ns;
+                if (run_batch(c, alg == 0, (double *)c->h_xyz.p, (double *)c->h_radii.p, off.data(), ns, probe, resolution,
+                              alg == 1 ? tp.data() : nullptr, (double *)c->h_sasa.p, nullptr, d_tot))
+                    break;
+                if (class_sums_out && freesasa_gpu_class_sums_dev(c, (double *)c->h_sasa.p, (const unsigned char *)c->h_counts.p, off.data(), ns, d_cls)) break;
+                double *h_out = (double *)c->stage_out;
+                if (hipMemcpyAsync(h_out, d_tot, 8 * (size_t)(class_sums_out ? 4 * ns : ns), hipMemcpyDeviceToHost, c->stream) != hipSuccess) { ctx_fail(c, "device-to-host copy failed"); break; }
+                if (hipStreamSynchronize(c->stream) != hipSuccess) { ctx_fail(c, "stream synchronize failed"); break; }
+                memcpy(totals_out + s0, h_out, 8 * (size_t)ns);
+                if (class_sums_out) memcpy(class_sums_out + 3 * (size_t)s0, h_out + ns, 8 * 3 * (size_t)ns);
+                rc = 0;
+            } while (0);
+            if (rc) {
+                (void)hipStreamSynchronize(c->stream);
+                fe.set(c->err[0] ? c->err : "GPU cache sweep failed");
+                break;
+            }
+        }
+        pool_put(c);
+    };
+    std::vector<std::thread> th;
+    for (int k = 1; k < n_lanes; ++k) th.emplace_back(lane, k);
+    if (n_lanes > 0) lane(0);
+    for (auto &t : th) t.join();
+    freesasa_ingest_cache_close(cache);
+    if (fe.failed.load()) return set_err(err_out, err_len, fe.text);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ trajectory driver */
+
+/* Frames of ONE system (same atoms, same radii) are independent structures: a SHARD is a run of frames_per_batch
+ * frames that goes through the engine as one batch.  A few host lanes PER DEVICE take shards from a shared counter; a
+ * lane owns a pooled context (stream, workspace, page-locked staging) of its device and does, for its shard,
+ *     read (memory or frame file) -> host-to-device -> [fp32 frames widened to fp64 on the device: an INPUT format,
+ *     the arithmetic stays fp64] -> cell sort + tile kernels -> device-to-host -> write (memory or files)
+ * while the other lanes are in another stage.  The radii live once per device context (shared by every frame of
+ * a batch).  With a done-list file every finished shard is recorded after its results are on disk; a later call
+ * with the same parameters skips the recorded shards: an interrupted run resumes — on any list of devices. */
+struct TrajIO {
+    const double *mem_in = nullptr; /* frames in host memory (fp64) ... */
+    int fd_in = -1;                 /* ... or in a file of raw frames */
+    int in_f32 = 0;
+    long long in_header = 0;
+    double *totals_mem = nullptr, *sasa_mem = nullptr;
+    int fd_totals = -1, fd_sasa = -1;
+    int fd_done = -1;               /* done-list (append) */
+    std::vector<char> done;         /* shards already recorded */
+};
+
+/* returns 0: all shards done, 1: stopped after max_new shards (more left), -1: error */
+int traj_run(TrajIO &io, const double *radii, int n_atoms, long long n_frames, int alg, double probe, int resolution,
+             int frames_per_batch, int lanes_per_device, long long max_new, const int *devices, int n_devices, char *err_out, int err_len)
+{
+    const size_t n = (size_t)n_atoms, FB = (size_t)frames_per_batch;
+    const long long n_shards = (n_frames + frames_per_batch - 1) / frames_per_batch;
+    if (io.done.size() < (size_t)n_shards) io.done.resize((size_t)n_shards, 0);
+    if (lanes_per_device <= 0) {
+        /* three lanes keep one device's PCIe in, kernels and PCIe out busy (measured, round 2); with several devices
+           the lanes also share the granted CPUs (a lane reads, copies and writes on the host): two each at least */
+        lanes_per_device = 3;
+        if (n_devices > 1) {
+            const int per = freesasa_ingest_usable_cpus() / n_devices;
+            lanes_per_device = per >= 3 ? 3 : 2;
+        }
+        if (const char *e = getenv("FREESASA_AMD_TRAJ_LANES")) lanes_per_device = atoi(e) > 0 ? atoi(e) : lanes_per_device; /* tuning aid */
+    }
+    if (lanes_per_device > 8) lanes_per_device = 8;
+    int n_lanes = lanes_per_device * n_devices;
+    if (n_lanes > n_shards) n_lanes = (int)n_shards;
+    std::vector<double> tp;
+    if (alg == 1) { tp.resize(3 * (size_t)resolution); freesasa_gpu_test_points(resolution, tp.data()); }
+    std::vector<int64_t> offs(FB + 1);
+    for (size_t k = 0; k <= FB; ++k) offs[k] = (int64_t)(k * n);
+    const bool in_pinned = io.mem_in && host_pinned(io.mem_in);
+    const bool out_pinned = io.totals_mem && host_pinned(io.totals_mem) && (!io.sasa_mem || host_pinned(io.sasa_mem));
+    const bool want_sasa = io.sasa_mem || io.fd_sasa >= 0;
+    std::atomic<long long> next(0), fresh(0);
+    std::atomic<int> stopped(0);
+    std::mutex done_mu;
+    FirstError fe;
+    auto lane = [&](int id) {
+        freesasa_gpu_ctx *c = pool_get(devices[id % n_devices]); /* lanes 0 .. n_devices-1 open one device each, the next n_devices the second lane of each, ... */
+        if (!c) { fe.set("could not create a GPU context"); return; }
+        bool radii_up = false;
+        for (;;) {
+            const long long k = next.fetch_add(1);
+            if (k >= n_shards || fe.failed.load()) break;
+            if (io.done[(size_t)k]) continue;
+            if (max_new > 0 && fresh.fetch_add(1) >= max_new) { stopped = 1; break; }
+            const long long f0 = k * frames_per_batch;
+            const int nf = (int)(n_frames - f0 < frames_per_batch ? n_frames - f0 : frames_per_batch);
+            const size_t na = n * (size_t)nf;
+            const size_t in_bytes = (io.in_f32 ? 12 : 24) * na;
+            int rc = -1;
+            do {
+                if (hipSetDevice(c->device) != hipSuccess) { ctx_fail(c, "hipSetDevice failed"); break; }
+                if (ensure(c, c->h_xyz, 24 * n * FB) || ensure(c, c->h_radii, 8 * n) || ensure(c, c->h_sasa, 8 * n * FB) ||
+                    ensure(c, c->h_totals, 8 * FB) || (io.in_f32 && ensure(c, c->h_counts, 12 * n * FB)))
+                    break;
+                if (!radii_up) { /* once per lane: the radii of the system */
+                    if (hipMemcpyAsync(c->h_radii.p, radii, 8 * n, hipMemcpyHostToDevice, c->stream) != hipSuccess) { ctx_fail(c, "radii upload failed"); break; }
+                    radii_up = true;
+                }
+                const void *src;
+                if (io.mem_in && in_pinned) {
+                    src = io.mem_in + 3 * n * (size_t)f0;
+                } else {
+                    if (ensure_pinned(c, &c->stage_in, &c->stage_in_cap, in_bytes)) break;
+                    if (io.mem_in) memcpy(c->stage_in, io.mem_in + 3 * n * (size_t)f0, in_bytes);
+                    else if (!pread_all(io.fd_in, c->stage_in, in_bytes, io.in_header + (long long)(io.in_f32 ? 12 : 24) * (long long)n * f0)) {
+                        ctx_fail(c, "could not read frames %lld..%lld of the frame file", f0, f0 + nf - 1);
+                        break;
+                    }
+                    src = c->stage_in;
+                }
+                if (io.in_f32) {
+                    if (hipMemcpyAsync(c->h_counts.p, src, in_bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) { ctx_fail(c, "host-to-device copy failed"); break; }
+                    if (kl_widen_f32((const float *)c->h_counts.p, (double *)c->h_xyz.p, (long long)(3 * na), c->stream) != hipSuccess) { ctx_fail(c, "widening launch failed"); break; }
+                } else if (hipMemcpyAsync(c->h_xyz.p, src, in_bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+                    ctx_fail(c, "host-to-device copy failed");
+                    break;
+                }
+                c->shared_radii = true;
+                const int rb = run_batch(c, alg == 0, (double *)c->h_xyz.p, (double *)c->h_radii.p, offs.data(), nf, probe, resolution,
+                                         alg == 1 ? tp.data() : nullptr, (double *)c->h_sasa.p, nullptr, (double *)c->h_totals.p);
+                c->shared_radii = false;
+                if (rb) break;
+                double *dst_tot = io.totals_mem ? io.totals_mem + f0 : nullptr, *dst_sasa = io.sasa_mem ? io.sasa_mem + n * (size_t)f0 : nullptr;
+                const bool staged = !(io.totals_mem && out_pinned);
+                if (staged) {
+                    if (ensure_pinned(c, &c->stage_out, &c->stage_out_cap, 8 * (size_t)nf + (want_sasa ? 8 * na : 0))) break;
+                    dst_tot = (double *)c->stage_out;
+                    dst_sasa = want_sasa ? (double *)c->stage_out + nf : nullptr;
+                }
+                bool ok = hipMemcpyAsync(dst_tot, c->h_totals.p, 8 * (size_t)nf, hipMemcpyDeviceToHost, c->stream) == hipSuccess;
+                if (ok && want_sasa) ok = hipMemcpyAsync(dst_sasa, c->h_sasa.p, 8 * na, hipMemcpyDeviceToHost, c->stream) == hipSuccess;
+                if (!ok) { ctx_fail(c, "device-to-host copy failed"); break; }
+                if (hipStreamSynchronize(c->stream) != hipSuccess) { ctx_fail(c, "stream synchronize failed"); break; }
+                if (staged) {
+                    if (io.totals_mem) memcpy(io.totals_mem + f0, dst_tot, 8 * (size_t)nf);
+                    if (io.sasa_mem) memcpy(io.sasa_mem + n * (size_t)f0, dst_sasa, 8 * na);
+                    if (io.fd_totals >= 0 && !pwrite_all(io.fd_totals, dst_tot, 8 * (size_t)nf, 8 * f0)) { ctx_fail(c, "could not write the totals file"); break; }
+                    if (io.fd_sasa >= 0 && !pwrite_all(io.fd_sasa, dst_sasa, 8 * na, 8 * (long long)n * f0)) { ctx_fail(c, "could not write the per-atom file"); break; }
+                }
+                if (io.fd_done >= 0) { /* results first, then the record: a shard is listed only when its numbers are on disk */
+                    if ((io.fd_totals >= 0 && fdatasync(io.fd_totals) != 0) || (io.fd_sasa >= 0 && fdatasync(io.fd_sasa) != 0)) {
+                        ctx_fail(c, "could not flush the result files: the shard is not listed as done"); break;
+                    }
+                    char line[96];
+                    const int len = snprintf(line, sizeof line, "shard %lld %lld %d\n", k, f0, nf);
+                    std::lock_guard<std::mutex> lk(done_mu);
+                    if (write(io.fd_done, line, (size_t)len) != len || fdatasync(io.fd_done) != 0) { ctx_fail(c, "could not append to the done-list"); break; }
+                }
+                io.done[(size_t)k] = 1;
+                rc = 0;
+            } while (0);
+            if (rc) {
+                c->shared_radii = false;
+                (void)hipStreamSynchronize(c->stream);
+                fe.set(c->err[0] ? c->err : "trajectory shard failed");
+                break;
+            }
+        }
+        pool_put(c);
+    };
+    std::vector<std::thread> th;
+    for (int k = 1; k < n_lanes; ++k) th.emplace_back(lane, k);
+    lane(0);
+    for (auto &t : th) t.join();
+    if (fe.failed.load()) return set_err(err_out, err_len, fe.text);
+    return stopped.load() ? 1 : 0;
+}
+
+} /* namespace */
+
+/* ------------------------------------------------------------------ entry points: sweeps */
+
+extern "C" int freesasa_gpu_sweep_files(const char *const *paths, int n_paths, int ingest_options, int n_threads,
+                                        int alg, double probe, int resolution, long long batch_atoms,
+                                        double *totals_out, double *class_sums_out, long long *atoms_out, int *status_out,
+                                        int device, char *err_out, int err_len)
+{
+    return sweep_impl(paths, n_paths, ingest_options, n_threads, alg, probe, resolution, batch_atoms, totals_out, class_sums_out,
+                      atoms_out, status_out, nullptr, 0, &device, 1, err_out, err_len);
+}
+
+extern "C" int freesasa_gpu_sweep_files_resumable(const char *const *paths, int n_paths, int ingest_options, int n_threads,
+                                                  int alg, double probe, int resolution, long long batch_atoms,
+                                                  double *totals_out, double *class_sums_out, long long *atoms_out, int *status_out,
+                                                  const char *done_path, long long max_new_batches, int device, char *err_out, int err_len)
+{
+    return sweep_impl(paths, n_paths, ingest_options, n_threads, alg, probe, resolution, batch_atoms, totals_out, class_sums_out,
+                      atoms_out, status_out, done_path, max_new_batches, &device, 1, err_out, err_len);
+}
+
+extern "C" int freesasa_gpu_sweep_files_devices(const char *const *paths, int n_paths, int ingest_options, int n_threads,
+                                                int alg, double probe, int resolution, long long batch_atoms,
+                                                double *totals_out, double *class_sums_out, long long *atoms_out, int *status_out,
+                                                const char *done_path, long long max_new_batches, const int *devices, int n_devices,
+                                                char *err_out, int err_len)
+{
+    return sweep_impl(paths, n_paths, ingest_options, n_threads, alg, probe, resolution, batch_atoms, totals_out, class_sums_out,
+                      atoms_out, status_out, done_path, max_new_batches, devices, n_devices, err_out, err_len);
+}
+
+extern "C" int freesasa_gpu_sweep_cache_devices(const char *cache_path, int alg, double probe, int resolution, long long batch_atoms,
+                                                double *totals_out, double *class_sums_out, long long *atoms_out, int *status_out, int n_out,
+                                                const int *devices, int n_devices, int lanes_per_device, char *err_out, int err_len)
+{
+    return sweep_cache_impl(cache_path, alg, probe, resolution, batch_atoms, totals_out, class_sums_out, atoms_out, status_out, n_out,
+                            devices, n_devices, lanes_per_device, err_out, err_len);
+}
+
+/* ------------------------------------------------------------------ entry points: trajectories */
+
+static int trajectory_mem(const double *xyz_frames, const double *radii, int n_atoms, int n_frames, int alg, double probe, int resolution,
+                          int frames_per_batch, double *totals_out, double *sasa_out, const int *devices, int n_devices, char *err_out, int err_len)
+{
+    if (err_out && err_len > 0) err_out[0] = 0;
+    if (!xyz_frames || !radii || !totals_out) return set_err(err_out, err_len, "null argument");
+    if (n_atoms <= 0 || n_frames <= 0) return set_err(err_out, err_len, "n_atoms and n_frames must be > 0");
+    if (alg != 0 && alg != 1) return set_err(err_out, err_len, "unknown algorithm");
+    if (resolution <= 0) return set_err(err_out, err_len, "resolution must be > 0");
+    if (check_devices(devices, n_devices, err_out, err_len)) return -1;
+    if (frames_per_batch <= 0) frames_per_batch = (int)(1250000 / n_atoms) + 1;
+    if (frames_per_batch > n_frames) frames_per_batch = n_frames;
+    if ((long long)frames_per_batch * n_atoms > (1LL << 30)) return set_err(err_out, err_len, "batch too large");
+    TrajIO io;
+    io.mem_in = xyz_frames; io.totals_mem = totals_out; io.sasa_mem = sasa_out;
+    return traj_run(io, radii, n_atoms, n_frames, alg, probe, resolution, frames_per_batch, 0, 0, devices, n_devices, err_out, err_len) < 0 ? -1 : 0;
+}
+
+extern "C" int freesasa_gpu_trajectory(const double *xyz_frames, const double *radii, int n_atoms, int n_frames,
+                                       int alg, double probe, int resolution, int frames_per_batch,
+                                       double *totals_out, double *sasa_out, int device, char *err_out, int err_len)
+{
+    return trajectory_mem(xyz_frames, radii, n_atoms, n_frames, alg, probe, resolution, frames_per_batch, totals_out, sasa_out, &device, 1, err_out, err_len);
+}
+
+extern "C" int freesasa_gpu_trajectory_devices(const double *xyz_frames, const double *radii, int n_atoms, int n_frames,
+                                               int alg, double probe, int resolution, int frames_per_batch,
+                                               double *totals_out, double *sasa_out, const int *devices, int n_devices, char *err_out, int err_len)
+{
+    return trajectory_mem(xyz_frames, radii, n_atoms, n_frames, alg, probe, resolution, frames_per_batch, totals_out, sasa_out, devices, n_devices, err_out, err_len);
+}
+
+/* Frame file -> result files, resumable (include/freesasa_gpu.h has the formats).  The done-list names its run: the
+ * parameters, the frame file's size and modification time and a checksum of the radii — NOT the devices: a run
+ * interrupted on eight GPUs may be finished on one, with the same files byte for byte. */
+extern "C" int freesasa_gpu_trajectory_file_devices(const char *frames_path, int frames_f32, long long header_bytes, const double *radii,
+                                                    int n_atoms, long long n_frames, int alg, double probe, int resolution,
+                                                    int frames_per_batch, const char *totals_path, const char *sasa_path,
+                                                    const char *done_path, long long max_new_shards, const int *devices, int n_devices,
+                                                    long long *frames_total_out, char *err_out, int err_len)
+{
+    if (err_out && err_len > 0) err_out[0] = 0;
+    if (!frames_path || !radii || !totals_path) return set_err(err_out, err_len, "null argument");
+    if (n_atoms <= 0 || header_bytes < 0) return set_err(err_out, err_len, "bad argument");
+    if (alg != 0 && alg != 1) return set_err(err_out, err_len, "unknown algorithm");
+    if (resolution <= 0) return set_err(err_out, err_len, "resolution must be > 0");
+    if (check_devices(devices, n_devices, err_out, err_len)) return -1;
+    TrajIO io;
+    int ret = -1;
+    do {
+        io.fd_in = open(frames_path, O_RDONLY);
+        if (io.fd_in < 0) { set_err(err_out, err_len, "cannot open the frame file"); break; }
+        struct stat st;
+        if (fstat(io.fd_in, &st) != 0) { set_err(err_out, err_len, "cannot stat the frame file"); break; }
+        const long long frame_bytes = (frames_f32 ? 12LL : 24LL) * n_atoms;
+        const long long in_file = ((long long)st.st_size - header_bytes) / frame_bytes;
+        if (n_frames <= 0) n_frames = in_file;
+        if (n_frames <= 0 || n_frames > in_file) { set_err(err_out, err_len, "the frame file holds fewer frames than asked for"); break; }
+        if (frames_total_out) *frames_total_out = n_frames;
+        if (frames_per_batch <= 0) frames_per_batch = (int)(1250000 / n_atoms) + 1;
+        if (frames_per_batch > n_frames) frames_per_batch = (int)n_frames;
+        if ((long long)frames_per_batch * n_atoms > (1LL << 30)) { set_err(err_out, err_len, "batch too large"); break; }
+        io.in_f32 = frames_f32 ? 1 : 0; io.in_header = header_bytes;
+        const long long n_shards = (n_frames + frames_per_batch - 1) / frames_per_batch;
+        io.done.assign((size_t)n_shards, 0);
+        unsigned long long hr = 1469598103934665603ULL; /* FNV-1a over the radii */
+        for (size_t q = 0; q < 8 * (size_t)n_atoms; ++q) hr = (hr ^ ((const unsigned char *)radii)[q]) * 1099511628211ULL;
+        char head[384];
+        snprintf(head, sizeof head, "freesasa_amd trajectory done-list v2 n_atoms=%d n_frames=%lld frames_per_batch=%d alg=%d resolution=%d probe=%.17g f32=%d "
+                 "header_bytes=%lld frames_size=%lld frames_mtime=%lld.%09ld radii=%016llx\n",
+                 n_atoms, n_frames, frames_per_batch, alg, resolution, probe, io.in_f32, header_bytes, (long long)st.st_size,
+                 (long long)st.st_mtim.tv_sec, (long)st.st_mtim.tv_nsec, hr);
+        bool resume = false;
+        if (done_path) {
+            FILE *fp = fopen(done_path, "r");
+            if (fp) {
+                char line[384];
+                if (fgets(line, sizeof line, fp)) {
+                    if (strcmp(line, head) != 0) { fclose(fp); set_err(err_out, err_len, "the done-list belongs to a run with other parameters, radii or frame file"); break; }
+                    resume = true;
+                    long long k, f0; int nf;
+                    while (fgets(line, sizeof line, fp))
+                        if (sscanf(line, "shard %lld %lld %d", &k, &f0, &nf) == 3 && k >= 0 && k < n_shards && f0 == k * frames_per_batch &&
+                            line[strlen(line) - 1] == '\n') /* (a record cut short by a crash does not count) */
+                            io.done[(size_t)k] = 1;
+                }
+                fclose(fp);
+            }
+        }
+        io.fd_totals = open(totals_path, resume ? O_WRONLY | O_CREAT : O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (io.fd_totals < 0) { set_err(err_out, err_len, "cannot open the totals file"); break; }
+        if (sasa_path) {
+            io.fd_sasa = open(sasa_path, resume ? O_WRONLY | O_CREAT : O_WRONLY | O_CREAT | O_TRUNC, 0644);
+            if (io.fd_sasa < 0) { set_err(err_out, err_len, "cannot open the per-atom file"); break; }
+        }
+        if (done_path) {
+            io.fd_done = open(done_path, resume ? O_WRONLY | O_APPEND : O_WRONLY | O_CREAT | O_TRUNC, 0644);
+            if (io.fd_done < 0) { set_err(err_out, err_len, "cannot open the done-list"); break; }
+            if (!resume && write(io.fd_done, head, strlen(head)) != (ssize_t)strlen(head)) { set_err(err_out, err_len, "cannot write the done-list"); break; }
+        }
+        ret = traj_run(io, radii, n_atoms, n_frames, alg, probe, resolution, frames_per_batch, 0, max_new_shards, devices, n_devices, err_out, err_len);
+    } while (0);
+    if (io.fd_in >= 0) close(io.fd_in);
+    if (io.fd_totals >= 0) close(io.fd_totals);
+    if (io.fd_sasa >= 0) close(io.fd_sasa);
+    if (io.fd_done >= 0) close(io.fd_done);
+    return ret;
+}
+
+extern "C" int freesasa_gpu_trajectory_file(const char *frames_path, int frames_f32, long long header_bytes, const double *radii,
+                                            int n_atoms, long long n_frames, int alg, double probe, int resolution,
+                                            int frames_per_batch, const char *totals_path, const char *sasa_path,
+                                            const char *done_path, long long max_new_shards, int device,
+                                            long long *frames_total_out, char *err_out, int err_len)
+{
+    return freesasa_gpu_trajectory_file_devices(frames_path, frames_f32, header_bytes, radii, n_atoms, n_frames, alg, probe, resolution,
+                                                frames_per_batch, totals_path, sasa_path, done_path, max_new_shards, &device, 1,
+                                                frames_total_out, err_out, err_len);
+}

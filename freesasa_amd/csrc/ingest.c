@@ -12,9 +12,13 @@
  * Lines are consumed the way fgets(line, 120) does (src/structure.c:654, src/pdb.h:22): physical
  * lines longer than 119 characters continue as a new "line".
  */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE /* sched_getaffinity, CPU_COUNT */
+#endif
 #include "freesasa_ingest.h"
 
 #include <ctype.h>
+#include <sched.h>
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1033,6 +1037,36 @@ void freesasa_ingest_free(freesasa_ingest_batch *b)
     memset(b, 0, sizeof *b);
 }
 
+/* CPUs this process may really use at once: its affinity mask, capped by the CPU quota of its cgroup (a GPU box can
+ * show 256 logical CPUs and grant 16 of them: threads beyond the quota only take turns).  cgroup v2 "cpu.max" =
+ * "<quota> <period>" or "max <period>"; v1: cpu.cfs_quota_us / cpu.cfs_period_us. */
+int freesasa_ingest_usable_cpus(void)
+{
+    int n = (int)sysconf(_SC_NPROCESSORS_ONLN);
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0 && CPU_COUNT(&set) < n) n = CPU_COUNT(&set);
+    double quota = -1, period = 0;
+    FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
+    if (f) {
+        char q[32];
+        if (fscanf(f, "%31s %lf", q, &period) == 2 && strcmp(q, "max") != 0) quota = atof(q);
+        fclose(f);
+    } else if ((f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"))) {
+        if (fscanf(f, "%lf", &quota) != 1) quota = -1;
+        fclose(f);
+        if ((f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r"))) {
+            if (fscanf(f, "%lf", &period) != 1) period = 0;
+            fclose(f);
+        }
+    }
+    if (quota > 0 && period > 0) {
+        const int g = (int)(quota / period);
+        if (g >= 1 && g < n) n = g;
+        else if (g < 1) n = 1;
+    }
+    return n < 1 ? 1 : n;
+}
+
 static int run(job *j, int n_threads, freesasa_ingest_batch *out)
 {
     memset(out, 0, sizeof *out);
@@ -1041,7 +1075,7 @@ static int run(job *j, int n_threads, freesasa_ingest_batch *out)
     if (j->options & ~supported) return FREESASA_INGEST_EOPTION;
     if (j->n < 0) return FREESASA_INGEST_EOPTION;
     if (n_threads <= 0) { /* default: the cores, but no more threads than pay for their start-up */
-        n_threads = (int)sysconf(_SC_NPROCESSORS_ONLN);
+        n_threads = freesasa_ingest_usable_cpus();
         /* one process per GPU (torchrun exports LOCAL_WORLD_SIZE): the ranks of a node share its cores */
         const char *lws = getenv("LOCAL_WORLD_SIZE");
         const int ranks = lws ? atoi(lws) : 1;

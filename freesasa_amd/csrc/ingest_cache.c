@@ -7,15 +7,18 @@
  * src/main.cc:763-779); what the batch holds is what the reference's structures hold (include/freesasa_ingest.h).
  *
  * File = header (128 bytes) + the arrays of the batch in the order of section_bytes() below, each padded to 16
- * bytes.  Little endian, IEEE doubles; the header carries a byte-order mark, the array lengths and a checksum of
- * the payload, and a file is only accepted when all of it adds up (truncated copies and edited files are refused,
- * not half-loaded).  Written to "<path>.tmp<pid>" and renamed, so a reader never sees a partial file under the
+ * bytes, + a table with one checksum per 1 MiB piece of every array (version 2: pieces are read and verified by
+ * several threads at once, and a sweep reads - and verifies - only the coordinates, radii and classes of the
+ * structures it is about to compute, straight into page-locked memory).  Little endian, IEEE doubles; the header
+ * carries a byte-order mark, the array lengths and a checksum of the table, and a file is only accepted when all of
+ * it adds up (truncated copies and edited files are refused, not half-loaded).  Written to "<path>.tmp<pid>" and renamed, so a reader never sees a partial file under the
  * final name.
  */
 #include "freesasa_ingest.h"
 
 #include <errno.h>
 #include <fcntl.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -23,7 +26,7 @@
 #include <unistd.h>
 
 #define CACHE_MAGIC "FSASABAT"
-#define CACHE_VERSION 1u
+#define CACHE_VERSION 2u
 #define CACHE_BOM 0x01020304u
 #define CACHE_SECTIONS 14
 
@@ -66,25 +69,46 @@ static void section_ptrs(const freesasa_ingest_batch *b, const void *ptr[CACHE_S
     ptr[9] = b->res_first; ptr[10] = b->res_ref; ptr[11] = b->res_name; ptr[12] = b->res_number; ptr[13] = b->res_chain;
 }
 
-/* checksum of a byte run, 8 bytes at a time (multiply-xorshift; the tail is zero-padded); chained through h */
-static uint64_t mix_bytes(uint64_t h, const void *p, uint64_t n)
+/* Checksums.  Version 2 cuts every section into PIECES of CACHE_PIECE bytes (the last one shorter) and keeps one
+ * checksum per piece in a table behind the payload; the header's checksum covers that table.  Pieces are independent:
+ * several threads read and verify them at once (freesasa_ingest_load_mt), and a reader that wants a run of atoms only
+ * (freesasa_ingest_cache_read_atoms: a sweep needs coordinates, radii and classes, not names) verifies exactly the
+ * pieces it touches.  Version 1 chained ONE checksum through the whole payload: one thread, 2.2e7 atoms/s.
+ * A piece: four interleaved multiply-xorshift lanes over 32 bytes a step (the lanes' dependent multiplications
+ * overlap: ~3 x the throughput of one chain), the tail zero-padded, the lanes folded with the length at the end. */
+#define CACHE_PIECE ((uint64_t)1 << 20)
+#define MIX_K 0x9E3779B97F4A7C15ull
+static inline uint64_t mix_step(uint64_t h, uint64_t w)
+{
+    h = (h ^ w) * MIX_K;
+    return h ^ (h >> 29);
+}
+static uint64_t mix_piece(const void *p, uint64_t n)
 {
     const unsigned char *q = (const unsigned char *)p;
+    uint64_t h[4] = {0x243F6A8885A308D3ull, 0x13198A2E03707344ull, 0xA4093822299F31D0ull, 0x082EFA98EC4E6C89ull};
     uint64_t i = 0;
-    for (; i + 8 <= n; i += 8) {
-        uint64_t w;
-        memcpy(&w, q + i, 8);
-        h = (h ^ w) * 0x9E3779B97F4A7C15ull;
-        h ^= h >> 29;
+    for (; i + 32 <= n; i += 32) {
+        uint64_t w[4];
+        memcpy(w, q + i, 32);
+        h[0] = mix_step(h[0], w[0]); h[1] = mix_step(h[1], w[1]); h[2] = mix_step(h[2], w[2]); h[3] = mix_step(h[3], w[3]);
     }
     if (i < n) {
-        uint64_t w = 0;
-        memcpy(&w, q + i, (size_t)(n - i));
-        h = (h ^ w) * 0x9E3779B97F4A7C15ull;
-        h ^= h >> 29;
+        uint64_t w[4] = {0, 0, 0, 0};
+        memcpy(w, q + i, (size_t)(n - i));
+        h[0] = mix_step(h[0], w[0]); h[1] = mix_step(h[1], w[1]); h[2] = mix_step(h[2], w[2]); h[3] = mix_step(h[3], w[3]);
     }
-    return (h ^ n) * 0xC2B2AE3D27D4EB4Full;
+    uint64_t r = mix_step(mix_step(mix_step(h[0], h[1]), h[2]), h[3]);
+    return (r ^ n) * 0xC2B2AE3D27D4EB4Full;
 }
+/* the header's checksum: the counts and every piece checksum, chained */
+static uint64_t mix_table(int32_t S, int64_t N, int64_t R, const uint64_t *table, uint64_t n_pieces)
+{
+    uint64_t h = mix_step(mix_step(mix_step(0x452821E638D01377ull, (uint64_t)(uint32_t)S), (uint64_t)N), (uint64_t)R);
+    for (uint64_t k = 0; k < n_pieces; ++k) h = mix_step(h, table[k]);
+    return (h ^ n_pieces) * 0xC2B2AE3D27D4EB4Full;
+}
+static uint64_t pieces_of(uint64_t len) { return (len + CACHE_PIECE - 1) / CACHE_PIECE; }
 
 static int write_all(int fd, const void *p, uint64_t n)
 {
@@ -97,14 +121,14 @@ static int write_all(int fd, const void *p, uint64_t n)
     }
     return 1;
 }
-static int read_all(int fd, void *p, uint64_t n)
+static int pread_all(int fd, void *p, uint64_t n, uint64_t off)
 {
     char *q = (char *)p;
     while (n > 0) {
-        const ssize_t r = read(fd, q, n > ((uint64_t)1 << 30) ? (size_t)1 << 30 : (size_t)n);
+        const ssize_t r = pread(fd, q, n > ((uint64_t)1 << 30) ? (size_t)1 << 30 : (size_t)n, (off_t)off);
         if (r < 0) { if (errno == EINTR) continue; return 0; }
         if (r == 0) return 0; /* short file */
-        q += r; n -= (uint64_t)r;
+        q += r; n -= (uint64_t)r; off += (uint64_t)r;
     }
     return 1;
 }
@@ -164,20 +188,25 @@ int freesasa_ingest_save(const freesasa_ingest_batch *b, const char *path)
     memcpy(h.magic, CACHE_MAGIC, 8);
     h.version = CACHE_VERSION; h.bom = CACHE_BOM;
     h.n_structs = b->n_structs; h.n_atoms = b->n_atoms; h.n_residues = b->n_residues;
-    uint64_t sum = 0x243F6A8885A308D3ull;
+    uint64_t n_pieces = 0;
     for (int k = 0; k < CACHE_SECTIONS; ++k) {
         h.payload_bytes += pad16(len[k]);
-        sum = mix_bytes(sum, ptr[k], len[k]);
+        n_pieces += pieces_of(len[k]);
         if (k < 8) h.section_bytes[k] = len[k];
     }
-    h.checksum = sum;
+    uint64_t *table = (uint64_t *)calloc((size_t)(n_pieces + 2), 8); /* (+ the padding to 16 bytes) */
+    if (!table) return FREESASA_INGEST_ENOMEM;
+    for (uint64_t k = 0, t = 0; k < CACHE_SECTIONS; ++k)
+        for (uint64_t o = 0; o < len[k]; o += CACHE_PIECE)
+            table[t++] = mix_piece((const char *)ptr[k] + o, len[k] - o < CACHE_PIECE ? len[k] - o : CACHE_PIECE);
+    h.checksum = mix_table(h.n_structs, h.n_atoms, h.n_residues, table, n_pieces);
 
     const size_t pl = strlen(path);
     char *tmp = (char *)malloc(pl + 32);
-    if (!tmp) return FREESASA_INGEST_ENOMEM;
+    if (!tmp) { free(table); return FREESASA_INGEST_ENOMEM; }
     snprintf(tmp, pl + 32, "%s.tmp%ld", path, (long)getpid());
     const int fd = open(tmp, O_WRONLY | O_CREAT | O_TRUNC, 0644);
-    if (fd < 0) { free(tmp); return FREESASA_INGEST_EIO; }
+    if (fd < 0) { free(tmp); free(table); return FREESASA_INGEST_EIO; }
     unsigned char head[CACHE_HEADER_BYTES];
     memset(head, 0, sizeof head);
     memcpy(head, &h, sizeof h);
@@ -187,59 +216,158 @@ int freesasa_ingest_save(const freesasa_ingest_batch *b, const char *path)
         ok = write_all(fd, ptr[k], len[k]);
         if (ok) ok = write_all(fd, zeros, pad16(len[k]) - len[k]);
     }
+    if (ok) ok = write_all(fd, table, pad16(8 * n_pieces));
     if (ok && fsync(fd) != 0) ok = 0;
     if (close(fd) != 0) ok = 0;
     if (ok && rename(tmp, path) != 0) ok = 0;
     if (!ok) (void)unlink(tmp);
     free(tmp);
+    free(table);
     return ok ? FREESASA_INGEST_OK : FREESASA_INGEST_EIO;
 }
 
-int freesasa_ingest_load(const char *path, freesasa_ingest_batch *out)
+/* ------------------------------------------------------------------ reading */
+
+/* An open cache file: the header, the piece table (verified against the header) and where every section starts.
+   Shared by the whole-batch loader and the partial reader. */
+struct freesasa_ingest_cache {
+    int fd;
+    cache_header h;
+    uint64_t len[CACHE_SECTIONS], start[CACHE_SECTIONS], first_piece[CACHE_SECTIONS];
+    uint64_t n_pieces, *table;
+    int64_t *offsets; /* [n_structs + 1], verified (the partial reader's index) */
+    int32_t *status;  /* [n_structs] */
+};
+
+static int read_section_verified(const freesasa_ingest_cache *c, int k, uint64_t p0, uint64_t p1, void *dst);
+
+static int cache_open(const char *path, freesasa_ingest_cache **out)
 {
-    if (!out) return FREESASA_INGEST_EFORMAT;
-    memset(out, 0, sizeof *out);
+    *out = NULL;
     if (!path) return FREESASA_INGEST_EIO;
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return FREESASA_INGEST_EIO;
+    freesasa_ingest_cache *c = (freesasa_ingest_cache *)calloc(1, sizeof *c);
+    if (!c) { (void)close(fd); return FREESASA_INGEST_ENOMEM; }
+    c->fd = fd;
     int rc = FREESASA_INGEST_EFORMAT;
-    void *arr[CACHE_SECTIONS] = {0};
     do {
         struct stat st;
         if (fstat(fd, &st) != 0) { rc = FREESASA_INGEST_EIO; break; }
         unsigned char head[CACHE_HEADER_BYTES];
-        if (st.st_size < (off_t)sizeof head || !read_all(fd, head, sizeof head)) break;
-        cache_header h;
-        memcpy(&h, head, sizeof h);
+        if (st.st_size < (off_t)sizeof head || !pread_all(fd, head, sizeof head, 0)) break;
+        memcpy(&c->h, head, sizeof c->h);
+        const cache_header *h = &c->h;
         int tail_zero = 1;
-        for (size_t q = sizeof h; q < sizeof head; ++q) if (head[q]) tail_zero = 0;
-        if (!tail_zero || h.reserved0 != 0) break;
-        if (memcmp(h.magic, CACHE_MAGIC, 8) != 0 || h.version != CACHE_VERSION || h.bom != CACHE_BOM) break;
-        if (h.n_structs < 0 || h.n_atoms < 0 || h.n_residues < 0 || h.n_atoms > ((int64_t)1 << 40) || h.n_residues > h.n_atoms) break;
-        uint64_t len[CACHE_SECTIONS], payload = 0;
-        section_bytes(h.n_structs, h.n_atoms, h.n_residues, len);
+        for (size_t q = sizeof *h; q < sizeof head; ++q) if (head[q]) tail_zero = 0;
+        if (!tail_zero || h->reserved0 != 0) break;
+        if (memcmp(h->magic, CACHE_MAGIC, 8) != 0 || h->version != CACHE_VERSION || h->bom != CACHE_BOM) break;
+        if (h->n_structs < 0 || h->n_atoms < 0 || h->n_residues < 0 || h->n_atoms > ((int64_t)1 << 40) || h->n_residues > h->n_atoms) break;
+        uint64_t payload = 0;
+        section_bytes(h->n_structs, h->n_atoms, h->n_residues, c->len);
         int same = 1;
         for (int k = 0; k < CACHE_SECTIONS; ++k) {
-            payload += pad16(len[k]);
-            if (k < 8 && h.section_bytes[k] != len[k]) same = 0;
+            c->start[k] = CACHE_HEADER_BYTES + payload;
+            c->first_piece[k] = c->n_pieces;
+            payload += pad16(c->len[k]);
+            c->n_pieces += pieces_of(c->len[k]);
+            if (k < 8 && h->section_bytes[k] != c->len[k]) same = 0;
         }
-        if (!same || payload != h.payload_bytes || (uint64_t)st.st_size != CACHE_HEADER_BYTES + payload) break;
-        uint64_t sum = 0x243F6A8885A308D3ull;
+        if (!same || payload != h->payload_bytes || (uint64_t)st.st_size != CACHE_HEADER_BYTES + payload + pad16(8 * c->n_pieces)) break;
+        c->table = (uint64_t *)malloc((size_t)pad16(8 * c->n_pieces) + 16);
+        if (!c->table) { rc = FREESASA_INGEST_ENOMEM; break; }
+        if (!pread_all(fd, c->table, pad16(8 * c->n_pieces), CACHE_HEADER_BYTES + payload)) break;
+        if ((c->n_pieces & 1) && c->table[c->n_pieces] != 0) break; /* (the table's padding is written as zeros) */
+        if (mix_table(h->n_structs, h->n_atoms, h->n_residues, c->table, c->n_pieces) != h->checksum) break;
+        *out = c;
+        return FREESASA_INGEST_OK;
+    } while (0);
+    free(c->table);
+    (void)close(fd);
+    free(c);
+    return rc;
+}
+
+/* pieces [p0, p1) of section k into dst (the section's byte p0 * CACHE_PIECE lands on dst[0]), each checked */
+static int read_section_verified(const freesasa_ingest_cache *c, int k, uint64_t p0, uint64_t p1, void *dst)
+{
+    for (uint64_t p = p0; p < p1; ++p) {
+        const uint64_t o = p * CACHE_PIECE, n = c->len[k] - o < CACHE_PIECE ? c->len[k] - o : CACHE_PIECE;
+        char *d = (char *)dst + (o - p0 * CACHE_PIECE);
+        if (!pread_all(c->fd, d, n, c->start[k] + o)) return 0;
+        if (mix_piece(d, n) != c->table[c->first_piece[k] + p]) return 0;
+    }
+    return 1;
+}
+
+typedef struct load_job {
+    const freesasa_ingest_cache *c;
+    void **arr;
+    uint64_t next; /* next piece (over all sections) */
+    int failed;
+    pthread_mutex_t mu;
+} load_job;
+static void *load_worker(void *arg)
+{
+    load_job *j = (load_job *)arg;
+    const freesasa_ingest_cache *c = j->c;
+    for (;;) {
+        pthread_mutex_lock(&j->mu);
+        const uint64_t t = j->failed ? c->n_pieces : j->next++;
+        pthread_mutex_unlock(&j->mu);
+        if (t >= c->n_pieces) break;
+        int k = CACHE_SECTIONS - 1;
+        while (k > 0 && c->first_piece[k] > t) --k;
+        while (pieces_of(c->len[k]) == 0 && k > 0) --k; /* (never: an empty section owns no piece) */
+        const uint64_t p = t - c->first_piece[k];
+        if (!read_section_verified(c, k, p, p + 1, (char *)j->arr[k] + p * CACHE_PIECE)) {
+            pthread_mutex_lock(&j->mu);
+            j->failed = 1;
+            pthread_mutex_unlock(&j->mu);
+        }
+    }
+    return NULL;
+}
+
+int freesasa_ingest_load_mt(const char *path, int n_threads, freesasa_ingest_batch *out)
+{
+    if (!out) return FREESASA_INGEST_EFORMAT;
+    memset(out, 0, sizeof *out);
+    freesasa_ingest_cache *c = NULL;
+    int rc = cache_open(path, &c);
+    if (rc) return rc;
+    void *arr[CACHE_SECTIONS] = {0};
+    rc = FREESASA_INGEST_EFORMAT;
+    do {
         int ok = 1;
-        for (int k = 0; ok && k < CACHE_SECTIONS; ++k) {
-            arr[k] = malloc(len[k] > 0 ? (size_t)len[k] : 1);
+        for (int k = 0; k < CACHE_SECTIONS; ++k) {
+            arr[k] = malloc(c->len[k] > 0 ? (size_t)c->len[k] : 1);
             if (!arr[k]) { rc = FREESASA_INGEST_ENOMEM; ok = 0; break; }
             unsigned char padding[16] = {0};
-            if (!read_all(fd, arr[k], len[k]) || !read_all(fd, padding, pad16(len[k]) - len[k])) { ok = 0; break; }
+            const uint64_t np = pad16(c->len[k]) - c->len[k];
+            if (np && !pread_all(c->fd, padding, np, c->start[k] + c->len[k])) { ok = 0; break; }
             for (int q = 0; q < 16; ++q) if (padding[q]) ok = 0; /* (the padding is written as zeros) */
             if (!ok) break;
-            sum = mix_bytes(sum, arr[k], len[k]);
         }
         if (!ok) break;
-        if (sum != h.checksum) break;
+        if (n_threads <= 0) { n_threads = freesasa_ingest_usable_cpus(); if (n_threads > 8) n_threads = 8; }
+        if ((uint64_t)n_threads > c->n_pieces) n_threads = (int)(c->n_pieces > 0 ? c->n_pieces : 1);
+        if (n_threads > 64) n_threads = 64;
+        load_job j;
+        memset(&j, 0, sizeof j);
+        j.c = c; j.arr = arr;
+        pthread_mutex_init(&j.mu, NULL);
+        pthread_t th[64];
+        int started = 0;
+        for (; started < n_threads - 1; ++started)
+            if (pthread_create(&th[started], NULL, load_worker, &j)) break;
+        load_worker(&j); /* the calling thread works too */
+        for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+        pthread_mutex_destroy(&j.mu);
+        if (j.failed) break;
         freesasa_ingest_batch b;
         memset(&b, 0, sizeof b);
-        b.n_structs = h.n_structs; b.n_atoms = h.n_atoms; b.n_residues = h.n_residues;
+        b.n_structs = c->h.n_structs; b.n_atoms = c->h.n_atoms; b.n_residues = c->h.n_residues;
         b.offsets = (int64_t *)arr[0]; b.res_offsets = (int64_t *)arr[1]; b.status = (int32_t *)arr[2];
         b.xyz = (double *)arr[3]; b.radii = (double *)arr[4]; b.atom_class = (uint8_t *)arr[5]; b.atom_backbone = (uint8_t *)arr[6];
         b.atom_name = (char *)arr[7]; b.atom_symbol = (char *)arr[8]; b.res_first = (int64_t *)arr[9]; b.res_ref = (int16_t *)arr[10];
@@ -250,6 +378,87 @@ int freesasa_ingest_load(const char *path, freesasa_ingest_batch *out)
         rc = FREESASA_INGEST_OK;
     } while (0);
     for (int k = 0; k < CACHE_SECTIONS; ++k) free(arr[k]);
-    (void)close(fd);
+    freesasa_ingest_cache_close(c);
     return rc;
+}
+
+int freesasa_ingest_load(const char *path, freesasa_ingest_batch *out) { return freesasa_ingest_load_mt(path, 0, out); }
+
+/* ------------------------------------------------------------------ partial reader (sweeps from a cache) */
+
+int freesasa_ingest_cache_open(const char *path, freesasa_ingest_cache **out)
+{
+    if (!out) return FREESASA_INGEST_EFORMAT;
+    freesasa_ingest_cache *c = NULL;
+    int rc = cache_open(path, &c);
+    if (rc) return rc;
+    rc = FREESASA_INGEST_EFORMAT;
+    do {
+        const int32_t S = c->h.n_structs;
+        c->offsets = (int64_t *)malloc(c->len[0] > 0 ? (size_t)c->len[0] : 8);
+        c->status = (int32_t *)malloc(c->len[2] > 0 ? (size_t)c->len[2] : 4);
+        if (!c->offsets || !c->status) { rc = FREESASA_INGEST_ENOMEM; break; }
+        if (!read_section_verified(c, 0, 0, pieces_of(c->len[0]), c->offsets) || !read_section_verified(c, 2, 0, pieces_of(c->len[2]), c->status)) break;
+        int ok = c->offsets[0] == 0 && c->offsets[S] == c->h.n_atoms;
+        for (int32_t s = 0; ok && s < S; ++s)
+            if (c->offsets[s + 1] < c->offsets[s] || c->offsets[s + 1] > c->h.n_atoms || c->status[s] < FREESASA_INGEST_OK || c->status[s] > FREESASA_INGEST_ENOMEM) ok = 0;
+        if (!ok) break;
+        *out = c;
+        return FREESASA_INGEST_OK;
+    } while (0);
+    freesasa_ingest_cache_close(c);
+    *out = NULL;
+    return rc;
+}
+void freesasa_ingest_cache_close(freesasa_ingest_cache *c)
+{
+    if (!c) return;
+    free(c->table); free(c->offsets); free(c->status);
+    if (c->fd >= 0) (void)close(c->fd);
+    free(c);
+}
+int32_t freesasa_ingest_cache_n_structs(const freesasa_ingest_cache *c) { return c->h.n_structs; }
+int64_t freesasa_ingest_cache_n_atoms(const freesasa_ingest_cache *c) { return c->h.n_atoms; }
+const int64_t *freesasa_ingest_cache_offsets(const freesasa_ingest_cache *c) { return c->offsets; }
+const int32_t *freesasa_ingest_cache_status(const freesasa_ingest_cache *c) { return c->status; }
+
+/* bytes [b0, b1) of section k into dst: whole pieces that lie inside the range are read and verified in place, the
+   one or two pieces that straddle its ends go through `scratch` (CACHE_PIECE bytes) */
+static int read_range_verified(const freesasa_ingest_cache *c, int k, uint64_t b0, uint64_t b1, void *dst, void *scratch)
+{
+    if (b1 > c->len[k] || b0 > b1) return 0;
+    char *d = (char *)dst;
+    uint64_t pos = b0;
+    while (pos < b1) {
+        const uint64_t p = pos / CACHE_PIECE, po = p * CACHE_PIECE;
+        const uint64_t pn = c->len[k] - po < CACHE_PIECE ? c->len[k] - po : CACHE_PIECE;
+        if (pos == po && po + pn <= b1) { /* a whole piece */
+            if (!read_section_verified(c, k, p, p + 1, d + (pos - b0))) return 0;
+            pos = po + pn;
+        } else {
+            if (!pread_all(c->fd, scratch, pn, c->start[k] + po) || mix_piece(scratch, pn) != c->table[c->first_piece[k] + p]) return 0;
+            const uint64_t e = po + pn < b1 ? po + pn : b1;
+            memcpy(d + (pos - b0), (const char *)scratch + (pos - po), (size_t)(e - pos));
+            pos = e;
+        }
+    }
+    return 1;
+}
+
+int freesasa_ingest_cache_read_atoms(const freesasa_ingest_cache *c, int64_t a0, int64_t a1, double *xyz, double *radii, uint8_t *atom_class)
+{
+    if (!c || a0 < 0 || a1 < a0 || a1 > c->h.n_atoms) return FREESASA_INGEST_EFORMAT;
+    if (a1 == a0) return FREESASA_INGEST_OK;
+    void *scratch = malloc((size_t)CACHE_PIECE);
+    if (!scratch) return FREESASA_INGEST_ENOMEM;
+    int ok = 1;
+    if (xyz) ok = read_range_verified(c, 3, 24 * (uint64_t)a0, 24 * (uint64_t)a1, xyz, scratch);
+    if (ok && radii) ok = read_range_verified(c, 4, 8 * (uint64_t)a0, 8 * (uint64_t)a1, radii, scratch);
+    if (ok && atom_class) {
+        ok = read_range_verified(c, 5, (uint64_t)a0, (uint64_t)a1, atom_class, scratch);
+        for (int64_t i = 0; ok && i < a1 - a0; ++i)
+            if (atom_class[i] > FREESASA_INGEST_UNKNOWN) ok = 0; /* (indexes the class sums on the device) */
+    }
+    free(scratch);
+    return ok ? FREESASA_INGEST_OK : FREESASA_INGEST_EFORMAT;
 }

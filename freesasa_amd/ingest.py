@@ -131,6 +131,15 @@ def _proto():
         L.freesasa_ingest_select.argtypes = [C.POINTER(_CBatch), C.c_int, C.c_char_p, C.c_char_p, C.POINTER(C.c_ubyte)]
         L.freesasa_ingest_save.argtypes = [C.POINTER(_CBatch), C.c_char_p]
         L.freesasa_ingest_load.argtypes = [C.c_char_p, C.POINTER(_CBatch)]
+        L.freesasa_ingest_load_mt.argtypes = [C.c_char_p, C.c_int, C.POINTER(_CBatch)]
+        L.freesasa_ingest_usable_cpus.restype = C.c_int
+        L.freesasa_ingest_cache_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        L.freesasa_ingest_cache_close.argtypes = [C.c_void_p]
+        L.freesasa_ingest_cache_n_structs.argtypes = [C.c_void_p]; L.freesasa_ingest_cache_n_structs.restype = C.c_int32
+        L.freesasa_ingest_cache_n_atoms.argtypes = [C.c_void_p]; L.freesasa_ingest_cache_n_atoms.restype = C.c_int64
+        L.freesasa_ingest_cache_offsets.argtypes = [C.c_void_p]; L.freesasa_ingest_cache_offsets.restype = C.POINTER(C.c_int64)
+        L.freesasa_ingest_cache_status.argtypes = [C.c_void_p]; L.freesasa_ingest_cache_status.restype = C.POINTER(C.c_int32)
+        L.freesasa_ingest_cache_read_atoms.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_ubyte)]
         L._ingest_ready = True
     return L
 
@@ -152,12 +161,55 @@ def load_pdb_files(paths, options=0, n_threads=0):
     return _finish(L, L.freesasa_ingest_pdb_files(arr, len(paths), options, n_threads, C.byref(cb)), cb)
 
 
-def load_cache(path):
-    """freesasa_ingest_load(): a Batch from the binary cache file Batch.save() wrote.  Raises RuntimeError with the
-    library's code (EIO: cannot open; EFORMAT: not a cache file, truncated, checksum or offsets wrong)."""
+def load_cache(path, n_threads=0):
+    """freesasa_ingest_load_mt(): a Batch from the binary cache file Batch.save() wrote, its 1 MiB pieces read and
+    verified by n_threads readers (<= 0: the usable CPUs, at most 8).  Raises RuntimeError with the library's code
+    (EIO: cannot open; EFORMAT: not a cache file, truncated, checksum or offsets wrong)."""
     L = _proto()
     cb = _CBatch()
-    return _finish(L, L.freesasa_ingest_load(str(path).encode(), C.byref(cb)), cb)
+    return _finish(L, L.freesasa_ingest_load_mt(str(path).encode(), int(n_threads), C.byref(cb)), cb)
+
+
+def usable_cpus():
+    """freesasa_ingest_usable_cpus(): the affinity mask capped by the cgroup's CPU quota."""
+    return int(_proto().freesasa_ingest_usable_cpus())
+
+
+class Cache:
+    """A cache file read partially (freesasa_ingest_cache_*): offsets and status of every structure, and
+    read_atoms(a0, a1) -> (xyz, radii, atom_class) of a run of atoms, verified piece by piece."""
+
+    def __init__(self, path):
+        L = _proto()
+        self._h = C.c_void_p()
+        rc = L.freesasa_ingest_cache_open(str(path).encode(), C.byref(self._h))
+        if rc:
+            raise RuntimeError(f"freesasa_ingest_cache_open failed with code {rc}")
+        self.n_structs = int(L.freesasa_ingest_cache_n_structs(self._h))
+        self.n_atoms = int(L.freesasa_ingest_cache_n_atoms(self._h))
+        self.offsets = np.ctypeslib.as_array(L.freesasa_ingest_cache_offsets(self._h), (self.n_structs + 1,)).copy()
+        self.status = (np.ctypeslib.as_array(L.freesasa_ingest_cache_status(self._h), (self.n_structs,)).copy()
+                       if self.n_structs else np.zeros(0, np.int32))
+
+    def read_atoms(self, a0, a1):
+        n = int(a1) - int(a0)
+        xyz, r, cls = np.empty((max(n, 0), 3)), np.empty(max(n, 0)), np.empty(max(n, 0), np.uint8)
+        rc = _proto().freesasa_ingest_cache_read_atoms(self._h, int(a0), int(a1), xyz.ctypes.data_as(C.POINTER(C.c_double)),
+                                                       r.ctypes.data_as(C.POINTER(C.c_double)), cls.ctypes.data_as(C.POINTER(C.c_ubyte)))
+        if rc:
+            raise RuntimeError(f"freesasa_ingest_cache_read_atoms failed with code {rc}")
+        return xyz, r, cls
+
+    def close(self):
+        if self._h:
+            _proto().freesasa_ingest_cache_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def load_pdb_texts(texts, options=0, n_threads=0):

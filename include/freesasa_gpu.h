@@ -187,6 +187,39 @@ int freesasa_gpu_sweep_files_resumable(const char *const *paths, int n_paths, in
                                        double *totals_out, double *class_sums_out, long long *atoms_out, int *status_out,
                                        const char *done_path, long long max_new_batches, int device, char *err, int err_len);
 
+/* The drivers over a LIST of devices of the node (BASELINE configs[3] "sharded across 8 x MI355X", configs[4] "frames
+   sharded 8 x MI355X with per-frame stream-out"), from one process.  Work units — batches of files, shards of frames —
+   are independent, so there is no exchange between devices: the workers of all devices take units from one shared
+   list (the file sweep: largest batch first, LPT on the file sizes), every result lands at its own place (the caller's
+   arrays; pwrite at the unit's offset of the result files) and ONE done-list serves all devices, so a run interrupted
+   on eight devices can be finished on one (or the other way round) with the same files byte for byte.  devices[]: 1 to
+   64 entries, each an existing device, repeats allowed (the entries of one device overlap their copies and kernels; a
+   one-GPU box runs [0, 0, 0]).  The host threads the CGROUP grants (freesasa_ingest_usable_cpus) are divided among the
+   devices' loaders / lanes.  Results are bit-identical to the single-device drivers', which are these with one entry.
+   _sweep_files_devices: as freesasa_gpu_sweep_files_resumable (done_path may be NULL, max_new_batches <= 0: all).
+   _sweep_cache_devices: the sweep of a binary cache (freesasa_ingest_save): lanes_per_device threads per device
+   (<= 0: the granted CPUs divided by the devices, 2 .. 4) read, VERIFY (1 MiB piece checksums) and upload exactly the
+   coordinates, radii and classes of their batch through page-locked staging; n_out = length of the output arrays
+   (>= the cache's structure count); class_sums_out / atoms_out / status_out may be NULL.  Returns 0 / -1.
+   _trajectory_devices, _trajectory_file_devices: as freesasa_gpu_trajectory / _trajectory_file. */
+int freesasa_gpu_sweep_files_devices(const char *const *paths, int n_paths, int ingest_options, int n_threads,
+                                     int alg, double probe_radius, int resolution, long long batch_atoms,
+                                     double *totals_out, double *class_sums_out, long long *atoms_out, int *status_out,
+                                     const char *done_path, long long max_new_batches, const int *devices, int n_devices,
+                                     char *err, int err_len);
+int freesasa_gpu_sweep_cache_devices(const char *cache_path, int alg, double probe_radius, int resolution, long long batch_atoms,
+                                     double *totals_out, double *class_sums_out, long long *atoms_out, int *status_out, int n_out,
+                                     const int *devices, int n_devices, int lanes_per_device, char *err, int err_len);
+int freesasa_gpu_trajectory_devices(const double *xyz_frames, const double *radii, int n_atoms, int n_frames,
+                                    int alg, double probe_radius, int resolution, int frames_per_batch,
+                                    double *totals_out, double *sasa_out, const int *devices, int n_devices,
+                                    char *err_out, int err_len);
+int freesasa_gpu_trajectory_file_devices(const char *frames_path, int frames_f32, long long header_bytes, const double *radii,
+                                         int n_atoms, long long n_frames, int alg, double probe_radius, int resolution,
+                                         int frames_per_batch, const char *totals_path, const char *sasa_path, const char *done_path,
+                                         long long max_new_shards, const int *devices, int n_devices,
+                                         long long *frames_total_out, char *err, int err_len);
+
 /* Host-pointer batch on a pooled per-thread context of `device` (-1: current default).
    alg/probe/resolution as in freesasa_parameters; counts_out may be NULL (S&R only);
    totals_out may be NULL.  Thread-safe.  Returns 0 / -1; message via err_out (>= len 1). */

@@ -78,7 +78,12 @@ typedef struct freesasa_ingest_batch {
     int32_t *status;      /* [n_structs] */
 } freesasa_ingest_batch;
 
-/* Read n_paths PDB or mmCIF files with n_threads host threads (<= 0: one per online core -- divided by
+/* CPUs this process may use at once: the affinity mask capped by the cgroup's CPU quota (a GPU box may show 256
+ * logical CPUs and grant 16).  What every "n_threads <= 0" default below, and the division of host threads among
+ * the devices of the multi-device drivers (include/freesasa_gpu.h), start from. */
+int freesasa_ingest_usable_cpus(void);
+
+/* Read n_paths PDB or mmCIF files with n_threads host threads (<= 0: one per usable CPU -- divided by
  * LOCAL_WORLD_SIZE when a launcher exports it, so the ranks of a node share the cores --, at most 64
  * and at most one per four inputs) into one batch.
  * Returns 0 if the batch could be built (individual failures are in status[]), a
@@ -101,6 +106,24 @@ void freesasa_ingest_free(freesasa_ingest_batch *batch);
  * holds inconsistent offsets (save: if the batch itself is inconsistent), FREESASA_INGEST_ENOMEM. */
 int freesasa_ingest_save(const freesasa_ingest_batch *batch, const char *path);
 int freesasa_ingest_load(const char *path, freesasa_ingest_batch *out);
+/* The same load with n_threads readers (<= 0: the usable CPUs, at most 8): since version 2 of the file every array is
+ * checksummed in 1 MiB pieces, which are read (pread) and verified independently. */
+int freesasa_ingest_load_mt(const char *path, int n_threads, freesasa_ingest_batch *out);
+
+/* A cache file read PARTIALLY: what a sweep needs of a run of structures - coordinates, radii, classes - and nothing
+ * else, verified piece by piece, straight into the caller's (e.g. page-locked) buffers; several threads may read from
+ * one handle at once.  _open reads and verifies the header, the checksum table, the structure offsets and the
+ * per-input status values; _read_atoms fills xyz [3 * (a1 - a0)], radii [a1 - a0], atom_class [a1 - a0] (each may be
+ * NULL) with atoms [a0, a1) of the batch.  Return codes as for freesasa_ingest_load. */
+typedef struct freesasa_ingest_cache freesasa_ingest_cache;
+int freesasa_ingest_cache_open(const char *path, freesasa_ingest_cache **out);
+void freesasa_ingest_cache_close(freesasa_ingest_cache *cache);
+int32_t freesasa_ingest_cache_n_structs(const freesasa_ingest_cache *cache);
+int64_t freesasa_ingest_cache_n_atoms(const freesasa_ingest_cache *cache);
+const int64_t *freesasa_ingest_cache_offsets(const freesasa_ingest_cache *cache); /* [n_structs + 1], owned by the handle */
+const int32_t *freesasa_ingest_cache_status(const freesasa_ingest_cache *cache);  /* [n_structs] */
+int freesasa_ingest_cache_read_atoms(const freesasa_ingest_cache *cache, int64_t a0, int64_t a1, double *xyz, double *radii,
+                                     uint8_t *atom_class);
 
 /* The reference's selection language ("name, resn ala+arg and not chain B", src/selection.c,
  * src/parser.y, src/lexer.l) on structure `structure` of a batch: mask_out[i] = 1 for the selected

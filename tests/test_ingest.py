@@ -472,16 +472,32 @@ def test_binary_cache_round_trip_and_refusals(tmp_path):
     assert not (tmp_path / "broken.fsab").exists()
 
 
-def _cache_checksum(payload_sections):
-    """The file's checksum (ingest_cache.c, mix_bytes): multiply-xorshift over every section, 8 bytes at a time."""
-    M, h = (1 << 64) - 1, 0x243F6A8885A308D3
-    for sec in payload_sections:
-        for i in range(0, len(sec), 8):
-            w = int.from_bytes(sec[i:i + 8].ljust(8, b"\0"), "little")
-            h = ((h ^ w) * 0x9E3779B97F4A7C15) & M
-            h ^= h >> 29
-        h = ((h ^ len(sec)) * 0xC2B2AE3D27D4EB4F) & M
-    return h
+_M64 = (1 << 64) - 1
+
+
+def _mix_step(h, w):
+    h = ((h ^ w) * 0x9E3779B97F4A7C15) & _M64
+    return h ^ (h >> 29)
+
+
+def _piece_checksum(piece):
+    """ingest_cache.c, mix_piece: four interleaved multiply-xorshift lanes, 32 bytes a step, the tail zero-padded."""
+    h = [0x243F6A8885A308D3, 0x13198A2E03707344, 0xA4093822299F31D0, 0x082EFA98EC4E6C89]
+    for i in range(0, len(piece), 32):
+        blk = piece[i:i + 32].ljust(32, b"\0")
+        for q in range(4):
+            h[q] = _mix_step(h[q], int.from_bytes(blk[8 * q:8 * q + 8], "little"))
+    r = _mix_step(_mix_step(_mix_step(h[0], h[1]), h[2]), h[3])
+    return ((r ^ len(piece)) * 0xC2B2AE3D27D4EB4F) & _M64
+
+
+def _cache_table(payload_sections, S, N, R):
+    """The piece table (one checksum per 1 MiB piece of every section) and the header's checksum over it (mix_table)."""
+    table = [_piece_checksum(sec[o:o + (1 << 20)]) for sec in payload_sections for o in range(0, len(sec), 1 << 20)]
+    h = _mix_step(_mix_step(_mix_step(0x452821E638D01377, S & 0xffffffff), N & _M64), R & _M64)
+    for t in table:
+        h = _mix_step(h, t)
+    return table, ((h ^ len(table)) * 0xC2B2AE3D27D4EB4F) & _M64
 
 
 def test_binary_cache_refuses_crafted_indices_behind_a_valid_checksum(tmp_path):
@@ -500,13 +516,16 @@ def test_binary_cache_refuses_crafted_indices_behind_a_valid_checksum(tmp_path):
     for ln in lens:
         starts.append(pos)
         pos += (ln + 15) & ~15
-    assert pos == len(raw)
+    n_pieces = sum((ln + (1 << 20) - 1) >> 20 for ln in lens)
+    assert pos + ((8 * n_pieces + 15) & ~15) == len(raw)                 # the piece table follows the payload
 
     def crafted(section, offset, fmt, value):
         data = bytearray(raw)
         struct.pack_into("<" + fmt, data, starts[section] + offset, value)
         secs = [bytes(data[st:st + ln]) for st, ln in zip(starts, lens)]
-        struct.pack_into("<Q", data, 48, _cache_checksum(secs))      # header: magic 8, version + byte-order mark 8, counts 8 + 16, payload 8, then the checksum
+        table, head_sum = _cache_table(secs, S, N, R)
+        struct.pack_into("<%dQ" % len(table), data, pos, *table)
+        struct.pack_into("<Q", data, 48, head_sum)      # header: magic 8, version + byte-order mark 8, counts 8 + 16, payload 8, then the checksum
         return bytes(data)
 
     assert ingest.load_cache(_write(tmp_path / "same.fsab", crafted(3, 0, "d", float(np.asarray(b.xyz).reshape(-1)[0])))).n_atoms == N   # the recipe itself is right

@@ -1,5 +1,5 @@
 # DEV: static instruction mix of the arc pass loops of the main L&R kernel (no GPU needed)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off "$@" -S --cuda-device-only -o /tmp/ge.s freesasa_amd/csrc/gpu_engine.hip 2>/dev/null
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off "$@" -S --cuda-device-only -o /tmp/ge.s freesasa_amd/csrc/gpu_kernels.hip 2>/dev/null
 K=_Z10k_lr2_tileILi4ELi0ELi4ELb0ELb1ELi1EEvN4sasa7Lr2ArgsE
 awk "/^$K:/{p=1} p{print} /^.Lfunc_end/{if(p){exit}}" /tmp/ge.s > /tmp/k4.s
 python tools/dev/isa_loops.py /tmp/ge.s $K > /tmp/loops.txt
