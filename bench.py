@@ -156,6 +156,181 @@ def checker_error(alg, xyz, r, got, resolution):
     return int(np.count_nonzero(np.asarray(want) != got))
 
 
+PDB_NAMES = ["1a0q", "3gnn", "5dx9", "2jo4", "3bkr", "1d3z", "1ubq"]
+
+
+def real_pdb_batch(min_atoms=3_000_000):
+    """The reference's own PDB test entries through the batched reader (its default filters, ProtOr radii), replicated to
+    >= min_atoms atoms: (xyz, radii, offsets, atoms per entry, copies) - the offline stand-in for BASELINE configs[1] / [3]
+    that is not a lattice."""
+    from freesasa_amd import ingest
+    pdb_dir = os.path.join(ROOT, "tests", "golden", "pdb")
+    b = ingest.load_pdb_files([os.path.join(pdb_dir, nm + ".pdb") for nm in PDB_NAMES])
+    per = [int(b.offsets[k + 1] - b.offsets[k]) for k in range(b.n_structs)]
+    reps = max(1, -(-min_atoms // int(b.n_atoms)))
+    px = np.ascontiguousarray(np.tile(b.xyz.reshape(-1), reps)); pr = np.ascontiguousarray(np.tile(b.radii, reps))
+    poffs = np.concatenate([[0], np.cumsum(np.tile(per, reps))]).astype(np.int64)
+    return px, pr, poffs, per, reps
+
+
+def sr_workloads(fa, torch, tools, d_xyz, d_r, offs, xyz, r, dev, local_rank, check, args):
+    """Shrake-Rupley (100 points) on the two batch workloads of the Lee-Richards lines - the 1000 x 10 000 coils and the
+    reference's PDB entries x 251 - with the share of the VALU issue slots the S&R tile kernel fills (one rocprofv3
+    --pmc SQ_INSTS_VALU pass of this script per workload, as for the headline)."""
+    out = {}
+
+    def run(name, dx, dr, o, hx, hr, wl, child_workload):
+        n = int(o[-1])
+        d_out = torch.empty(n, dtype=torch.float64, device=dev)
+        d_cnt = torch.empty(n, dtype=torch.int32, device=dev)
+        ctx = fa.GpuContext(local_rank, timing=True)
+        call = lambda: ctx.shrake_rupley(dx.data_ptr(), dr.data_ptr(), o, d_out.data_ptr(), d_cnt.data_ptr(), 0, probe=1.4, n_points=100)
+        for _ in range(3):
+            call()
+        torch.cuda.synchronize()
+        ks, ps, t0 = [], [], time.perf_counter()
+        for _ in range(10):
+            call()
+            st = ctx.stats(); ks.append(st["ms_kernel"]); ps.append(st["ms_prep"])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 10
+        st = ctx.stats()
+        res = {"value": n / dt, "unit": "atoms/s", "ms_per_step": 1e3 * dt, "kernel_ms": float(np.mean(ks)), "prep_ms": float(np.mean(ps)), "steps": 10,
+               "kernel_atoms_per_s": n / (1e-3 * float(np.mean(ks))), "workload": wl, "tile_atoms": st["tile_atoms"],
+               "block_threads": st["block_threads"], "max_neighbors_per_atom": st["max_neighbors"], "fallback_tiles": st["fallback_tiles"]}
+        if check:
+            k1 = int(o[1])
+            res["atoms_with_a_different_count"] = checker_error("sr", hx[:3 * k1], hr[:k1], d_cnt[:k1].cpu().numpy(), 100)
+        ctx.close()
+        import copy
+        a2 = copy.copy(args); a2.workload = child_workload; a2.points = 100
+        live = live_counters(a2, counters=("SQ_INSTS_VALU",))
+        if live:
+            valu = live[1]
+            res["valu_issue"] = {"wave_instructions_per_launch": valu, "wave_instructions_per_atom": valu / n,
+                                 "frac_of_issue_slots": valu * CYCLES_PER_VALU / (1e-3 * float(np.mean(ks)) * SIMDS * CLOCK_HZ), "source": live[2]}
+        out[name] = res
+
+    try:
+        run("coil_sr100", d_xyz, d_r, offs, xyz.reshape(-1), r, f"{len(offs) - 1} coils x {int(offs[1])} atoms (the headline batch), Shrake-Rupley 100 points", "coil_sr")
+    except Exception as exc:
+        out["coil_sr100"] = {"error": repr(exc)}
+    try:
+        px, pr, poffs, per, reps = real_pdb_batch()
+        dpx, dpr = torch.from_numpy(px).to(dev), torch.from_numpy(pr).to(dev)
+        run("real_pdb_sr100", dpx, dpr, poffs, px, pr, f"{reps} x the PDB entries {', '.join(PDB_NAMES)} ({len(poffs) - 1} structures, {len(pr)} atoms), Shrake-Rupley 100 points", "pdb_sr")
+    except Exception as exc:
+        out["real_pdb_sr100"] = {"error": repr(exc)}
+    return out
+
+
+def latency_us(fa, tools):
+    """What BASELINE configs[0] feels: ONE structure through the drop-in entry freesasa_calc_coord (host arrays in, host
+    areas out, a pooled context): median and best of 60 calls, 1UBQ (602 atoms) and 1A0Q (3 3xx atoms), both algorithms."""
+    from freesasa_amd import ingest
+    pdb_dir = os.path.join(ROOT, "tests", "golden", "pdb")
+    out = {}
+    for nm in ("1ubq", "1a0q"):
+        b = ingest.load_pdb_files([os.path.join(pdb_dir, nm + ".pdb")])
+        x, rr = np.ascontiguousarray(b.xyz.reshape(-1, 3)), np.ascontiguousarray(b.radii)
+        for alg, tag, kw in ((fa.LEE_RICHARDS, "lr20", {"n_slices": 20}), (fa.SHRAKE_RUPLEY, "sr100", {"n_points": 100})):
+            for _ in range(5):
+                fa.calc_coord(x, rr, alg, **kw)
+            ts = []
+            for _ in range(60):
+                t0 = time.perf_counter()
+                fa.calc_coord(x, rr, alg, **kw)
+                ts.append(time.perf_counter() - t0)
+            out[f"{nm}_{tag}"] = {"atoms": int(b.n_atoms), "median_us": 1e6 * float(np.median(ts)), "best_us": 1e6 * float(np.min(ts))}
+    out["note"] = "freesasa_calc_coord per call: upload, cell sort, tile kernel, totals, download, status readback (Python ctypes overhead ~10 us included)"
+    return out
+
+
+def driver_workloads(fa, tools, local_rank, scratch):
+    """BASELINE configs[3] / configs[4] as one GPU's shard, through the REAL drivers, with the host rates beside them:
+    sweep_files (PDB + mmCIF files on local disk -> totals), sweep_cache (the same structures from the binary cache),
+    trajectory_file (frames of a 100 000-atom system from a raw frame file, fp64 and fp32, per-atom areas streamed out)."""
+    import shutil
+    from freesasa_amd import ingest
+    out = {}
+    cpus = ingest.usable_cpus()
+    # ---- files: the reference's 7 PDB entries + 4 mmCIF fixtures, copied until >= 3e6 atoms
+    try:
+        pdb_dir, cif_dir = os.path.join(ROOT, "tests", "golden", "pdb"), os.path.join(ROOT, "tests", "golden", "cif")
+        srcs = [os.path.join(pdb_dir, nm + ".pdb") for nm in PDB_NAMES] + sorted(os.path.join(cif_dir, f) for f in os.listdir(cif_dir) if f.endswith(".cif"))[:4]
+        one = ingest.load_pdb_files(srcs)
+        reps = max(1, -(-3_000_000 // int(one.n_atoms)))
+        d = os.path.join(scratch, "sweep_files")
+        os.makedirs(d, exist_ok=True)
+        paths = []
+        for k in range(reps):
+            for sp in srcs:
+                dst = os.path.join(d, f"{k:04d}_{os.path.basename(sp)}")
+                if not os.path.exists(dst):
+                    shutil.copyfile(sp, dst)
+                paths.append(dst)
+        nbytes = sum(os.path.getsize(q) for q in paths)
+        t0 = time.perf_counter(); b = ingest.load_pdb_files(paths); t_load = time.perf_counter() - t0      # the loader alone (all granted CPUs)
+        n = int(b.n_atoms)
+        fa.sweep_files(paths[:len(srcs)], device=local_rank)                                                # warm-up: context, workspace
+        t0 = time.perf_counter(); tot, cls, atoms, status = fa.sweep_files(paths, device=local_rank); t_sweep = time.perf_counter() - t0
+        want, _, wtot = fa.calc_batch(b.xyz, b.radii, b.offsets, fa.LEE_RICHARDS, 1.4, 20, device=local_rank)
+        t0 = time.perf_counter(); fa.calc_batch(b.xyz, b.radii, b.offsets, fa.LEE_RICHARDS, 1.4, 20, device=local_rank); t_gpu = time.perf_counter() - t0
+        out["sweep_files"] = {"value": n / t_sweep, "unit": "atoms/s", "files": len(paths), "atoms": n, "file_bytes": nbytes, "seconds": t_sweep,
+                              "loader_atoms_per_s": n / t_load, "loader_MB_per_s": nbytes / t_load / 1e6, "loader_threads": cpus,
+                              "gpu_atoms_per_s_host_arrays": n / t_gpu, "totals_equal_load_then_batch": bool(np.array_equal(tot, wtot)),
+                              "workload": f"{reps} copies of {len(srcs)} files ({', '.join(os.path.basename(q) for q in srcs)}) on local disk (page cache warm), "
+                                          "freesasa_gpu_sweep_files: Lee-Richards 20 slices, totals and class sums per file; host-bound: the loader rate is the ceiling"}
+        # ---- the same structures from the binary cache
+        cache = os.path.join(scratch, "sweep.fsab")
+        t0 = time.perf_counter(); b.save(cache); t_save = time.perf_counter() - t0
+        best_load = None
+        for nt in (1, 0):
+            t0 = time.perf_counter(); c = ingest.load_cache(cache, n_threads=nt); dt = time.perf_counter() - t0
+            best_load = (dt, nt) if nt == 0 else best_load
+            if nt == 1: t_load1 = dt
+            del c
+        fa.sweep_cache(cache, device=local_rank)                                                            # warm-up (page-locked staging of the lanes)
+        t0 = time.perf_counter(); ctot, ccls, catoms, cstatus = fa.sweep_cache(cache, device=local_rank); t_cs = time.perf_counter() - t0
+        out["sweep_cache"] = {"value": n / t_cs, "unit": "atoms/s", "atoms": n, "seconds": t_cs, "cache_bytes": os.path.getsize(cache),
+                              "full_load_atoms_per_s_1_thread": n / t_load1, "full_load_atoms_per_s_all_threads": n / best_load[0], "threads": min(cpus, 8),
+                              "save_seconds": t_save, "totals_equal_file_sweep": bool(np.array_equal(ctot, tot) and np.array_equal(ccls, cls)),
+                              "workload": "the same structures from the version-2 cache file (page cache warm): freesasa_gpu_sweep_cache_devices, one device, "
+                                          "lanes read + verify (1 MiB piece checksums) coordinates, radii and classes only, into page-locked staging"}
+        del b
+    except Exception as exc:
+        out.setdefault("sweep_files", {"error": repr(exc)})
+        out.setdefault("sweep_cache", {"error": repr(exc)})
+    # ---- trajectory: 1000 frames x 100 000 atoms from a frame file, per-atom stream-out
+    try:
+        n_atoms, n_frames = 100_000, 1000
+        base, r = tools.globule(n_atoms, 5)
+        f64, f32 = os.path.join(scratch, "frames.f64"), os.path.join(scratch, "frames.f32")
+        if not (os.path.exists(f64) and os.path.getsize(f64) == 24 * n_atoms * n_frames and os.path.exists(f32)):
+            with open(f64, "wb") as a, open(f32, "wb") as c:
+                for f in range(n_frames):
+                    fr = tools.jitter(base, 100 + f, 0.5)
+                    fr.tofile(a); fr.astype(np.float32).tofile(c)
+        res = {}
+        for tag, path, is32 in (("f64", f64, False), ("f32", f32, True)):
+            tp, sp = os.path.join(scratch, f"tot_{tag}.bin"), os.path.join(scratch, f"sasa_{tag}.bin")
+            fa.trajectory_file(path, r, tp, sp, f32=is32, n_frames=24, device=local_rank)                    # warm-up
+            t0 = time.perf_counter(); done, got = fa.trajectory_file(path, r, tp, sp, f32=is32, device=local_rank); dt = time.perf_counter() - t0
+            res[tag] = {"value": n_atoms * n_frames / dt, "unit": "atom-frames/s", "seconds": dt, "frames": int(got), "complete": bool(done),
+                        "in_GB_per_s": (12 if is32 else 24) * n_atoms * n_frames / dt / 1e9, "out_GB_per_s": 8 * n_atoms * n_frames / dt / 1e9}
+        t64 = np.fromfile(os.path.join(scratch, "tot_f64.bin"))
+        res["value"], res["unit"] = res["f64"]["value"], "atom-frames/s"
+        res["mean_total_A2"] = float(t64.mean())
+        res["workload"] = (f"{n_frames} frames x {n_atoms} atoms (globule + 0.5 A jitter) from a raw frame file (page cache warm), freesasa_gpu_trajectory_file: "
+                           "totals file + per-atom areas file (8 B per atom-frame) written; fp64 frames, and fp32 frames widened on the device; 3 host lanes")
+        out["trajectory_file"] = res
+        for q in (f64, f32):
+            pass
+    except Exception as exc:
+        out["trajectory_file"] = {"error": repr(exc)}
+    return out
+
+
 def secondary_workloads(fa, torch, tools, d_xyz, d_r, offs, xyz, r, dev, local_rank, check):
     """The other single-GPU configurations of BASELINE.json, one short measurement each in this same process:
     configs[2] as written (L&R 100 slices on the 1000 x 10 000 coils), protein density (10 000-atom globules, L&R 20),
@@ -208,14 +383,8 @@ def secondary_workloads(fa, torch, tools, d_xyz, d_r, offs, xyz, r, dev, local_r
     del dgx, dgr, dgo
     # real proteins: the reference's own test entries, ProtOr radii through the batched reader, replicated to >= 3e6 atoms
     try:
-        from freesasa_amd import ingest
-        pdb_dir = os.path.join(ROOT, "tests", "golden", "pdb")
-        names = ["1a0q", "3gnn", "5dx9", "2jo4", "3bkr", "1d3z", "1ubq"]
-        b = ingest.load_pdb_files([os.path.join(pdb_dir, nm + ".pdb") for nm in names])
-        per = [int(b.offsets[k + 1] - b.offsets[k]) for k in range(b.n_structs)]
-        reps = max(1, -(-3_000_000 // int(b.n_atoms)))
-        px = np.ascontiguousarray(np.tile(b.xyz.reshape(-1), reps)); pr = np.ascontiguousarray(np.tile(b.radii, reps))
-        poffs = np.concatenate([[0], np.cumsum(np.tile(per, reps))]).astype(np.int64)
+        names = PDB_NAMES
+        px, pr, poffs, per, reps = real_pdb_batch()
         dpx, dpr = torch.from_numpy(px).to(dev), torch.from_numpy(pr).to(dev)
         dpo = torch.empty(len(pr), dtype=torch.float64, device=dev)
         ctx = fa.GpuContext(local_rank, timing=True)
@@ -256,7 +425,7 @@ def secondary_workloads(fa, torch, tools, d_xyz, d_r, offs, xyz, r, dev, local_r
     return out
 
 
-def live_counters(args, timeout_s=75):
+def live_counters(args, timeout_s=75, counters=("SQ_INSTS_VALU", "FETCH_SIZE", "WRITE_SIZE")):
     """HBM bytes and wave-level VALU instructions per launch of the dominant kernel, measured NOW: one extra run of this
     script (one timed step, synchronous entry, nothing secondary) under rocprofv3 per counter - FETCH_SIZE, WRITE_SIZE
     and SQ_INSTS_VALU in separate --pmc passes, as MI355X_MICROARCH.md prescribes - when rocprofv3 is on PATH.  Values
@@ -273,11 +442,11 @@ def live_counters(args, timeout_s=75):
     per = {}
     try:
         with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
-            for counter in ("SQ_INSTS_VALU", "FETCH_SIZE", "WRITE_SIZE"):
+            for counter in counters:
                 cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", os.path.join(tmp, counter), "-o", "c", "--",
                        sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--structs", str(args.structs), "--atoms", str(args.atoms),
                        "--slices", str(args.slices), "--workload", args.workload, "--points", str(args.points), "--sync-entry",
-                       "--no-cpu-baseline", "--no-end-to-end", "--no-secondary", "--no-neighbors", "--no-live-counters"]
+                       "--no-cpu-baseline", "--no-end-to-end", "--no-secondary", "--no-neighbors", "--no-live-counters", "--no-drivers"]
                 env = dict(os.environ, FREESASA_AMD_BENCH_CHILD="1", TMPDIR="/tmp")
                 res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd="/tmp", env=env)
                 if res.returncode != 0:
@@ -297,6 +466,8 @@ def live_counters(args, timeout_s=75):
     if not tiles:
         return None
     main = max(tiles, key=tiles.get)
+    if "FETCH_SIZE" not in counters:
+        return None, tiles[main], f"live: rocprofv3 --pmc pass of this run ({main.split('(')[0]})"
     if main not in per.get("FETCH_SIZE", {}) or main not in per.get("WRITE_SIZE", {}):
         return None
     # both counters are in KB; on gfx950 FETCH_SIZE reports 0.500 x the bytes moved and WRITE_SIZE 1.000 x (copy kernels of known
@@ -370,10 +541,11 @@ def main():
     ap.add_argument("--structs", type=int, default=1000, help="structures per GPU")
     ap.add_argument("--atoms", type=int, default=10000, help="atoms per structure")
     ap.add_argument("--slices", type=int, default=20)
-    ap.add_argument("--workload", default="coil_lr", choices=["coil_lr", "globule_sr", "traj_lr", "sweep_lr"],
+    ap.add_argument("--workload", default="coil_lr", choices=["coil_lr", "globule_sr", "traj_lr", "sweep_lr", "coil_sr", "pdb_lr", "pdb_sr"],
                     help="coil_lr: the headline metric (default).  globule_sr: BASELINE configs[1] proxy, "
                          "ONE 200k-atom globule per GPU, Shrake-Rupley 100 points (secondary line).  sweep_lr: configs[3] proxy, "
-                         "structures of log-uniform size 500..50 000 atoms dealt to the ranks by LPT on atom count")
+                         "structures of log-uniform size 500..50 000 atoms dealt to the ranks by LPT on atom count.  coil_sr: the headline "
+                         "batch through Shrake-Rupley; pdb_lr / pdb_sr: the reference's PDB entries x 251 (what the secondary keys and their counter passes run)")
     ap.add_argument("--points", type=int, default=100)
     ap.add_argument("--sync-entry", action="store_true", help="time freesasa_gpu_lr_batch_dev (one synchronous call per step) instead of the asynchronous batch entry")
     ap.add_argument("--no-live-counters", action="store_true", help="do not re-run under rocprofv3 for roofline.traffic / valu_issue (the committed profile is quoted instead)")
@@ -381,6 +553,8 @@ def main():
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-neighbors", action="store_true", help="skip the neighbor count (one launch of the kernel's neighbor phase): the counter passes of tools/gpu_round.sh want the tile kernel's own launches only")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short measurements of the other single-GPU configurations")
+    ap.add_argument("--no-drivers", action="store_true", help="skip the file sweep / cache sweep / trajectory-file / latency keys (they write ~4 GB of scratch files under /tmp)")
+    ap.add_argument("--sustain-seconds", type=float, default=2.0, help="length of the sustained run reported next to the headline (0: none)")
     ap.add_argument("--dry-run", action="store_true",
                     help="TEST ONLY (tests/test_distributed.py): the rank / argument / JSON plumbing on CPU under gloo, "
                          "with a stand-in for the engine that computes nothing; prints \"dry_run\": true")
@@ -396,7 +570,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dry = args.dry_run
-    if world > 1:
+    # FREESASA_AMD_BENCH_FORCE_DIST=1 (tests/test_distributed.py, -m gpu): the N-rank plumbing - init_process_group("nccl"),
+    # barrier, both all_reduces, destroy - with ONE rank, so that RCCL is initialised by this code on an MI355X before the
+    # driver's 8-GPU run ever happens
+    dist_on = world > 1 or (os.environ.get("FREESASA_AMD_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if dry:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -416,11 +594,14 @@ def main():
 
     if args.workload == "traj_lr":
         return bench_trajectory(args, rank, world, local_rank)
-    sr = args.workload == "globule_sr"
-    if sr:
+    sr = args.workload in ("globule_sr", "coil_sr", "pdb_sr")
+    if args.workload == "globule_sr":
         args.structs, args.atoms = 1, 200_000
         xyz, r = tools.globule(args.atoms, 77 + rank)
         offs = np.array([0, args.atoms], dtype=np.int64)
+    elif args.workload in ("pdb_lr", "pdb_sr"):
+        xyz, r, offs, _, _ = real_pdb_batch()
+        args.structs, args.atoms = len(offs) - 1, int(offs[-1] // (len(offs) - 1))
     elif args.workload == "sweep_lr":
         # whole-PDB sweep proxy: one global list of ragged structures, dealt to the ranks by
         # longest-processing-time-first on the atom count (freesasa_amd/shard.py); weak scaling:
@@ -484,7 +665,7 @@ def main():
 
     def barrier():
         sync()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         sync()
 
@@ -507,14 +688,30 @@ def main():
         k_ms = k_ms[2:] + [st["ms_kernel"]] if len(k_ms) > 2 else [st["ms_kernel"]]
         prep_ms = prep_ms[2:] + [st["ms_prep"]] if len(prep_ms) > 2 else [st["ms_prep"]]
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     na = torch.tensor([float(n_atoms)], dtype=torch.float64, device=dev)   # ragged shards differ per rank
-    if world > 1:
+    if dist_on:
         dist.all_reduce(na, op=dist.ReduceOp.SUM)
     atoms_all_ranks = int(na.item())
     st = ctx.stats()
+    # the same loop held for >= --sustain-seconds: under sustained load the chip does not keep the clock of a 0.2 s burst
+    # (DESIGN.md 8), so the figure a long job sees is reported next to the headline (every rank runs it; rank 0 reports)
+    sustained = None
+    if not dry and args.sustain_seconds > 0 and args.workload == "coil_lr":
+        n_sus, t_sus = 0, time.perf_counter()
+        while True:
+            for _ in range(max(4, args.steps)):
+                step()
+            n_sus += max(4, args.steps)
+            if time.perf_counter() - t_sus >= args.sustain_seconds:
+                break
+        drain()
+        sync()
+        dt_sus = time.perf_counter() - t_sus
+        sustained = {"value": world * n_atoms * n_sus / dt_sus, "unit": "atoms/s", "steps": n_sus, "seconds": dt_sus, "ms_per_step": 1e3 * dt_sus / n_sus,
+                     "note": "the timed loop continued for >= %.1f s (not max-reduced over ranks)" % args.sustain_seconds}
 
     if rank == 0:
         total_atoms = atoms_all_ranks * args.steps
@@ -530,7 +727,8 @@ def main():
             traffic = None
             metric = f"atoms/sec SASA (S&R {args.points} points)"
             wl = (f"one synthetic {args.atoms}-atom globule per GPU (BASELINE configs[1] proxy: 4V6X is not available "
-                  f"offline), Shrake-Rupley {args.points} test points, probe 1.4 A, inputs resident in HBM")
+                  f"offline), Shrake-Rupley {args.points} test points, probe 1.4 A, inputs resident in HBM") if args.workload == "globule_sr" else \
+                 (f"{args.structs} structures, {n_atoms} atoms per GPU ({args.workload}), Shrake-Rupley {args.points} test points, probe 1.4 A, inputs resident in HBM")
         elif args.workload == "sweep_lr":
             traffic = None
             metric = f"atoms/sec SASA (L&R {args.slices} slices), ragged sweep"
@@ -571,11 +769,15 @@ def main():
                              "frac_of_issue_slots": PROFILED_VALU * CYCLES_PER_VALU / (kern_s * SIMDS * CLOCK_HZ),
                              "source": traffic_src}},
         }
+        if sustained:
+            out["sustained"] = sustained
+        if dist_on:
+            out["config"]["process_group"] = f"{dist.get_backend()} world {dist.get_world_size()} (barrier + 2 all_reduce around the timed region)"
         if dry:
             out["dry_run"] = True
             out["atoms_all_ranks"] = atoms_all_ranks
             print(json.dumps(out), flush=True)
-            if world > 1:
+            if dist_on:
                 dist.barrier()
                 dist.destroy_process_group()
             return
@@ -596,6 +798,16 @@ def main():
                                         "identical_outputs": bool(torch.equal(got_async, d_sasa))}
         if world == 1 and args.workload == "coil_lr" and not args.no_secondary and (args.structs, args.atoms, args.slices) == (1000, 10000, 20):
             out.update(secondary_workloads(fa, torch, tools, d_xyz, d_r, offs, xyz, r, dev, local_rank, check=not args.no_cpu_baseline))
+        if world == 1 and args.workload == "coil_lr" and not args.no_secondary and (args.structs, args.atoms, args.slices) == (1000, 10000, 20):
+            out.update(sr_workloads(fa, torch, tools, d_xyz, d_r, offs, xyz, r, dev, local_rank, not args.no_cpu_baseline, args))
+        if world == 1 and args.workload == "coil_lr" and not args.no_drivers and (args.structs, args.atoms, args.slices) == (1000, 10000, 20):
+            scratch = os.path.join(os.environ.get("FREESASA_AMD_BENCH_CACHE", "/tmp"), f"freesasa_amd_bench_u{os.getuid()}")
+            os.makedirs(scratch, exist_ok=True)
+            try:
+                out["latency_us"] = latency_us(fa, tools)
+            except Exception as exc:
+                out["latency_us"] = {"error": repr(exc)}
+            out.update(driver_workloads(fa, tools, local_rank, scratch))
         if world == 1 and args.workload == "coil_lr" and not args.no_end_to_end:
             out["two_passes_in_flight"] = two_streams(fa, torch, d_xyz, d_r, offs, args, dev, local_rank, args.steps)
             out["end_to_end"] = end_to_end(fa, torch, xyz, r, offs, args, local_rank, d_sasa.cpu().numpy())
@@ -605,7 +817,7 @@ def main():
             out["max_abs_dsasa_vs_cpu"] = err
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -7,6 +7,8 @@ import subprocess
 import sys
 import textwrap
 
+import pytest
+
 from conftest import ROOT
 
 WORKER = textwrap.dedent("""
@@ -191,3 +193,45 @@ def test_bench_py_eight_ranks_dry_run_share_the_cpus_and_the_cache(tmp_path):
         assert len(files) == 8 and all(f.endswith(".npy") and ".tmp." not in f for f in files), files   # one per rank, no leftovers
     for r in res:
         assert r["dry_run"] is True and r["n_gpus"] == 8 and r["atoms_all_ranks"] == 8 * 250 * 4000 and r["scaling"] == "weak"
+
+
+def test_bench_py_one_rank_dry_run_with_the_process_group_forced():
+    """FREESASA_AMD_BENCH_FORCE_DIST=1: the N-rank code of bench.py (init_process_group, barrier, both all_reduces,
+    destroy_process_group) at world size 1 - here on CPU under gloo, and on the MI355X under nccl in the test below."""
+    import json
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FREESASA_AMD_BENCH_FORCE_DIST="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--structs", "4", "--atoms", "300", "--dry-run"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert res["dry_run"] is True and res["config"]["process_group"].startswith("gloo world 1")
+
+
+@pytest.mark.gpu
+def test_bench_py_one_rank_initialises_rccl_on_the_gpu():
+    """Round-4 review, item 6: bench.py's multi-rank plumbing ran only for world > 1, i.e. never on hardware before the
+    driver's 8-GPU run.  With FREESASA_AMD_BENCH_FORCE_DIST=1 one rank, launched through torch.distributed.run as the
+    driver launches N, initialises the nccl (= RCCL) process group on the MI355X, passes the barrier and both
+    all_reduces around the timed region and leaves the group; the line it prints says so, and carries the sustained
+    figure next to the headline."""
+    import json
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FREESASA_AMD_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--structs", "60", "--atoms", "5000", "--sustain-seconds", "0.5", "--no-live-counters", "--no-cpu-baseline",
+           "--no-end-to-end", "--no-secondary", "--no-neighbors", "--no-drivers"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["config"]["process_group"].startswith("nccl world 1")
+    assert res["n_gpus"] == 1 and res["value"] > 1e7 and res["sustained"]["seconds"] >= 0.5 and res["sustained"]["value"] > 1e7

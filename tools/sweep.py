@@ -2,12 +2,14 @@
 """Whole-directory sweep: PDB files -> batched ingestion on host threads -> SASA on the GPU ->
 per-structure totals (BASELINE configs[3] in miniature; SURVEY §8f N1 + the batch entry point).
 
-    python tools/sweep.py [--replicate N] [--threads T] [--batch-atoms A] [paths ...]
+    python tools/sweep.py [--replicate N] [--threads T] [--batch-atoms A] [--devices 0,1,...] [--done FILE] [--cache FILE] [paths ...]
 
 Without paths it sweeps the PDB fixtures under tests/golden/pdb, replicated N times.  Loading of
 batch k+1 runs on host threads while the GPU computes batch k.  Prints one JSON line with the
 end-to-end rate, the loader-only rate and (if oracle/_ref is present) the reference reader's
-single-thread rate on the same files."""
+single-thread rate on the same files.  --devices: the GPUs that share the batches (freesasa_gpu_sweep_files_devices;
+default: every visible device; entries may repeat); --done: a done-list, so that an interrupted sweep resumes — on any
+device list; --cache FILE: sweep the binary cache FILE instead (written first from the files if it does not exist)."""
 import argparse
 import glob
 import json
@@ -30,6 +32,9 @@ def main():
     ap.add_argument("--batch-atoms", type=int, default=4_000_000)
     ap.add_argument("--slices", type=int, default=20)
     ap.add_argument("--no-gpu", action="store_true", help="time the loader only")
+    ap.add_argument("--devices", default="", help="comma-separated device list (default: all visible devices)")
+    ap.add_argument("--done", default=None, help="done-list file: resume an interrupted sweep")
+    ap.add_argument("--cache", default=None, help="binary cache file to sweep (created from the files when missing)")
     ap.add_argument("--engine", choices=["python", "c"], default="c",
                     help="c: freesasa_gpu_sweep_files (loader thread || GPU inside the library); "
                          "python: the same pipeline written with the two-step Python API")
@@ -51,14 +56,33 @@ def main():
     out = {"files": len(paths), "batches": len(chunks), "threads": args.threads or os.cpu_count(),
            "loader_atoms_per_s": probe.n_atoms / t_load1, "loader_MB_per_s": sum(os.path.getsize(p) for p in chunks[0]) / t_load1 / 1e6}
 
-    if not args.no_gpu and args.engine == "c":
-        fa.sweep_files(chunks[0][:20], fa.LEE_RICHARDS, resolution=args.slices)                      # warm-up
+    devices = [int(d) for d in args.devices.split(",") if d != ""] or list(range(max(1, fa.device_count())))
+    out["devices"] = devices
+    if not args.no_gpu and args.cache:
+        if not os.path.exists(args.cache):
+            t0 = time.perf_counter()
+            ingest.load_pdb_files(paths, n_threads=args.threads).save(args.cache)
+            out["cache_build_seconds"] = time.perf_counter() - t0
         t0 = time.perf_counter()
-        totals, _, atoms, status = fa.sweep_files(paths, fa.LEE_RICHARDS, resolution=args.slices, n_threads=args.threads,
-                                                  batch_atoms=args.batch_atoms, class_sums=True)
+        totals, _, atoms, status = fa.sweep_cache(args.cache, fa.LEE_RICHARDS, resolution=args.slices, batch_atoms=args.batch_atoms, devices=devices)
         dt = time.perf_counter() - t0
         ok = status == 0
-        out.update({"engine": "freesasa_gpu_sweep_files", "atoms": int(atoms.sum()), "structures": int(ok.sum()),
+        out.update({"engine": "freesasa_gpu_sweep_cache_devices", "atoms": int(atoms.sum()), "structures": int(ok.sum()),
+                    "failed_inputs": int((~ok).sum()), "seconds": dt, "end_to_end_atoms_per_s": float(atoms.sum()) / dt,
+                    "structures_per_s": float(ok.sum()) / dt, "mean_total_A2": float(totals[ok].mean())})
+    elif not args.no_gpu and args.engine == "c":
+        fa.sweep_files(chunks[0][:20], fa.LEE_RICHARDS, resolution=args.slices)                      # warm-up
+        t0 = time.perf_counter()
+        if args.done:
+            complete, totals, _, atoms, status = fa.sweep_files_resumable(paths, args.done, fa.LEE_RICHARDS, resolution=args.slices, n_threads=args.threads,
+                                                                         batch_atoms=args.batch_atoms, devices=devices)
+            out["complete"] = bool(complete)
+        else:
+            totals, _, atoms, status = fa.sweep_files(paths, fa.LEE_RICHARDS, resolution=args.slices, n_threads=args.threads,
+                                                      batch_atoms=args.batch_atoms, class_sums=True, devices=devices)
+        dt = time.perf_counter() - t0
+        ok = status == 0
+        out.update({"engine": "freesasa_gpu_sweep_files_devices", "atoms": int(atoms.sum()), "structures": int(ok.sum()),
                     "failed_inputs": int((~ok).sum()), "seconds": dt, "end_to_end_atoms_per_s": float(atoms.sum()) / dt,
                     "structures_per_s": float(ok.sum()) / dt, "mean_total_A2": float(totals[ok].mean())})
     elif not args.no_gpu:
