@@ -59,8 +59,12 @@ long long wave_exchange(long long v, int src);
 #define LR2_INC_LDS(p) (++*(p))
 namespace sasa_emu { extern long long lr2_count[16]; } /* wave-level trip counts (lane 0 counts): 0 tiles, 1 arc iterations, 2 refills, 3 P1 test rounds, 4 rank trips, 5 screening trips, 6 P3 rounds */
 #define LR2_COUNT(k, n) do { if (lane == 0) sasa_emu::lr2_count[(k)] += (n); } while (0)
+/* (every lane of the wave: the largest and the sum of the lanes' trip counts of a divergent loop - what the wave pays and what the lanes use) */
+#define LR2_COUNT_LANES(kmax, ksum, v) do { int mx_ = (v), sm_ = (v); for (int d_ = 1; d_ < 64; d_ <<= 1) { const int om_ = LR2_SHFL(mx_, lane ^ d_), os_ = LR2_SHFL(sm_, lane ^ d_); mx_ = mx_ > om_ ? mx_ : om_; sm_ += os_; } \
+        if (lane == 0) { sasa_emu::lr2_count[(kmax)] += mx_; sasa_emu::lr2_count[(ksum)] += sm_; } } while (0)
 #else
 #define LR2_COUNT(k, n) do { } while (0)
+#define LR2_COUNT_LANES(kmax, ksum, v) do { } while (0)
 #define LR2_BALLOT(p) __builtin_amdgcn_ballot_w64(p)
 /* One wave per workgroup: the LDS executes a wave's instructions in the order they were issued, so a read that
    follows a write in program order sees it, whichever lane wrote.  What is needed between phases is only that
@@ -84,7 +88,10 @@ namespace sasa_emu { extern long long lr2_count[16]; } /* wave-level trip counts
 /* index arithmetic on small non-negative numbers: v_mul_u32_u24 runs at full rate, the 32-bit v_mul_lo_u32 /
    v_mul_hi at a quarter of it (what the compiler emits when it cannot see that an index is small) */
 #define LR2_MUL24(a, b) ((int)__umul24((unsigned)(a), (unsigned)(b)))
-#define LR2_UMUL24(a, b) __umul24((unsigned)(a), (unsigned)(b)) /* (the product's low 32 bits, unsigned) */
+/* (the product's low 32 bits AS AN UNSIGNED NUMBER: the header's __umul24 returns int, and a right shift of a product
+   with bit 31 set was arithmetic - v_ashrrev_i32 - until round 5: P1 decoded i / hc wrongly from i * 2^17 >= 2^31, i.e.
+   for the 16 384th candidate of a row onwards; found by tests/test_adversarial.py's giant-cell case on the MI355X) */
+#define LR2_UMUL24(a, b) ((unsigned)__umul24((unsigned)(a), (unsigned)(b)))
 #define LR2_RCPF(x) __builtin_amdgcn_rcpf(x)
 #define LR2_RSQF(x) __builtin_amdgcn_rsqf(x)
 #define LR2_ADD64_LDS(p, v) atomicAdd((p), (v))
@@ -994,6 +1001,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             }
             LR2_SYNC();
         }
+        int cnt_rank_[RMAX] = {0}; (void)cnt_rank_;
         for (int r = 0; r < RMAX; ++r) {
             if (r_pos[r] < 0) continue;
             const int o = r_pos[r] & 0xffff, nn = r_pos[r] >> 16;
@@ -1005,6 +1013,9 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                 rank = lo;
                 for (int q = lo; q < hi; ++q) rank += m.keys[o + q] < kme ? 1 : 0;
                 t = nn;
+#ifdef SASA_EMU
+                cnt_rank_[r] = hi - lo;
+#endif
             }
             for (; t + 4 <= nn; t += 4) { /* two keys per LDS read (o is even), two reads per trip */
                 const Arc2 k0 = *(const Arc2 *)(m.keys + o + t), k1 = *(const Arc2 *)(m.keys + o + t + 2);
@@ -1028,6 +1039,9 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                     LR2_OR_LDS(&m.cmask[LR2_MUL24(la, mw) + (rank >> 5)], 1u << (rank & 31));
             }
         }
+#ifdef SASA_EMU
+        if (bk) for (int r = 0; r < RMAX; ++r) LR2_COUNT_LANES(4, 5, cnt_rank_[r]);
+#endif
         if (lane < TA && (m.acnt[lane] & 1)) { /* padding record: cos(alpha) huge, never an arc */
             int zero = 0; SASA_OPAQUE(zero); /* (made here: as a hoisted 64-bit constant it was kept in scratch) */
             Ab16 rc; rc.a = (double)zero; rc.b = 1e300;
@@ -1053,6 +1067,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     LR2_SYNC();
     /* what is left to do for an item once its arcs are known: the cover filter (dense tiles), its word for the arc pass
        or its area, its place in the queue */
+    int cnt_filter_[2] = {0, 0}, cnt_filter_k_ = 0, cnt_screen_ = 0; (void)cnt_filter_; (void)cnt_filter_k_; (void)cnt_screen_;
     auto finish_item = [&](int it, int la, double t, double h2, double Ri, int o, int cnt, bool buried, bool circle) {
         double area = 0;
         if (buried || !circle) cnt = 0; /* circle i inside a neighbor's: buried (ref: :327-330); no circle: ref :310-312 */
@@ -1065,6 +1080,9 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                 while (wc != 0) { /* (the wave runs as many trips as its busiest lane) */
                     const int q = R + __builtin_ctz(wc);
                     wc &= wc - 1;
+#ifdef SASA_EMU
+                    ++cnt_filter_[cnt_filter_k_ & 1];
+#endif
                     const Ab16 ab = m.ab[q];
                     const double bt = m.beta[q];
                     const double c = fma(t, ab.a, ab.b) * h2;
@@ -1077,6 +1095,9 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             }
             if (cte - cts >= SASA_TWOPI) cnt = 0; /* covered: area 0 */
         }
+#ifdef SASA_EMU
+        ++cnt_filter_k_;
+#endif
         m.it_tc[it] = cnt == 0 ? area : 0.5 * h2; /* (an item with arcs: 1/(4 Ri') for the arc pass - see lr2_arc_alpha -, which puts the area in its place) */
         unsigned short qt = 0xffff;
         if (cnt > 0) { /* queue: heaviest first (bin 0 = 63 arcs or more); inside a bin in order of arrival */
@@ -1191,6 +1212,9 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         finish_item(it, la, t, h2, Ri, o, cnt, buried, A > 0);
     }
     LR2_SYNC();
+#ifdef SASA_EMU
+    if (cover) { LR2_COUNT_LANES(12, 13, cnt_filter_[0]); LR2_COUNT_LANES(12, 13, cnt_filter_[1]); LR2_COUNT(10, 1); }
+#endif
 
     LR2_STOP(4);
     LR2_MARK(4);
@@ -1229,6 +1253,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     lr2_pre_c<SHAPE>(a, pre, nan, lane); /* (until round 4's last session these two went out behind the arc pass and P0 waited for them: -1.5 %) */
     /* ------------------------------------------------------------ P6 arc pass */
     int maxd = 0;
+    LR2_COUNT(6, nq); LR2_COUNT(8, 1);
     if (COVER && nq * 2 <= LR2_LANES) {
         const int shb = nq * 4 <= LR2_LANES ? 2 : 1, share = 1 << shb; /* (uniform) 4 lanes per item, or 2 */
         /* Few items are left (dense tiles behind the cover filter: ~9 of 60, two of them with ~27 arcs): one item
@@ -1243,6 +1268,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         int my = 0, la = 0;
         Lr2Union u;
         lr2_union_reset(u);
+        int cnt_shared_ = 0; (void)cnt_shared_;
         if (valid) {
             const int e = (int)m.queue[qi];
             my = e & 1023; la = e >> 10;
@@ -1260,6 +1286,9 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                 while (w != 0) { /* (the wave runs as many trips as its busiest lane) */
                     const int q = R + __builtin_ctz(w);
                     w &= w - 1;
+#ifdef SASA_EMU
+                    ++cnt_shared_;
+#endif
                     const Ab16 ab = m.ab[q];
                     const double bt = m.beta[q];
                     const double alpha = lr2_arc_alpha(t, ab, hh);
@@ -1267,6 +1296,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                 }
             }
         }
+        LR2_COUNT_LANES(14, 15, cnt_shared_);
         for (int st = 1; st < share; st <<= 1) { /* merge: lane j + st into lane j, for j a multiple of 2 st */
             LR2_SYNC();
             const int src = lane + st < LR2_LANES ? lane + st : lane;

@@ -161,17 +161,19 @@ def test_probe_zero_extreme_radii_and_slice_counts(fa, checker):
     assert max(worst.values()) < TOL
 
 
-def test_a_giant_radius_that_puts_tens_of_thousands_of_atoms_into_one_cell(fa, checker):
-    """Round-4 advisor (high): one atom of radius 30 A makes cells of 62.8 A, and 20 000 small atoms then share two of
-    them: a candidate row of the tile kernel holds 20 000 candidates, and a tile of six atoms of one cell 40 000 work
-    items - more than the 15 bits P1 decodes an item's place in its row with.  Round 4 wrapped there (candidates tested
-    twice, others never: wrong areas, no error); now such a tile is handed on (halves, the second launch, the slab
-    launch that walks its candidates one by one).  Sparse enough (39 neighbors per atom on average) that the tile
-    kernel would otherwise keep most of these tiles: the areas of ALL atoms are compared."""
+@pytest.mark.parametrize("n", [20000, 34000])
+def test_a_giant_radius_that_puts_tens_of_thousands_of_atoms_into_one_cell(fa, checker, n):
+    """Round-4 advisor (high): one atom of radius 30 A makes cells of 62.8 A, and tens of thousands of small atoms then
+    share two of them: a candidate row of the tile kernel holds ALL of them.  P1 decodes a work item's place in its row
+    with a 15-bit index and a 24-bit multiplication.  n = 20 000: inside that range (a one-atom tile has 20 000 items) -
+    and wrong on the MI355X until round 5, from the 16 384th candidate on: HIP's __umul24 returns int, so the shift
+    behind it was arithmetic (no emulation shows that; this test found it).  A six-atom tile there has 40 000 items,
+    and n = 34 000 has more than 2^15 even for one atom: such tiles are handed on (halves, the second launch, the slab
+    launch that walks its candidates one by one).  Sparse enough (39 / 66 neighbors per atom on average) that the tile
+    kernel keeps most lists: the areas of ALL atoms are compared."""
     rng = np.random.default_rng(3)
-    n = 20000
     xyz = np.vstack([rng.uniform([0, 0, 0], [60, 31, 31], size=(n, 3)), [[260.0, 15.0, 15.0]]])
     r = np.append(np.full(n, 0.1), 30.0)
     worst = _run(fa, checker, [(xyz, r)], 1.4, 20)
-    print(f"\n[adversarial] 20 000 atoms in two cells (one giant radius): max |dSASA| {worst:.3g} A^2")
+    print(f"\n[adversarial] {n} atoms in two cells (one giant radius): max |dSASA| {worst:.3g} A^2")
     assert worst < TOL
