@@ -506,6 +506,10 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
             pool = (pool + 1) & ~1;
             if (pool < 32) pool = 32;
             if (pool > 4096) pool = 4096;
+            if (!lr) { /* S&R: records per atom's segment: the longest list of a tile is ~1.5 x the mean */
+                pool = (((int)(1.5 * nn_est) + 8 + 7) / 8) * 8;
+                pool = pool < SR_CAP_MIN ? SR_CAP_MIN : (pool > SR_CAP_MAX ? SR_CAP_MAX : pool);
+            }
             c->hint_res[hi] = resolution;
             c->hint_ta[hi] = probe_cfg.TA;
             c->hint_pool[hi] = pool;
@@ -518,7 +522,8 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
         if (sscanf(e, "%d,%d,%d,%d", &b, &t, &pl, &d) == 4 && (b == 64 || b == 128 || b == 256) && t >= 1 && t <= b &&
             (!lr || !cfg.tab || t * resolution <= 4096)) {
             cfg.B = b; cfg.TA = t; cfg.pool = pl; cfg.ds = lr ? d : 0;
-            cfg.items = lr ? (cfg.tab ? cfg.TA * resolution : cfg.B) : 1;
+            if (!lr) { cfg.cap_idx = pl > 0 ? pl : cfg.cap_idx; cfg.pool = cfg.TA * cfg.cap_idx; } /* (S&R: "pool" = records per atom) */
+            cfg.items = lr ? (cfg.tab ? cfg.TA * resolution : cfg.B) : sr_items(cfg.TA, resolution);
             cfg.lds = tile_fixed_bytes(cfg.TA, cfg.items) + tile_list_bytes(cfg.TA, cfg.cap_idx, cfg.pool, cfg.lr, cfg.ds, cfg.B);
         }
     }
@@ -630,7 +635,7 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
     /* learn the pool size for the next batch of this kind (trajectory frames, sweeps) */
     c->hint_res[hi] = resolution;
     c->hint_ta[hi] = cfg.TA;
-    c->hint_pool[hi] = pool_from_hist(status_h + ST_HIST, cfg.TA);
+    c->hint_pool[hi] = lr ? pool_from_hist(status_h + ST_HIST, cfg.TA) : sr_cap_from_hist(status_h + ST_HIST);
     if (lr) c->hint_bucket = mean_from_hist(status_h + ST_HIST, cfg.TA) > 30.0 * cfg.TA;
     return 0;
 }

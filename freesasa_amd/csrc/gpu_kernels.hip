@@ -558,7 +558,10 @@ hipError_t kl_lr2_main(int rmax, int grid, size_t lds, hipStream_t st, const Lr2
 }
 
 template <int B, bool GLOBAL, int TIER>
-__global__ __launch_bounds__(B) void k_sr_tile(TileArgs a, int items)
+#ifndef SR_WPE
+#define SR_WPE 7 /* waves per SIMD the S&R kernel's registers are capped for (72 registers: seven 256-thread tiles per CU, what their LDS allows; the kernel is latency-bound - 67 % of its issue slots used - and measured on the MI355X, round 5, PDB entries x 251 / coil batch: uncapped (92 registers, 5 waves) 4.52 / 12.2 ms, 6 waves 4.16 / 11.2, 7 waves 4.04 / 11.0, 8 waves 4.49 / 11.4) */
+#endif
+__global__ __launch_bounds__(B) __attribute__((amdgpu_waves_per_eu(SR_WPE, SR_WPE))) void k_sr_tile(TileArgs a, int items)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -569,18 +572,25 @@ __global__ __launch_bounds__(B) void k_sr_tile(TileArgs a, int items)
     for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
         const int tile = a.work_tiles ? a.work_tiles[w] : xcd_tile(w, a.n_tiles);
         if (tile >= a.n_tiles) continue;
-        tile_phase_load(a, m, tile, tid, B);
+#ifndef SR_STOP_AFTER /* dev only (tools/build_variant.sh): leave the tile after phase k, for instruction / time attribution */
+#define SR_STOP_AFTER 99
+#endif
+        sr_phase_load(a, m, tile, tid, B);
         __syncthreads();
-        tile_phase_neighbors(a, m, tile, tid, B);
+        if (SR_STOP_AFTER == 0) continue;
+        sr_phase_neighbors(a, m, tile, tid, B);
         __syncthreads();
-        tile_phase_offsets(a, m, tid);
-        sr_phase_cursors(a, m, tid);
+        if (SR_STOP_AFTER == 1) continue;
+        sr_phase_lists(a, m, tid);
         __syncthreads();
-        tile_report<GLOBAL>(a, m, tile, tid, wg_max_nn);
-        sr_phase_pairs(a, m, tid, B);
+        sr_report<GLOBAL>(a, m, tile, tid, wg_max_nn);
+        if constexpr (GLOBAL) sr_order_serial(a, m, tid); /* (the slab launch: segments of 4096 records) */
+        else sr_order_wave(a, m, tid, B);                 /* (LDS launches: C <= 64 * SR_ORDER_RECS, see choose_cfg / mid_cfg) */
         __syncthreads();
+        if (SR_STOP_AFTER == 2) continue;
         sr_phase_points(a, m, tile, tid, B);
         __syncthreads();
+        if (SR_STOP_AFTER == 3) continue;
         sr_phase_points2(a, m, tid, B);
         __syncthreads();
         sr_phase_store(a, m, tile, tid);

@@ -581,7 +581,7 @@ SASA_HD size_t tile_fixed_bytes(int TA, int items)
 #endif
 SASA_HD size_t tile_union_bytes(int TA, int cap_idx, int pool, int ds, int B, bool lr)
 {
-    size_t u1 = align16(sizeof(int) * (size_t)TA * cap_idx) + (lr ? align16(sizeof(double) * (size_t)pool) : 0);
+    size_t u1 = lr ? align16(sizeof(int) * (size_t)TA * cap_idx) + align16(sizeof(double) * (size_t)pool) : 0; /* (S&R: no index lists since round 5) */
     size_t u2 = sizeof(Arc) * (size_t)ds * B;
     return u1 > u2 ? u1 : u2;
 }
@@ -1504,41 +1504,178 @@ SASA_D void sasa_wave_count(int *ctrs, int key, bool pred)
 }
 #endif
 
-/* with phase O: zero the front/back cursors of phase P (they live in the candidate-run words,
- * which are dead once the neighbors are found) */
-SASA_D void sr_phase_cursors(const TileArgs &a, TileMem &m, int tid)
+/* ---- Shrake & Rupley, second arrangement (round 5) ----------------------------------------------------------
+ * Until round 4 the S&R tile went  neighbors (candidate INDICES into per-atom lists) -> offsets -> pairs (every
+ * neighbor fetched from global memory a second time, its record (x, y, z, Rj^2) written to the packed pool, big caps
+ * to the front) -> points.  The profile of round 5 (profiles/r05_sr_phase_ablation.txt) put 23 % of the kernel on the
+ * reference's PDB entries into that second fetch: a dependent global load per pair behind LDS atomics.  Now the
+ * neighbor phase itself keeps what it has in registers the moment the contact test passes - (x, y, z, Rj) of the
+ * candidate - in a FIXED segment of C = cap_idx records per atom, in order of discovery (one LDS atomic and one
+ * 32-byte store in the sparse hit path: nothing else belongs there, a wave runs it for one lane in seven).  A dense
+ * pass (sr_order_wave: one wave per atom, every lane a record) then squares the radius and moves the neighbors with a
+ * large cap on the atom's sphere to the front of the list, the others to its end, in place.  No index lists, no offsets phase, no
+ * second fetch.  An atom with more than C neighbors sends its tile to the next launch (larger C), as a list overflow
+ * did before; C for the next batch follows the sampled histogram of the tiles' longest lists (sr_cap_from_hist).
+ * Counts are unchanged bit for bit: the point test is an OR over the same neighbor set. */
+
+SASA_D void sr_phase_load(const TileArgs &a, TileMem &m, int tile, int tid, int B)
 {
-    if (tid < a.TA) { m.rowlo[2 * tid] = 0; m.rowlo[2 * tid + 1] = 0; }
+    tile_phase_load(a, m, tile, tid, B);
+    if (tid < a.TA) m.aoff[tid] = 0; /* (front cursor of sr_phase_order) */
 }
 
-/* phase P: neighbor records (x, y, z, R^2) */
-SASA_D void sr_phase_pairs(const TileArgs &a, TileMem &m, int tid, int B)
+/* contact test of the reference, operand for operand (src/nb.c:483-492, as nb_test); a neighbor's (x, y, z, R) is kept */
+SASA_D void sr_nb_test(const TileArgs &a, TileMem &m, int la, int p, int q, double xi, double yi,
+                       double zi, double ri, double xq, double yq, double zq, double rq)
+{
+    if (q == p) return;
+    const double cut2 = (ri + rq) * (ri + rq);
+    const double dx = xq - xi, dy = yq - yi, dz = zq - zi;
+    if (dx * dx + dy * dy + dz * dz < cut2) {
+        const int s = SASA_ATOMIC_ADD_LDS(&m.acnt[la], 1);
+        if (s < a.cap_idx) { Quad rec; rec.x = xq; rec.y = yq; rec.z = zq; rec.w = rq; m.pq[la * a.cap_idx + s] = rec; }
+    }
+}
+
+/* phase N: neighbor discovery.  SUB = B/TA lanes share one atom and stride over the concatenation of its 9 candidate
+ * runs, three candidates per trip (tile_phase_neighbors' loop, with the neighbor kept at once) */
+SASA_D void sr_phase_neighbors(const TileArgs &a, TileMem &m, int tile, int tid, int B)
+{
+    const int na = tile_atoms(a, tile), p0 = tile_first_atom(a, tile);
+    const int SUB = B / a.TA;
+    const int la = tid / SUB, sub = tid - la * SUB;
+    if (la >= na) return;
+    const int p = p0 + la;
+    const double xi = m.ax[la], yi = m.ay[la], zi = m.az[la], ri = m.aR[la];
+    const int *rl = m.rowlo + 9 * la, *rc = m.rowcnt + 9 * la;
+    int total = 0;
+    for (int r = 0; r < 9; ++r) total += rc[r];
+    int r = 0, base = 0, cnt = rc[0];
+    for (int f = sub; f < total; f += SASA_NB_UNROLL * SUB) {
+        int q[SASA_NB_UNROLL];
+        double x[SASA_NB_UNROLL], y[SASA_NB_UNROLL], z[SASA_NB_UNROLL], rq[SASA_NB_UNROLL];
+        for (int j = 0; j < SASA_NB_UNROLL; ++j) {
+            const int fj = f + j * SUB;
+            if (fj < total) {
+                while (fj >= base + cnt) { base += cnt; ++r; cnt = rc[r]; }
+                q[j] = rl[r] + (fj - base);
+            } else {
+                q[j] = p; /* the atom itself: never a neighbor */
+            }
+        }
+        for (int j = 0; j < SASA_NB_UNROLL; ++j) {
+            const unsigned u = (unsigned)q[j];
+            { const Quad v = a.sq[u]; x[j] = v.x; y[j] = v.y; z[j] = v.z; rq[j] = v.w; }
+        }
+        for (int j = 0; j < SASA_NB_UNROLL; ++j) sr_nb_test(a, m, la, p, q[j], xi, yi, zi, ri, x[j], y[j], z[j], rq[j]);
+    }
+}
+
+/* behind the barrier that follows phase N: does every list fit its segment?  The longest list of the tile. */
+SASA_D void sr_phase_lists(const TileArgs &a, TileMem &m, int tid)
+{
+    if (tid >= a.TA) return;
+    const int c = m.acnt[tid];
+    if (c > a.cap_idx) m.flags[0] = 1;
+    SASA_ATOMIC_MAX_LDS(&m.flags[2], c);
+}
+
+/* The ordering pass over the neighbors found squares the radius (ref: src/sasa_sr.c:146) and moves every record to its
+ * place in the atom's list: neighbors whose sphere hides a large cap of atom i from the FRONT, the others from the END
+ * of the list.  The point test is an OR over neighbors (any order gives the same counts), and with the big caps first
+ * almost every covered point is rejected by the first SR_FIRST tests (measured at protein density: 2 % of the points
+ * survive instead of 21 %).  Cap of half-angle theta: cos(theta) = (Ri^2 + d^2 - Rj^2)/(2 Ri d) < 0.6, without the root. */
+#define SR_ORDER_RECS 2 /* records of one atom a lane of the ordering wave holds: C <= 64 * SR_ORDER_RECS in the LDS launches */
+#ifndef SASA_EMU
+/* ONE WAVE orders one atom's list in place (wave w the atoms w, w + waves, ...): lane l takes records l and l + 64 into
+ * registers, the wave's ballots say how many big caps stand before each, and every record goes to its place - no
+ * atomics, and no workgroup barrier inside: the LDS executes a wave's instructions in order, so all of the list is in
+ * registers before the first record is written back (the compiler is kept from moving the stores up). */
+SASA_D void sr_order_wave(const TileArgs &a, TileMem &m, int tid, int B)
 {
     if (m.flags[0]) return;
-    const int total = m.aoff[a.TA];
-    for (int gp = tid; gp < total; gp += B) {
-        int la = 0;
-        while (m.aoff[la + 1] <= gp) ++la;
-        const int o = m.aoff[la], nn = m.aoff[la + 1] - o;
-        const int q = m.idx[la * a.cap_idx + (gp - o)];
-        const Quad vj = a.sq[q];
-        const double rj = vj.w;
-        Quad rec;
-        rec.x = vj.x; rec.y = vj.y; rec.z = vj.z;
-        rec.w = rj * rj; /* ref: src/sasa_sr.c:146 */
-        /* Neighbors whose sphere hides a large cap of atom i go to the FRONT of its list, the others
-           to the back: the point test is an OR over neighbors (any order gives the same counts),
-           and with the big caps first almost every covered point is rejected by the first
-           SR_FIRST tests (measured at protein density: 2 % of the points survive instead of 21 %).
-           Cap of half-angle theta: cos(theta) = (Ri^2 + d^2 - Rj^2)/(2 Ri d) < 0.6, without the root. */
-        const double ri = m.aR[la];
-        const double dx = rec.x - m.ax[la], dy = rec.y - m.ay[la], dz = rec.z - m.az[la];
+    const int lane = tid & 63, C = a.cap_idx;
+    for (int la = tid >> 6; la < a.TA; la += B >> 6) { /* (uniform per wave) */
+        const int nn = m.acnt[la];
+        const double ri = m.aR[la], xi = m.ax[la], yi = m.ay[la], zi = m.az[la];
+        Quad *L = m.pq + la * C;
+        Quad rec[SR_ORDER_RECS];
+        bool big[SR_ORDER_RECS];
+#pragma unroll
+        for (int j = 0; j < SR_ORDER_RECS; ++j) {
+            const int k = lane + 64 * j;
+            big[j] = false;
+            if (k < nn) {
+                rec[j] = L[k];
+                const double dx = rec[j].x - xi, dy = rec[j].y - yi, dz = rec[j].z - zi;
+                const double d2 = dx * dx + dy * dy + dz * dz;
+                rec[j].w = rec[j].w * rec[j].w; /* ref: src/sasa_sr.c:146 */
+                const double num = ri * ri + d2 - rec[j].w;
+                big[j] = num < 0 || num * num < 1.44 * (ri * ri) * d2;
+            }
+        }
+        __atomic_signal_fence(__ATOMIC_SEQ_CST); __builtin_amdgcn_wave_barrier(); __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        int nf = 0, nb = 0; /* big / small caps in the chunks before this one (uniform) */
+#pragma unroll
+        for (int j = 0; j < SR_ORDER_RECS; ++j) {
+            const int k = lane + 64 * j;
+            const unsigned long long mb = __builtin_amdgcn_ballot_w64(big[j]), mv = __builtin_amdgcn_ballot_w64(k < nn);
+            const int before = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0u));
+            const unsigned long long ms = mv & ~mb;
+            const int sbefore = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ms >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ms, 0u));
+            if (k < nn) L[big[j] ? nf + before : nn - 1 - (nb + sbefore)] = rec[j];
+            nf += __popcll(mb); nb += __popcll(ms);
+        }
+    }
+}
+#endif
+/* launches whose segments are longer than the lanes can hold across a barrier (the slab launch: C = 4096): one lane
+   per atom orders its list in place - squares every radius, then swaps big caps forward */
+SASA_D void sr_order_serial(const TileArgs &a, TileMem &m, int tid)
+{
+    if (m.flags[0] || tid >= a.TA) return;
+    const int C = a.cap_idx, nn = m.acnt[tid];
+    const double ri = m.aR[tid], xi = m.ax[tid], yi = m.ay[tid], zi = m.az[tid];
+    Quad *L = m.pq + tid * C;
+    int nf = 0;
+    for (int k = 0; k < nn; ++k) {
+        Quad rec = L[k];
+        const double dx = rec.x - xi, dy = rec.y - yi, dz = rec.z - zi;
         const double d2 = dx * dx + dy * dy + dz * dz;
+        rec.w = rec.w * rec.w;
         const double num = ri * ri + d2 - rec.w;
         const bool big = num < 0 || num * num < 1.44 * (ri * ri) * d2;
-        const int slot = big ? SASA_ATOMIC_ADD_LDS(&m.rowlo[2 * la], 1)
-                             : nn - 1 - SASA_ATOMIC_ADD_LDS(&m.rowlo[2 * la + 1], 1);
-        m.pq[o + slot] = rec;
+        if (big) { /* (L[nf .. k) are small caps, already squared: the first of them makes room) */
+            if (k != nf) { const double mx = L[nf].x, my = L[nf].y, mz = L[nf].z, mw = L[nf].w; L[k].x = mx; L[k].y = my; L[k].z = mz; L[k].w = mw; }
+            L[nf] = rec;
+            ++nf;
+        } else {
+            L[k] = rec;
+        }
+    }
+}
+SASA_HD bool sr_order_in_wave(int C) { return C <= 64 * SR_ORDER_RECS; }
+SASA_HD int sr_items(int TA, int n_points) { return (TA * n_points + 1) / 2; } /* S&R: the tile's slice-area table (unused) holds the survivor list, an entry per (atom, point) */
+SASA_HD int sr_hist_bin(int longest) { return longest >> 1; } /* demand histogram of S&R batches: tiles by their longest neighbor list, bins of 2 */
+template <bool GLOBAL>
+SASA_D void sr_report(const TileArgs &a, TileMem &m, int tile, int tid, int &wg_max_nn)
+{
+    if (tid != 0) return;
+    if (m.flags[2] > wg_max_nn) wg_max_nn = m.flags[2];
+    /* one tile in 32, picked by a hash of its number: tiles are in cell order, so "every 32nd tile" samples the same
+       places of every structure of a batch of equal structures (round 5: it put the capacity of the coil batch at 48
+       records where the 98.5th percentile of all tiles needs 56, and a tenth of the tiles went to the second launch) */
+    if (!a.work_tiles && (((unsigned)tile * 2654435761u) >> 27) == 0) {
+        const int need = sr_hist_bin(m.flags[2]);
+        SASA_ATOMIC_ADD_GLB(&a.status[ST_HIST + (need < 63 ? need : 63)], 1);
+    }
+    if (m.flags[0]) {
+        if (!a.ovf_tiles) {
+            SASA_ATOMIC_MAX_GLB(&a.status[ST_ERROR], (int)ERR_NEIGHBOR_CAP);
+        } else {
+            const int w = SASA_ATOMIC_ADD_GLB(a.ovf_count, 1);
+            a.ovf_tiles[w] = tile;
+        }
     }
 }
 
@@ -1548,22 +1685,22 @@ SASA_D void sr_phase_pairs(const TileArgs &a, TileMem &m, int tid, int B)
  * most of them by one of the first few neighbors, while an exposed point must be tested against
  * all of them: with one lane per point a wave would run the full neighbor loop with a quarter
  * of its lanes alive.  So L1 tests only the first SR_FIRST neighbors — the ones with the largest
- * caps, see sr_phase_pairs — and appends the survivors (still uncovered, neighbors left) to a
+ * caps, see sr_nb_test — and appends the survivors (still uncovered, neighbors left) to a
  * compact LDS list; L2 finishes them with dense lanes. */
 #ifndef SR_FIRST
 #define SR_FIRST 8
 #endif
-SASA_D bool sr_compact_ok(const TileArgs &a, int items)
+SASA_D bool sr_inside(const Quad q, double tx, double ty, double tz)
 {
-    return a.TA <= 64 && a.n_res <= 65536 && items <= a.TA * a.cap_idx; /* one 32-bit entry per survivor in the idx lists */
+    const double dx = tx - q.x, dy = ty - q.y, dz = tz - q.z;
+    return dx * dx + dy * dy + dz * dz <= q.w; /* ref: src/sasa_sr.c:324 */
 }
+/* is the point inside one of the neighbors k0 .. k1-1 of the list at `o`?  One neighbor per look: most covered points are
+ * inside the first or second (grouping the tests four by four, with one exit per group, was 35 % slower: round 5, measured) */
 SASA_D bool sr_covered(const TileMem &m, int o, int k0, int k1, double tx, double ty, double tz)
 {
-    for (int k = k0; k < k1; ++k) {
-        const Quad q = m.pq[o + k];
-        const double dx = tx - q.x, dy = ty - q.y, dz = tz - q.z;
-        if (dx * dx + dy * dy + dz * dz <= q.w) return true; /* ref: src/sasa_sr.c:324 */
-    }
+    for (int k = k0; k < k1; ++k)
+        if (sr_inside(m.pq[o + k], tx, ty, tz)) return true;
     return false;
 }
 SASA_D void sr_point(const TileArgs &a, const TileMem &m, int la, int pt, double &tx, double &ty, double &tz)
@@ -1580,9 +1717,9 @@ SASA_D void sr_phase_points(const TileArgs &a, TileMem &m, int tile, int tid, in
     return;
 #endif
     const int na = tile_atoms(a, tile);
-    const int np = a.n_res, items = na * np;
-    const bool compact = sr_compact_ok(a, a.TA * np);
-    unsigned *surv = (unsigned *)m.idx; /* the index lists are dead after phase P */
+    const int np = a.n_res, items = na * np, C = a.cap_idx;
+    const bool compact = a.TA <= 64 && np <= 65536;
+    unsigned *surv = (unsigned *)m.contrib; /* an entry per (atom, point): sr_items() */
     for (int it0 = 0; it0 < items; it0 += B) { /* (trip count uniform over the workgroup: the wave operations below need every lane) */
         const int it = it0 + tid;
         const bool have = it < items;
@@ -1591,9 +1728,9 @@ SASA_D void sr_phase_points(const TileArgs &a, TileMem &m, int tile, int tid, in
         if (have) {
             double tx, ty, tz;
             sr_point(a, m, la, pt, tx, ty, tz);
-            const int o = m.aoff[la], nn = m.aoff[la + 1] - o;
+            const int nn = m.acnt[la];
             const int k1 = compact && nn > SR_FIRST ? SR_FIRST : nn;
-            if (!sr_covered(m, o, 0, k1, tx, ty, tz)) {
+            if (!sr_covered(m, la * C, 0, k1, tx, ty, tz)) {
                 exposed = k1 == nn;
                 survivor = !exposed;
             }
@@ -1609,7 +1746,8 @@ SASA_D void sr_phase_points(const TileArgs &a, TileMem &m, int tile, int tid, in
 SASA_D void sr_phase_points2(const TileArgs &a, TileMem &m, int tid, int B)
 {
     if (m.flags[0]) return;
-    const unsigned *surv = (const unsigned *)m.idx;
+    const unsigned *surv = (const unsigned *)m.contrib;
+    const int C = a.cap_idx;
     const int ns = m.flags[3];
     for (int s0 = 0; s0 < ns; s0 += B) {
         const int s = s0 + tid;
@@ -1619,8 +1757,7 @@ SASA_D void sr_phase_points2(const TileArgs &a, TileMem &m, int tid, int B)
         if (have) {
             double tx, ty, tz;
             sr_point(a, m, la, pt, tx, ty, tz);
-            const int o = m.aoff[la], nn = m.aoff[la + 1] - o;
-            exposed = !sr_covered(m, o, SR_FIRST, nn, tx, ty, tz);
+            exposed = !sr_covered(m, la * C, SR_FIRST, m.acnt[la], tx, ty, tz);
         }
         sasa_wave_count(m.aexp, la, exposed);
     }
@@ -1782,6 +1919,10 @@ struct TileCfg {
     size_t lds;
 };
 
+#define SR_CAP_DEFAULT 64 /* S&R: records per atom's segment (main launch) without history */
+#define SR_CAP_MIN 32
+#define SR_CAP_MAX 112
+#define SR_CAP_MID 128     /* ... of the second launch (two records per lane of the ordering wave: sr_order_in_wave) */
 #define SASA_ITEMS_CAP 640
 #define SASA_TA_MAX 16
 /* Three launches share one tiling.  1: small LDS lists sized for the typical tile (most
@@ -1834,14 +1975,18 @@ static inline TileCfg choose_cfg(int resolution, bool lr, int pool_hint = 0)
         c.B = 256;
         c.TA = ta < 1 ? 1 : (ta > 8 ? 8 : ta);
     }
-    c.items = lr ? (c.tab ? c.TA * resolution : c.B) : 1;
+    c.items = lr ? (c.tab ? c.TA * resolution : c.B) : sr_items(c.TA, resolution);
     c.lr = lr ? 1 : 0;
     c.cap_idx = 128;
     c.pool = 64 * c.TA < 128 ? 128 : 64 * c.TA;
     if (pool_hint > 0) c.pool = pool_hint;
+    if (!lr) { /* S&R (second arrangement): a fixed segment of cap_idx records per atom; pool_hint = that capacity (sr_cap_from_hist) */
+        c.cap_idx = pool_hint > 0 ? pool_hint : SR_CAP_DEFAULT;
+        c.pool = c.TA * c.cap_idx;
+    }
     c.ds = lr ? 3 : 0; /* deeper arc stacks are rare: those tiles go to the second launch */
     c.lds = tile_fixed_bytes(c.TA, c.items) + tile_list_bytes(c.TA, c.cap_idx, c.pool, c.lr, c.ds, c.B);
-    if (pool_hint > 0) {
+    if (pool_hint > 0 && lr) {
         /* occupancy comes in steps of whole workgroups per CU (160 KB of LDS): spend the slack of
            the current step on a larger pool instead of leaving it unused */
         const size_t cu_lds = 160 * 1024;
@@ -1860,6 +2005,26 @@ static inline TileCfg choose_cfg(int resolution, bool lr, int pool_hint = 0)
         }
     }
     return c;
+}
+
+/* S&R: records per atom's segment for the NEXT batch on this context, from the sampled histogram of the tiles' longest
+ * neighbor lists (sr_hist_bin): what all but ~1.5 % of the tiles need, a multiple of 8 in [SR_CAP_MIN, SR_CAP_MAX] -
+ * the few tiles above go to the second launch, and every 8 records less are 2 KB of LDS per 8-atom tile. */
+static inline int sr_cap_from_hist(const int *hist)
+{
+    long long total = 0;
+    for (int k = 0; k < 64; ++k) total += hist[k];
+    if (total <= 0) return 0;
+    long long allowed = total / 64, acc = 0;
+    int k = 63;
+    for (; k > 0; --k) {
+        acc += hist[k];
+        if (acc > allowed) break;
+    }
+    int cap = ((2 * (k + 1) + 7) / 8) * 8;
+    if (cap < SR_CAP_MIN) cap = SR_CAP_MIN;
+    if (cap > SR_CAP_MAX) cap = SR_CAP_MAX;
+    return cap;
 }
 
 /* Pool size for the NEXT batch on this context from the demand histogram of the last one: the
@@ -1897,6 +2062,12 @@ static inline double mean_from_hist(const int *hist, int TA)
 static inline TileCfg mid_cfg(const TileCfg &main_cfg, bool lr)
 {
     TileCfg c = main_cfg;
+    if (!lr) { /* S&R: segments of SR_CAP_MID records per atom */
+        c.cap_idx = SR_CAP_MID > main_cfg.cap_idx ? SR_CAP_MID : main_cfg.cap_idx;
+        c.pool = c.TA * c.cap_idx;
+        c.lds = tile_fixed_bytes(c.TA, c.items) + tile_list_bytes(c.TA, c.cap_idx, c.pool, c.lr, c.ds, c.B);
+        return c;
+    }
     c.cap_idx = 256;
     c.pool = 2 * main_cfg.pool < 64 * c.TA ? 64 * c.TA : 2 * main_cfg.pool; /* twice the (adaptive) main pool */
     if (c.pool > 3072) c.pool = 3072;
@@ -1914,7 +2085,7 @@ static inline TileCfg fallback_cfg(const TileCfg &main_cfg, bool lr)
 {
     TileCfg fb = main_cfg;
     fb.cap_idx = SASA_FB_CAP;
-    fb.pool = SASA_FB_POOL;
+    fb.pool = lr ? SASA_FB_POOL : fb.TA * SASA_FB_CAP; /* (S&R: a segment of SASA_FB_CAP records per atom, in the slab) */
     fb.ds = lr ? SASA_FB_DS : 0;
     fb.lds = tile_fixed_bytes(fb.TA, fb.items);
     return fb;

@@ -110,9 +110,20 @@ static void emu_tile_kernel(bool lr, const TileCfg &cfg, TileArgs a, int grid)
             const int tile = a.work_tiles ? a.work_tiles[w] : xcd_tile(w, a.n_tiles);
             if (tile >= a.n_tiles) continue;
 #define PHASE(call) for (int tid = 0; tid < B; ++tid) { call; }
+            if (!lr) { /* Shrake-Rupley: records written by the neighbor phase, no offsets / pairs phases (gpu_kernels.hip, k_sr_tile) */
+                PHASE(sr_phase_load(a, m, tile, tid, B));
+                PHASE(sr_phase_neighbors(a, m, tile, tid, B));
+                PHASE(sr_phase_lists(a, m, tid));
+                PHASE(sr_report<GLOBAL>(a, m, tile, tid, wg_max_nn[tid]));
+                PHASE(sr_order_serial(a, m, tid)); /* (the device orders a list with one wave's ballots: the same partition up to the order inside each part, which no count depends on) */
+                PHASE(sr_phase_points(a, m, tile, tid, B));
+                PHASE(sr_phase_points2(a, m, tid, B));
+                PHASE(sr_phase_store(a, m, tile, tid));
+                continue;
+            }
             PHASE(tile_phase_load(a, m, tile, tid, B, lr && emu_bucket));
             PHASE(tile_phase_neighbors(a, m, tile, tid, B));
-            PHASE(tile_phase_offsets(a, m, tid); if (!lr) sr_phase_cursors(a, m, tid));
+            PHASE(tile_phase_offsets(a, m, tid));
             if (lr) {
                 PHASE(tile_report<GLOBAL>(a, m, tile, tid, wg_max_nn[tid]); lr_phase_beta(a, m, tid, B, emu_bucket));
                 if (emu_bucket && lr_bucket_path(a, m, B)) {
@@ -126,11 +137,6 @@ static void emu_tile_kernel(bool lr, const TileCfg &cfg, TileArgs a, int grid)
                 }
                 PHASE(lr_phase_slices(a, m, tile, tid, B));
                 PHASE(lr_phase_store<GLOBAL>(a, m, tile, tid, B));
-            } else {
-                PHASE(tile_report<GLOBAL>(a, m, tile, tid, wg_max_nn[tid]); sr_phase_pairs(a, m, tid, B));
-                PHASE(sr_phase_points(a, m, tile, tid, B));
-                PHASE(sr_phase_points2(a, m, tid, B));
-                PHASE(sr_phase_store(a, m, tile, tid));
             }
         }
         PHASE(tile_report_flush(a, tid, wg_max_nn[tid]));
@@ -329,6 +335,7 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
     if (force_cap_idx > 0) cfg.cap_idx = force_cap_idx;
     if (force_pool > 0) cfg.pool = force_pool;
     if (force_ds >= 0 && lr) cfg.ds = force_ds;
+    if (!lr) cfg.pool = cfg.TA * cfg.cap_idx; /* (S&R: a segment of cap_idx records per atom) */
     cfg.lds = tile_fixed_bytes(cfg.TA, cfg.items) + tile_list_bytes(cfg.TA, cfg.cap_idx, cfg.pool, cfg.lr, cfg.ds, cfg.B);
     const int n_tiles = (n + cfg.TA - 1) / cfg.TA;
     std::vector<int> ovf_tiles(n_tiles + 1);
@@ -352,6 +359,7 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
         if (mid_cap_idx > 0) mc.cap_idx = mid_cap_idx;
         if (mid_pool > 0) mc.pool = mid_pool;
         if (mid_ds >= 0 && lr) mc.ds = mid_ds;
+        if (!lr) mc.pool = mc.TA * mc.cap_idx;
         mc.lds = tile_fixed_bytes(mc.TA, mc.items) + tile_list_bytes(mc.TA, mc.cap_idx, mc.pool, mc.lr, mc.ds, mc.B);
         TileArgs tm = ta;
         tm.cap_idx = mc.cap_idx; tm.pool = mc.pool; tm.ds = mc.ds;
@@ -364,6 +372,7 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
         if (fb_cap_idx > 0) fb.cap_idx = fb_cap_idx;
         if (fb_pool > 0) fb.pool = fb_pool;
         if (fb_ds > 0 && lr) fb.ds = fb_ds;
+        if (!lr) fb.pool = fb.TA * fb.cap_idx;
         const size_t stride = tile_slab_bytes(fb.TA, fb.cap_idx, fb.pool, fb.lr, fb.ds, fb.B);
         const int fb_blocks = 3; /* fewer than SASA_FB_BLOCKS so that the work loop wraps */
         std::vector<char> slab(stride * fb_blocks + 64);
