@@ -168,8 +168,14 @@ def test_hot_kernels_do_not_spill(L):
     for n, (v, sc) in seen.items():
         if "k_lr2_tileILi" in n and "ELi0ELi4E" in n:          # every main-launch variant
             assert v <= 128 and sc == 0, (n, v, sc)
-        if "k_sr_tileILi256ELb0ELi0" in n or "k_lr_tileILi64ELb0ELi0ELi4ELb1" in n:
+        if "k_lr_tileILi64ELb0ELi0ELi4ELb1" in n:
             assert sc == 0, n
+        if "k_sr_tileILi256ELb0ELi0" in n:
+            # Shrake-Rupley is latency-bound (67 % of its issue slots used), so its registers are CAPPED for seven waves
+            # per SIMD (gpu_kernels.hip, SR_WPE): measured on the MI355X in round 5, seven waves with a few spilled
+            # dwords beat six by 3 %, and the uncapped build (92 registers, five waves) loses 12 %.  What this guards is
+            # the cap itself and that the spill stays a handful of dwords.
+            assert v <= 72 and sc <= 96, (n, v, sc)
     # the first-generation L&R kernel (resolutions above 256 slices, last-resort launch) is capped at 96 VGPRs for
     # 5 waves per SIMD and may keep a few bytes in scratch (measured: no slower than the spill-free 4-wave build)
     old = [n for n in seen if n.startswith("_Z9k_lr_tileILi64ELb0ELi0ELi5ELb0")]
