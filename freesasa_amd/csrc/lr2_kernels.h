@@ -586,6 +586,24 @@ SASA_D void lr2_overflow(const Lr2Args &a, int p0, int na, int err_code)
  * the arc pass spends on its acos - and the slice table (a 20-step dependent loop on 6 of 64 lanes) is gone, its LDS
  * word per item free to carry 1/(2 Ri') from the screening to the arc pass. */
 SASA_D double lr2_slice_height(int s, double delta, double Ri) { return fma((double)s + 0.5, delta, -Ri); }
+/* ... and for atoms FAR from the origin the reference's own plane: it walks in absolute coordinates, z = zi - Ri - delta/2,
+ * then z += delta per slice (src/sasa_lr.c:304-307), and every addition rounds to half an ulp of |z|, so at |z| = 1.6e4 A
+ * its plane sits ~1e-11 A off the exact one - nothing for an ordinary arc, but where a neighbor's circle is TANGENT to
+ * the atom's the arc's half-width is the square root of that (round 4, tests/test_adversarial.py: 2.9e-5 A^2 at 1.6e4 A
+ * against 1.7e-7 at the origin, and growing with |z|).  Beyond LR2_WALK_Z the kernel therefore walks exactly as the
+ * reference does and takes t = z - zi (exact: the two are within a factor of two), which is the reference's plane bit for
+ * bit at any distance from the origin; inside, the closed form stays (a drift of at most ~6e-13 A there).  The switch
+ * is per ATOM (its own z), so an area does not depend on which atoms share its tile. */
+#ifndef LR2_WALK_Z
+#define LR2_WALK_Z 256.0
+#endif
+SASA_D double lr2_slice_height_at(int s, double delta, double Ri, double zi)
+{
+    if (!(fabs(zi) > LR2_WALK_Z)) return lr2_slice_height(s, delta, Ri);
+    double z = (zi - Ri) - 0.5 * delta; /* ref: src/sasa_lr.c:305 */
+    for (int k = 0; k <= s; ++k) z += delta; /* ref: :307 */
+    return z - zi;
+}
 
 /* The order of two neighbors whose beta agree in their leading 40 bits: by 12 bits of the pair's own geometry (the
  * low mantissa words of xd, yd, zd), not by when the neighbor was found — the order, and with it every bit of the
@@ -1121,7 +1139,8 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             const int sa_ = 2 * j, it0 = LR2_MUL24(la, ns) + sa_;
             const bool second = sa_ + 1 < ns; /* (ns odd: the atom's last pair is one slice) */
             const double Ri = m.atom[la].w, del = m.adel[la];
-            const double t0 = lr2_slice_height(sa_, del, Ri), t1 = lr2_slice_height(second ? sa_ + 1 : sa_, del, Ri);
+            const double zi_ = m.atom[la].z;
+            const double t0 = lr2_slice_height_at(sa_, del, Ri, zi_), t1 = lr2_slice_height_at(second ? sa_ + 1 : sa_, del, Ri, zi_);
             const double A0 = Ri * Ri - t0 * t0, A1 = Ri * Ri - t1 * t1; /* Ri'^2, ref: src/sasa_lr.c:309 */
             const bool circ0 = A0 > 0, circ1 = second && A1 > 0; /* ref: :310-312 */
             double h0, h1;
@@ -1171,7 +1190,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     for (int it = lane; it < items; it += LR2_LANES) {
         int la = (int)(((float)it + 0.5f) * inv_ns), s = it - LR2_MUL24(la, ns); /* it / ns without the integer-division sequence */
         if (s < 0) { --la; s += ns; } else if (s >= ns) { ++la; s -= ns; }
-        const double Ri = m.atom[la].w, t = lr2_slice_height(s, m.adel[la], Ri);
+        const double Ri = m.atom[la].w, t = lr2_slice_height_at(s, m.adel[la], Ri, m.atom[la].z);
         const double A = Ri * Ri - t * t; /* Ri'^2, ref: src/sasa_lr.c:309 */
         double h2 = 0;
         int cnt = 0, o = 0;
@@ -1273,7 +1292,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             const int e = (int)m.queue[qi];
             my = e & 1023; la = e >> 10;
             const int o = m.aoff[la], nn = m.aoff[la + 1] - o;
-            const double t = lr2_slice_height(my - LR2_MUL24(la, ns), m.adel[la], m.atom[la].w); /* as P4: bit for bit */
+            const double t = lr2_slice_height_at(my - LR2_MUL24(la, ns), m.adel[la], m.atom[la].w, m.atom[la].z); /* as P4: bit for bit */
             const double hh = m.it_tc[my];
             const int lo = LR2_MUL24(nn, j) >> shb, hi = LR2_MUL24(nn, j + 1) >> shb; /* list positions of this lane */
             for (int wi = 0; wi < mwt; ++wi) {
@@ -1336,7 +1355,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         if (my != LR2_NONE) {                                                                      \
             la = e_ >> 10;                                                                         \
             { const int o_ = m.aoff[la]; Rab = m.ab + o_; Rbt = m.beta + o_; } hh = m.it_tc[my];     \
-            t = lr2_slice_height(my - LR2_MUL24(la, ns), m.adel[la], m.atom[la].w); /* as P4: bit for bit */ \
+            t = lr2_slice_height_at(my - LR2_MUL24(la, ns), m.adel[la], m.atom[la].w, m.atom[la].z); /* as P4: bit for bit */ \
             mk = m.it_mask + LR2_MUL24(my, mw); w = *mk; wleft = mwt - 1;                          \
             LR2_NEXT_WORD();                                                                       \
         }                                                                                          \

@@ -198,7 +198,7 @@ int freesasa_gpu_sweep_files_resumable(const char *const *paths, int n_paths, in
    devices' loaders / lanes.  Results are bit-identical to the single-device drivers', which are these with one entry.
    _sweep_files_devices: as freesasa_gpu_sweep_files_resumable (done_path may be NULL, max_new_batches <= 0: all).
    _sweep_cache_devices: the sweep of a binary cache (freesasa_ingest_save): lanes_per_device threads per device
-   (<= 0: the granted CPUs divided by the devices, 2 .. 4) read, VERIFY (1 MiB piece checksums) and upload exactly the
+   (<= 0: the granted CPUs divided by the devices, 2 .. 8; batch_atoms <= 0: 1e6) read, VERIFY (1 MiB piece checksums) and upload exactly the
    coordinates, radii and classes of their batch through page-locked staging; n_out = length of the output arrays
    (>= the cache's structure count); class_sums_out / atoms_out / status_out may be NULL.  Returns 0 / -1.
    _trajectory_devices, _trajectory_file_devices: as freesasa_gpu_trajectory / _trajectory_file. */
