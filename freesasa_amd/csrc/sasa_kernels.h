@@ -1688,7 +1688,7 @@ SASA_D void sr_report(const TileArgs &a, TileMem &m, int tile, int tid, int &wg_
  * caps, see sr_nb_test — and appends the survivors (still uncovered, neighbors left) to a
  * compact LDS list; L2 finishes them with dense lanes. */
 #ifndef SR_FIRST
-#define SR_FIRST 8
+#define SR_FIRST 6 /* (round 5, MI355X, coil batch / PDB entries x 251: 6 neighbors 10.39 / 3.92 ms, 8: 10.63 / 3.95, 10: 10.97 / 3.98, 4: slower on the PDB entries) */
 #endif
 SASA_D bool sr_inside(const Quad q, double tx, double ty, double tz)
 {

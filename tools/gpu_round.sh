@@ -2,7 +2,7 @@
 #   bash tools/gpu_round.sh r04        (outputs under gpurun_out/<tag>_*; copy the summaries into profiles/)
 # Build the phase-ablation variants first if the per-phase instruction counts are wanted:
 #   for k in 0 1 2 3 4 5; do bash tools/build_variant.sh stop$k -DLR2_STOP_AFTER=$k; done; bash tools/build_variant.sh pt -DSASA_PHASE_TIMING
-TAG=${1:-r04}
+TAG=${1:-r05}
 mkdir -p gpurun_out
 export PYTHONUNBUFFERED=1
 REPO=$(pwd)
@@ -14,10 +14,10 @@ grep "adversarial" $O/${TAG}_pytest_gpu.log > $O/${TAG}_adversarial.txt
 grep '^{' $O/${TAG}_bench.out | tail -1 > $O/${TAG}_bench.json
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-end-to-end --no-secondary --no-neighbors --no-live-counters"
+BENCH="python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-end-to-end --no-secondary --no-neighbors --no-live-counters --no-drivers --sustain-seconds 0"
 (timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -o trace -- $BENCH) > $O/rocprof_trace.log 2>&1
 cp $O/prof_$TAG/trace_kernel_stats.csv $O/${TAG}_kernel_stats.csv
-PM="python $REPO/bench.py --steps 1 --warmup 1 --sync-entry --no-cpu-baseline --no-end-to-end --no-secondary --no-neighbors --no-live-counters"
+PM="python $REPO/bench.py --steps 1 --warmup 1 --sync-entry --no-cpu-baseline --no-end-to-end --no-secondary --no-neighbors --no-live-counters --no-drivers --sustain-seconds 0"
 (timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU --output-format csv -d $O/prof_$TAG -o pmc1 -- $PM) > $O/rocprof_pmc1.log 2>&1
 (timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_VALU --output-format csv -d $O/prof_$TAG -o pmc2 -- $PM) > $O/rocprof_pmc2.log 2>&1
 (timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/prof_$TAG -o pmc3 -- $PM) > $O/rocprof_pmc3.log 2>&1
@@ -57,5 +57,10 @@ if [ -f freesasa_amd/lib/libvar_stop0.so ]; then
    SLICES=100 STRUCTS=100 bash tools/gpu_ablate.sh "0,0,-1,0" freesasa_amd/lib/libvar_stop0.so freesasa_amd/lib/libvar_stop1.so freesasa_amd/lib/libvar_stop2.so freesasa_amd/lib/libvar_stop3.so freesasa_amd/lib/libvar_stop4.so freesasa_amd/lib/libvar_stop5.so freesasa_amd/lib/libfreesasa_amd.so) 2>&1 | grep "==\|coils\|lr2_tile<" | sed "s/vgpr[^ ]* //" > $O/${TAG}_lr100_phase_valu.txt
 fi
 (timeout 600 python tools/deep_parity.py 120 24 2>/dev/null | tail -1) > $O/${TAG}_deep_parity.json
+(timeout 900 python tools/deep_parity.py 500 100 2>/dev/null | tail -1) > $O/${TAG}_deep_parity_large.json
+# Shrake-Rupley: kernel trace + counters on its three workloads, and its phases (variants built with -DSR_STOP_AFTER=k)
+(bash tools/gpu_sr.sh $TAG) > $O/${TAG}_sr_session.txt 2>&1
+if [ -f freesasa_amd/lib/libvar_srstop0.so ]; then (bash tools/gpu_sr_ablate.sh) > $O/${TAG}_sr_phase_ablation.txt 2>&1; fi
+(timeout 300 python tools/dev/driver_tuning.py) > $O/${TAG}_driver_tuning.txt 2>&1
 (timeout 120 tools/dev/ubench) > $O/${TAG}_ubench.txt 2>&1
 tail -2 $O/${TAG}_smoke.log; tail -4 $O/${TAG}_pytest_gpu.log; cut -c1-400 $O/${TAG}_bench.json; cat $O/${TAG}_kernel_stats.csv | cut -d, -f1-4 | head -12; cat $O/${TAG}_fetch_calibration.txt; cat $O/${TAG}_deep_parity.json
