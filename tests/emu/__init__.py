@@ -20,7 +20,14 @@ def _load():
         _lib = C.CDLL(_SO)
         _lib.emu_run_batch.argtypes = [C.c_int, _dp, _dp, _lp, C.c_int, C.c_double, C.c_int, _dp,
                                        _dp, _ip, _dp, C.POINTER(C.c_longlong)] + [C.c_int] * 9
+        _lib.emu_set_lr2_opts.argtypes = [C.c_int]
     return _lib
+
+
+def set_lr2_opts(shape_builds=False, compact_cells=False):
+    """Run the Lee-Richards tile kernel's shape-specialised builds where the device would, and / or look cells up in the
+    compact cell table (single-structure batches)."""
+    _load().emu_set_lr2_opts((1 if shape_builds else 0) | (2 if compact_cells else 0))
 
 
 def run_batch(lr, xyz, radii, offsets=None, probe=1.4, resolution=20, unit_pts=None,

@@ -149,22 +149,42 @@ static int emu_lr2 = 1, emu_lr2_ta = 0, emu_lr2_refill = 0;
 extern "C" void emu_lr2_counts(long long *out, int reset) { for (int k = 0; k < 16; ++k) { out[k] = sasa_emu::lr2_count[k]; if (reset) sasa_emu::lr2_count[k] = 0; } }
 extern "C" void emu_set_lr2(int on, int ta, int refill) { emu_lr2 = on; emu_lr2_ta = ta; emu_lr2_refill = refill; }
 
-struct Lr2Run { const Lr2Args *a; Lr2Mem *m; int first, stride; int rmax; int *wg_max; };
+/* emu_set_lr2_opts: bit 0 = run the shape-specialised builds where the device would (launch_lr2_main: template parameter
+   SHAPE 1..4, with the COVER / PAIRS / RMAX combination each is launched with); bit 1 = the COMPACT cell table
+   (k_sort_struct's form: a bit per cell, occupied cells before each 32-cell word, first atoms of the occupied cells)
+   instead of the dense one, for single-structure batches (whose cell numbering starts at a multiple of 32 either way) */
+static int emu_lr2_opts = 0, emu_last_shape = 0, emu_last_compact = 0;
+extern "C" void emu_set_lr2_opts(int opts) { emu_lr2_opts = opts; }
+extern "C" int emu_last_lr2_variant(void) { return emu_last_shape | (emu_last_compact << 4); } /* what the last main launch ran: SHAPE | compact table << 4 */
+struct Lr2Run { const Lr2Args *a; Lr2Mem *m; int first, stride; int rmax; int *wg_max; int shape; };
 static void lr2_lane_body(int lane, void *ctx)
 {
     Lr2Run *r = (Lr2Run *)ctx;
     const bool pairs = r->rmax == LR2_RMAX_MAIN && lr2_pairs_shape(r->a->TA, r->a->ns); /* (as launch_lr2_main) */
-    if (r->rmax == LR2_RMAX_MAIN && pairs) lr2_wave<LR2_RMAX_MAIN, true, true>(*r->a, *r->m, r->first, r->stride, lane, r->wg_max[lane]);
+    if (r->shape == 1) lr2_wave<LR2_RMAX_MAIN, false, true, 1>(*r->a, *r->m, r->first, r->stride, lane, r->wg_max[lane]);
+    else if (r->shape == 2) lr2_wave<2, false, false, 2>(*r->a, *r->m, r->first, r->stride, lane, r->wg_max[lane]);
+    else if (r->shape == 3) lr2_wave<LR2_RMAX_MAIN, true, false, 3>(*r->a, *r->m, r->first, r->stride, lane, r->wg_max[lane]);
+    else if (r->shape == 4) lr2_wave<LR2_RMAX_MAIN, true, true, 4>(*r->a, *r->m, r->first, r->stride, lane, r->wg_max[lane]);
+    else if (r->rmax == LR2_RMAX_MAIN && pairs) lr2_wave<LR2_RMAX_MAIN, true, true>(*r->a, *r->m, r->first, r->stride, lane, r->wg_max[lane]);
     else if (r->rmax == LR2_RMAX_MAIN) lr2_wave<LR2_RMAX_MAIN, true, false>(*r->a, *r->m, r->first, r->stride, lane, r->wg_max[lane]);
     else lr2_wave<LR2_RMAX_MID, true, false>(*r->a, *r->m, r->first, r->stride, lane, r->wg_max[lane]);
 }
-static void emu_lr2_kernel(const Lr2Cfg &cfg, Lr2Args a, int grid)
+static void emu_lr2_kernel(const Lr2Cfg &cfg, Lr2Args a, int grid, bool main_launch = false)
 {
     std::vector<char> smem(cfg.lds + 64);
+    int shape = 0;
+    if (main_launch && (emu_lr2_opts & 1)) { /* the build launch_lr2_main would pick */
+        const int sid = lr2_shape_id(a.TA, a.ns, a.mw, a.ds);
+        if (sid == 1 && cfg.rmax == LR2_RMAX_MAIN && lr2_pairs_shape(a.TA, a.ns)) shape = 1;
+        if (sid == 2 && cfg.rmax <= 2) shape = 2;
+        if ((sid == 3 || sid == 4) && cfg.rmax == LR2_RMAX_MAIN) shape = sid;
+    }
+    if (main_launch) { emu_last_shape = shape; emu_last_compact = a.cell_tbl != nullptr; }
     for (int blk = 0; blk < grid; ++blk) {
-        Lr2Mem m = lr2_carve<0>(a, smem.data());
+        Lr2Mem m = shape == 1 ? lr2_carve<1>(a, smem.data()) : shape == 2 ? lr2_carve<2>(a, smem.data()) : shape == 3 ? lr2_carve<3>(a, smem.data())
+                 : shape == 4 ? lr2_carve<4>(a, smem.data()) : lr2_carve<0>(a, smem.data());
         std::vector<int> wg_max(64, 0);
-        Lr2Run run = {&a, &m, blk, grid, cfg.rmax, wg_max.data()};
+        Lr2Run run = {&a, &m, blk, grid, cfg.rmax, wg_max.data(), shape};
         sasa_emu::run_wave(lr2_lane_body, &run);
         if (wg_max[0] > a.status[ST_MAX_NN]) a.status[ST_MAX_NN] = wg_max[0];
     }
@@ -282,7 +302,25 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
         la.sasa = sasa; la.status = status.data();
         /* main launch: a tile that does not fit is split in place; halves that still do not fit go to the list */
         la.ovf_items = ovf2x.data(); la.ovf_count = status.data() + ST_OVF2_TILES; la.split_count = status.data() + ST_SPLIT;
-        emu_lr2_kernel(c2, la, ((n_tiles2 + 7) / 8) * 8);
+        /* the compact cell table, built from the dense one the way k_sort_struct's stage F leaves it (single structure) */
+        std::vector<unsigned long long> ctbl;
+        std::vector<int> cfirst;
+        if ((emu_lr2_opts & 2) && n_structs == 1) {
+            const long long C = ncells[0];
+            ctbl.assign((size_t)((C + 1 + 31) >> 5) + 1, 0ull);
+            int occ = 0;
+            for (long long w = 0; w * 32 < C; ++w) {
+                unsigned bits = 0;
+                const int before = occ;
+                for (int b = 0; b < 32 && w * 32 + b < C; ++b)
+                    if (cell_start[w * 32 + b + 1] > cell_start[w * 32 + b]) { bits |= 1u << b; cfirst.push_back(cell_start[w * 32 + b]); ++occ; }
+                ctbl[(size_t)w] = (unsigned long long)bits | ((unsigned long long)(unsigned)before << 32);
+            }
+            cfirst.push_back(n); /* the entry behind the last cell: the structure's end */
+            if ((C & 31) == 0) ctbl[(size_t)(C >> 5)] = (unsigned long long)(unsigned)occ << 32; /* (cell C opens a word of its own) */
+            la.cell_tbl = ctbl.data(); la.cell_first = cfirst.data();
+        }
+        emu_lr2_kernel(c2, la, ((n_tiles2 + 7) / 8) * 8, true);
         Lr2Cfg cm = lr2_mid_cfg(c2);
         if (mid_cap_idx > 0) cm.mw = (mid_cap_idx + 31) / 32;
         if (mid_pool > 0) cm.pool = mid_pool;
@@ -307,7 +345,8 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
             TileArgs tf;
             memset(&tf, 0, sizeof tf);
             tf.sq = pa.sq; tf.s_idx = pa.s_idx;
-            tf.grid = pa.grid; tf.cell_start = pa.cell_start; tf.n_atoms = n; tf.n_tiles = n; tf.TA = 1; tf.n_res = resolution; tf.tab = fb.tab;
+            tf.grid = pa.grid; tf.cell_start = pa.cell_start; tf.cell_tbl = la.cell_tbl; tf.cell_first = la.cell_first;
+            tf.n_atoms = n; tf.n_tiles = n; tf.TA = 1; tf.n_res = resolution; tf.tab = fb.tab;
             tf.sasa = sasa; tf.lr = 1; tf.status = status.data();
             tf.cap_idx = fb.cap_idx; tf.pool = fb.pool; tf.ds = fb.ds;
             tf.work_tiles = ovf3.data(); tf.work_count = status.data() + ST_OVF3_ATOMS;

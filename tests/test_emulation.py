@@ -400,3 +400,52 @@ def test_tiles_with_too_many_candidate_items_are_handed_on(tmp_path):
     assert outs[0]["err"] < LR_TOL and outs[0]["slab"] == 0
     assert outs[300]["fb"] > outs[0]["fb"] and 0 < outs[300]["slab"] < 100 and outs[300]["err"] < LR_TOL  # halves, second launch, a few atoms to the slab
     assert outs[40]["slab"] > 500 and outs[40]["err"] < LR_TOL                                            # nearly every atom through the slab launch
+
+
+def test_shape_builds_and_the_compact_cell_table_give_the_generic_bits(oracle_lib):
+    """Round-4 advisor (low): the CPU emulation ran the Lee-Richards tile kernel only in its generic build (SHAPE 0) over
+    the dense cell table.  Here the builds with a compile-time tile shape - 6 x 20 (coils), 3 x 100 (100 slices), 3 x 20
+    and 4 x 20 with three mask words and the cover filter (protein density) - run where launch_lr2_main would pick them,
+    and the cells are looked up in the COMPACT table (a bit per cell, occupied cells before each 32-cell word, first atoms
+    of the occupied cells: cell_rank, lr2_pre_b / b2), built the way k_sort_struct's stage F leaves it, including a cell
+    count that is a multiple of 32 (the sentinel word).  Every variant must reproduce the generic build's areas bit for
+    bit (the device-side twins: test_shape_builds_give_the_generic_builds_bits,
+    test_cell_sort_in_one_kernel_equals_the_general_pipeline in tests/test_gpu_parity.py)."""
+    L = emu._load()
+    g = load_golden("1ubq")
+    coil = tools.coil(1500, 77)
+    cases = [("coil, 6 x 20 (shape 1)", 1, coil[0], coil[1], 20, 0, 0, 0),
+             ("coil, 3 x 100 (shape 2)", 2, coil[0][:600], coil[1][:600], 100, 0, 0, 128),
+             ("1ubq, 3 x 20, three mask words (shape 3)", 3, g["xyz"], g["radii"], 20, 3, 96, 0),
+             ("1ubq, 4 x 20, three mask words (shape 4)", 4, g["xyz"], g["radii"], 20, 4, 96, 0)]
+    try:
+        for name, shape, x, r, ns, ta, cap, pool in cases:
+            L.emu_set_lr2(1, ta, 0)
+            emu.set_lr2_opts(False, False)
+            base, _, _, st0 = run_batch(True, x, r, resolution=ns, cap_idx=cap, pool=pool)
+            assert L.emu_last_lr2_variant() == 0
+            assert close(base, oracle_lib.lee_richards(x.reshape(-1, 3), r, 1.4, ns)), name
+            for shapes, compact in ((True, False), (False, True), (True, True)):
+                emu.set_lr2_opts(shapes, compact)
+                got, _, _, st = run_batch(True, x, r, resolution=ns, cap_idx=cap, pool=pool)
+                assert L.emu_last_lr2_variant() == (shape if shapes else 0) | (16 if compact else 0), (name, shapes, compact)
+                assert np.array_equal(got, base), (name, shapes, compact)
+                assert st["TA"] == st0["TA"]
+        # a grid whose cell count is a multiple of 32: the entry behind the last cell opens a table word of its own
+        emu.set_lr2_opts(False, False)
+        L.emu_set_lr2(1, 0, 0)
+        found = False
+        for n in range(60, 400, 7):
+            x, r = tools.coil(n, 500 + n)
+            a, _, _, st = run_batch(True, x, r)
+            if st["cells"] % 32 == 0:
+                emu.set_lr2_opts(True, True)
+                b, *_ = run_batch(True, x, r)
+                emu.set_lr2_opts(False, False)
+                assert np.array_equal(a, b)
+                found = True
+                break
+        assert found, "no coil with a cell count that is a multiple of 32 among the sizes tried"
+    finally:
+        emu.set_lr2_opts(False, False)
+        L.emu_set_lr2(1, 0, 0)
