@@ -459,7 +459,12 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
     /* batches of small structures: bounds, grid and cell sort of a structure in one workgroup (k_sort_struct) */
     long long biggest = 0;
     for (int s_ = 0; s_ < n_structs; ++s_) biggest = offsets[s_ + 1] - offsets[s_] > biggest ? offsets[s_ + 1] - offsets[s_] : biggest;
-    const bool fused = c->sort_fused && biggest <= SORT_ATOMS && n_structs >= 8 && !getenv("FREESASA_AMD_NO_FUSED_SORT");
+    /* (... and a call with a few SMALL structures - freesasa_calc_coord on one protein - where one launch instead of nine
+       is worth more than the general pipeline's parallelism: round 5, MI355X, median of freesasa_calc_coord on 1UBQ / 1A0Q /
+       a 4000-atom coil, L&R 142 -> 134 / 174 -> 165 / 185 -> 177 us, S&R 131 -> 116 / 124 -> 115 / 140 -> 130 us; from
+       8000 atoms on the general pipeline wins; FREESASA_AMD_SMALL_FUSED=n moves the limit) */
+    static const long long small_fused = getenv("FREESASA_AMD_SMALL_FUSED") ? atoll(getenv("FREESASA_AMD_SMALL_FUSED")) : 4096;
+    const bool fused = c->sort_fused && biggest <= SORT_ATOMS && (n_structs >= 8 || biggest <= small_fused) && !getenv("FREESASA_AMD_NO_FUSED_SORT");
     /* ... which writes the cell table in its compact form for the Lee-Richards tile kernel (PipeArgs::cell_tbl) */
     const bool compact = fused && lr && lr2_supported(resolution) && !getenv("FREESASA_AMD_LR1") && !getenv("FREESASA_AMD_DENSE_CELLS");
     if (compact) {
