@@ -242,13 +242,14 @@ static int finish_batch(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_st
 }
 
 /* what a completed Lee-Richards batch teaches the context about the next one of its kind (trajectory frames, sweeps) */
-static void lr2_learn(freesasa_gpu_ctx *c, const int *status_h, int TA, int ns, int mw, int ds)
+static void lr2_learn(freesasa_gpu_ctx *c, const int *status_h, int TA, int ns, int mw, int ds, int n_tiles)
 {
     const int learnt = lr2_need_from_hist(status_h + ST_HIST, TA);
     if (learnt > 0) c->hint_nn = (double)(learnt - 8) / TA;
     c->hint_pool2 = lr2_pool_from_hist(status_h + ST_HIST, TA, ns, mw, ds, &c->hint_split2); /* (see there: pool vs occupancy) */
     c->hint_ta2 = TA; c->hint_mw2 = mw;
     c->hint_nn_max = status_h[ST_MAX_NN] + 4; /* the longest list of this batch, a little room */
+    c->hint_far = 4LL * status_h[ST_FAR] >= (long long)n_tiles && n_tiles > 0; /* (see lr2_slice_height_at: such tiles go through the second launch unless the main launch walks itself) */
 }
 
 /* defer: enqueue only (freesasa_gpu_lr_batch_dev_async); the caller completes the batch later (complete_pending) */
@@ -315,6 +316,8 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
     }
     la.nn_out = c->dbg_nn; la.nb_out = c->dbg_nb; la.nb_cap = c->dbg_cap;
     la.hooks = (c->dbg_nn ? 1 : 0) | (c->dbg_nb ? 2 : 0);
+    la.walk = c->hint_far && c->hint_res[0] == resolution ? 1 : 0;
+    if (const char *e = getenv("FREESASA_AMD_WALK")) la.walk = atoi(e); /* tuning / test aid: force (1) or forbid (0) the walking build of the main launch */
     hipError_t le = kl_lr2_main(cfg.rmax, grid_main, (size_t)cfg.lds, st, la);
     if (le != hipSuccess) return ctx_fail(c, "tile kernel launch failed: %s", hipGetErrorString(le));
     if (c->timing) HIP_TRY(c, hipEventRecord(ctx_ev(c)[2], st));
@@ -331,7 +334,9 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
         lm.ovf_atoms = (int *)c->ovf_atoms.p;
         lm.ovf_count = (int *)c->status.p + ST_OVF3_ATOMS;
         lm.split_count = nullptr;
-        const int grid_mid = n_tiles < SASA_MID_BLOCKS ? n_tiles : SASA_MID_BLOCKS;
+        /* (usually a handful of halves; but a batch far from the origin sends EVERY tile here - lr2_slice_height_at - so the
+           grid is sized to fill the chip then: workgroups that find the list short leave at once) */
+        const int grid_mid = n_tiles < LR2_MID_BLOCKS ? n_tiles : LR2_MID_BLOCKS;
         le = kl_lr2_mid(grid_mid, (size_t)cm.lds, st, lm);
         if (le != hipSuccess) return ctx_fail(c, "second tile launch failed: %s", hipGetErrorString(le));
     }
@@ -362,7 +367,7 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
     if (defer) return 0;
     const int rc = complete_batch(c, n, n_structs, cfg.TA, 64, cfg.lds);
     if (rc) return rc;
-    lr2_learn(c, status_h, cfg.TA, cfg.ns, cfg.mw, cfg.ds);
+    lr2_learn(c, status_h, cfg.TA, cfg.ns, cfg.mw, cfg.ds, n_tiles);
     return 0;
 }
 
@@ -684,7 +689,7 @@ static int complete_pending(freesasa_gpu_ctx *c, int slot)
     int rc = complete_batch(c, P.n, P.n_structs, P.TA, 64, P.lds);
     /* (what it teaches is keyed to the resolution and probe the hints stand for NOW: a later batch of another kind may
        have reset them since this one was enqueued) */
-    if (rc == 0 && P.resolution == c->hint_res[0] && P.probe == c->hint_probe) lr2_learn(c, ctx_status_h(c), P.TA, P.resolution, P.mw, P.ds);
+    if (rc == 0 && P.resolution == c->hint_res[0] && P.probe == c->hint_probe) lr2_learn(c, ctx_status_h(c), P.TA, P.resolution, P.mw, P.ds, (P.n + P.TA - 1) / P.TA);
     c->slot = keep;
     P.active = false;
     if (rc == RC_RETRY) {

@@ -522,7 +522,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     PIPE_GATE(a.status);
     Lr2Mem m = lr2_carve<SHAPE>(a, smem);
     int wg_max_nn = 0;
-    lr2_wave<RMAX, COVER, PAIRS, SHAPE, (TIER & 4) != 0>(a, m, blockIdx.x, gridDim.x, lane, wg_max_nn);
+    /* (TIER 2, the second launch, and TIER 1, the main launch of batches that lie far from the origin: the builds that walk to
+       the slice planes of atoms beyond LR2_WALK_Z as the reference walks to them) */
+    lr2_wave<RMAX, COVER, PAIRS, SHAPE, (TIER & 4) != 0, TIER == 2 || TIER == 1>(a, m, blockIdx.x, gridDim.x, lane, wg_max_nn);
     if (lane == 0 && wg_max_nn > a.status[ST_MAX_NN]) atomicMax(&a.status[ST_MAX_NN], wg_max_nn);
 }
 __global__ __launch_bounds__(64) void k_lr2_arc_kat(const double *arcs, const int *first, int n_sets, double *out)
@@ -545,6 +547,14 @@ hipError_t kl_lr2_main(int rmax, int grid, size_t lds, hipStream_t st, const Lr2
             else hipLaunchKernelGGL((k_lr2_tile<R, 0, 4, false, true>), dim3(grid), dim3(64), lds, st, la); \
         } else if (la.cover > 0) hipLaunchKernelGGL((k_lr2_tile<R, 0, 4, true>), dim3(grid), dim3(64), lds, st, la); \
         else hipLaunchKernelGGL((k_lr2_tile<R, 0, 4, false>), dim3(grid), dim3(64), lds, st, la); } while (0)
+    /* a batch most of whose tiles lie beyond LR2_WALK_Z (the context learnt it from the batch before: ST_FAR): the walking
+       builds, generic shape, four rounds of pair records (they hold any pool of the main launch) */
+    if (!la.hooks && la.walk) {
+        const bool pr = lr2_pairs_shape(la.TA, la.ns);
+        if (la.cover > 0) { if (pr) hipLaunchKernelGGL((k_lr2_tile<4, 1, 4, true, true>), dim3(grid), dim3(64), lds, st, la); else hipLaunchKernelGGL((k_lr2_tile<4, 1, 4, true, false>), dim3(grid), dim3(64), lds, st, la); }
+        else { if (pr) hipLaunchKernelGGL((k_lr2_tile<4, 1, 4, false, true>), dim3(grid), dim3(64), lds, st, la); else hipLaunchKernelGGL((k_lr2_tile<4, 1, 4, false, false>), dim3(grid), dim3(64), lds, st, la); }
+        return hipGetLastError();
+    }
     /* shapes 2-4 (lr2_shape_id), each with the pair-record rounds its workload asks for; any other combination: the generic builds below */
     if (!la.hooks && !getenv("FREESASA_AMD_NO_SHAPE")) {
         const int sid = lr2_shape_id(la.TA, la.ns, la.mw, la.ds);

@@ -275,6 +275,7 @@ struct Lr2Args {
        workgroups, 1e7 atoms).  seg_grid 0: one part (work lists, small launches). */
     int seg_grid, seg_tiles;
     int hooks; /* bit 0: nn_out is set, bit 1: nb_out is set (what the tile body tests; the pointers themselves are cold) */
+    int walk;  /* host side only (kl_lr2_main): launch the main launch's walking build - most tiles of the last batch had an atom beyond LR2_WALK_Z */
 };
 #include <stddef.h>
 /* Arguments only rare paths need (overflow lists, statistics, the test hooks): read from the kernel-argument
@@ -590,16 +591,19 @@ SASA_D double lr2_slice_height(int s, double delta, double Ri) { return fma((dou
  * then z += delta per slice (src/sasa_lr.c:304-307), and every addition rounds to half an ulp of |z|, so at |z| = 1.6e4 A
  * its plane sits ~1e-11 A off the exact one - nothing for an ordinary arc, but where a neighbor's circle is TANGENT to
  * the atom's the arc's half-width is the square root of that (round 4, tests/test_adversarial.py: 2.9e-5 A^2 at 1.6e4 A
- * against 1.7e-7 at the origin, and growing with |z|).  Beyond LR2_WALK_Z the kernel therefore walks exactly as the
- * reference does and takes t = z - zi (exact: the two are within a factor of two), which is the reference's plane bit for
- * bit at any distance from the origin; inside, the closed form stays (a drift of at most ~6e-13 A there).  The switch
- * is per ATOM (its own z), so an area does not depend on which atoms share its tile. */
+ * against 1.7e-7 at the origin, and growing with |z|).  Beyond LR2_WALK_Z an atom's planes are therefore walked exactly as
+ * the reference walks them, t = z - zi (exact: the two are within a factor of two): the reference's plane bit for bit at
+ * any distance from the origin.  The check is NOT in the ordinary tile (measured, round 5: a per-item test of |zi| cost
+ * the 100-slice kernel 6 % of its instructions and 9 % of its time, the 20-slice one 0.9 %): the builds of the main launch
+ * (WALK = false) hand a tile with such an atom on, like a tile whose lists do not fit, and the second launch's build
+ * (WALK = true) walks - per ATOM, by its own z, so no area depends on which atoms share a tile. */
 #ifndef LR2_WALK_Z
-#define LR2_WALK_Z 256.0
+#define LR2_WALK_Z 1024.0 /* (closed form inside: the reference's drift is <= 2.3e-12 A there; tangent constructions at |z| = 1000 A: tests/test_adversarial.py) */
 #endif
+template <bool WALK>
 SASA_D double lr2_slice_height_at(int s, double delta, double Ri, double zi)
 {
-    if (!(fabs(zi) > LR2_WALK_Z)) return lr2_slice_height(s, delta, Ri);
+    if (!WALK || !(fabs(zi) > LR2_WALK_Z)) return lr2_slice_height(s, delta, Ri);
     double z = (zi - Ri) - 0.5 * delta; /* ref: src/sasa_lr.c:305 */
     for (int k = 0; k <= s; ++k) z += delta; /* ref: :307 */
     return z - zi;
@@ -746,12 +750,13 @@ SASA_D void lr2_pre_c(const Lr2Args &a, Lr2Pre &pre, int na, int lane)
 /* The whole tile, executed by the 64 lanes of one wave.  RMAX = rounds of 64 pair records a lane
  * keeps in registers in P3 (pool <= 64 * RMAX). */
 /* returns 0: the atoms' areas are stored; 1: the tile does not fit this launch's capacities (nothing stored); 2: two
-   neighbors of an atom with equal sort keys (nothing stored; see lr2_tie12): once more with tie_by_place */
+   neighbors of an atom with equal sort keys (nothing stored; see lr2_tie12): once more with tie_by_place; 3 (builds with
+   WALK = false): an atom of the tile lies beyond LR2_WALK_Z (nothing stored): a tile for the walking build */
 /* pre: what P0 loads, possibly fetched ahead by the previous call; (p0n, nan): the tile this wave does next (its
    own again when there is none), fetched ahead by this call */
-template <int RMAX, bool COVER, bool PAIRS, int SHAPE, bool HOOKS>
+template <int RMAX, bool COVER, bool PAIRS, int SHAPE, bool HOOKS, bool WALK>
 SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool sample, bool tie_by_place, int lane_of_wave, int &wg_max_nn,
-                    Lr2Pre &pre, int p0n, int nan)
+                    Lr2Pre &pre, int p0n, int nan, int &far_tiles)
 {
     /* Whatever depends on the lane and the launch alone (row and atom of the lane, its LDS addresses, its item) the
        compiler computes once per wave, outside the tile loop, and holds in registers through every phase of every
@@ -773,6 +778,13 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         lr2_pre_a<SHAPE>(a, pre, p0, na, lane);
         lr2_pre_b<SHAPE>(a, pre, na, lane);
         lr2_pre_b2<SHAPE>(a, pre);
+    }
+    if ((!WALK || !a.work_items) && LR2_BALLOT(lane < na && fabs(pre.q.z) > LR2_WALK_Z) != 0) { /* (uniform) an atom beyond the closed-form range of the slice planes (lr2_slice_height_at) */
+        ++far_tiles; /* (counted by every build of the main launch: the share of such tiles decides which build the next batch gets) */
+        if (!WALK) { /* not a tile for this build */
+            lr2_pre_none(pre);
+            return 3;
+        }
     }
     if (lane < TA) {
         Quad q = pre.q;
@@ -1139,8 +1151,8 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             const int sa_ = 2 * j, it0 = LR2_MUL24(la, ns) + sa_;
             const bool second = sa_ + 1 < ns; /* (ns odd: the atom's last pair is one slice) */
             const double Ri = m.atom[la].w, del = m.adel[la];
-            const double zi_ = m.atom[la].z;
-            const double t0 = lr2_slice_height_at(sa_, del, Ri, zi_), t1 = lr2_slice_height_at(second ? sa_ + 1 : sa_, del, Ri, zi_);
+            const double zi_ = WALK ? m.atom[la].z : 0.0;
+            const double t0 = lr2_slice_height_at<WALK>(sa_, del, Ri, zi_), t1 = lr2_slice_height_at<WALK>(second ? sa_ + 1 : sa_, del, Ri, zi_);
             const double A0 = Ri * Ri - t0 * t0, A1 = Ri * Ri - t1 * t1; /* Ri'^2, ref: src/sasa_lr.c:309 */
             const bool circ0 = A0 > 0, circ1 = second && A1 > 0; /* ref: :310-312 */
             double h0, h1;
@@ -1190,7 +1202,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     for (int it = lane; it < items; it += LR2_LANES) {
         int la = (int)(((float)it + 0.5f) * inv_ns), s = it - LR2_MUL24(la, ns); /* it / ns without the integer-division sequence */
         if (s < 0) { --la; s += ns; } else if (s >= ns) { ++la; s -= ns; }
-        const double Ri = m.atom[la].w, t = lr2_slice_height_at(s, m.adel[la], Ri, m.atom[la].z);
+        const double Ri = m.atom[la].w, t = lr2_slice_height_at<WALK>(s, m.adel[la], Ri, WALK ? m.atom[la].z : 0.0);
         const double A = Ri * Ri - t * t; /* Ri'^2, ref: src/sasa_lr.c:309 */
         double h2 = 0;
         int cnt = 0, o = 0;
@@ -1292,7 +1304,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             const int e = (int)m.queue[qi];
             my = e & 1023; la = e >> 10;
             const int o = m.aoff[la], nn = m.aoff[la + 1] - o;
-            const double t = lr2_slice_height_at(my - LR2_MUL24(la, ns), m.adel[la], m.atom[la].w, m.atom[la].z); /* as P4: bit for bit */
+            const double t = lr2_slice_height_at<WALK>(my - LR2_MUL24(la, ns), m.adel[la], m.atom[la].w, WALK ? m.atom[la].z : 0.0); /* as P4: bit for bit */
             const double hh = m.it_tc[my];
             const int lo = LR2_MUL24(nn, j) >> shb, hi = LR2_MUL24(nn, j + 1) >> shb; /* list positions of this lane */
             for (int wi = 0; wi < mwt; ++wi) {
@@ -1355,7 +1367,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         if (my != LR2_NONE) {                                                                      \
             la = e_ >> 10;                                                                         \
             { const int o_ = m.aoff[la]; Rab = m.ab + o_; Rbt = m.beta + o_; } hh = m.it_tc[my];     \
-            t = lr2_slice_height_at(my - LR2_MUL24(la, ns), m.adel[la], m.atom[la].w, m.atom[la].z); /* as P4: bit for bit */ \
+            t = lr2_slice_height_at<WALK>(my - LR2_MUL24(la, ns), m.adel[la], m.atom[la].w, WALK ? m.atom[la].z : 0.0); /* as P4: bit for bit */ \
             mk = m.it_mask + LR2_MUL24(my, mw); w = *mk; wleft = mwt - 1;                          \
             LR2_NEXT_WORD();                                                                       \
         }                                                                                          \
@@ -1434,7 +1446,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
 /* The work items of one wave (items first, first + stride, ... of the launch).  A tile that does not fit is redone
  * at once as two halves (1.5 % of the 6-atom tiles of random coils at a pool of 224 records); what still does not fit
  * goes to the next launch's list. */
-template <int RMAX, bool COVER, bool PAIRS, int SHAPE = 0, bool HOOKS = false>
+template <int RMAX, bool COVER, bool PAIRS, int SHAPE = 0, bool HOOKS = false, bool WALK = false>
 SASA_D void lr2_wave(const Lr2Args &a, const Lr2Mem &m, int first, int stride, int lane, int &wg_max_nn)
 {
     /* all tiles (main launch, rounded up to whole XCD groups) or the items of a work list */
@@ -1445,7 +1457,7 @@ SASA_D void lr2_wave(const Lr2Args &a, const Lr2Mem &m, int first, int stride, i
         else { tile0 = a.seg_tiles; n_seg = a.n_tiles - a.seg_tiles; first -= a.seg_grid; stride -= a.seg_grid; }
         n_work = ((n_seg + 7) >> 3) << 3;
     }
-    int splits = 0;
+    int splits = 0, far_tiles = 0;
     Lr2Pre pre;
     lr2_pre_none(pre);
     for (int w = first; w < n_work; w += stride) {
@@ -1471,9 +1483,14 @@ SASA_D void lr2_wave(const Lr2Args &a, const Lr2Mem &m, int first, int stride, i
         for (;;) {
             /* (what comes next: the second half of a split tile, else the wave's next tile) */
             const bool nxt = rest_n > 0 || nan > 0;
-            int fail = lr2_tile<RMAX, COVER, PAIRS, SHAPE, HOOKS>(a, m, p0, na, sample, by_place, lane, wg_max_nn, pre,
-                                             rest_n > 0 ? rest0 : (nxt ? p0n : p0), rest_n > 0 ? rest_n : (nxt ? nan : na));
+            int fail = lr2_tile<RMAX, COVER, PAIRS, SHAPE, HOOKS, WALK>(a, m, p0, na, sample && whole, by_place, lane, wg_max_nn, pre,
+                                             rest_n > 0 ? rest0 : (nxt ? p0n : p0), rest_n > 0 ? rest_n : (nxt ? nan : na), far_tiles);
             sample = false;
+            if (fail == 3) { /* an atom beyond the closed-form range of the slice planes: the whole tile to the next launch, whose build walks to them (no halves: they would say the same) */
+                ++splits;
+                if (lane == 0) lr2_overflow(a, p0, na, ERR_NEIGHBOR_CAP);
+                break;
+            }
             if (fail == 2) { /* equal sort keys: once more, ties by place of discovery */
                 if (!by_place) { by_place = true; continue; }
                 fail = 1;
@@ -1499,6 +1516,7 @@ SASA_D void lr2_wave(const Lr2Args &a, const Lr2Mem &m, int first, int stride, i
         int *const split_count = LR2_COLD(a, split_count);
         if (split_count) SASA_ATOMIC_ADD_GLB(&split_count[first & 63], splits);
     }
+    if (lane == 0 && far_tiles > 0 && !a.work_items) SASA_ATOMIC_ADD_GLB(&LR2_COLD(a, status)[ST_FAR], far_tiles);
 }
 
 /* launch configuration (host side; shared by gpu_engine.hip and the test emulation) */
@@ -1510,6 +1528,7 @@ struct Lr2Cfg {
 #define LR2_NS_MAX 256      /* finer resolutions use the first-generation kernel */
 #define LR2_RMAX_MAIN 4
 #define LR2_RMAX_MID 6
+#define LR2_MID_BLOCKS 32768 /* workgroups of the second launch (they share its work list) */
 
 static inline bool lr2_supported(int ns) { return ns >= 1 && ns <= LR2_NS_MAX; }
 /* tile shapes whose (atom, slice) items are more than the wave's lanes but at most two per lane (6 atoms x 20 slices:

@@ -130,7 +130,8 @@ enum {
                           redoes the batch with a table of ncells[n_structs] cells (gpu_engine.hip) */
     ST_HIST = 8,       /* [64] tiles by neighbor records needed, bins of hist_bin_width(TA) */
     ST_SPLIT = 72,     /* [64] L&R (lr2_kernels.h): tiles redone as two halves, counted in 64 buckets */
-    ST_WORDS = 136
+    ST_FAR = 136,      /* L&R (lr2_kernels.h): tiles of the main launch with an atom beyond LR2_WALK_Z (slice planes walked as the reference walks them) */
+    ST_WORDS = 137
 };
 enum {
     ERR_NONE = 0,

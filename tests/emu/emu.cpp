@@ -167,7 +167,7 @@ static void lr2_lane_body(int lane, void *ctx)
     else if (r->shape == 4) lr2_wave<LR2_RMAX_MAIN, true, true, 4>(*r->a, *r->m, r->first, r->stride, lane, r->wg_max[lane]);
     else if (r->rmax == LR2_RMAX_MAIN && pairs) lr2_wave<LR2_RMAX_MAIN, true, true>(*r->a, *r->m, r->first, r->stride, lane, r->wg_max[lane]);
     else if (r->rmax == LR2_RMAX_MAIN) lr2_wave<LR2_RMAX_MAIN, true, false>(*r->a, *r->m, r->first, r->stride, lane, r->wg_max[lane]);
-    else lr2_wave<LR2_RMAX_MID, true, false>(*r->a, *r->m, r->first, r->stride, lane, r->wg_max[lane]);
+    else lr2_wave<LR2_RMAX_MID, true, false, 0, false, true>(*r->a, *r->m, r->first, r->stride, lane, r->wg_max[lane]); /* (the second launch: WALK) */
 }
 static void emu_lr2_kernel(const Lr2Cfg &cfg, Lr2Args a, int grid, bool main_launch = false)
 {
