@@ -471,7 +471,8 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
     static const long long small_fused = getenv("FREESASA_AMD_SMALL_FUSED") ? atoll(getenv("FREESASA_AMD_SMALL_FUSED")) : 4096;
     const bool fused = c->sort_fused && biggest <= SORT_ATOMS && (n_structs >= 8 || biggest <= small_fused) && !getenv("FREESASA_AMD_NO_FUSED_SORT");
     /* ... which writes the cell table in its compact form for the Lee-Richards tile kernel (PipeArgs::cell_tbl) */
-    const bool compact = fused && lr && lr2_supported(resolution) && !getenv("FREESASA_AMD_LR1") && !getenv("FREESASA_AMD_DENSE_CELLS");
+    /* (... and, since round 5, for the Shrake-Rupley kernel too: tile_phase_load looks cells up through cell_first_atom) */
+    const bool compact = fused && (!lr || (lr2_supported(resolution) && !getenv("FREESASA_AMD_LR1"))) && !getenv("FREESASA_AMD_DENSE_CELLS");
     if (compact) {
         if (ensure(c, c->cell_tbl, sizeof(unsigned long long) * ((size_t)(cells_cap >> 5) + 2)) || ensure(c, c->cell_first, sizeof(int) * (nb + (size_t)n_structs + 2)))
             return -1;
@@ -543,6 +544,7 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
         cfg.pool = (cfg.pool * 3 / 4) & ~1;
         cfg.lds = tile_fixed_bytes(cfg.TA, cfg.items) + tile_list_bytes(cfg.TA, cfg.cap_idx, cfg.pool, cfg.lr, cfg.ds, cfg.B);
     }
+    if (getenv("FREESASA_AMD_SHOW_SHAPE")) fprintf(stderr, "%s tile shape: B %d TA %d cap_idx %d pool %d ds %d lds %zu (hint %d)\n", lr ? "lr1" : "sr", cfg.B, cfg.TA, cfg.cap_idx, cfg.pool, cfg.ds, cfg.lds, c->hint_res[hi] == resolution ? c->hint_pool[hi] : 0); /* (dev aid) */
     const int n_tiles = (n + cfg.TA - 1) / cfg.TA;
     if (ensure(c, c->ovf_tiles, sizeof(int) * ((size_t)n_tiles + 1)) || ensure(c, c->ovf_tiles2, sizeof(int) * ((size_t)n_tiles + 1))) return -1;
 
@@ -550,7 +552,7 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
     memset(&ta, 0, sizeof ta);
     ta.sq = pa.sq;
     ta.s_idx = pa.s_idx;
-    ta.grid = pa.grid; ta.cell_start = pa.cell_start;
+    ta.grid = pa.grid; ta.cell_start = pa.cell_start; ta.cell_tbl = pa.cell_tbl; ta.cell_first = pa.cell_first;
     ta.n_atoms = n; ta.n_tiles = n_tiles; ta.TA = cfg.TA; ta.n_res = resolution; ta.tab = cfg.tab;
     ta.sasa = d_sasa; ta.counts = d_counts;
     ta.cap_idx = cfg.cap_idx; ta.pool = cfg.pool; ta.lr = cfg.lr; ta.ds = cfg.ds;
@@ -646,6 +648,7 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
     c->hint_res[hi] = resolution;
     c->hint_ta[hi] = cfg.TA;
     c->hint_pool[hi] = lr ? pool_from_hist(status_h + ST_HIST, cfg.TA) : sr_cap_from_hist(status_h + ST_HIST);
+    if (!lr && getenv("FREESASA_AMD_SHOW_HIST")) { fprintf(stderr, "sr hist:"); for (int k = 0; k < 64; ++k) fprintf(stderr, " %d", status_h[ST_HIST + k]); fprintf(stderr, " -> cap %d, ovf %d\n", c->hint_pool[hi], status_h[ST_OVF_TILES]); } /* (dev aid) */
     if (lr) c->hint_bucket = mean_from_hist(status_h + ST_HIST, cfg.TA) > 30.0 * cfg.TA;
     return 0;
 }

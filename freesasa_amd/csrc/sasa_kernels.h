@@ -2009,14 +2009,14 @@ static inline TileCfg choose_cfg(int resolution, bool lr, int pool_hint = 0)
 }
 
 /* S&R: records per atom's segment for the NEXT batch on this context, from the sampled histogram of the tiles' longest
- * neighbor lists (sr_hist_bin): what all but ~1.5 % of the tiles need, a multiple of 8 in [SR_CAP_MIN, SR_CAP_MAX] -
+ * neighbor lists (sr_hist_bin): what all but ~0.5 % of the tiles need, a multiple of 8 in [SR_CAP_MIN, SR_CAP_MAX] -
  * the few tiles above go to the second launch, and every 8 records less are 2 KB of LDS per 8-atom tile. */
 static inline int sr_cap_from_hist(const int *hist)
 {
     long long total = 0;
     for (int k = 0; k < 64; ++k) total += hist[k];
     if (total <= 0) return 0;
-    long long allowed = total / 64, acc = 0;
+    long long allowed = total / 200, acc = 0; /* (measured on the coil batch, round 5: 1 % of the tiles in the second launch - 48 records - costs more than 8 records more per atom: step 11.8 ms at 48, 11.7 at 56 and 64) */
     int k = 63;
     for (; k > 0; --k) {
         acc += hist[k];
