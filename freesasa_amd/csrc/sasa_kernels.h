@@ -1704,6 +1704,32 @@ SASA_D bool sr_covered(const TileMem &m, int o, int k0, int k1, double tx, doubl
         if (sr_inside(m.pq[o + k], tx, ty, tz)) return true;
     return false;
 }
+/* the same for the SURVIVORS of the first look (sr_phase_points2).  Most of them are exposed points, whose loop never leaves
+ * early, so reading two or four records together before one exit looked right - and measured wrong on the MI355X (round 5,
+ * coil batch / PDB entries x 251, kernel ms: one record per look 10.30 / 3.89, two 10.50 / 3.98, four 12.99 / 4.90: under
+ * the 72-register cap of seven waves the wider loop body spills).  One per look it stays; the variants remain for the record. */
+#ifndef SR_GROUP2
+#define SR_GROUP2 1
+#endif
+SASA_D bool sr_covered_rest(const TileMem &m, int o, int k0, int k1, double tx, double ty, double tz)
+{
+    int k = k0;
+#if SR_GROUP2 == 4
+    for (; k + 4 <= k1; k += 4) {
+        const Quad q0 = m.pq[o + k], q1 = m.pq[o + k + 1], q2 = m.pq[o + k + 2], q3 = m.pq[o + k + 3];
+        const bool c0 = sr_inside(q0, tx, ty, tz), c1 = sr_inside(q1, tx, ty, tz), c2 = sr_inside(q2, tx, ty, tz), c3 = sr_inside(q3, tx, ty, tz);
+        if (c0 | c1 | c2 | c3) return true;
+    }
+#elif SR_GROUP2 == 2
+    for (; k + 2 <= k1; k += 2) {
+        const Quad q0 = m.pq[o + k], q1 = m.pq[o + k + 1];
+        if (sr_inside(q0, tx, ty, tz) | sr_inside(q1, tx, ty, tz)) return true;
+    }
+#endif
+    for (; k < k1; ++k)
+        if (sr_inside(m.pq[o + k], tx, ty, tz)) return true;
+    return false;
+}
 SASA_D void sr_point(const TileArgs &a, const TileMem &m, int la, int pt, double &tx, double &ty, double &tz)
 {
     const double ri = m.aR[la];
@@ -1758,7 +1784,7 @@ SASA_D void sr_phase_points2(const TileArgs &a, TileMem &m, int tid, int B)
         if (have) {
             double tx, ty, tz;
             sr_point(a, m, la, pt, tx, ty, tz);
-            exposed = !sr_covered(m, la * C, SR_FIRST, m.acnt[la], tx, ty, tz);
+            exposed = !sr_covered_rest(m, la * C, SR_FIRST, m.acnt[la], tx, ty, tz);
         }
         sasa_wave_count(m.aexp, la, exposed);
     }
