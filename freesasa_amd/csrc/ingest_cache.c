@@ -16,6 +16,8 @@
  */
 #include "freesasa_ingest.h"
 
+int ingest_batch_alloc__(freesasa_ingest_batch *b, int32_t ns, int64_t na, int64_t nr); /* ingest.c: a batch's arrays in one pooled block; freesasa_ingest_free gives it back */
+
 #include <errno.h>
 #include <fcntl.h>
 #include <pthread.h>
@@ -337,12 +339,15 @@ int freesasa_ingest_load_mt(const char *path, int n_threads, freesasa_ingest_bat
     int rc = cache_open(path, &c);
     if (rc) return rc;
     void *arr[CACHE_SECTIONS] = {0};
+    freesasa_ingest_batch b;
+    /* the arrays of the batch, in one pooled block like the parser's (ingest.c); section k of the file is array k */
+    if (ingest_batch_alloc__(&b, c->h.n_structs, c->h.n_atoms, c->h.n_residues)) { freesasa_ingest_cache_close(c); return FREESASA_INGEST_ENOMEM; }
+    arr[0] = b.offsets; arr[1] = b.res_offsets; arr[2] = b.status; arr[3] = b.xyz; arr[4] = b.radii; arr[5] = b.atom_class; arr[6] = b.atom_backbone;
+    arr[7] = b.atom_name; arr[8] = b.atom_symbol; arr[9] = b.res_first; arr[10] = b.res_ref; arr[11] = b.res_name; arr[12] = b.res_number; arr[13] = b.res_chain;
     rc = FREESASA_INGEST_EFORMAT;
     do {
         int ok = 1;
         for (int k = 0; k < CACHE_SECTIONS; ++k) {
-            arr[k] = malloc(c->len[k] > 0 ? (size_t)c->len[k] : 1);
-            if (!arr[k]) { rc = FREESASA_INGEST_ENOMEM; ok = 0; break; }
             unsigned char padding[16] = {0};
             const uint64_t np = pad16(c->len[k]) - c->len[k];
             if (np && !pread_all(c->fd, padding, np, c->start[k] + c->len[k])) { ok = 0; break; }
@@ -365,19 +370,12 @@ int freesasa_ingest_load_mt(const char *path, int n_threads, freesasa_ingest_bat
         for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
         pthread_mutex_destroy(&j.mu);
         if (j.failed) break;
-        freesasa_ingest_batch b;
-        memset(&b, 0, sizeof b);
-        b.n_structs = c->h.n_structs; b.n_atoms = c->h.n_atoms; b.n_residues = c->h.n_residues;
-        b.offsets = (int64_t *)arr[0]; b.res_offsets = (int64_t *)arr[1]; b.status = (int32_t *)arr[2];
-        b.xyz = (double *)arr[3]; b.radii = (double *)arr[4]; b.atom_class = (uint8_t *)arr[5]; b.atom_backbone = (uint8_t *)arr[6];
-        b.atom_name = (char *)arr[7]; b.atom_symbol = (char *)arr[8]; b.res_first = (int64_t *)arr[9]; b.res_ref = (int16_t *)arr[10];
-        b.res_name = (char *)arr[11]; b.res_number = (char *)arr[12]; b.res_chain = (char *)arr[13];
         if (!batch_indices_ok(&b)) break;
         *out = b;
-        memset(arr, 0, sizeof arr);
+        memset(&b, 0, sizeof b);
         rc = FREESASA_INGEST_OK;
     } while (0);
-    for (int k = 0; k < CACHE_SECTIONS; ++k) free(arr[k]);
+    freesasa_ingest_free(&b); /* (nothing, when the batch went to the caller) */
     freesasa_ingest_cache_close(c);
     return rc;
 }

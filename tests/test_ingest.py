@@ -565,3 +565,41 @@ def test_sweep_from_the_binary_cache_equals_the_sweep_from_the_files(tmp_path):
     got, _, gtot = fa.calc_batch(c.xyz, c.radii, c.offsets, fa.LEE_RICHARDS, 1.4, 20)
     assert np.array_equal(want, got) and np.array_equal(wtot, gtot)
     assert np.array_equal(b.residue_sums(want), c.residue_sums(got))
+
+
+def test_batches_in_reused_blocks_equal_fresh_ones(tmp_path):
+    """Round 5: a batch's arrays lie in one block, and the blocks of freed batches serve the next batches (a sweep builds
+    a ~40 MB batch every few milliseconds: fresh from malloc that was an mmap, ten thousand page faults and a munmap
+    each time).  Batches of changing sizes, from the parser and from the binary cache, built and freed in a row and by
+    several threads at once, must equal the first ones built - whatever block they landed in."""
+    import threading
+    names = [fixture(n) for n in ("1a0q.pdb", "1d3z.pdb", "1ubq.pdb", "2jo4.pdb", "3bkr.pdb", "1ubq.cif", "5dx9.cif")]
+    big = [n for n in names for _ in range(12)]           # ~2e5 atoms: above the size from which blocks are kept
+    sets = [big, names[:2], big[:50], names, big[:17], names[:1]]
+    keys = ("xyz", "radii", "offsets", "atom_name_raw", "res_number_raw", "status", "res_first", "atom_class")
+    fresh = []
+    for s_ in sets:                                       # (the first pass takes every block from malloc)
+        b = ingest.load_pdb_files(s_, n_threads=3)
+        fresh.append({k: np.array(getattr(b, k)).copy() for k in keys})
+
+    def same(b, ref):
+        return all(np.array_equal(np.array(getattr(b, k)), ref[k]) for k in keys)
+    for rep in range(3):                                  # now out of kept blocks, in another order
+        for k in (0, 2, 1, 4, 3, 5):
+            assert same(ingest.load_pdb_files(sets[k], n_threads=1 + (rep + k) % 4), fresh[k]), (rep, k)
+    cache = str(tmp_path / "big.bin")
+    ingest.load_pdb_files(big, n_threads=2).save(cache)
+    bad = []
+
+    def hammer(seed):
+        for k in np.random.default_rng(seed).permutation(len(sets)):
+            if not same(ingest.load_pdb_files(sets[k], n_threads=2), fresh[k]):
+                bad.append((seed, int(k)))
+            if not same(ingest.load_cache(cache, n_threads=2), fresh[0]):
+                bad.append((seed, "cache"))
+    th = [threading.Thread(target=hammer, args=(s_,)) for s_ in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not bad, bad
