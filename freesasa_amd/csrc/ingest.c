@@ -324,6 +324,30 @@ static inline int field_token(const char *f, int w, const char **tok)
     return n;
 }
 
+/* The coordinate section as nearly every file writes it: three fields of the form "%8.3f" - blanks, an optional '-',
+ * digits, '.', three digits - each beginning with a blank or its '-' (so that sscanf's whitespace-delimited numbers,
+ * ref: src/pdb.c:176-197, ARE the three columns: digits that run into the next field would be one number for it).
+ * 1: v[] holds what scan_double would have returned (an integer below 2^53 divided by 1000: the correctly rounded
+ * value of the decimal); 0: not of this form, nothing decided. */
+static inline int coords_8_3(const char *sec, double v[3])
+{
+    for (int f = 0; f < 3; ++f) {
+        const char *c = sec + 8 * f;
+        const unsigned d3 = (unsigned)(c[3] - '0'), d5 = (unsigned)(c[5] - '0'), d6 = (unsigned)(c[6] - '0'), d7 = (unsigned)(c[7] - '0');
+        if (c[4] != '.' || d3 > 9 || d5 > 9 || d6 > 9 || d7 > 9 || !(c[0] == ' ' || c[0] == '-')) return 0;
+        unsigned m = d3, mul = 10;
+        int i = 2;
+        for (; i >= 0 && (unsigned)(c[i] - '0') <= 9; --i) { m += (unsigned)(c[i] - '0') * mul; mul *= 10; }
+        int neg = 0;
+        if (i >= 0 && c[i] == '-') { neg = 1; --i; }
+        for (; i >= 0; --i)
+            if (c[i] != ' ') return 0;
+        const double x = (double)(m * 1000u + d5 * 100u + d6 * 10u + d7) / 1000.0;
+        v[f] = neg ? -x : x;
+    }
+    return 1;
+}
+
 /* Parses into p's buffers, which are reused from call to call (only the counters are reset).
  * Round 5: an atom line is read where it lies (no copy into a line buffer: an embedded NUL ends the line, as it does for
  * the reference's strlen on its fgets buffer, by a memchr), its name fields are trimmed once and serve the radius
@@ -381,14 +405,16 @@ static void parse_pdb(const char *text, size_t len, int options, parsed *p)
 
             /* coordinates (ref: src/pdb.c:176-197) */
             if (n < 54) { p->status = FREESASA_INGEST_EFORMAT; return; }
-            char sec[25];
-            memcpy(sec, line + 30, 24);
-            sec[24] = '\0';
             double v[3];
-            const char *sp = sec;
-            if (!scan_double(&sp, &v[0]) || !scan_double(&sp, &v[1]) || !scan_double(&sp, &v[2])) {
-                p->status = FREESASA_INGEST_EFORMAT;
-                return;
+            if (!coords_8_3(line + 30, v)) {
+                char sec[25];
+                memcpy(sec, line + 30, 24);
+                sec[24] = '\0';
+                const char *sp = sec;
+                if (!scan_double(&sp, &v[0]) || !scan_double(&sp, &v[1]) || !scan_double(&sp, &v[2])) {
+                    p->status = FREESASA_INGEST_EFORMAT;
+                    return;
+                }
             }
 
             /* radius (ref: src/structure.c:519-550, 606-612); the names trimmed once */

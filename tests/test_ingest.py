@@ -603,3 +603,46 @@ def test_batches_in_reused_blocks_equal_fresh_ones(tmp_path):
     for t in th:
         t.join()
     assert not bad, bad
+
+
+def test_coordinate_columns_that_run_together_are_read_like_sscanf_reads_them():
+    """The reference reads the coordinates with sscanf("%lf%lf%lf") on columns 31-54 (src/pdb.c:176-197): numbers are
+    whitespace-delimited, so a field that neither begins with a blank nor with its sign continues the number before
+    it.  The loader's fixed-column conversion (coords_8_3, round 5) may only take a section whose three fields are
+    delimited; everything else must come out as sscanf's tokens do - emulated here with strtod's grammar."""
+    import re
+    num = re.compile(r"[ \t\n\v\f\r]*([+-]?(?:\d+\.?\d*|\.\d+)(?:[eE][+-]?\d+)?)")
+    rng = np.random.default_rng(23)
+
+    def field():
+        kind = rng.integers(0, 7)
+        if kind == 0: return f"{rng.uniform(-999, 9999):8.3f}"[:8]        # the standard form, sometimes without a blank in front
+        if kind == 1: return f"{rng.uniform(1000, 9999):8.3f}"              # fills its field: runs into its neighbor
+        if kind == 2: return f"{rng.uniform(-999, -100):8.3f}"              # begins with its sign
+        if kind == 3: return f"{rng.uniform(-9, 99):8.2f}"                  # '.' in another column
+        if kind == 4: return f"{rng.integers(0, 999):4d}.000"
+        if kind == 5: return f"{rng.uniform(0, 99):8.3f}".replace(" ", "0", 1) if rng.integers(0, 2) else "  -0.000"
+        return f"{rng.uniform(0, 9):8.4f}"
+    lines, want, ok = [], [], []
+    for k in range(3000):
+        sec = field() + field() + field()
+        assert len(sec) == 24
+        vals, pos = [], 0
+        for _ in range(3):
+            m = num.match(sec, pos)
+            if not m:
+                break
+            vals.append(float(m.group(1)))
+            pos = m.end()
+        lines.append(f"ATOM  {k % 99999:5d}  CA  ALA A{k % 9999:4d}    {sec}  1.00  0.00           C  ")
+        ok.append(len(vals) == 3)
+        want.append(vals if len(vals) == 3 else [0, 0, 0])
+    assert sum(ok) > 2500 and any(not q for q in ok) or all(ok)
+    b = ingest.load_pdb_texts([ln + "\n" for ln in lines])
+    for k in range(len(lines)):
+        if ok[k]:
+            assert b.status[k] == ingest.OK, (k, lines[k])
+            got = b.xyz[b.offsets[k]]
+            assert np.array_equal(got, np.array(want[k])) and np.array_equal(np.signbit(got), np.signbit(np.array(want[k]))), (lines[k], got, want[k])
+        else:
+            assert b.status[k] != ingest.OK, (k, lines[k])
