@@ -619,6 +619,116 @@ slow:
     f->base = NULL;
     return cif_next_inl(lx);
 }
+/* Rows by TEMPLATE (round 5).  The files of the wwPDB pad the values of an _atom_site loop so that every row has its
+ * tokens in the same columns (left-aligned: the lengths differ from row to row, the starts do not).  When two
+ * consecutive rows have been tokenized one token at a time, the second one becomes a template: the stride S to the
+ * next row's first token and where each of its tokens starts.  A following row whose S bytes show token starts -
+ * a non-blank behind a blank - in exactly those places has its tokens there, each as long as its run of non-blanks:
+ * provided none of them is anything but a plain value, i.e. none starts with a quote, '#', ';' or '_' and none is a
+ * keyword (loop_, data_..., save_...: an underscore as fifth character, as cif_row_next tests it - here refused for
+ * a token of any length).  A quoted value with a blank inside shows the starts of two plain ones, so the first
+ * characters of ALL tokens are looked at, not only of the twelve wanted.  Three bit masks of the row (SSE2 compares)
+ * replace 21 trips through the token scanner; any difference - the row behind the loop's last, a value that outgrew
+ * its column, a comment - hands the row to the scanner, and the next two rows it tokenizes make the next template. */
+#define CIF_TPL_MAX 256 /* bytes of a row's stride */
+typedef struct { uint64_t w[CIF_TPL_MAX / 64]; } cif_bits;
+static inline void cif_row_masks(const unsigned char *p, int nblk, cif_bits *ws, cif_bits *special, cif_bits *under)
+{
+    const __m128i sp = _mm_set1_epi8(' '), nl = _mm_set1_epi8('\n'), tb = _mm_set1_epi8('\t'), cr = _mm_set1_epi8('\r');
+    const __m128i q1 = _mm_set1_epi8('\''), q2 = _mm_set1_epi8('"'), hs = _mm_set1_epi8('#'), sc = _mm_set1_epi8(';'), us = _mm_set1_epi8('_');
+    for (int b = 0; b < nblk; ++b) {
+        uint64_t mw = 0, mq = 0, mu = 0;
+        for (int k = 0; k < 4; ++k) {
+            const __m128i v = _mm_loadu_si128((const __m128i *)(p + 64 * b + 16 * k));
+            const __m128i w = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(v, sp), _mm_cmpeq_epi8(v, nl)), _mm_or_si128(_mm_cmpeq_epi8(v, tb), _mm_cmpeq_epi8(v, cr)));
+            const __m128i u = _mm_cmpeq_epi8(v, us);
+            const __m128i q = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(v, q1), _mm_cmpeq_epi8(v, q2)), _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(v, hs), _mm_cmpeq_epi8(v, sc)), u));
+            mw |= (uint64_t)(unsigned)_mm_movemask_epi8(w) << (16 * k);
+            mq |= (uint64_t)(unsigned)_mm_movemask_epi8(q) << (16 * k);
+            mu |= (uint64_t)(unsigned)_mm_movemask_epi8(u) << (16 * k);
+        }
+        ws->w[b] = mw; special->w[b] = mq; under->w[b] = mu;
+    }
+}
+#if defined(__x86_64__) && defined(__GNUC__)
+/* the same with 32-byte registers where the CPU has them (decided once, at the first row) */
+#include <immintrin.h>
+__attribute__((target("avx2"))) static void cif_row_masks_avx2(const unsigned char *p, int nblk, cif_bits *ws, cif_bits *special, cif_bits *under)
+{
+    const __m256i sp = _mm256_set1_epi8(' '), nl = _mm256_set1_epi8('\n'), tb = _mm256_set1_epi8('\t'), cr = _mm256_set1_epi8('\r');
+    const __m256i q1 = _mm256_set1_epi8('\''), q2 = _mm256_set1_epi8('"'), hs = _mm256_set1_epi8('#'), sc = _mm256_set1_epi8(';'), us = _mm256_set1_epi8('_');
+    for (int b = 0; b < nblk; ++b) {
+        uint64_t mw = 0, mq = 0, mu = 0;
+        for (int k = 0; k < 2; ++k) {
+            const __m256i v = _mm256_loadu_si256((const __m256i *)(p + 64 * b + 32 * k));
+            const __m256i w = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(v, sp), _mm256_cmpeq_epi8(v, nl)), _mm256_or_si256(_mm256_cmpeq_epi8(v, tb), _mm256_cmpeq_epi8(v, cr)));
+            const __m256i u = _mm256_cmpeq_epi8(v, us);
+            const __m256i q = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(v, q1), _mm256_cmpeq_epi8(v, q2)), _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(v, hs), _mm256_cmpeq_epi8(v, sc)), u));
+            mw |= (uint64_t)(unsigned)_mm256_movemask_epi8(w) << (32 * k);
+            mq |= (uint64_t)(unsigned)_mm256_movemask_epi8(q) << (32 * k);
+            mu |= (uint64_t)(unsigned)_mm256_movemask_epi8(u) << (32 * k);
+        }
+        ws->w[b] = mw; special->w[b] = mq; under->w[b] = mu;
+    }
+}
+static int cif_have_avx2 = -1;
+static inline void cif_row_masks_best(const unsigned char *p, int nblk, cif_bits *ws, cif_bits *special, cif_bits *under)
+{
+    if (cif_have_avx2 < 0) cif_have_avx2 = __builtin_cpu_supports("avx2") ? 1 : 0; /* (a benign race: every thread stores the same value) */
+    if (cif_have_avx2) cif_row_masks_avx2(p, nblk, ws, special, under);
+    else cif_row_masks(p, nblk, ws, special, under);
+}
+#else
+#define cif_row_masks_best cif_row_masks
+#endif
+typedef struct {
+    int S, nblk;          /* stride in bytes, 64-byte blocks of it */
+    uint64_t last;        /* the bits of the last block that belong to the stride */
+    cif_bits starts, t4;  /* first characters of the tokens; their fifth characters */
+} cif_tpl;
+/* do the S bytes at `row` hold plain tokens starting exactly where the template's do?  ws: the row's blanks (bits behind
+   the stride set), for the lengths */
+static inline int cif_tpl_match(const cif_tpl *T, const unsigned char *row, cif_bits *ws)
+{
+    cif_bits sp, un;
+    cif_row_masks_best(row, T->nblk, ws, &sp, &un);
+    uint64_t bad = 0, carry = 1; /* (the byte before the row is a blank: the last of the row before, or where the scanner came from) */
+    for (int b = 0; b < T->nblk; ++b) {
+        const uint64_t m = b == T->nblk - 1 ? T->last : ~(uint64_t)0;
+        const uint64_t w = ws->w[b] | ~m; /* (behind the stride: as if blank) */
+        ws->w[b] = w;
+        bad |= ((~w & ((w << 1) | carry)) ^ T->starts.w[b]) | (sp.w[b] & T->starts.w[b]) | (un.w[b] & T->t4.w[b]);
+        carry = w >> 63;
+    }
+    const int e = T->S - 1;
+    return bad == 0 && ((ws->w[e >> 6] >> (e & 63)) & 1); /* ... and a blank before the next row */
+}
+/* length of the token that starts at bit o: up to the next blank (there is one inside the stride) */
+static inline int cif_tpl_len(const cif_bits *ws, int o)
+{
+    int b = o >> 6;
+    uint64_t w = ws->w[b] >> (o & 63);
+    if (w) return __builtin_ctzll(w);
+    int n = 64 - (o & 63);
+    for (++b; !ws->w[b]; ++b) n += 64;
+    return n + __builtin_ctzll(ws->w[b]);
+}
+/* the row at `row` (its tokens at off[k], ncol of them), S bytes to the next: a template, or 0 */
+static int cif_tpl_make(cif_tpl *T, const unsigned char *row, int S, const unsigned short *off, int ncol)
+{
+    if (S < 2 || S > CIF_TPL_MAX) return 0;
+    T->S = S; T->nblk = (S + 63) / 64;
+    T->last = (S & 63) ? (((uint64_t)1 << (S & 63)) - 1) : ~(uint64_t)0;
+    memset(&T->starts, 0, sizeof T->starts); memset(&T->t4, 0, sizeof T->t4);
+    for (int k = 0; k < ncol; ++k) {
+        if ((int)off[k] >= S) return 0;
+        T->starts.w[off[k] >> 6] |= (uint64_t)1 << (off[k] & 63);
+        if (off[k] + 4 < S) T->t4.w[(off[k] + 4) >> 6] |= (uint64_t)1 << ((off[k] + 4) & 63);
+    }
+    cif_bits ws;
+    return cif_tpl_match(T, row, &ws); /* the row itself: its tokens are exactly its runs of non-blanks, all plain values */
+}
+#define CIF_TEMPLATES 1
 #else
 typedef struct { int unused; } cif_fast;
 static inline cif_tok cif_row_next(cif_lex *lx, cif_fast *f) { (void)f; return cif_next_inl(lx); }
@@ -704,14 +814,56 @@ static int cif_walk(const char *text, size_t len, cif_row_fn visit, void *ctx)
         cif_tok row[12];
         int c = 0;
         cif_fast fast = {0};
+#ifdef CIF_TEMPLATES
+        unsigned short toff[64], tlen[64]; /* the row being tokenized: where its tokens lie behind its first, their lengths */
+        const char *row0 = NULL, *prev0 = NULL; /* its first token; the first token of the row before it (NULL: not a row to learn from) */
+        int fits = 0;
+        const int learn = complete && ncol <= 64;
+#endif
         while (t.type == T_VALUE) {
             if (complete && slot_of[c] >= 0) row[slot_of[c]] = t;
+#ifdef CIF_TEMPLATES
+            if (learn) {
+                if (c == 0) { row0 = t.p; fits = 1; }
+                if (t.p - row0 < CIF_TPL_MAX && t.n < CIF_TPL_MAX) { toff[c] = (unsigned short)(t.p - row0); tlen[c] = (unsigned short)t.n; } else fits = 0;
+            }
+#endif
             if (++c == ncol) {
                 c = 0;
                 if (complete) {
                     const int rc = visit(row, ctx);
                     if (rc) return rc;
                 }
+#ifdef CIF_TEMPLATES
+                if (learn) {
+                    cif_tpl T;
+                    const char *const last_end = row0 + toff[ncol - 1] + tlen[ncol - 1];
+                    /* (the 64-byte blocks read from a row reach at most 63 bytes behind its stride) */
+                    if (fits && prev0 && lx.cur == last_end && row0 - prev0 <= CIF_TPL_MAX && lx.end - row0 >= 2 * (row0 - prev0) + 128 &&
+                        cif_tpl_make(&T, (const unsigned char *)row0, (int)(row0 - prev0), toff, ncol)) {
+                        const char *r = row0 + T.S, *done = NULL; /* candidate row; the last row taken by template */
+                        cif_bits ws;
+                        int last_len = 0;
+                        while (lx.end - r >= T.S + 128 && cif_tpl_match(&T, (const unsigned char *)r, &ws)) {
+                            for (int k = 0; k < ncol; ++k)
+                                if (slot_of[k] >= 0) { cif_tok v = {r + toff[k], (size_t)cif_tpl_len(&ws, toff[k]), T_VALUE}; row[slot_of[k]] = v; }
+                            last_len = cif_tpl_len(&ws, toff[ncol - 1]);
+                            const int rc = visit(row, ctx);
+                            if (rc) return rc;
+                            done = r;
+                            r += T.S;
+                        }
+                        if (done) { /* the scanner goes on behind the last token of the last row taken */
+                            lx.cur = done + toff[ncol - 1] + last_len;
+                            lx.bol = 0;
+                            fast.base = NULL;
+                        }
+                        prev0 = NULL; /* (two more rows by the scanner before the next template) */
+                    } else {
+                        prev0 = fits ? row0 : NULL;
+                    }
+                }
+#endif
             }
             t = cif_row_next(&lx, &fast);
         }

@@ -646,3 +646,94 @@ def test_coordinate_columns_that_run_together_are_read_like_sscanf_reads_them():
             assert np.array_equal(got, np.array(want[k])) and np.array_equal(np.signbit(got), np.signbit(np.array(want[k]))), (lines[k], got, want[k])
         else:
             assert b.status[k] != ingest.OK, (k, lines[k])
+
+
+def test_mmcif_rows_by_template_equal_the_byte_at_a_time_tokenizer():
+    """Round 5: rows of an _atom_site loop whose tokens start in the same columns as the row before are taken by template
+    (cif_tpl_match: three bit masks of the row instead of 21 trips through the token scanner).  Aligned loops as the wwPDB
+    writes them - and everything that must throw a row back to the scanner: a value that outgrows its column, a quoted
+    value with a blank inside that shows the starts of two plain ones, quotes / '#' / ';' / '_' at a token start, keywords
+    in value position (loop_, data_x, save_), comment lines and blank lines between rows, tabs, CRLF, rows split over two
+    lines, a second loop right behind, the text ending inside the last row's stride - against the scalar twin of the same
+    source (-DFREESASA_INGEST_NO_SIMD: no templates, no bit masks)."""
+    import ctypes as C
+    from freesasa_amd.ingest import _CBatch, Batch
+    path = os.path.join(ROOT, "tests", "emu", "libingest_scalar.so")
+    if not os.path.exists(path):
+        pytest.skip("scalar twin not built (make emu)")
+    S = C.CDLL(path)
+    S.freesasa_ingest_pdb_texts.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.c_int, C.POINTER(_CBatch)]
+    S.freesasa_ingest_free.argtypes = [C.POINTER(_CBatch)]
+    S.freesasa_ingest_free.restype = None
+
+    def scalar(texts, options):
+        raw = [t.encode() for t in texts]
+        arr = (C.c_char_p * len(raw))(*raw)
+        lens = (C.c_size_t * len(raw))(*[len(t) for t in raw])
+        cb = _CBatch()
+        assert S.freesasa_ingest_pdb_texts(arr, lens, len(raw), options, 1, C.byref(cb)) == 0
+        try:
+            return Batch(cb)
+        finally:
+            S.freesasa_ingest_free(C.byref(cb))
+
+    rng = np.random.default_rng(29)
+    cols = ["group_PDB", "id", "type_symbol", "label_atom_id", "label_alt_id", "label_comp_id", "label_asym_id", "label_entity_id",
+            "label_seq_id", "pdbx_PDB_ins_code", "Cartn_x", "Cartn_y", "Cartn_z", "occupancy", "B_iso_or_equiv", "pdbx_formal_charge",
+            "auth_seq_id", "auth_comp_id", "auth_asym_id", "auth_atom_id", "pdbx_PDB_model_num"]
+    widths = {"group_PDB": 6, "id": 5, "type_symbol": 2, "label_atom_id": 4, "label_alt_id": 1, "label_comp_id": 3, "label_asym_id": 2,
+              "label_entity_id": 1, "label_seq_id": 4, "pdbx_PDB_ins_code": 1, "Cartn_x": 7, "Cartn_y": 7, "Cartn_z": 7, "occupancy": 4,
+              "B_iso_or_equiv": 6, "pdbx_formal_charge": 1, "auth_seq_id": 4, "auth_comp_id": 3, "auth_asym_id": 2, "auth_atom_id": 4,
+              "pdbx_PDB_model_num": 1}
+    res = ["ALA", "LEU", "SER", "ASP", "GLY", "DA", "HOH", "MSE"]
+    atoms = ["N", "CA", "C", "O", "CB", "CG", "OXT", "SE", "H", "OD1"]
+    odd = ["\"C1'\"", "'O P'", "\"N A\"", "_x", "#c", ";t", "loop_", "data_x", "save_", "'C'", "stop_", "AB_DE"]
+
+    def make_text():
+        order = list(range(len(cols))) if rng.random() < 0.6 else list(rng.permutation(len(cols)))
+        out = ["data_fuzz\n", "#\n", "_cell.length_a 10.0\n", "loop_\n"]
+        out += ["_atom_site.%s\n" % cols[k] for k in order]
+        n = int(rng.integers(3, 90))
+        eol = "\r\n" if rng.random() < 0.15 else "\n"
+        sep = "\t" if rng.random() < 0.1 else " "
+        for i in range(n):
+            rn, an = res[rng.integers(len(res))], atoms[rng.integers(len(atoms))]
+            sym = an[0] if an != "SE" else "SE"
+            seq = str(int(rng.integers(1, 400)))
+            vals = {"group_PDB": "ATOM" if rng.random() < 0.9 else "HETATM", "id": str(i + 1), "type_symbol": sym, "label_atom_id": an,
+                    "label_alt_id": [".", ".", ".", "A", "B"][rng.integers(5)], "label_comp_id": rn, "label_asym_id": "A",
+                    "label_entity_id": "1", "label_seq_id": seq, "pdbx_PDB_ins_code": ["?", "?", "?", "A"][rng.integers(4)],
+                    "Cartn_x": "%.3f" % rng.uniform(-99, 99), "Cartn_y": "%.3f" % rng.uniform(-99, 99), "Cartn_z": "%.3f" % rng.uniform(-99, 99),
+                    "occupancy": "1.00", "B_iso_or_equiv": "%.2f" % rng.uniform(0, 99), "pdbx_formal_charge": "?", "auth_seq_id": seq,
+                    "auth_comp_id": rn, "auth_asym_id": ["A", "B", "AA"][rng.integers(3)], "auth_atom_id": an,
+                    "pdbx_PDB_model_num": "1" if rng.random() < 0.95 else "2"}
+            u = rng.random()
+            if u < 0.04:
+                vals["Cartn_y"] = "%.5f" % rng.uniform(-9999, 9999)                    # outgrows its column
+            elif u < 0.10:
+                vals[["auth_atom_id", "label_atom_id", "auth_asym_id", "label_comp_id", "B_iso_or_equiv"][rng.integers(5)]] = odd[rng.integers(len(odd))]
+            row = sep.join(vals[cols[k]].ljust(widths[cols[k]]) for k in order) + sep
+            u = rng.random()
+            if u < 0.03:
+                cut_at = row.find(sep, len(row) // 2)
+                row = row[:cut_at] + eol + row[cut_at + 1:]                             # a row over two lines
+            out.append(row + eol)
+            u = rng.random()
+            if u < 0.03: out.append("# a comment between rows" + eol)
+            elif u < 0.05: out.append(eol)
+        tail = ["", "#\n", "loop_\n_x.a\n_x.b\n1 2\n3 4\n", "_after.tag value\n", "\n;text\nfield\n;\n", "data_next\n", "loop_\n_atom_site.group_PDB\nATOM\n"][rng.integers(7)]
+        out.append(tail)
+        text = "".join(out)
+        if rng.random() < 0.3:
+            text = text[:len(text) - int(rng.integers(0, 150))]                          # ends somewhere in the last rows
+        else:
+            text += " " * int(rng.integers(0, 200))
+        return text
+
+    texts = [make_text() for _ in range(500)]
+    for options in (0, ingest.INCLUDE_HETATM | ingest.INCLUDE_HYDROGEN, ingest.JOIN_MODELS):
+        a = ingest.load_pdb_texts(texts, options=options, n_threads=3)
+        b = scalar(texts, options)
+        assert a.n_atoms == b.n_atoms and a.n_atoms > 5000
+        for f in BATCH_ARRAYS:
+            assert np.array_equal(getattr(a, f), getattr(b, f)), (options, f)
