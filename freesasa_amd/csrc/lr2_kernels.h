@@ -556,9 +556,13 @@ SASA_D double lr2_arc_kat(const double *arcs, const int *first, int k, Arc2 *stk
 #ifndef LR2_ARC_STEPS
 #define LR2_ARC_STEPS 2 /* arc steps between two looks at how many lanes wait for a refill */
 #endif
-#define LR2_NB_UNROLL 3 /* candidates a lane has in flight per round of P1 (coils: three rounds per tile = one trip; measured 1 / 2 / 3: 3.59 / 3.63 / 3.58 ms per 3e6 atoms) */
+#define LR2_NB_UNROLL 1 /* candidates a lane has in flight per round of P1.  Round 2 measured 1 / 2 / 3 on coils: 3.59 / 3.63 / 3.58 ms per 3e6 atoms, and 3 it was; the items of a tile are a multiple of 64 x 3 only by chance, and since the kernel's time became its instruction count the padded rounds cost what they compute: round 5, MI355X, kernel ms on the coil batch / the PDB entries, 1: 8.84 / 6.36, 2: 8.86 / 6.38, 3: 8.90 / 6.43, 4: 9.22 / 6.55 */
 #endif
 #define LR2_P1_G 3 /* atoms of a cell group one work item of P1 tests its candidate against */
+/* ... in the build for tiles of four atoms at protein density (SHAPE 4) all four: there the four atoms of a tile mostly
+   share their cell (1a0q: 563 of 1062 groups), and with three to an item the fourth atom costs every candidate a second
+   item - its fetch, its decoding and two idle test slots (round 5: the phase -19 % by count) */
+#define LR2_P1_G_OF(shape) ((shape) == 4 ? 4 : LR2_P1_G)
 #ifndef LR2_P1_ITEMS_MAX
 #define LR2_P1_ITEMS_MAX 0x8000 /* P1's work items per tile, exclusive: the decode of an item's place in its row is exact below 2^15 (tests build with less to walk the hand-on path) */
 #endif
@@ -807,9 +811,9 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         const int la = lr2_div9(lane);
         if (la < na && (pre.rfl & 3) == 2) { /* inside the grid, and its atom leads a group */
             const unsigned above = lm >> (la + 1);
-            const int gs = (above ? la + 1 + __builtin_ctz(above) : na) - la, hc = lr2_div3(gs + LR2_P1_G - 1);
+            const int gs = (above ? la + 1 + __builtin_ctz(above) : na) - la, hc = LR2_P1_G_OF(SHAPE) == 4 ? (gs + 3) >> 2 : lr2_div3(gs + LR2_P1_G - 1);
             lo = pre.s0;
-            my_cnt = LR2_MUL24(pre.s1 - pre.s0, hc); /* P1's work items of the row: (candidate, up to LR2_P1_G atoms of the group) */
+            my_cnt = LR2_MUL24(pre.s1 - pre.s0, hc); /* P1's work items of the row: (candidate, up to P1_G atoms of the group) */
             info = la | (gs << 4) | (hc << 8) | ((hc == 1 ? 0x20000 : (hc == 2 ? 0x10000 : 0xaaab)) << 10); /* (bits 10..27: 2^17 / hc, rounded up) */
         }
     }
@@ -849,7 +853,8 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                 if (t + step <= nrows - 1 && m.cpre[t + step] <= f) t += step;
             c_lo = m.cpre[t]; c_hi = m.cpre[t + 1]; rl = m.rowlo[t]; ri_ = m.rinfo[t];
         }
-        LR2_COUNT(3, (per + LR2_NB_UNROLL - 1) / LR2_NB_UNROLL * LR2_NB_UNROLL * LR2_P1_G);
+        constexpr int P1_G = LR2_P1_G_OF(SHAPE);
+        LR2_COUNT(3, (per + LR2_NB_UNROLL - 1) / LR2_NB_UNROLL * LR2_NB_UNROLL * P1_G);
         for (int base = 0; base < per; base += LR2_NB_UNROLL) { /* (wave-uniform trip count) */
             int q[LR2_NB_UNROLL], la0[LR2_NB_UNROLL], two[LR2_NB_UNROLL];
             double x[LR2_NB_UNROLL], y[LR2_NB_UNROLL], z[LR2_NB_UNROLL], rq[LR2_NB_UNROLL];
@@ -866,16 +871,16 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
                 const unsigned i = (unsigned)(fj - c_lo) & 0x7fffu;
                 const unsigned c = LR2_UMUL24(i, (unsigned)ri_ >> 10) >> 17; /* i / hc (hc <= 3: gs <= 7; i < 2^15) */
                 const int h = (int)i - LR2_MUL24(c, hc);
-                const int left = gs - LR2_P1_G * h; /* atoms of this item */
+                const int left = gs - P1_G * h; /* atoms of this item */
                 q[j] = live ? rl + (int)c : -1;
-                la0[j] = live ? lead + LR2_P1_G * h : 0;
-                two[j] = live ? (left < LR2_P1_G ? left : LR2_P1_G) : 0;
+                la0[j] = live ? lead + P1_G * h : 0;
+                two[j] = live ? (left < P1_G ? left : P1_G) : 0;
             }
             for (int j = 0; j < LR2_NB_UNROLL; ++j) {
                 const unsigned u = (unsigned)(q[j] < 0 ? 0 : q[j]);
                 { const Quad v = a.sq[u]; x[j] = v.x; y[j] = v.y; z[j] = v.z; rq[j] = v.w; }
             }
-            for (int g = 0; g < LR2_P1_G; ++g) {
+            for (int g = 0; g < P1_G; ++g) {
                 bool hit[LR2_NB_UNROLL];
                 double dx[LR2_NB_UNROLL], dy[LR2_NB_UNROLL], dz[LR2_NB_UNROLL];
                 Quad ai[LR2_NB_UNROLL];
