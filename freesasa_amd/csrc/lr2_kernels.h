@@ -562,7 +562,12 @@ SASA_D double lr2_arc_kat(const double *arcs, const int *first, int k, Arc2 *stk
 /* ... in the build for tiles of four atoms at protein density (SHAPE 4) all four: there the four atoms of a tile mostly
    share their cell (1a0q: 563 of 1062 groups), and with three to an item the fourth atom costs every candidate a second
    item - its fetch, its decoding and two idle test slots (round 5: the phase -19 % by count) */
-#define LR2_P1_G_OF(shape) ((shape) == 4 ? 4 : LR2_P1_G)
+#ifndef LR2_P1_G_COILS
+#define LR2_P1_G_COILS LR2_P1_G /* (the coil shape, 6 x 20: groups of every size from one to six; round 5, MI355X, kernel ms with 2 / 3 / 4 atoms to an item: 8.79 / 8.80 / 9.01 - as the count of instructions says) */
+#endif
+#define LR2_P1_G_OF(shape) ((shape) == 4 ? 4 : ((shape) == 1 ? LR2_P1_G_COILS : LR2_P1_G))
+/* items per candidate of a group of gs atoms, g atoms to an item (gs <= 7) */
+#define LR2_P1_HC(gs, g) ((g) == 4 ? ((gs) + 3) >> 2 : ((g) == 2 ? ((gs) + 1) >> 1 : lr2_div3((gs) + 2)))
 #ifndef LR2_P1_ITEMS_MAX
 #define LR2_P1_ITEMS_MAX 0x8000 /* P1's work items per tile, exclusive: the decode of an item's place in its row is exact below 2^15 (tests build with less to walk the hand-on path) */
 #endif
@@ -811,7 +816,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         const int la = lr2_div9(lane);
         if (la < na && (pre.rfl & 3) == 2) { /* inside the grid, and its atom leads a group */
             const unsigned above = lm >> (la + 1);
-            const int gs = (above ? la + 1 + __builtin_ctz(above) : na) - la, hc = LR2_P1_G_OF(SHAPE) == 4 ? (gs + 3) >> 2 : lr2_div3(gs + LR2_P1_G - 1);
+            const int gs = (above ? la + 1 + __builtin_ctz(above) : na) - la, hc = LR2_P1_HC(gs, LR2_P1_G_OF(SHAPE));
             lo = pre.s0;
             my_cnt = LR2_MUL24(pre.s1 - pre.s0, hc); /* P1's work items of the row: (candidate, up to P1_G atoms of the group) */
             info = la | (gs << 4) | (hc << 8) | ((hc == 1 ? 0x20000 : (hc == 2 ? 0x10000 : 0xaaab)) << 10); /* (bits 10..27: 2^17 / hc, rounded up) */
