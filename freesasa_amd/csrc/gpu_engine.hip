@@ -249,6 +249,16 @@ static void lr2_learn(freesasa_gpu_ctx *c, const int *status_h, int TA, int ns, 
     c->hint_pool2 = lr2_pool_from_hist(status_h + ST_HIST, TA, ns, mw, ds, &c->hint_split2); /* (see there: pool vs occupancy) */
     c->hint_ta2 = TA; c->hint_mw2 = mw;
     c->hint_nn_max = status_h[ST_MAX_NN] + 4; /* the longest list of this batch, a little room */
+    if (getenv("FREESASA_AMD_SHOW_SHAPE")) { /* (dev aid) */
+        fprintf(stderr, "lr2 learnt: TA %d need96 %d nn %.1f pool2 %d split16 %.3f |", TA, learnt, c->hint_nn, c->hint_pool2, c->hint_split2);
+        for (int ta = TA - 1; ta <= TA + 1; ++ta) {
+            if (ta < 1 || ta > 7) continue;
+            double ab = 0;
+            const double r = lr2_rounds_per_atom(status_h + ST_HIST, TA, ta, lr2_pool_for_step(ta, ns, mw, ds, 16, LR2_LANES * LR2_RMAX_MAIN), &ab);
+            fprintf(stderr, " ta %d: %.3f rounds/atom, %.3f above the pool;", ta, r, ab);
+        }
+        fprintf(stderr, "\n");
+    }
     c->hint_far = 4LL * status_h[ST_FAR] >= (long long)n_tiles && n_tiles > 0; /* (see lr2_slice_height_at: such tiles go through the second launch unless the main launch walks itself) */
 }
 
@@ -267,12 +277,13 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
         long long total_cells = 0;
         const int rcs = collect_status(c, n_structs, 8, &total_cells);
         if (rcs) return rcs;
-        c->hint_nn = status_h[ST_OCC_N] > 0 ? 1.25 * 3.1 * (double)status_h[ST_OCC_SUM] / (double)status_h[ST_OCC_N] + 2.0 : 0.0;
+        c->hint_occ = status_h[ST_OCC_N] > 0 ? (double)status_h[ST_OCC_SUM] / (double)status_h[ST_OCC_N] : 0.0;
+        c->hint_nn = status_h[ST_OCC_N] > 0 ? 1.25 * 3.1 * c->hint_occ + 2.0 : 0.0;
         c->hint_nn_max = (int)(1.45 * c->hint_nn); /* longest list ~ 1.6 x the mean on coils, globules and proteins alike */
         c->hint_res[0] = resolution;
         c->hint_pool2 = 0;
     }
-    Lr2Cfg cfg = lr2_choose_cfg(resolution, c->hint_nn, ta_env, c->hint_nn_max, c->hint_pool2 > 0 ? c->hint_ta2 : 0, c->hint_split2);
+    Lr2Cfg cfg = lr2_choose_cfg(resolution, c->hint_nn, ta_env, c->hint_nn_max, c->hint_pool2 > 0 ? c->hint_ta2 : 0, c->hint_split2, c->hint_occ);
     if (c->hint_pool2 > 0 && c->hint_ta2 == cfg.TA && c->hint_mw2 == cfg.mw) { /* same tile shape as the last batch: its demand histogram decides */
         cfg.pool = c->hint_pool2;
         cfg.rmax = (cfg.pool + LR2_LANES - 1) / LR2_LANES;

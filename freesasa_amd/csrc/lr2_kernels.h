@@ -1584,7 +1584,7 @@ static inline int lr2_pool_for_step(int TA, int ns, int mw, int ds, int tiles_pe
  * longest list expected; last_ta / last_split: atoms per tile of the previous batch of this kind on the context
  * and the share of its tiles that exceeded the 16-per-CU pool (last_ta 0: no history) */
 static inline Lr2Cfg lr2_choose_cfg(int ns, double nn_hint = 0, int ta_override = 0, int nn_max_hint = 0, int last_ta = 0,
-                                    double last_split = 0)
+                                    double last_split = 0, double occ_hint = 0)
 {
     Lr2Cfg c;
     c.ns = ns;
@@ -1606,8 +1606,17 @@ static inline Lr2Cfg lr2_choose_cfg(int ns, double nn_hint = 0, int ta_override 
     if (last_ta > 0) {
         /* history: stay, unless too many tiles were split (one atom less) or one atom more clearly fits */
         ta = last_ta < ta_cap ? last_ta : ta_cap;
-        if (ta > 1 && last_split > lr2_split_limit(ta, ns)) --ta;
-        else if (ta < ta_cap && per_atom * (ta + 1) + 8 <= lr2_pool_for_step(ta + 1, ns, c.mw, c.ds, 16, pool_max)) ++ta;
+        /* Protein density at the default resolution (lists beyond 64 common, <= 32 slices: tiles of 3 or 4 atoms) - round
+           5, measured on the final kernel: the reference's PDB entries run 2.3 % faster with 3 atoms per tile than with
+           the 4 that fit (6.08 against 6.24 ms: an item per lane in the screening, fewer tiles redone as halves), the
+           lattice globules 9 % faster with 4 (2.06 against 2.26: there the four atoms of a tile share their cell - 15.7
+           atoms in an atom's own cell against the entries' 12.9 -, and the neighbor search tests a candidate against all
+           four in one work item).  So the atoms in an atom's own cell (occ_hint: the density sample of the context's
+           first batch) decide how full the pool may be before a tile gets one atom less or one more. */
+        const bool dense20 = c.mw >= 3 && ns <= 32;
+        const double fit = !dense20 ? 1.0 : (occ_hint >= 14.0 ? 1.05 : 0.90);
+        if (ta > 1 && (last_split > lr2_split_limit(ta, ns) || (dense20 && per_atom * ta + 8 > fit * lr2_pool_for_step(ta, ns, c.mw, c.ds, 16, pool_max)))) --ta;
+        else if (ta < ta_cap && per_atom * (ta + 1) + 8 <= fit * lr2_pool_for_step(ta + 1, ns, c.mw, c.ds, 16, pool_max)) ++ta;
     } else {
         /* first batch: from the density estimate; 0.8 (0.95) of the 96th-percentile demand in the pool leaves
            ~10 % (~5 %) of the tiles to be split */
@@ -1628,6 +1637,28 @@ static inline Lr2Cfg lr2_choose_cfg(int ns, double nn_hint = 0, int ta_override 
     c.lds = lr2_layout(c.TA, c.ns, c.pool, c.mw, c.ds).total;
     c.rmax = (c.pool + LR2_LANES - 1) / LR2_LANES;
     return c;
+}
+
+/* Rounds of 64 pair records (P3) per ATOM that tiles of `ta` atoms would take, from the sampled demand histogram of a
+ * batch run with tiles of TA atoms (records per tile scale with the atoms per tile), and the share of such tiles that
+ * would not fit `pool` records.  P3 costs a round whatever it holds: 3 atoms x 48 neighbors are three rounds for three
+ * atoms, 4 x 48 three rounds for four. */
+static inline double lr2_rounds_per_atom(const int *hist, int TA, int ta, int pool, double *above = nullptr)
+{
+    long long total = 0;
+    for (int k = 0; k < 64; ++k) total += hist[k];
+    if (above) *above = 0;
+    if (total <= 0 || TA <= 0 || ta <= 0) return 0;
+    const int w = hist_bin_width(TA);
+    double rounds = 0, ab = 0;
+    for (int k = 0; k < 64; ++k) {
+        if (!hist[k]) continue;
+        const double d = (k + 0.5) * w * (double)ta / (double)TA;
+        rounds += hist[k] * (double)(((int)d + LR2_LANES - 1) / LR2_LANES);
+        if (d > pool) ab += hist[k];
+    }
+    if (above) *above = ab / (double)total;
+    return rounds / (double)total / (double)ta;
 }
 
 /* neighbor records per tile that all but ~4 % of the tiles of the last batch needed (sampled demand
