@@ -111,7 +111,6 @@ struct freesasa_gpu_ctx {
     double hint_nn = 0;       /* L&R (lr2): neighbor records per atom the main launch should hold */
     int hint_nn_max = 0;      /* ... and the longest neighbor list expected (mask words per item) */
     double hint_split2 = 0;   /* ... the share of its tiles above the 16-tiles-per-CU pool */
-    double hint_occ = 0;      /* ... atoms in an atom's own cell (density sample of the first batch at this resolution) */
     bool hint_far = false;    /* ... a quarter or more of its tiles had an atom beyond LR2_WALK_Z: the next batch gets the walking build of the main launch */
     int hint_pool2 = 0, hint_ta2 = 0, hint_mw2 = 0; /* ... and the pool the last batch's demand histogram asks for, for tiles of that shape */
     int *dbg_nn = nullptr, *dbg_nb = nullptr; /* test hook: freesasa_gpu_lr_neighbors_dev */

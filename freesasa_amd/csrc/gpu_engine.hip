@@ -277,13 +277,12 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
         long long total_cells = 0;
         const int rcs = collect_status(c, n_structs, 8, &total_cells);
         if (rcs) return rcs;
-        c->hint_occ = status_h[ST_OCC_N] > 0 ? (double)status_h[ST_OCC_SUM] / (double)status_h[ST_OCC_N] : 0.0;
-        c->hint_nn = status_h[ST_OCC_N] > 0 ? 1.25 * 3.1 * c->hint_occ + 2.0 : 0.0;
+        c->hint_nn = status_h[ST_OCC_N] > 0 ? 1.25 * 3.1 * (double)status_h[ST_OCC_SUM] / (double)status_h[ST_OCC_N] + 2.0 : 0.0;
         c->hint_nn_max = (int)(1.45 * c->hint_nn); /* longest list ~ 1.6 x the mean on coils, globules and proteins alike */
         c->hint_res[0] = resolution;
         c->hint_pool2 = 0;
     }
-    Lr2Cfg cfg = lr2_choose_cfg(resolution, c->hint_nn, ta_env, c->hint_nn_max, c->hint_pool2 > 0 ? c->hint_ta2 : 0, c->hint_split2, c->hint_occ);
+    Lr2Cfg cfg = lr2_choose_cfg(resolution, c->hint_nn, ta_env, c->hint_nn_max, c->hint_pool2 > 0 ? c->hint_ta2 : 0, c->hint_split2);
     if (c->hint_pool2 > 0 && c->hint_ta2 == cfg.TA && c->hint_mw2 == cfg.mw) { /* same tile shape as the last batch: its demand histogram decides */
         cfg.pool = c->hint_pool2;
         cfg.rmax = (cfg.pool + LR2_LANES - 1) / LR2_LANES;

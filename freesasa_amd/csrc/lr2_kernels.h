@@ -1584,7 +1584,7 @@ static inline int lr2_pool_for_step(int TA, int ns, int mw, int ds, int tiles_pe
  * longest list expected; last_ta / last_split: atoms per tile of the previous batch of this kind on the context
  * and the share of its tiles that exceeded the 16-per-CU pool (last_ta 0: no history) */
 static inline Lr2Cfg lr2_choose_cfg(int ns, double nn_hint = 0, int ta_override = 0, int nn_max_hint = 0, int last_ta = 0,
-                                    double last_split = 0, double occ_hint = 0)
+                                    double last_split = 0)
 {
     Lr2Cfg c;
     c.ns = ns;
@@ -1607,14 +1607,14 @@ static inline Lr2Cfg lr2_choose_cfg(int ns, double nn_hint = 0, int ta_override 
         /* history: stay, unless too many tiles were split (one atom less) or one atom more clearly fits */
         ta = last_ta < ta_cap ? last_ta : ta_cap;
         /* Protein density at the default resolution (lists beyond 64 common, <= 32 slices: tiles of 3 or 4 atoms) - round
-           5, measured on the final kernel: the reference's PDB entries run 2.3 % faster with 3 atoms per tile than with
-           the 4 that fit (6.08 against 6.24 ms: an item per lane in the screening, fewer tiles redone as halves), the
-           lattice globules 9 % faster with 4 (2.06 against 2.26: there the four atoms of a tile share their cell - 15.7
-           atoms in an atom's own cell against the entries' 12.9 -, and the neighbor search tests a candidate against all
-           four in one work item).  So the atoms in an atom's own cell (occ_hint: the density sample of the context's
-           first batch) decide how full the pool may be before a tile gets one atom less or one more. */
+           5, measured on the final kernel: with 3 atoms per tile the reference's PDB entries run 2.3 % faster than with the
+           4 that just fit (6.08 against 6.24 ms), the bench's lattice globules 3 % (5.66 / 5.83) - an item per lane in the
+           screening, fewer tiles redone as halves - so a tile of such a batch gets a fourth atom only where the pool has a
+           tenth to spare.  (Another lattice, tools/gpu_shapes.py g100, prefers 4 by 9 %: its four atoms share a cell more
+           often, and the neighbor search tests a candidate against all four in one work item.  A rule on the atoms per
+           cell that told the two apart sent the bench's globules the wrong way, and was taken out again.) */
         const bool dense20 = c.mw >= 3 && ns <= 32;
-        const double fit = !dense20 ? 1.0 : (occ_hint >= 14.0 ? 1.05 : 0.90);
+        const double fit = dense20 ? 0.90 : 1.0;
         if (ta > 1 && (last_split > lr2_split_limit(ta, ns) || (dense20 && per_atom * ta + 8 > fit * lr2_pool_for_step(ta, ns, c.mw, c.ds, 16, pool_max)))) --ta;
         else if (ta < ta_cap && per_atom * (ta + 1) + 8 <= fit * lr2_pool_for_step(ta + 1, ns, c.mw, c.ds, 16, pool_max)) ++ta;
     } else {

@@ -442,11 +442,9 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
 /* scalar device math helpers, exposed for unit tests */
 /* the aggregation kernels' phase functions (per-residue and per-class sums) */
 /* host-side launch shaping of the L&R kernel (lr2_kernels.h), for tests/test_emulation.py */
-static double emu_occ_hint = 0;
-extern "C" void emu_set_occ_hint(double v) { emu_occ_hint = v; } /* atoms in an atom's own cell, as the context's first batch samples it */
 extern "C" void emu_lr2_shape(int ns, double nn_hint, int nn_max_hint, int last_ta, double last_split, int *out /* TA, pool, mw, ds, lds, rmax */)
 {
-    const Lr2Cfg c = lr2_choose_cfg(ns, nn_hint, 0, nn_max_hint, last_ta, last_split, emu_occ_hint);
+    const Lr2Cfg c = lr2_choose_cfg(ns, nn_hint, 0, nn_max_hint, last_ta, last_split);
     out[0] = c.TA; out[1] = c.pool; out[2] = c.mw; out[3] = c.ds; out[4] = c.lds; out[5] = c.rmax;
 }
 extern "C" int emu_lr2_pool_from_hist(const int *hist, int TA, int ns, int mw, int ds) { return lr2_pool_from_hist(hist, TA, ns, mw, ds); }

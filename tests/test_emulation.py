@@ -199,18 +199,10 @@ def test_lr_launch_shape_follows_density_and_demand():
     assert shape(20, 62.0, 74, last_ta=3, last_split=0.005)["TA"] == 3      # ... and TA 3 stays
     assert shape(100, 33.7, 77, last_ta=3, last_split=0.075)["TA"] == 3     # 100 slices: halves fill the wave
     assert shape(20, 12.0, 30, last_ta=4, last_split=0.0)["TA"] == 5        # sparse: one more fits
-    # protein density at 20 slices: 3 or 4 atoms per tile by the atoms in an atom's own cell (round 5, measured: the
-    # reference's PDB entries - 12.9 - run faster with 3, the lattice globules - 15.7 - with 4; lr2_choose_cfg)
-    lib.emu_set_occ_hint.argtypes = [C.c_double]
-    try:
-        lib.emu_set_occ_hint(12.9)
-        assert shape(20, 58.0, 74, last_ta=4, last_split=0.014)["TA"] == 3 and shape(20, 56.0, 74, last_ta=3, last_split=0.0)["TA"] == 3
-        lib.emu_set_occ_hint(15.7)
-        assert shape(20, 58.7, 74, last_ta=3, last_split=0.0)["TA"] == 4 and shape(20, 58.0, 74, last_ta=4, last_split=0.023)["TA"] == 4
-        assert shape(20, 58.0, 74, last_ta=4, last_split=0.12)["TA"] == 3                                  # ... unless too many tiles split
-        assert shape(20, 33.7, 77, last_ta=6, last_split=0.03)["TA"] == 6                                  # coils: not this rule's business
-    finally:
-        lib.emu_set_occ_hint(0.0)
+    # protein density at 20 slices: a fourth atom only where the pool has a tenth to spare (round 5, measured: the
+    # reference's PDB entries and the bench's globules both run faster with 3 than with the 4 that just fit)
+    assert shape(20, 58.0, 74, last_ta=4, last_split=0.014)["TA"] == 3 and shape(20, 56.0, 74, last_ta=3, last_split=0.0)["TA"] == 3
+    assert shape(20, 47.0, 70, last_ta=3, last_split=0.0)["TA"] == 4 and shape(20, 47.0, 70, last_ta=4, last_split=0.01)["TA"] == 4
     very_dense = shape(20, 400.0, 500)     # one atom per tile and still more records than 16 tiles per CU leave room for
     assert very_dense["TA"] == 1 and very_dense["pool"] == 256 and very_dense["lds"] * 16 > 160 * 1024
 
