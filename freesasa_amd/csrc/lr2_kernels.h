@@ -224,8 +224,9 @@ SASA_D double lr2_arc_limit(double A, double h)
 #define LR2_SHAPE_DS 2
 /* Three more shapes have builds of their own since the end of round 4, when the kernel had become bound by its
    instruction count alone: 2 = 3 atoms x 100 slices, two mask words (coils at 100 slices: BASELINE
-   configs[2] as written), 3 = 3 x 20 with three mask words (protein density on a lattice), 4 = 4 x 20 with three
-   (the reference's PDB entries); all with two spilled stack levels. */
+   configs[2] as written), 3 = 3 x 20 with three mask words (protein density: the lattice globules and, since the chooser
+   learnt at the end of round 5 that three atoms beat the four that just fit, the reference's PDB entries), 4 = 4 x 20
+   with three (inputs a little less dense); all with two spilled stack levels. */
 SASA_HD constexpr int lr2_shape_ta(int s) { return s == 1 ? LR2_SHAPE_TA : (s == 4 ? 4 : 3); }
 SASA_HD constexpr int lr2_shape_ns(int s) { return s == 2 ? 100 : LR2_SHAPE_NS; }
 SASA_HD constexpr int lr2_shape_mw(int s) { return s <= 2 ? 2 : 3; }
