@@ -557,7 +557,7 @@ SASA_D double lr2_arc_kat(const double *arcs, const int *first, int k, Arc2 *stk
 #ifndef LR2_ARC_STEPS
 #define LR2_ARC_STEPS 2 /* arc steps between two looks at how many lanes wait for a refill */
 #endif
-#define LR2_NB_UNROLL 1 /* candidates a lane has in flight per round of P1.  Round 2 measured 1 / 2 / 3 on coils: 3.59 / 3.63 / 3.58 ms per 3e6 atoms, and 3 it was; the items of a tile are a multiple of 64 x 3 only by chance, and since the kernel's time became its instruction count the padded rounds cost what they compute: round 5, MI355X, kernel ms on the coil batch / the PDB entries, 1: 8.84 / 6.36, 2: 8.86 / 6.38, 3: 8.90 / 6.43, 4: 9.22 / 6.55 */
+#define LR2_NB_UNROLL 1 /* candidates a lane has in flight per round of P1.  Round 2 measured 1 / 2 / 3 on coils: 3.59 / 3.63 / 3.58 ms per 3e6 atoms, and 3 it was; the items of a tile are a multiple of 64 x 3 only by chance, and since the kernel's time became its instruction count the padded rounds cost what they compute: round 5, MI355X, kernel ms on the coil batch / the PDB entries, 1: 8.84 / 6.36, 2: 8.86 / 6.38, 3: 8.90 / 6.43, 4: 9.22 / 6.55; with one per round and the NEXT item's candidate fetched while this one is tested (built, measured): no difference - four waves per SIMD hide the load */
 #endif
 #define LR2_P1_G 3 /* atoms of a cell group one work item of P1 tests its candidate against */
 /* ... in the build for tiles of four atoms at protein density (SHAPE 4) all four: there the four atoms of a tile mostly
