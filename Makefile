@@ -37,32 +37,42 @@ $(LIBDIR)/testpoints.o: $(CSRC)/testpoints.c include/freesasa_gpu.h
 	@mkdir -p $(LIBDIR)
 	$(CC) $(CFLAGS) -c $< -o $@
 
-$(LIBDIR)/api.o: $(CSRC)/api.c include/freesasa_amd.h
+$(LIBDIR)/api.o: $(CSRC)/api.c include/freesasa_amd.h $(CSRC)/hostfault.h
 	@mkdir -p $(LIBDIR)
 	$(CC) $(CFLAGS) -c $< -o $@
 
-$(LIBDIR)/ingest.o: $(CSRC)/ingest.c $(CSRC)/protor_table.h include/freesasa_ingest.h
+# host-side fault injection (tests): the countdown every allocation / thread creation of the host code asks, and - in
+# the shared library ONLY, never in the seam archive that is linked into the reference's build - the library-local
+# operator new that puts the engine's C++ allocations behind it (hostfault.h)
+$(LIBDIR)/hostfault.o: $(CSRC)/hostfault.c $(CSRC)/hostfault.h
+	@mkdir -p $(LIBDIR)
+	$(CC) $(CFLAGS) -c $< -o $@
+$(LIBDIR)/hostfault_new.o: $(CSRC)/hostfault_new.cpp $(CSRC)/hostfault.h
+	@mkdir -p $(LIBDIR)
+	$(CXX) -O2 -std=c++17 -fPIC -Wall -c $< -o $@
+
+$(LIBDIR)/ingest.o: $(CSRC)/ingest.c $(CSRC)/protor_table.h include/freesasa_ingest.h $(CSRC)/hostfault.h
 	@mkdir -p $(LIBDIR)
 	$(CC) $(CFLAGS) -Iinclude -pthread -c $< -o $@
 
-$(LIBDIR)/select.o: $(CSRC)/select.c include/freesasa_ingest.h
+$(LIBDIR)/select.o: $(CSRC)/select.c include/freesasa_ingest.h $(CSRC)/hostfault.h
 	@mkdir -p $(LIBDIR)
 	$(CC) $(CFLAGS) -Iinclude -c $< -o $@
 
-$(LIBDIR)/ingest_cache.o: $(CSRC)/ingest_cache.c include/freesasa_ingest.h
+$(LIBDIR)/ingest_cache.o: $(CSRC)/ingest_cache.c include/freesasa_ingest.h $(CSRC)/hostfault.h
 	@mkdir -p $(LIBDIR)
 	$(CC) $(CFLAGS) -Iinclude -pthread -c $< -o $@
 
-$(LIBDIR)/libfreesasa_amd.so: $(GPU_OBJS) $(LIBDIR)/seam.o $(LIBDIR)/testpoints.o $(LIBDIR)/api.o $(LIBDIR)/ingest.o $(LIBDIR)/select.o $(LIBDIR)/ingest_cache.o $(CSRC)/exports.map
+$(LIBDIR)/libfreesasa_amd.so: $(GPU_OBJS) $(LIBDIR)/seam.o $(LIBDIR)/testpoints.o $(LIBDIR)/api.o $(LIBDIR)/ingest.o $(LIBDIR)/select.o $(LIBDIR)/ingest_cache.o $(LIBDIR)/hostfault.o $(LIBDIR)/hostfault_new.o $(CSRC)/exports.map
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -Wl,--version-script=$(CSRC)/exports.map -o $@ $(filter %.o,$^)
 
-$(LIBDIR)/libfreesasa_amd_seam.a: $(GPU_OBJS) $(LIBDIR)/seam.o $(LIBDIR)/testpoints.o $(LIBDIR)/ingest.o $(LIBDIR)/ingest_cache.o
+$(LIBDIR)/libfreesasa_amd_seam.a: $(GPU_OBJS) $(LIBDIR)/seam.o $(LIBDIR)/testpoints.o $(LIBDIR)/ingest.o $(LIBDIR)/ingest_cache.o $(LIBDIR)/hostfault.o
 	rm -f $@; ar rcs $@ $^
 
 emu: tests/emu/libsasa_emu.so tests/emu/libingest_scalar.so
 # the loader with its byte-at-a-time mmCIF tokenizer only: the differential twin of the SSE2 row scanner
-tests/emu/libingest_scalar.so: $(CSRC)/ingest.c $(CSRC)/protor_table.h include/freesasa_ingest.h
-	$(CC) $(CFLAGS) -DFREESASA_INGEST_NO_SIMD -Iinclude -pthread -shared -o $@ $(CSRC)/ingest.c -lm
+tests/emu/libingest_scalar.so: $(CSRC)/ingest.c $(CSRC)/hostfault.c $(CSRC)/hostfault.h $(CSRC)/protor_table.h include/freesasa_ingest.h
+	$(CC) $(CFLAGS) -DFREESASA_INGEST_NO_SIMD -Iinclude -pthread -shared -o $@ $(CSRC)/ingest.c $(CSRC)/hostfault.c -lm
 tests/emu/libsasa_emu.so: tests/emu/emu.cpp $(CSRC)/sasa_kernels.h $(CSRC)/lr2_kernels.h
 	$(CXX) -O2 -std=c++17 -fPIC -ffp-contract=off -DSASA_EMU -shared -o $@ tests/emu/emu.cpp -lm
 
@@ -72,13 +82,13 @@ tests/emu/libsasa_emu.so: tests/emu/emu.cpp $(CSRC)/sasa_kernels.h $(CSRC)/lr2_k
 ASAN_SO = tests/emu/libfreesasa_amd_asan.so
 SANFLAGS = -O1 -g -std=gnu99 -fPIC -ffp-contract=off -Wall -fsanitize=address,undefined -fno-omit-frame-pointer -fno-sanitize-recover=undefined
 asan: $(ASAN_SO)
-$(ASAN_SO): $(CSRC)/api.c $(CSRC)/seam.c $(CSRC)/testpoints.c $(CSRC)/ingest.c $(CSRC)/select.c $(CSRC)/ingest_cache.c $(CSRC)/protor_table.h $(GPU_OBJS) include/freesasa_amd.h include/freesasa_gpu.h include/freesasa_ingest.h
-	for f in api seam testpoints ingest select ingest_cache; do $(CC) $(SANFLAGS) -Iinclude -pthread -c $(CSRC)/$$f.c -o /tmp/asan_$$f.o || exit 1; done
-	$(CXX) -shared -fPIC -o $@ /tmp/asan_api.o /tmp/asan_seam.o /tmp/asan_testpoints.o /tmp/asan_ingest.o /tmp/asan_select.o /tmp/asan_ingest_cache.o $(GPU_OBJS) \
+$(ASAN_SO): $(CSRC)/api.c $(CSRC)/seam.c $(CSRC)/testpoints.c $(CSRC)/ingest.c $(CSRC)/select.c $(CSRC)/ingest_cache.c $(CSRC)/hostfault.c $(CSRC)/hostfault.h $(CSRC)/protor_table.h $(GPU_OBJS) include/freesasa_amd.h include/freesasa_gpu.h include/freesasa_ingest.h
+	for f in api seam testpoints ingest select ingest_cache hostfault; do $(CC) $(SANFLAGS) -Iinclude -pthread -c $(CSRC)/$$f.c -o /tmp/asan_$$f.o || exit 1; done
+	$(CXX) -shared -fPIC -o $@ /tmp/asan_api.o /tmp/asan_seam.o /tmp/asan_testpoints.o /tmp/asan_ingest.o /tmp/asan_select.o /tmp/asan_ingest_cache.o /tmp/asan_hostfault.o $(GPU_OBJS) \
 	    -fsanitize=address,undefined -L/opt/rocm/lib -Wl,-rpath,/opt/rocm/lib -lamdhip64 -lpthread -lm
 asan-test: $(ASAN_SO)
 	LD_PRELOAD="$$($(CC) -print-file-name=libasan.so) $$($(CC) -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 \
-	    FREESASA_AMD_LIB=$(CURDIR)/$(ASAN_SO) python -m pytest tests/test_ingest.py tests/test_select.py tests/test_capi.py -q -m "not gpu" -p no:cacheprovider
+	    FREESASA_AMD_LIB=$(CURDIR)/$(ASAN_SO) python -m pytest tests/test_ingest.py tests/test_select.py tests/test_capi.py tests/test_hostfault.py -q -m "not gpu" -p no:cacheprovider
 
 oracle: $(LIBDIR)/libfreesasa_amd_seam.a
 	$(MAKE) -C oracle all dropin

@@ -131,6 +131,8 @@ def lib():
         L.freesasa_gpu_release_pool.restype = None
         L.freesasa_gpu_test_fail_after.argtypes = [C.c_int]
         L.freesasa_gpu_test_fail_after.restype = None
+        L.freesasa_host_test_fail_after.argtypes = [C.c_int]
+        L.freesasa_host_test_fail_after.restype = C.c_int
         L.freesasa_gpu_shard_cuts.argtypes = [_lp, C.c_int, C.c_int, _ip]
         L.freesasa_gpu_shard_cuts.restype = None
         L.freesasa_gpu_sweep_files.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
@@ -368,6 +370,12 @@ def trajectory_file(frames_path, radii, totals_path, sasa_path=None, done_path=N
     if ret < 0:
         raise RuntimeError("freesasa_gpu_trajectory_file: " + err.value.decode())
     return ret == 0, int(total.value)
+
+
+def host_test_fail_after(n):
+    """freesasa_host_test_fail_after(): the n-th host allocation / thread creation of the library's own code fails
+    (n <= 0: off); returns what was left of the previous countdown (tests/test_hostfault.py)."""
+    return int(lib().freesasa_host_test_fail_after(int(n)))
 
 
 def test_points(n_points):

@@ -17,6 +17,7 @@
 
 #include <stdint.h>
 #include <stddef.h>
+#include <thread>
 #include <vector>
 
 #include "../../include/freesasa_gpu.h"
@@ -145,6 +146,76 @@ int run_batch(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, const double *d
 freesasa_gpu_ctx *pool_get(int device);
 void pool_put(freesasa_gpu_ctx *c);
 int set_err(char *out, int len, const char *msg); /* returns -1 */
+
+/* ------------------------------------------------------------------ the C boundary and C++ exceptions
+ * The engine is C++ behind a C ABI whose contract is the reference's: NULL / FREESASA_FAIL / -1 with a message, never
+ * exit() (ref: src/util.c:89-113) - and therefore never an exception: a std::bad_alloc from a std::vector, or a
+ * std::system_error from a thread that cannot start under a cgroup's pid limit, must not reach a C caller (it would end
+ * in std::terminate).  Every extern "C" entry runs its body through guarded() / guarded_ctx(); every worker-thread
+ * body catches for itself (an exception that leaves a std::thread's function terminates the process) and reports
+ * through its FirstError / error slot; what a scope owns - threads, pooled contexts, loader batches, descriptors - is
+ * held by the small RAII types below so that unwinding releases it.  tests/test_hostfault.py walks the n-th host
+ * allocation / thread creation failing (hostfault.h) through the drivers. */
+extern "C" int freesasa_hostfault_hit(void); /* hostfault.c: 1 = this thread creation has to fail (tests) */
+/* text for the exception being handled (call inside a catch block) */
+const char *exception_text(char *buf, size_t len) noexcept;
+
+template <class F> int guarded(char *err_out, int err_len, F &&body) noexcept
+{
+    try { return body(); }
+    catch (...) { char msg[200]; return set_err(err_out, err_len, exception_text(msg, sizeof msg)); }
+}
+/* ... for the entries that report through a context: nothing may still run on its stream when the caller is back */
+template <class F> int guarded_ctx(freesasa_gpu_ctx *c, F &&body) noexcept
+{
+    try { return body(); }
+    catch (...) {
+        char msg[200];
+        exception_text(msg, sizeof msg);
+        if (!c) return -1;
+        (void)hipStreamSynchronize(c->stream);
+        return ctx_fail(c, "%s", msg);
+    }
+}
+
+/* threads of one scope: joined on every way out of it */
+struct ThreadGroup {
+    std::vector<std::thread> th;
+    ThreadGroup() = default;
+    ThreadGroup(const ThreadGroup &) = delete;
+    ThreadGroup &operator=(const ThreadGroup &) = delete;
+    ~ThreadGroup() { join(); }
+    void join() noexcept
+    {
+        for (auto &t : th)
+            if (t.joinable()) t.join();
+        th.clear();
+    }
+    /* false: the thread did not start (no memory for its state, EAGAIN from the system, or the test hook) */
+    template <class F, class... A> bool spawn(F &&f, A &&...a) noexcept
+    {
+        try {
+            if (freesasa_hostfault_hit()) return false;
+            th.emplace_back(std::forward<F>(f), std::forward<A>(a)...);
+            return true;
+        } catch (...) { return false; }
+    }
+};
+
+/* a pooled context for the length of a scope; on the way out nothing is left running on its stream */
+struct PoolLease {
+    freesasa_gpu_ctx *c;
+    explicit PoolLease(int device) : c(pool_get(device)) {}
+    PoolLease(const PoolLease &) = delete;
+    PoolLease &operator=(const PoolLease &) = delete;
+    ~PoolLease()
+    {
+        if (!c) return;
+        c->shared_radii = false;
+        (void)hipStreamSynchronize(c->stream);
+        pool_put(c);
+    }
+};
 bool host_pinned(const void *p); /* page-locked already (hipHostMalloc / hipHostRegister, e.g. a pinned tensor)? */
 int ensure_pinned(freesasa_gpu_ctx *c, void **p, size_t *cap, size_t bytes); /* grow a context's page-locked staging buffer */
 

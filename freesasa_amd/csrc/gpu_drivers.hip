@@ -79,6 +79,30 @@ int threads_per_worker(int n_threads, int n_workers)
     return per < 1 ? 1 : per;
 }
 
+/* what a driver's scope owns besides threads and contexts (engine_internal.h): released on every way out of it */
+struct Fd {
+    int fd = -1;
+    Fd() = default;
+    Fd(const Fd &) = delete;
+    Fd &operator=(const Fd &) = delete;
+    ~Fd() { if (fd >= 0) close(fd); }
+};
+struct Batch { /* a loader batch (freesasa_ingest.h) */
+    freesasa_ingest_batch b;
+    Batch() { memset(&b, 0, sizeof b); }
+    Batch(const Batch &) = delete;
+    Batch &operator=(const Batch &) = delete;
+    ~Batch() { freesasa_ingest_free(&b); }
+    void take(Batch &o) { freesasa_ingest_free(&b); b = o.b; memset(&o.b, 0, sizeof o.b); }
+};
+struct Cache {
+    freesasa_ingest_cache *c = nullptr;
+    Cache() = default;
+    Cache(const Cache &) = delete;
+    Cache &operator=(const Cache &) = delete;
+    ~Cache() { if (c) freesasa_ingest_cache_close(c); }
+};
+
 /* first failure of a set of workers wins; the others stop taking work */
 struct FirstError {
     std::mutex mu;
@@ -89,6 +113,11 @@ struct FirstError {
         std::lock_guard<std::mutex> lk(mu);
         if (!failed.load()) snprintf(text, sizeof text, "%s", msg && msg[0] ? msg : "GPU driver failed");
         failed = 1;
+    }
+    void set_exception() noexcept /* inside a catch block */
+    {
+        char msg[200];
+        try { set(exception_text(msg, sizeof msg)); } catch (...) { failed = 1; }
     }
 };
 
@@ -116,6 +145,7 @@ int sweep_impl(const char *const *paths, int n_paths, int ingest_options, int n_
     if (check_devices(devices, n_devices, err_out, err_len)) return -1;
     if (n_paths == 0) return 0;
     if (batch_atoms <= 0) batch_atoms = 2000000;
+    return guarded(err_out, err_len, [&]() -> int {
     /* batches of roughly batch_atoms atoms, estimated from the file sizes (~81 bytes per ATOM line) */
     std::vector<int> cut(1, 0);
     std::vector<long long> batch_bytes;
@@ -132,7 +162,8 @@ int sweep_impl(const char *const *paths, int n_paths, int ingest_options, int n_
     const int n_batches = (int)cut.size() - 1;
     /* done-list and result file */
     std::vector<char> done((size_t)n_batches, 0);
-    int fd_done = -1, fd_res = -1;
+    Fd f_done, f_res; /* (closed on every way out) */
+    int &fd_done = f_done.fd, &fd_res = f_res.fd;
     if (done_path) {
         unsigned long long h = 1469598103934665603ULL; /* FNV-1a over the files' names, sizes and modification times: the done-list belongs to THESE files as they are now */
         for (int k = 0; k < n_paths; ++k) {
@@ -162,11 +193,8 @@ int sweep_impl(const char *const *paths, int n_paths, int ingest_options, int n_
         }
         fd_res = open(res_path.c_str(), resume ? O_RDWR | O_CREAT : O_RDWR | O_CREAT | O_TRUNC, 0644);
         fd_done = open(done_path, resume ? O_WRONLY | O_APPEND : O_WRONLY | O_CREAT | O_TRUNC, 0644);
-        if (fd_res < 0 || fd_done < 0 || (!resume && write(fd_done, head, strlen(head)) != (ssize_t)strlen(head))) {
-            if (fd_res >= 0) close(fd_res);
-            if (fd_done >= 0) close(fd_done);
+        if (fd_res < 0 || fd_done < 0 || (!resume && write(fd_done, head, strlen(head)) != (ssize_t)strlen(head)))
             return set_err(err_out, err_len, "cannot open the done-list or its result file");
-        }
         for (int b = 0; b < n_batches; ++b) { /* results of the batches already done */
             if (!done[(size_t)b]) continue;
             std::vector<SweepRec> recs((size_t)(cut[b + 1] - cut[b]));
@@ -184,8 +212,7 @@ int sweep_impl(const char *const *paths, int n_paths, int ingest_options, int n_
         if (!done[(size_t)b]) todo.push_back(b);
     bool stopped = false;
     if (max_new_batches > 0 && (long long)todo.size() > max_new_batches) { todo.resize((size_t)max_new_batches); stopped = true; }
-    auto close_files = [&] { if (fd_res >= 0) close(fd_res); if (fd_done >= 0) close(fd_done); };
-    if (todo.empty()) { close_files(); return stopped ? 1 : 0; }
+    if (todo.empty()) return stopped ? 1 : 0;
     /* largest first (LPT): whoever is free takes the largest batch left */
     std::stable_sort(todo.begin(), todo.end(), [&](int x, int y) { return batch_bytes[(size_t)x] > batch_bytes[(size_t)y]; });
     int n_workers = n_devices < (int)todo.size() ? n_devices : (int)todo.size();
@@ -197,15 +224,16 @@ int sweep_impl(const char *const *paths, int n_paths, int ingest_options, int n_
     std::mutex done_mu;
     FirstError fe;
 
-    auto worker = [&](int w) {
-        freesasa_gpu_ctx *c = pool_get(devices[w]);
-        if (!c) { fe.set("could not create a GPU context"); return; }
+    auto worker = [&](int w) noexcept {
+      try {
         std::vector<double> cls_tmp;
-        freesasa_ingest_batch cur, nxt;
+        Batch cur_b, nxt_b; /* (declared before the context: freed after its stream is idle) */
+        freesasa_ingest_batch &cur = cur_b.b, &nxt = nxt_b.b;
         int cur_rc = 0, nxt_rc = 0;
-        memset(&cur, 0, sizeof cur);
-        memset(&nxt, 0, sizeof nxt);
-        auto load = [&](int b, freesasa_ingest_batch *out, int *rc) {
+        PoolLease lease(devices[w]);
+        freesasa_gpu_ctx *c = lease.c;
+        if (!c) { fe.set("could not create a GPU context"); return; }
+        auto load = [&](int b, freesasa_ingest_batch *out, int *rc) noexcept { /* (C code: nothing to catch) */
             *rc = freesasa_ingest_pdb_files(paths + cut[b], cut[b + 1] - cut[b], ingest_options, loader_threads, out);
         };
         size_t ti = next.fetch_add(1);
@@ -213,8 +241,8 @@ int sweep_impl(const char *const *paths, int n_paths, int ingest_options, int n_
         while (ti < todo.size() && !fe.failed.load()) {
             const int b = todo[ti];
             const size_t tn = next.fetch_add(1); /* the batch this worker does next: read while this one computes */
-            std::thread loader;
-            if (tn < todo.size()) loader = std::thread(load, todo[tn], &nxt, &nxt_rc);
+            ThreadGroup loader; /* (joined before nxt can go away, whatever happens below) */
+            if (tn < todo.size() && !loader.spawn(load, todo[tn], &nxt, &nxt_rc)) { fe.set("could not start a loader thread"); break; }
             const int first = cut[b], ns = cut[b + 1] - cut[b];
             int ret = 0;
             do {
@@ -274,23 +302,24 @@ int sweep_impl(const char *const *paths, int n_paths, int ingest_options, int n_
                 }
             }
             if (ret) fe.set(c->err[0] ? c->err : "GPU sweep failed");
-            if (loader.joinable()) loader.join();
-            freesasa_ingest_free(&cur);
-            cur = nxt;
+            loader.join();
+            cur_b.take(nxt_b);
             cur_rc = nxt_rc;
-            memset(&nxt, 0, sizeof nxt);
             ti = tn;
         }
-        freesasa_ingest_free(&cur);
-        pool_put(c);
+      } catch (...) { /* (an exception that leaves a thread's function ends the process: it ends the sweep instead) */
+        fe.set_exception();
+      }
     };
-    std::vector<std::thread> th;
-    for (int w = 1; w < n_workers; ++w) th.emplace_back(worker, w);
-    worker(0);
-    for (auto &t : th) t.join();
-    close_files();
+    {
+        ThreadGroup tg;
+        for (int w = 1; w < n_workers; ++w)
+            if (!tg.spawn(worker, w)) { fe.set("could not start a worker thread"); break; }
+        if (!fe.failed.load()) worker(0);
+    }
     if (fe.failed.load()) return set_err(err_out, err_len, fe.text);
     return stopped ? 1 : 0;
+    });
 }
 
 /* ------------------------------------------------------------------ structure sweep: from a binary cache */
@@ -311,22 +340,24 @@ int sweep_cache_impl(const char *cache_path, int alg, double probe, int resoluti
     if (alg != 0 && alg != 1) return set_err(err_out, err_len, "unknown algorithm");
     if (resolution <= 0) return set_err(err_out, err_len, "resolution must be > 0");
     if (check_devices(devices, n_devices, err_out, err_len)) return -1;
-    freesasa_ingest_cache *cache = nullptr;
-    const int orc = freesasa_ingest_cache_open(cache_path, &cache);
+    return guarded(err_out, err_len, [&]() -> int {
+    Cache cache_h; /* (closed on every way out) */
+    const int orc = freesasa_ingest_cache_open(cache_path, &cache_h.c);
     if (orc) {
         char msg[96];
         snprintf(msg, sizeof msg, "cannot open the cache file (freesasa_ingest code %d)", orc);
         return set_err(err_out, err_len, msg);
     }
+    freesasa_ingest_cache *const cache = cache_h.c;
     const int S = freesasa_ingest_cache_n_structs(cache);
     const int64_t *offs = freesasa_ingest_cache_offsets(cache);
     const int32_t *stat = freesasa_ingest_cache_status(cache);
-    if (n_out < S) { freesasa_ingest_cache_close(cache); return set_err(err_out, err_len, "the output arrays are shorter than the cache's structure count"); }
+    if (n_out < S) return set_err(err_out, err_len, "the output arrays are shorter than the cache's structure count");
     if (batch_atoms <= 0) batch_atoms = 1000000; /* (measured, round 5, 1.2e7 protein atoms on one MI355X with 16 CPUs: 8 lanes x 1e6 atoms 3.5e8 atoms/s, 4 x 2e6 3.1e8, 2 x 2e6 2.6e8; the kernels alone run 4.5e8 at this density) */
     if (batch_atoms > (1LL << 30)) batch_atoms = 1LL << 30;
     std::vector<int> cut(1, 0);
     for (int s = 0; s < S; ++s) {
-        if (offs[s + 1] - offs[s] > (1LL << 30)) { freesasa_ingest_cache_close(cache); return set_err(err_out, err_len, "a structure of the cache is too large for one batch"); }
+        if (offs[s + 1] - offs[s] > (1LL << 30)) return set_err(err_out, err_len, "a structure of the cache is too large for one batch");
         if (offs[s + 1] - offs[cut.back()] > batch_atoms && s > cut.back()) cut.push_back(s); /* (a batch never exceeds batch_atoms unless one structure does) */
     }
     cut.push_back(S);
@@ -349,8 +380,10 @@ int sweep_cache_impl(const char *cache_path, int alg, double probe, int resoluti
     if (alg == 1) { tp.resize(3 * (size_t)resolution); freesasa_gpu_test_points(resolution, tp.data()); }
     std::atomic<int> next(0);
     FirstError fe;
-    auto lane = [&](int id) {
-        freesasa_gpu_ctx *c = pool_get(devices[id % n_devices]);
+    auto lane = [&](int id) noexcept {
+      try {
+        PoolLease lease(devices[id % n_devices]);
+        freesasa_gpu_ctx *c = lease.c;
         if (!c) { fe.set("could not create a GPU context"); return; }
         std::vector<int64_t> off;
         for (;;) {
@@ -397,15 +430,19 @@ int sweep_cache_impl(const char *cache_path, int alg, double probe, int resoluti
                 break;
             }
         }
-        pool_put(c);
+      } catch (...) {
+        fe.set_exception();
+      }
     };
-    std::vector<std::thread> th;
-    for (int k = 1; k < n_lanes; ++k) th.emplace_back(lane, k);
-    if (n_lanes > 0) lane(0);
-    for (auto &t : th) t.join();
-    freesasa_ingest_cache_close(cache);
+    {
+        ThreadGroup tg;
+        for (int k = 1; k < n_lanes; ++k)
+            if (!tg.spawn(lane, k)) { fe.set("could not start a worker thread"); break; }
+        if (n_lanes > 0 && !fe.failed.load()) lane(0);
+    }
     if (fe.failed.load()) return set_err(err_out, err_len, fe.text);
     return 0;
+    });
 }
 
 /* ------------------------------------------------------------------ trajectory driver */
@@ -433,6 +470,7 @@ struct TrajIO {
 int traj_run(TrajIO &io, const double *radii, int n_atoms, long long n_frames, int alg, double probe, int resolution,
              int frames_per_batch, int lanes_per_device, long long max_new, const int *devices, int n_devices, char *err_out, int err_len)
 {
+    return guarded(err_out, err_len, [&]() -> int {
     const size_t n = (size_t)n_atoms, FB = (size_t)frames_per_batch;
     const long long n_shards = (n_frames + frames_per_batch - 1) / frames_per_batch;
     if (io.done.size() < (size_t)n_shards) io.done.resize((size_t)n_shards, 0);
@@ -460,8 +498,10 @@ int traj_run(TrajIO &io, const double *radii, int n_atoms, long long n_frames, i
     std::atomic<int> stopped(0);
     std::mutex done_mu;
     FirstError fe;
-    auto lane = [&](int id) {
-        freesasa_gpu_ctx *c = pool_get(devices[id % n_devices]); /* lanes 0 .. n_devices-1 open one device each, the next n_devices the second lane of each, ... */
+    auto lane = [&](int id) noexcept {
+      try {
+        PoolLease lease(devices[id % n_devices]); /* lanes 0 .. n_devices-1 open one device each, the next n_devices the second lane of each, ... */
+        freesasa_gpu_ctx *c = lease.c;
         if (!c) { fe.set("could not create a GPU context"); return; }
         bool radii_up = false;
         for (;;) {
@@ -543,14 +583,19 @@ int traj_run(TrajIO &io, const double *radii, int n_atoms, long long n_frames, i
                 break;
             }
         }
-        pool_put(c);
+      } catch (...) {
+        fe.set_exception();
+      }
     };
-    std::vector<std::thread> th;
-    for (int k = 1; k < n_lanes; ++k) th.emplace_back(lane, k);
-    lane(0);
-    for (auto &t : th) t.join();
+    {
+        ThreadGroup tg;
+        for (int k = 1; k < n_lanes; ++k)
+            if (!tg.spawn(lane, k)) { fe.set("could not start a worker thread"); break; }
+        if (!fe.failed.load()) lane(0);
+    }
     if (fe.failed.load()) return set_err(err_out, err_len, fe.text);
     return stopped.load() ? 1 : 0;
+    });
 }
 
 } /* namespace */
@@ -607,9 +652,11 @@ static int trajectory_mem(const double *xyz_frames, const double *radii, int n_a
     if (frames_per_batch <= 0) frames_per_batch = (int)(1250000 / n_atoms) + 1;
     if (frames_per_batch > n_frames) frames_per_batch = n_frames;
     if ((long long)frames_per_batch * n_atoms > (1LL << 30)) return set_err(err_out, err_len, "batch too large");
-    TrajIO io;
-    io.mem_in = xyz_frames; io.totals_mem = totals_out; io.sasa_mem = sasa_out;
-    return traj_run(io, radii, n_atoms, n_frames, alg, probe, resolution, frames_per_batch, 0, 0, devices, n_devices, err_out, err_len) < 0 ? -1 : 0;
+    return guarded(err_out, err_len, [&]() -> int {
+        TrajIO io;
+        io.mem_in = xyz_frames; io.totals_mem = totals_out; io.sasa_mem = sasa_out;
+        return traj_run(io, radii, n_atoms, n_frames, alg, probe, resolution, frames_per_batch, 0, 0, devices, n_devices, err_out, err_len) < 0 ? -1 : 0;
+    });
 }
 
 extern "C" int freesasa_gpu_trajectory(const double *xyz_frames, const double *radii, int n_atoms, int n_frames,
@@ -641,7 +688,12 @@ extern "C" int freesasa_gpu_trajectory_file_devices(const char *frames_path, int
     if (alg != 0 && alg != 1) return set_err(err_out, err_len, "unknown algorithm");
     if (resolution <= 0) return set_err(err_out, err_len, "resolution must be > 0");
     if (check_devices(devices, n_devices, err_out, err_len)) return -1;
+    return guarded(err_out, err_len, [&]() -> int {
     TrajIO io;
+    struct Closer { /* (the descriptors are closed on every way out) */
+        TrajIO &io;
+        ~Closer() { for (int fd : {io.fd_in, io.fd_totals, io.fd_sasa, io.fd_done}) if (fd >= 0) close(fd); }
+    } closer{io};
     int ret = -1;
     do {
         io.fd_in = open(frames_path, O_RDONLY);
@@ -696,11 +748,8 @@ extern "C" int freesasa_gpu_trajectory_file_devices(const char *frames_path, int
         }
         ret = traj_run(io, radii, n_atoms, n_frames, alg, probe, resolution, frames_per_batch, 0, max_new_shards, devices, n_devices, err_out, err_len);
     } while (0);
-    if (io.fd_in >= 0) close(io.fd_in);
-    if (io.fd_totals >= 0) close(io.fd_totals);
-    if (io.fd_sasa >= 0) close(io.fd_sasa);
-    if (io.fd_done >= 0) close(io.fd_done);
     return ret;
+    });
 }
 
 extern "C" int freesasa_gpu_trajectory_file(const char *frames_path, int frames_f32, long long header_bytes, const double *radii,

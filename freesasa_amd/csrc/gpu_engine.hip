@@ -8,6 +8,7 @@
 
 #include <math.h>
 #include <atomic>
+#include <new>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -88,7 +89,8 @@ extern "C" freesasa_gpu_ctx *freesasa_gpu_ctx_create(int device, void *stream)
     if (n <= 0 || device >= n) return nullptr;
     if (device < 0 && hipGetDevice(&device) != hipSuccess) return nullptr;
     if (hipSetDevice(device) != hipSuccess) return nullptr;
-    freesasa_gpu_ctx *c = new freesasa_gpu_ctx();
+    freesasa_gpu_ctx *c = new (std::nothrow) freesasa_gpu_ctx(); /* (no exception across the C boundary: engine_internal.h) */
+    if (!c) return nullptr;
     c->device = device;
     if (stream) {
         c->stream = (hipStream_t)stream;
@@ -544,16 +546,23 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
             (!lr || !cfg.tab || t * resolution <= 4096)) {
             cfg.B = b; cfg.TA = t; cfg.pool = pl; cfg.ds = lr ? d : 0;
             if (!lr) { cfg.cap_idx = pl > 0 ? pl : cfg.cap_idx; cfg.pool = cfg.TA * cfg.cap_idx; } /* (S&R: "pool" = records per atom) */
-            cfg.items = lr ? (cfg.tab ? cfg.TA * resolution : cfg.B) : sr_items(cfg.TA, resolution);
+            if (!lr) cfg.tab = sr_survivors_fit(cfg.TA, resolution) ? 1 : 0;
+            cfg.items = lr ? (cfg.tab ? cfg.TA * resolution : cfg.B) : (cfg.tab ? sr_items(cfg.TA, resolution) : 1);
             cfg.lds = tile_fixed_bytes(cfg.TA, cfg.items) + tile_list_bytes(cfg.TA, cfg.cap_idx, cfg.pool, cfg.lr, cfg.ds, cfg.B);
         }
     }
     /* whatever the estimate or the tuning aid asked for: the main launch's lists must fit the CU's LDS (dense tiles
        then go to the later launches instead of failing the launch) */
-    while (cfg.lds > 160 * 1024 && cfg.pool > 32) {
-        cfg.pool = (cfg.pool * 3 / 4) & ~1;
+    while (cfg.lds > 160 * 1024 && (lr ? cfg.pool > 32 : cfg.cap_idx > 8)) {
+        if (lr) {
+            cfg.pool = (cfg.pool * 3 / 4) & ~1;
+        } else { /* S&R: the pool IS TA segments of cap_idx records (sr_nb_test writes pq[la * cap_idx + s]): they shrink together */
+            cfg.cap_idx = ((cfg.cap_idx * 3 / 4) + 7) & ~7;
+            cfg.pool = cfg.TA * cfg.cap_idx;
+        }
         cfg.lds = tile_fixed_bytes(cfg.TA, cfg.items) + tile_list_bytes(cfg.TA, cfg.cap_idx, cfg.pool, cfg.lr, cfg.ds, cfg.B);
     }
+    if (cfg.lds > 160 * 1024) return ctx_fail(c, "tile shape does not fit the LDS of a compute unit (%zu bytes)", cfg.lds);
     if (getenv("FREESASA_AMD_SHOW_SHAPE")) fprintf(stderr, "%s tile shape: B %d TA %d cap_idx %d pool %d ds %d lds %zu (hint %d)\n", lr ? "lr1" : "sr", cfg.B, cfg.TA, cfg.cap_idx, cfg.pool, cfg.ds, cfg.lds, c->hint_res[hi] == resolution ? c->hint_pool[hi] : 0); /* (dev aid) */
     const int n_tiles = (n + cfg.TA - 1) / cfg.TA;
     if (ensure(c, c->ovf_tiles, sizeof(int) * ((size_t)n_tiles + 1)) || ensure(c, c->ovf_tiles2, sizeof(int) * ((size_t)n_tiles + 1))) return -1;
@@ -730,7 +739,7 @@ extern "C" int freesasa_gpu_wait(freesasa_gpu_ctx *c)
 {
     if (!c) return -1;
     if (hipSetDevice(c->device) != hipSuccess) return ctx_fail(c, "hipSetDevice failed");
-    return drain_pending(c);
+    return guarded_ctx(c, [&]() -> int { return drain_pending(c); });
 }
 
 extern "C" int freesasa_gpu_lr_batch_dev_async(freesasa_gpu_ctx *c, const double *d_xyz, const double *d_radii,
@@ -739,6 +748,7 @@ extern "C" int freesasa_gpu_lr_batch_dev_async(freesasa_gpu_ctx *c, const double
 {
     if (!c) return -1;
     if (hipSetDevice(c->device) != hipSuccess) return ctx_fail(c, "hipSetDevice failed");
+    return guarded_ctx(c, [&]() -> int {
     /* the set this batch takes may still belong to the batch submitted two calls ago: collect that one first */
     if (c->pend[c->slot].active && complete_pending(c, c->slot)) return -1;
     bool deferred = false;
@@ -751,11 +761,13 @@ extern "C" int freesasa_gpu_lr_batch_dev_async(freesasa_gpu_ctx *c, const double
     }
     if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
     freesasa_gpu_ctx::Pend &P = c->pend[c->slot];
+    P.offsets.assign(offsets, offsets + n_structs + 1); /* (may throw: the set is not marked in flight before it has what a redo needs) */
     P.active = true;
-    P.d_xyz = d_xyz; P.d_radii = d_radii; P.offsets.assign(offsets, offsets + n_structs + 1);
+    P.d_xyz = d_xyz; P.d_radii = d_radii;
     P.probe = probe; P.d_sasa = d_sasa; P.d_totals = d_totals;
     c->slot ^= 1;
     return 0;
+    });
 }
 
 extern "C" int freesasa_gpu_lr_batch_dev(freesasa_gpu_ctx *c, const double *d_xyz, const double *d_radii,
@@ -764,7 +776,7 @@ extern "C" int freesasa_gpu_lr_batch_dev(freesasa_gpu_ctx *c, const double *d_xy
 {
     if (!c) return -1;
     if (freesasa_gpu_wait(c)) return -1; /* (batches submitted asynchronously come first) */
-    return run_batch(c, true, d_xyz, d_radii, offsets, n_structs, probe, n_slices, nullptr, d_sasa, nullptr, d_totals);
+    return guarded_ctx(c, [&]() -> int { return run_batch(c, true, d_xyz, d_radii, offsets, n_structs, probe, n_slices, nullptr, d_sasa, nullptr, d_totals); });
 }
 
 extern "C" int freesasa_gpu_sr_batch_dev(freesasa_gpu_ctx *c, const double *d_xyz, const double *d_radii,
@@ -773,6 +785,6 @@ extern "C" int freesasa_gpu_sr_batch_dev(freesasa_gpu_ctx *c, const double *d_xy
 {
     if (!c) return -1;
     if (freesasa_gpu_wait(c)) return -1;
-    return run_batch(c, false, d_xyz, d_radii, offsets, n_structs, probe, n_points, unit_points, d_sasa, d_counts, d_totals);
+    return guarded_ctx(c, [&]() -> int { return run_batch(c, false, d_xyz, d_radii, offsets, n_structs, probe, n_points, unit_points, d_sasa, d_counts, d_totals); });
 }
 

@@ -6,7 +6,10 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <exception>
 #include <mutex>
+#include <new>
+#include <system_error>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -35,10 +38,14 @@ freesasa_gpu_ctx *pool_get(int device)
     }
     return freesasa_gpu_ctx_create(device, nullptr);
 }
-void pool_put(freesasa_gpu_ctx *c)
+void pool_put(freesasa_gpu_ctx *c) /* (called from destructors: must not throw - a context the pool cannot list is destroyed) */
 {
-    std::lock_guard<std::mutex> lk(g_pool_mu);
-    g_pool.push_back(c);
+    try {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        g_pool.push_back(c);
+    } catch (...) {
+        freesasa_gpu_ctx_destroy(c);
+    }
 }
 
 /* Destroy the idle contexts of the pool (their streams, workspaces and staging buffers): device memory goes back
@@ -59,6 +66,16 @@ int set_err(char *out, int len, const char *msg)
     return -1;
 }
 
+const char *exception_text(char *buf, size_t len) noexcept
+{
+    try { throw; }
+    catch (const std::bad_alloc &) { snprintf(buf, len, "out of host memory"); }
+    catch (const std::system_error &e) { snprintf(buf, len, "system error: %s", e.what()); }
+    catch (const std::exception &e) { snprintf(buf, len, "internal error: %s", e.what()); }
+    catch (...) { snprintf(buf, len, "internal error (unknown C++ exception)"); }
+    return buf;
+}
+
 extern "C" int freesasa_gpu_calc_batch(const double *xyz, const double *radii, const int64_t *offsets, int n_structs,
                                        int alg, double probe, int resolution, double *sasa_out, int *counts_out,
                                        double *totals_out, int device, char *err_out, int err_len)
@@ -67,7 +84,9 @@ extern "C" int freesasa_gpu_calc_batch(const double *xyz, const double *radii, c
     if (!xyz || !radii || !offsets || !sasa_out) return set_err(err_out, err_len, "null argument");
     if (freesasa_gpu_device_count() <= 0)
         return set_err(err_out, err_len, "no HIP device available: libfreesasa_amd has no CPU path");
-    freesasa_gpu_ctx *c = pool_get(device);
+    return guarded(err_out, err_len, [&]() -> int {
+    PoolLease lease(device); /* (returned to the pool, its stream idle, on every way out - an exception included) */
+    freesasa_gpu_ctx *c = lease.c;
     if (!c) return set_err(err_out, err_len, "could not create a GPU context");
     int ret = -1;
     do {
@@ -108,8 +127,8 @@ extern "C" int freesasa_gpu_calc_batch(const double *xyz, const double *radii, c
         (void)hipStreamSynchronize(c->stream); /* the caller's arrays must not be read after we return */
         set_err(err_out, err_len, c->err[0] ? c->err : "GPU batch failed");
     }
-    pool_put(c);
     return ret;
+    });
 }
 
 /* ------------------------------------------------------------------ several GPUs, one process */
@@ -143,28 +162,38 @@ extern "C" int freesasa_gpu_calc_batch_devices(const double *xyz, const double *
     if (n_dev <= 0) return set_err(err_out, err_len, "no HIP device available: libfreesasa_amd has no CPU path");
     for (int k = 0; k < n_devices; ++k)
         if (devices[k] < 0 || devices[k] >= n_dev) return set_err(err_out, err_len, "device index out of range");
+    return guarded(err_out, err_len, [&]() -> int {
     const int nd = n_devices;
     std::vector<int> cut(nd + 1);
     freesasa_gpu_shard_cuts(offsets, n_structs, nd, cut.data());
     std::vector<int> rc(nd, 0);
     std::vector<std::vector<char>> errs(nd, std::vector<char>(256, 0));
-    auto run = [&](int k) {
-        const int s0 = cut[k], ns = cut[k + 1] - cut[k];
-        if (ns <= 0 || offsets[s0 + ns] == offsets[s0]) return;
-        std::vector<int64_t> off(ns + 1); /* the shard's own CSR offsets start at 0 */
-        for (int i = 0; i <= ns; ++i) off[i] = offsets[s0 + i] - offsets[s0];
-        const int64_t a0 = offsets[s0];
-        rc[k] = freesasa_gpu_calc_batch(xyz + 3 * a0, radii + a0, off.data(), ns, alg, probe, resolution, sasa_out + a0,
-                                        counts_out ? counts_out + a0 : nullptr, totals_out ? totals_out + s0 : nullptr,
-                                        devices[k], errs[k].data(), (int)errs[k].size());
+    auto run = [&](int k) noexcept {
+        try {
+            const int s0 = cut[k], ns = cut[k + 1] - cut[k];
+            if (ns <= 0 || offsets[s0 + ns] == offsets[s0]) return;
+            std::vector<int64_t> off(ns + 1); /* the shard's own CSR offsets start at 0 */
+            for (int i = 0; i <= ns; ++i) off[i] = offsets[s0 + i] - offsets[s0];
+            const int64_t a0 = offsets[s0];
+            rc[k] = freesasa_gpu_calc_batch(xyz + 3 * a0, radii + a0, off.data(), ns, alg, probe, resolution, sasa_out + a0,
+                                            counts_out ? counts_out + a0 : nullptr, totals_out ? totals_out + s0 : nullptr,
+                                            devices[k], errs[k].data(), (int)errs[k].size());
+        } catch (...) { /* (an exception that leaves a thread's function ends the process) */
+            exception_text(errs[k].data(), errs[k].size());
+            rc[k] = -1;
+        }
     };
-    std::vector<std::thread> th;
-    for (int k = 1; k < nd; ++k) th.emplace_back(run, k);
-    run(0);
-    for (auto &t : th) t.join();
+    bool started = true;
+    {
+        ThreadGroup tg; /* joined on every way out */
+        for (int k = 1; k < nd && started; ++k) started = tg.spawn(run, k);
+        if (started) run(0);
+    }
+    if (!started) return set_err(err_out, err_len, "could not start a worker thread");
     for (int k = 0; k < nd; ++k)
         if (rc[k]) return set_err(err_out, err_len, errs[k].data()[0] ? errs[k].data() : "a device shard failed");
     return 0;
+    });
 }
 
 extern "C" int freesasa_gpu_calc_batch_multi(const double *xyz, const double *radii, const int64_t *offsets, int n_structs,
@@ -174,12 +203,12 @@ extern "C" int freesasa_gpu_calc_batch_multi(const double *xyz, const double *ra
     if (err_out && err_len > 0) err_out[0] = 0;
     const int n_dev = freesasa_gpu_device_count();
     if (n_dev <= 0) return set_err(err_out, err_len, "no HIP device available: libfreesasa_amd has no CPU path");
-    std::vector<int> devs;
+    int devs[32], nd = 0;
     for (int d = 0; d < 32 && d < n_dev; ++d)
-        if (device_mask & (1u << d)) devs.push_back(d);
-    if (devs.empty()) return set_err(err_out, err_len, "device mask selects no available device");
+        if (device_mask & (1u << d)) devs[nd++] = d;
+    if (nd == 0) return set_err(err_out, err_len, "device mask selects no available device");
     return freesasa_gpu_calc_batch_devices(xyz, radii, offsets, n_structs, alg, probe, resolution, sasa_out, counts_out,
-                                           totals_out, devs.data(), (int)devs.size(), err_out, err_len);
+                                           totals_out, devs, nd, err_out, err_len);
 }
 
 /* ------------------------------------------------------------------ host arrays in, host arrays out, pipelined */
@@ -230,6 +259,7 @@ extern "C" int freesasa_gpu_calc_batch_pipelined(const double *xyz, const double
                                                               staging through page-locked buffers also spends host memcpy time) */
     if (n_lanes > 8) n_lanes = 8;
     if (chunk_atoms <= 0) chunk_atoms = 1250000;
+    return guarded(err_out, err_len, [&]() -> int {
     std::vector<int> cut(1, 0);
     for (int s = 0; s < n_structs; ++s)
         if (offsets[s + 1] - offsets[cut.back()] >= chunk_atoms && s + 1 < n_structs) cut.push_back(s + 1);
@@ -240,8 +270,10 @@ extern "C" int freesasa_gpu_calc_batch_pipelined(const double *xyz, const double
     if (alg == 1) { tp.resize(3 * (size_t)(resolution > 0 ? resolution : 1)); if (resolution > 0) freesasa_gpu_test_points(resolution, tp.data()); }
     std::atomic<int> next(0), failed(0);
     std::vector<std::vector<char>> errs(n_lanes, std::vector<char>(256, 0));
-    auto lane = [&](int id) {
-        freesasa_gpu_ctx *c = pool_get(device);
+    auto lane = [&](int id) noexcept {
+      try {
+        PoolLease lease(device);
+        freesasa_gpu_ctx *c = lease.c;
         if (!c) { snprintf(errs[id].data(), 256, "could not create a GPU context"); failed = 1; return; }
         std::vector<int64_t> off;
         for (;;) {
@@ -305,15 +337,21 @@ extern "C" int freesasa_gpu_calc_batch_pipelined(const double *xyz, const double
                 break;
             }
         }
-        pool_put(c);
+      } catch (...) { /* (the lease has left the stream idle and returned the context) */
+        exception_text(errs[id].data(), errs[id].size());
+        failed = 1;
+      }
     };
-    std::vector<std::thread> th;
-    for (int k = 1; k < n_lanes; ++k) th.emplace_back(lane, k);
-    lane(0);
-    for (auto &t : th) t.join();
+    {
+        ThreadGroup tg;
+        for (int k = 1; k < n_lanes; ++k)
+            if (!tg.spawn(lane, k)) { snprintf(errs[0].data(), 256, "could not start a worker thread"); failed = 1; break; }
+        if (!failed.load()) lane(0);
+    }
     if (failed.load())
         for (int k = 0; k < n_lanes; ++k)
             if (errs[k][0]) return set_err(err_out, err_len, errs[k].data());
     return failed.load() ? set_err(err_out, err_len, "GPU batch failed") : 0;
+    });
 }
 

@@ -17,6 +17,7 @@ extern "C" int freesasa_gpu_segment_sums_dev(freesasa_gpu_ctx *c, const double *
                                              int n_segs, double *d_out)
 {
     if (!c) return -1;
+    return guarded_ctx(c, [&]() -> int {
     c->err[0] = 0;
     if (!d_sasa || !seg || !d_out || n_segs <= 0) return ctx_fail(c, "bad argument");
     for (int k = 0; k < n_segs; ++k)
@@ -27,12 +28,14 @@ extern "C" int freesasa_gpu_segment_sums_dev(freesasa_gpu_ctx *c, const double *
     HIP_TRY(c, kl_segment_sums(d_sasa, (const int64_t *)c->seg.p, n_segs, seg[n_segs] - seg[0] < (int64_t)64 * n_segs, d_out, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return 0;
+    });
 }
 
 extern "C" int freesasa_gpu_class_sums_dev(freesasa_gpu_ctx *c, const double *d_sasa, const unsigned char *d_class,
                                            const int64_t *offsets, int n_structs, double *d_out)
 {
     if (!c) return -1;
+    return guarded_ctx(c, [&]() -> int {
     c->err[0] = 0;
     if (!d_sasa || !d_class || !offsets || !d_out || n_structs <= 0) return ctx_fail(c, "bad argument");
     for (int k = 0; k < n_structs; ++k)
@@ -43,6 +46,7 @@ extern "C" int freesasa_gpu_class_sums_dev(freesasa_gpu_ctx *c, const double *d_
     HIP_TRY(c, kl_class_sums(d_sasa, d_class, (const int64_t *)c->seg.p, n_structs, d_out, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return 0;
+    });
 }
 
 extern "C" int freesasa_gpu_residue_areas_dev(freesasa_gpu_ctx *c, const double *d_sasa, const unsigned char *d_class,
@@ -51,6 +55,7 @@ extern "C" int freesasa_gpu_residue_areas_dev(freesasa_gpu_ctx *c, const double 
                                               double *d_abs, double *d_rel)
 {
     if (!c) return -1;
+    return guarded_ctx(c, [&]() -> int {
     c->err[0] = 0;
     if (!d_sasa || !d_class || !d_backbone || !res_first || !d_abs || n_res <= 0) return ctx_fail(c, "bad argument");
     if (d_rel && (!ref_row || !ref_table || ref_rows <= 0)) return ctx_fail(c, "relative areas need the reference rows and table");
@@ -74,6 +79,7 @@ extern "C" int freesasa_gpu_residue_areas_dev(freesasa_gpu_ctx *c, const double 
                                 d_rel ? (const double *)(base + b_first) : nullptr, d_abs, d_rel, n_res, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return 0;
+    });
 }
 
 /* ------------------------------------------------------------------ test hooks of the L&R kernel's integer parts */
@@ -85,16 +91,19 @@ extern "C" int freesasa_gpu_lr_neighbors_dev(freesasa_gpu_ctx *c, const double *
                                              int n_structs, double probe, int *d_nn, int *d_nb, int nb_cap)
 {
     if (!c) return -1;
+    return guarded_ctx(c, [&]() -> int {
     if (!d_nn || (d_nb && nb_cap <= 0)) return ctx_fail(c, "bad argument");
     const int64_t n = offsets && n_structs > 0 ? offsets[n_structs] : 0;
     if (n <= 0) return ctx_fail(c, "empty batch");
     if (freesasa_gpu_wait(c)) return -1; /* (batches submitted asynchronously come first, as for every synchronous entry) */
     if (hipSetDevice(c->device) != hipSuccess || ensure(c, c->h_sasa, 8 * (size_t)n)) return -1;
+    struct Hooks { /* (taken off the context on every way out) */
+        freesasa_gpu_ctx *c;
+        ~Hooks() { c->dbg_nn = c->dbg_nb = nullptr; c->dbg_cap = 0; }
+    } hooks{c};
     c->dbg_nn = d_nn; c->dbg_nb = d_nb; c->dbg_cap = nb_cap;
-    const int rc = run_batch(c, true, d_xyz, d_radii, offsets, n_structs, probe, 20, nullptr,
-                             (double *)c->h_sasa.p, nullptr, nullptr);
-    c->dbg_nn = c->dbg_nb = nullptr; c->dbg_cap = 0;
-    return rc;
+    return run_batch(c, true, d_xyz, d_radii, offsets, n_structs, probe, 20, nullptr, (double *)c->h_sasa.p, nullptr, nullptr);
+    });
 }
 
 /* The exposed arc length of n_sets sets of arcs (start, end pairs in [0, 2 pi], set k = arcs first[k] .. first[k+1]),
@@ -103,6 +112,7 @@ extern "C" int freesasa_gpu_lr_neighbors_dev(freesasa_gpu_ctx *c, const double *
 extern "C" int freesasa_gpu_arc_union_dev(freesasa_gpu_ctx *c, const double *arcs, const int *first, int n_sets, double *out)
 {
     if (!c) return -1;
+    return guarded_ctx(c, [&]() -> int {
     if (!arcs || !first || !out || n_sets <= 0 || n_sets > 64) return ctx_fail(c, "bad argument");
     const int total = first[n_sets];
     /* the arc pass feeds the union in the order of the arcs' mid-points (the neighbors' directions) */
@@ -125,5 +135,6 @@ extern "C" int freesasa_gpu_arc_union_dev(freesasa_gpu_ctx *c, const double *arc
     HIP_TRY(c, hipMemcpyAsync(out, d_out, sizeof(double) * (size_t)n_sets, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return 0;
+    });
 }
 

@@ -27,6 +27,7 @@
 #include <unistd.h>
 
 #include "protor_table.h"
+#include "hostfault.h"
 
 #define CHUNK 119 /* fgets(line, PDB_MAX_LINE_STRL = 120) */
 
@@ -220,22 +221,22 @@ static int grow_atoms(parsed *p)
 {
     if (p->n < p->cap) return 0;
     const int64_t cap = p->cap ? 2 * p->cap : 4096;
-    double *x = realloc(p->xyz, sizeof(double) * 3 * (size_t)cap);
+    double *x = hf_realloc(p->xyz, sizeof(double) * 3 * (size_t)cap);
     if (!x) return -1;
     p->xyz = x;
-    double *r = realloc(p->rad, sizeof(double) * (size_t)cap);
+    double *r = hf_realloc(p->rad, sizeof(double) * (size_t)cap);
     if (!r) return -1;
     p->rad = r;
-    uint8_t *c = realloc(p->cls, (size_t)cap);
+    uint8_t *c = hf_realloc(p->cls, (size_t)cap);
     if (!c) return -1;
     p->cls = c;
-    uint8_t *b = realloc(p->bb, (size_t)cap);
+    uint8_t *b = hf_realloc(p->bb, (size_t)cap);
     if (!b) return -1;
     p->bb = b;
-    char *an = realloc(p->aname, 4 * (size_t)cap);
+    char *an = hf_realloc(p->aname, 4 * (size_t)cap);
     if (!an) return -1;
     p->aname = an;
-    char *as = realloc(p->asym, 2 * (size_t)cap);
+    char *as = hf_realloc(p->asym, 2 * (size_t)cap);
     if (!as) return -1;
     p->asym = as;
     p->cap = cap;
@@ -246,19 +247,19 @@ static int grow_res(parsed *p)
 {
     if (p->nres < p->rescap) return 0;
     const int64_t cap = p->rescap ? 2 * p->rescap : 512;
-    int64_t *f = realloc(p->res_first, sizeof(int64_t) * (size_t)cap);
+    int64_t *f = hf_realloc(p->res_first, sizeof(int64_t) * (size_t)cap);
     if (!f) return -1;
     p->res_first = f;
-    int16_t *rr = realloc(p->res_ref, sizeof(int16_t) * (size_t)cap);
+    int16_t *rr = hf_realloc(p->res_ref, sizeof(int16_t) * (size_t)cap);
     if (!rr) return -1;
     p->res_ref = rr;
-    char *a = realloc(p->res_name, 4 * (size_t)cap);
+    char *a = hf_realloc(p->res_name, 4 * (size_t)cap);
     if (!a) return -1;
     p->res_name = a;
-    char *b = realloc(p->res_number, 6 * (size_t)cap);
+    char *b = hf_realloc(p->res_number, 6 * (size_t)cap);
     if (!b) return -1;
     p->res_number = b;
-    char *c = realloc(p->res_chain, 4 * (size_t)cap);
+    char *c = hf_realloc(p->res_chain, 4 * (size_t)cap);
     if (!c) return -1;
     p->res_chain = c;
     p->rescap = cap;
@@ -1031,17 +1032,19 @@ static void parse_any(const char *text, size_t len, int options, parsed *p)
     else parse_pdb(text, len, options, p);
 }
 
-/* Whole file into a buffer that is reused from call to call.  0 on success. */
+/* Whole file into a buffer that is reused from call to call.  0 on success, else the input's status
+   (FREESASA_INGEST_EIO, or FREESASA_INGEST_ENOMEM when the buffer could not grow: round 6, found by tests/test_hostfault.py -
+   it used to be reported as an unreadable file). */
 static int read_file(const char *path, char **buf, size_t *cap, size_t *len)
 {
     FILE *f = fopen(path, "rb");
-    if (!f) return -1;
+    if (!f) return FREESASA_INGEST_EIO;
     size_t n = 0;
     for (;;) {
         if (n == *cap) {
             const size_t nc = *cap ? 2 * *cap : (size_t)1 << 20;
-            char *nb = realloc(*buf, nc);
-            if (!nb) { fclose(f); return -1; }
+            char *nb = hf_realloc(*buf, nc);
+            if (!nb) { fclose(f); return FREESASA_INGEST_ENOMEM; }
             *buf = nb;
             *cap = nc;
         }
@@ -1052,7 +1055,7 @@ static int read_file(const char *path, char **buf, size_t *cap, size_t *len)
     const int bad = ferror(f);
     fclose(f);
     *len = n;
-    return bad ? -1 : 0;
+    return bad ? FREESASA_INGEST_EIO : 0;
 }
 
 /* ------------------------------------------------------------------ the batch */
@@ -1154,7 +1157,7 @@ static void *worker(void *arg)
             parse_any(j->texts[k], j->lens[k], j->options, A);
         } else {
             size_t len = 0;
-            if (read_file(j->paths[k], &text, &cap, &len)) A->status = FREESASA_INGEST_EIO;
+            if ((A->status = read_file(j->paths[k], &text, &cap, &len)) != 0) { /* (EIO or ENOMEM) */ }
             else parse_any(text, len, j->options, A);
         }
         slot *s = &j->slots[k];
@@ -1227,7 +1230,7 @@ static void *block_get(size_t bytes, size_t *cap_out)
         g_blocks[best] = g_blocks[--g_nblocks];
     }
     pthread_mutex_unlock(&g_block_mu);
-    if (!p) { p = malloc(bytes); *cap_out = bytes; }
+    if (!p) { p = hf_malloc(bytes); *cap_out = bytes; }
     return p;
 }
 static void block_put(void *p, size_t cap)
@@ -1334,11 +1337,11 @@ static int run(job *j, int n_threads, freesasa_ingest_batch *out)
     if (n_threads > j->n) n_threads = j->n;
     if (n_threads < 1) n_threads = 1;
     j->out = out;
-    j->slots = calloc((size_t)(j->n > 0 ? j->n : 1), sizeof(slot));
-    j->arena = calloc((size_t)n_threads, sizeof(parsed));
-    j->a_off = malloc(sizeof(int64_t) * ((size_t)j->n + 1));
-    j->r_off = malloc(sizeof(int64_t) * ((size_t)j->n + 1));
-    pthread_t *th = calloc((size_t)n_threads, sizeof(pthread_t));
+    j->slots = hf_calloc((size_t)(j->n > 0 ? j->n : 1), sizeof(slot));
+    j->arena = hf_calloc((size_t)n_threads, sizeof(parsed));
+    j->a_off = hf_malloc(sizeof(int64_t) * ((size_t)j->n + 1));
+    j->r_off = hf_malloc(sizeof(int64_t) * ((size_t)j->n + 1));
+    pthread_t *th = hf_calloc((size_t)n_threads, sizeof(pthread_t));
     if (!j->slots || !j->arena || !j->a_off || !j->r_off || !th) {
         free(j->slots); free(j->arena); free(j->a_off); free(j->r_off); free(th);
         return FREESASA_INGEST_ENOMEM;
@@ -1353,7 +1356,7 @@ static int run(job *j, int n_threads, freesasa_ingest_batch *out)
        start gate (the mutex) until the count is known */
     pthread_mutex_lock(&j->mu);
     for (; started < n_threads - 1; ++started)
-        if (pthread_create(&th[started], NULL, worker, j)) break;
+        if (hf_thread_create(&th[started], NULL, worker, j)) break;
     pthread_barrier_init(bar, NULL, (unsigned)started + 1);
     pthread_mutex_unlock(&j->mu);
     worker(j); /* the calling thread works too */

@@ -26,6 +26,7 @@ int ingest_batch_alloc__(freesasa_ingest_batch *b, int32_t ns, int64_t na, int64
 #include <string.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include "hostfault.h"
 
 #define CACHE_MAGIC "FSASABAT"
 #define CACHE_VERSION 2u
@@ -196,7 +197,7 @@ int freesasa_ingest_save(const freesasa_ingest_batch *b, const char *path)
         n_pieces += pieces_of(len[k]);
         if (k < 8) h.section_bytes[k] = len[k];
     }
-    uint64_t *table = (uint64_t *)calloc((size_t)(n_pieces + 2), 8); /* (+ the padding to 16 bytes) */
+    uint64_t *table = (uint64_t *)hf_calloc((size_t)(n_pieces + 2), 8); /* (+ the padding to 16 bytes) */
     if (!table) return FREESASA_INGEST_ENOMEM;
     for (uint64_t k = 0, t = 0; k < CACHE_SECTIONS; ++k)
         for (uint64_t o = 0; o < len[k]; o += CACHE_PIECE)
@@ -204,7 +205,7 @@ int freesasa_ingest_save(const freesasa_ingest_batch *b, const char *path)
     h.checksum = mix_table(h.n_structs, h.n_atoms, h.n_residues, table, n_pieces);
 
     const size_t pl = strlen(path);
-    char *tmp = (char *)malloc(pl + 32);
+    char *tmp = (char *)hf_malloc(pl + 32);
     if (!tmp) { free(table); return FREESASA_INGEST_ENOMEM; }
     snprintf(tmp, pl + 32, "%s.tmp%ld", path, (long)getpid());
     const int fd = open(tmp, O_WRONLY | O_CREAT | O_TRUNC, 0644);
@@ -249,7 +250,7 @@ static int cache_open(const char *path, freesasa_ingest_cache **out)
     if (!path) return FREESASA_INGEST_EIO;
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return FREESASA_INGEST_EIO;
-    freesasa_ingest_cache *c = (freesasa_ingest_cache *)calloc(1, sizeof *c);
+    freesasa_ingest_cache *c = (freesasa_ingest_cache *)hf_calloc(1, sizeof *c);
     if (!c) { (void)close(fd); return FREESASA_INGEST_ENOMEM; }
     c->fd = fd;
     int rc = FREESASA_INGEST_EFORMAT;
@@ -276,7 +277,7 @@ static int cache_open(const char *path, freesasa_ingest_cache **out)
             if (k < 8 && h->section_bytes[k] != c->len[k]) same = 0;
         }
         if (!same || payload != h->payload_bytes || (uint64_t)st.st_size != CACHE_HEADER_BYTES + payload + pad16(8 * c->n_pieces)) break;
-        c->table = (uint64_t *)malloc((size_t)pad16(8 * c->n_pieces) + 16);
+        c->table = (uint64_t *)hf_malloc((size_t)pad16(8 * c->n_pieces) + 16);
         if (!c->table) { rc = FREESASA_INGEST_ENOMEM; break; }
         if (!pread_all(fd, c->table, pad16(8 * c->n_pieces), CACHE_HEADER_BYTES + payload)) break;
         if ((c->n_pieces & 1) && c->table[c->n_pieces] != 0) break; /* (the table's padding is written as zeros) */
@@ -365,7 +366,7 @@ int freesasa_ingest_load_mt(const char *path, int n_threads, freesasa_ingest_bat
         pthread_t th[64];
         int started = 0;
         for (; started < n_threads - 1; ++started)
-            if (pthread_create(&th[started], NULL, load_worker, &j)) break;
+            if (hf_thread_create(&th[started], NULL, load_worker, &j)) break;
         load_worker(&j); /* the calling thread works too */
         for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
         pthread_mutex_destroy(&j.mu);
@@ -393,8 +394,8 @@ int freesasa_ingest_cache_open(const char *path, freesasa_ingest_cache **out)
     rc = FREESASA_INGEST_EFORMAT;
     do {
         const int32_t S = c->h.n_structs;
-        c->offsets = (int64_t *)malloc(c->len[0] > 0 ? (size_t)c->len[0] : 8);
-        c->status = (int32_t *)malloc(c->len[2] > 0 ? (size_t)c->len[2] : 4);
+        c->offsets = (int64_t *)hf_malloc(c->len[0] > 0 ? (size_t)c->len[0] : 8);
+        c->status = (int32_t *)hf_malloc(c->len[2] > 0 ? (size_t)c->len[2] : 4);
         if (!c->offsets || !c->status) { rc = FREESASA_INGEST_ENOMEM; break; }
         if (!read_section_verified(c, 0, 0, pieces_of(c->len[0]), c->offsets) || !read_section_verified(c, 2, 0, pieces_of(c->len[2]), c->status)) break;
         int ok = c->offsets[0] == 0 && c->offsets[S] == c->h.n_atoms;
@@ -447,7 +448,7 @@ int freesasa_ingest_cache_read_atoms(const freesasa_ingest_cache *c, int64_t a0,
 {
     if (!c || a0 < 0 || a1 < a0 || a1 > c->h.n_atoms) return FREESASA_INGEST_EFORMAT;
     if (a1 == a0) return FREESASA_INGEST_OK;
-    void *scratch = malloc((size_t)CACHE_PIECE);
+    void *scratch = hf_malloc((size_t)CACHE_PIECE);
     if (!scratch) return FREESASA_INGEST_ENOMEM;
     int ok = 1;
     if (xyz) ok = read_range_verified(c, 3, 24 * (uint64_t)a0, 24 * (uint64_t)a1, xyz, scratch);

@@ -1657,6 +1657,12 @@ SASA_D void sr_order_serial(const TileArgs &a, TileMem &m, int tid)
 }
 SASA_HD bool sr_order_in_wave(int C) { return C <= 64 * SR_ORDER_RECS; }
 SASA_HD int sr_items(int TA, int n_points) { return (TA * n_points + 1) / 2; } /* S&R: the tile's slice-area table (unused) holds the survivor list, an entry per (atom, point) */
+/* ... while it fits: 4 bytes per (atom, point) of the tile.  The reference takes any number of test points
+   (src/sasa_sr.c:56-90, :168-224); from a table of 32 KB on (one atom per tile and more than 8192 points) the tile runs
+   without the survivor list (TileArgs::tab = 0) instead of asking for more LDS than a CU has (round-5 advisor: 39.9k
+   points and more failed the launch, and a narrow range below that overran the shrunk segment) */
+#define SR_SURVIVOR_BYTES_MAX (32 * 1024)
+SASA_HD bool sr_survivors_fit(int TA, int n_points) { return (long long)TA * n_points * 4 <= SR_SURVIVOR_BYTES_MAX; }
 SASA_HD int sr_hist_bin(int longest) { return longest >> 1; } /* demand histogram of S&R batches: tiles by their longest neighbor list, bins of 2 */
 template <bool GLOBAL>
 SASA_D void sr_report(const TileArgs &a, TileMem &m, int tile, int tid, int &wg_max_nn)
@@ -1745,7 +1751,10 @@ SASA_D void sr_phase_points(const TileArgs &a, TileMem &m, int tile, int tid, in
 #endif
     const int na = tile_atoms(a, tile);
     const int np = a.n_res, items = na * np, C = a.cap_idx;
-    const bool compact = a.TA <= 64 && np <= 65536;
+    /* (a.tab, S&R launches: the tile has a survivor table - an entry per (atom, point), sr_items() - in LDS.  Point
+       counts whose table would not fit (sr_survivors_fit) run without: every point meets its atom's whole list in this
+       first look, as until round 4, and the second look finds nothing to do) */
+    const bool compact = a.tab != 0 && a.TA <= 64 && np <= 65536;
     unsigned *surv = (unsigned *)m.contrib; /* an entry per (atom, point): sr_items() */
     for (int it0 = 0; it0 < items; it0 += B) { /* (trip count uniform over the workgroup: the wave operations below need every lane) */
         const int it = it0 + tid;
@@ -2002,7 +2011,8 @@ static inline TileCfg choose_cfg(int resolution, bool lr, int pool_hint = 0)
         c.B = 256;
         c.TA = ta < 1 ? 1 : (ta > 8 ? 8 : ta);
     }
-    c.items = lr ? (c.tab ? c.TA * resolution : c.B) : sr_items(c.TA, resolution);
+    if (!lr) c.tab = sr_survivors_fit(c.TA, resolution) ? 1 : 0; /* (S&R: tab = the tile has a survivor table) */
+    c.items = lr ? (c.tab ? c.TA * resolution : c.B) : (c.tab ? sr_items(c.TA, resolution) : 1);
     c.lr = lr ? 1 : 0;
     c.cap_idx = 128;
     c.pool = 64 * c.TA < 128 ? 128 : 64 * c.TA;

@@ -19,6 +19,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include "hostfault.h"
 
 /* ------------------------------------------------------------------ lexer */
 
@@ -99,7 +100,7 @@ typedef struct { lex_t lx; tok_t cur; int err; } parser;
 static void advance(parser *ps) { ps->cur = next_token(&ps->lx); }
 static expr *node(int type, expr *l, expr *r)
 {
-    expr *e = calloc(1, sizeof *e);
+    expr *e = hf_calloc(1, sizeof *e);
     if (e) { e->type = type; e->l = l; e->r = r; }
     return e;
 }
@@ -341,7 +342,7 @@ static int eval(ctx_t *c, const expr *e, unsigned char *mask)
         for (int64_t i = 0; i < c->n; ++i) mask[i] = !mask[i];
         return 0;
     default: { /* E_AND, E_OR */
-        unsigned char *tmp = malloc((size_t)(c->n ? c->n : 1));
+        unsigned char *tmp = hf_malloc((size_t)(c->n ? c->n : 1));
         if (!tmp) return -1;
         int rc = eval(c, e->l, mask) || eval(c, e->r, tmp);
         if (!rc)
@@ -377,7 +378,7 @@ int freesasa_ingest_select(const freesasa_ingest_batch *b, int structure, const 
         snprintf(name_out, FREESASA_INGEST_MAX_SELECTION_NAME + 1, "%.50s", name);
         return 0;
     }
-    int64_t *res = malloc(sizeof(int64_t) * (size_t)c.n);
+    int64_t *res = hf_malloc(sizeof(int64_t) * (size_t)c.n);
     if (!res) { free_expr(e); return FREESASA_INGEST_SELECT_FAIL; }
     for (int64_t r = b->res_offsets[structure]; r < b->res_offsets[structure + 1]; ++r)
         for (int64_t a = b->res_first[r]; a < b->res_first[r + 1]; ++a) res[a - c.a0] = r;

@@ -150,6 +150,13 @@ void freesasa_gpu_release_pool(void);
    tests/test_freesasa.c:475-514): every entry point must then return its failure value with a message, leave
    nothing running on its stream, and work again on the next call. */
 void freesasa_gpu_test_fail_after(int n);
+/* ... and its HOST-side twin: the n-th allocation (malloc / calloc / realloc of the C sources, operator new of the C++
+   sources) or thread creation of the library's own host code from now on fails - the loaders (freesasa_ingest_*), the
+   cache reader, the selection parser, freesasa_calc / result_new and every driver below.  n <= 0: off.  Returns what
+   was left of the previous countdown (0: it fired, or was not armed).  Every extern "C" entry point catches what its
+   C++ code throws (std::bad_alloc, std::system_error from a thread that does not start) and returns its failure value
+   with a message: no exception crosses this boundary (ref: src/util.c:89-113, "never exit()"). */
+int freesasa_host_test_fail_after(int n);
 
 /* Test hooks: the integer / exact parts of the Lee-Richards kernel, run on the device on their own.
    _lr_neighbors_dev: the neighbor sets it finds (what freesasa_nb_new builds, src/nb.c:524-557; the reference's

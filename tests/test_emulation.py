@@ -167,6 +167,11 @@ def test_launch_configurations():
     for npts in (1, 13, 100, 257, 4096, 4097):
         _, c, _, st = run_batch(False, xyz, r, resolution=npts, unit_pts=o.test_points(npts))
         assert np.array_equal(c, o.shrake_rupley(xyz, r, 1.4, npts)[1]), (npts, st)
+    # beyond 8192 points the tile runs without its survivor table (sr_survivors_fit): any point count works
+    xs, rs = xyz[:3 * 40], r[:40]
+    for npts in (8192, 8193, 45000):
+        _, c, _, st = run_batch(False, xs, rs, resolution=npts, unit_pts=o.test_points(npts))
+        assert np.array_equal(c, o.shrake_rupley(xs, rs, 1.4, npts)[1]), (npts, st)
 
 
 def test_lr_launch_shape_follows_density_and_demand():

@@ -101,6 +101,19 @@ def test_analytic_two_spheres(fa):
         assert abs(tot - exact) / (tot + exact) < 1e-3
 
 
+def test_shrake_rupley_takes_any_number_of_test_points(fa):
+    """The reference accepts any point count (src/sasa_sr.c:56-90, :168-224).  Round-5 advisor: from ~39.9k points on the
+    tile's survivor table no longer fitted the CU's LDS (launch failure), and just below that the clamp shrank the pool
+    without the per-atom segment (neighbors dropped, counts too high, no error).  Counts must be the oracle's."""
+    import oracle
+    o = oracle.Oracle()
+    xyz, r = tools.globule(60, 5)
+    for npts in (8192, 8193, 20000, 40500, 50000):
+        sasa, _ = fa.calc_coord(xyz, r, fa.SHRAKE_RUPLEY, n_points=npts)
+        want, _ = o.shrake_rupley(xyz, r, 1.4, npts)
+        assert np.array_equal(sasa, want), npts
+
+
 def test_single_and_isolated_atoms(fa):
     R = 2.4
     lr, tot = fa.calc_coord([[1.0, 2.0, 3.0]], [1.0], fa.LEE_RICHARDS)
