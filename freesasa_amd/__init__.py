@@ -396,6 +396,11 @@ class GpuContext:
             lib().freesasa_gpu_ctx_set_timing(self._h, 1)
         self._tp = {}
 
+    def set_timing(self, on):
+        """freesasa_gpu_ctx_set_timing(): HIP events around the cell sort and the tile kernel of every batch (stats():
+        ms_prep, ms_kernel, ms_total); off by default - the four event records cost a small batch ~35 us of its step."""
+        lib().freesasa_gpu_ctx_set_timing(self._h, 1 if on else 0)
+
     def close(self):
         if self._h:
             lib().freesasa_gpu_ctx_destroy(self._h)

@@ -104,6 +104,7 @@ struct freesasa_gpu_ctx {
     int *pinned = nullptr; /* page-locked host words for the small device->host readbacks: two sets of ST_WORDS + 4 */
     long long max_cells = 1LL << 30;
     long long cells_hint = 0; /* cells the last batch needed, with a margin: the table is never sized below it */
+    int scan_epoch = 0;       /* batches that went through the general cell sort's chained scan (PipeArgs::scan_epoch) */
     /* adaptive neighbor-pool size, per algorithm: (resolution, TA) it was learnt for and the value */
     int hint_res[2] = {0, 0}, hint_ta[2] = {0, 0}, hint_pool[2] = {0, 0};
     double hint_probe = -1.0; /* the probe radius the hints were learnt with (another probe: other neighbor counts, so they start over) */

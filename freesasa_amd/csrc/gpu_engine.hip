@@ -170,9 +170,8 @@ static int collect_status(freesasa_gpu_ctx *c, int n_structs, int words, long lo
 {
     hipStream_t st = c->stream;
     int *status_h = ctx_status_h(c);
-    long long *total_p = (long long *)(status_h + ST_WORDS + 2);
-    HIP_TRY(c, hipMemcpyAsync(total_p, (long long *)c->ncells.p + n_structs, sizeof(long long), hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(status_h, c->status.p, sizeof(int) * (size_t)words, hipMemcpyDeviceToHost, st));
+    (void)words; (void)n_structs; /* (all of them: the cell total rides behind the others, sasa_kernels.h ST_CELLS) */
+    HIP_TRY(c, hipMemcpyAsync(status_h, c->status.p, sizeof(int) * (size_t)ST_WORDS, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     return judge_status(c, status_h, total_cells);
 }
@@ -180,7 +179,7 @@ static int collect_status(freesasa_gpu_ctx *c, int n_structs, int words, long lo
 /* the verdict of a batch's status words (already in host memory) */
 static int judge_status(freesasa_gpu_ctx *c, const int *status_h, long long *total_cells)
 {
-    const long long *total_p = (const long long *)(status_h + ST_WORDS + 2);
+    const long long *total_p = (const long long *)(status_h + ST_CELLS);
     *total_cells = *total_p;
     if (status_h[ST_ERROR]) return ctx_fail(c, "%s", err_text(status_h[ST_ERROR]));
     if (*total_p <= 0 || *total_p > c->max_cells) return ctx_fail(c, "%s", err_text(ERR_GRID_TOO_BIG));
@@ -205,7 +204,6 @@ static int enqueue_tail(freesasa_gpu_ctx *c, const PipeArgs &pa, int n_structs, 
     }
     if (c->timing) HIP_TRY(c, hipEventRecord(ctx_ev(c)[3], st));
     int *status_h = ctx_status_h(c);
-    HIP_TRY(c, hipMemcpyAsync(status_h + ST_WORDS + 2, (long long *)c->ncells.p + n_structs, sizeof(long long), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(status_h, c->status.p, sizeof(int) * (size_t)ST_WORDS, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipEventRecord(c->done[c->slot], st));
     return 0;
@@ -442,7 +440,9 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
         HIP_TRY(c, hipMemcpy(c->struct_chunk0.p, sc0.data(), 4 * ((size_t)n_structs + 1), hipMemcpyHostToDevice));
         c->offsets_host.assign(offsets, offsets + n_structs + 1);
     }
-    HIP_TRY(c, hipMemsetAsync(c->status.p, 0, sizeof(int) * ST_WORDS, st));
+    /* (a whole number of 64-byte lines - the buffer has the room, ensure() adds slack: the runtime clears a length that is
+       not a multiple of 16 with TWO fill kernels, seen in the round-6 kernel trace of the 200 000-atom case, 7 us apart) */
+    HIP_TRY(c, hipMemsetAsync(c->status.p, 0, (sizeof(int) * ST_WORDS + 63) & ~(size_t)63, st));
     if (c->timing) HIP_TRY(c, hipEventRecord(ctx_ev(c)[0], st));
 
     PipeArgs pa;
@@ -490,15 +490,22 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
             return -1;
         pa.cell_tbl = (unsigned long long *)c->cell_tbl.p;
         pa.cell_first = (int *)c->cell_first.p;
-    } else if (ensure(c, c->cell_start, sizeof(int) * ((size_t)cells_cap + 2)) || ensure(c, c->blk_sums, sizeof(int) * ((size_t)nblk_scan + 1))) {
-        return -1;
+    } else {
+        const void *const desc_was = c->blk_sums.p;
+        if (ensure(c, c->cell_start, sizeof(int) * ((size_t)cells_cap + 4)) || ensure(c, c->blk_sums, sizeof(unsigned long long) * ((size_t)nblk_scan + 1)))
+            return -1;
+        /* the chained scan's block descriptors carry the batch's epoch (sasa_kernels.h, K4): fresh memory must not look
+           like a descriptor of this epoch, so a new array is cleared once (epoch 0 is never used) */
+        if (c->blk_sums.p != desc_was) HIP_TRY(c, hipMemsetAsync(c->blk_sums.p, 0, c->blk_sums.cap, st));
     }
     pa.cell_start = (int *)c->cell_start.p;
-    pa.blk_sums = (int *)c->blk_sums.p;
+    pa.scan_desc = (unsigned long long *)c->blk_sums.p;
+    c->scan_epoch = c->scan_epoch >= (1 << 30) - 1 ? 1 : c->scan_epoch + 1;
+    pa.scan_epoch = c->scan_epoch;
+    pa.zero_n = cells_cap + 2;
     pa.cells_cap = cells_cap;
 
     if (fused) {
-        HIP_TRY(c, hipMemsetAsync((long long *)c->ncells.p + n_structs, 0, sizeof(long long), st)); /* the cell counter */
         HIP_TRY(c, kl_prep_fused(pa, st));
     } else {
         HIP_TRY(c, kl_prep_general(pa, cells_cap, st));

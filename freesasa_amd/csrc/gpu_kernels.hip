@@ -25,27 +25,51 @@ using namespace sasa;
 
 /* ------------------------------------------------------------------ kernels */
 
-__global__ __launch_bounds__(SASA_PIPE_B) void k_bounds(PipeArgs a)
+/* K1 + K2 of the general cell sort in ONE launch (round 6; until then bounds, grids, cell bases and the clearing of
+ * the histogram were four): workgroups [0, n_chunks) reduce the bounds of their chunk of <= SASA_BOUNDS_CHUNK atoms,
+ * every workgroup - these and the extra ones the launch adds for the purpose - clears its share of the cell histogram
+ * (the whole capacity of the table: its used length is only known at the end of this kernel), and the workgroup that
+ * finishes LAST (a ticket behind a device-scope fence) derives every structure's grid from the chunk bounds and scans
+ * the cells per structure into the structures' cell bases. */
+__global__ __launch_bounds__(SASA_PIPE_B) void k_prep_general(PipeArgs a)
 {
-    __shared__ double red[7 * SASA_PIPE_B];
-    bounds_phase0(a, red, blockIdx.x, threadIdx.x, SASA_PIPE_B);
+    __shared__ double red[7 * SASA_PIPE_B], red2[7 * 16];
+    __shared__ int last;
+    {
+        const Int4 z = {0, 0, 0, 0};
+        const long long words = a.zero_n >> 2; /* (whole 16-byte words; the tail below) */
+        for (long long w = (long long)blockIdx.x * SASA_PIPE_B + threadIdx.x; w < words; w += (long long)gridDim.x * SASA_PIPE_B)
+            ((Int4 *)a.cell_start)[w] = z;
+        if (blockIdx.x == 0 && threadIdx.x < (a.zero_n & 3)) a.cell_start[(words << 2) + threadIdx.x] = 0;
+    }
+    if ((int)blockIdx.x < a.n_chunks) {
+        bounds_phase0(a, red, blockIdx.x, threadIdx.x, SASA_PIPE_B);
+        __syncthreads();
+        bounds_phase1(red, red2, threadIdx.x, SASA_PIPE_B);
+        __syncthreads();
+        bounds_phase2(a, red2, blockIdx.x, threadIdx.x);
+    }
+    __threadfence(); /* this workgroup's chunk bounds and zeros before its ticket */
     __syncthreads();
-    bounds_phase1(a, red, blockIdx.x, threadIdx.x, SASA_PIPE_B);
-}
-
-__global__ __launch_bounds__(64) void k_grid(PipeArgs a)
-{
-    grid_struct(a, blockIdx.x * 64 + threadIdx.x);
-}
-
-__global__ __launch_bounds__(SASA_PIPE_B) void k_cell_base(PipeArgs a)
-{
-    __shared__ long long part[SASA_PIPE_B];
+    if (threadIdx.x == 0) last = atomicAdd(&a.status[ST_TICKET_PREP], 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!last) return;
+    __threadfence(); /* every other workgroup's bounds after their tickets */
+    for (int s0 = 0; s0 < a.n_structs; s0 += SASA_PIPE_B / SASA_GRID_GROUP) { /* sixteen structures at a time, sixteen threads each */
+        __syncthreads();
+        grid_phase0(a, red, s0, threadIdx.x);
+        __syncthreads();
+        grid_phase1(a, red, s0, threadIdx.x);
+    }
+    __syncthreads();
+    long long *part = (long long *)red, *part2 = (long long *)red2;
     cellbase_phase0(a, part, threadIdx.x, SASA_PIPE_B);
     __syncthreads();
-    cellbase_phase1(a, part, threadIdx.x, SASA_PIPE_B);
+    cellbase_phase1(part, part2, threadIdx.x, SASA_PIPE_B);
     __syncthreads();
-    cellbase_phase2(a, part, threadIdx.x, SASA_PIPE_B);
+    cellbase_phase1b(a, part2, threadIdx.x);
+    __syncthreads();
+    cellbase_phase2(a, part, part2, threadIdx.x, SASA_PIPE_B);
 }
 
 /* Everything behind K2 is launched without the host having seen K2's result (no readback in the middle of the
@@ -54,20 +78,6 @@ __global__ __launch_bounds__(SASA_PIPE_B) void k_cell_base(PipeArgs a)
  * on - uniformly, first thing in every kernel - and the host, which reads the status once at the end, reports the
  * error or redoes the batch with the table K2 asked for. */
 #define PIPE_GATE(st) do { if ((st)[ST_ERROR] | (st)[ST_RETRY]) return; } while (0)
-
-/* zero the histogram: cell_start[0 .. total cells + 1] (the total is on the device).  A workgroup clears 16 KB:
- * four rounds of one 16-byte store per thread, consecutive threads at consecutive addresses. */
-__global__ __launch_bounds__(SASA_PIPE_B) void k_zero_cells(PipeArgs a)
-{
-    PIPE_GATE(a.status);
-    const long long n = a.ncells[a.n_structs] + 2;
-    const Int4 z = {0, 0, 0, 0};
-    for (int k = 0; k < 4; ++k) {
-        const long long base = (((long long)blockIdx.x * 4 + k) * SASA_PIPE_B + threadIdx.x) * 4;
-        if (base + 4 <= n) *(Int4 *)(a.cell_start + base) = z;
-        else for (long long i = base; i < n; ++i) a.cell_start[i] = 0;
-    }
-}
 
 __global__ __launch_bounds__(SASA_PIPE_B) void k_count(PipeArgs a)
 {
@@ -82,50 +92,29 @@ __global__ __launch_bounds__(SASA_PIPE_B) void k_count(PipeArgs a)
 }
 
 static_assert(SASA_PIPE_B == SASA_SCAN_GROUP * SASA_SCAN_GROUP, "two-level combine of the scan partials");
-/* n = total cells and the number of scan blocks follow from K2's total on the device; the launches are sized for
- * the table's capacity, blocks beyond the end leave at once */
+/* n = total cells and the number of scan blocks follow from K2's total on the device; the launch is sized for
+ * the table's capacity, workgroups whose ticket lies beyond the end leave at once */
 __device__ __forceinline__ int scan_blocks(long long n)
 {
     return (int)((n + 1 + (long long)SASA_PIPE_B * SASA_SCAN_ITEMS - 1) / ((long long)SASA_PIPE_B * SASA_SCAN_ITEMS));
 }
-__global__ __launch_bounds__(SASA_PIPE_B) void k_scan1(PipeArgs a)
+__global__ __launch_bounds__(SASA_PIPE_B) void k_scan(PipeArgs a)
 {
-    __shared__ int part[SASA_PIPE_B], part2[SASA_SCAN_GROUP];
-    PIPE_GATE(a.status);
-    const long long n = a.ncells[a.n_structs];
-    if ((int)blockIdx.x >= scan_blocks(n)) return;
-    scan1_phase0(a, n, part, blockIdx.x, threadIdx.x, SASA_PIPE_B);
-    __syncthreads();
-    scan_group_sums(part, part2, threadIdx.x);
-    __syncthreads();
-    scan1_phase2(a, part2, blockIdx.x, threadIdx.x);
-}
-__global__ __launch_bounds__(SASA_PIPE_B) void k_scan2(PipeArgs a)
-{
-    __shared__ int part[SASA_PIPE_B];
-    PIPE_GATE(a.status);
-    const int nblk = scan_blocks(a.ncells[a.n_structs]);
-    scan2_phase0(a, nblk, part, threadIdx.x, SASA_PIPE_B);
-    __syncthreads();
-    scan2_phase1(part, threadIdx.x, SASA_PIPE_B);
-    __syncthreads();
-    scan2_phase2(a, nblk, part, threadIdx.x, SASA_PIPE_B);
-}
-
-__global__ __launch_bounds__(SASA_PIPE_B) void k_scan3(PipeArgs a)
-{
-    __shared__ int part[SASA_PIPE_B], part2[SASA_SCAN_GROUP];
+    __shared__ int part[SASA_PIPE_B], part2[SASA_SCAN_GROUP], blk_s, before;
     ScanRegs r;
     PIPE_GATE(a.status);
-    const long long n = a.ncells[a.n_structs];
-    if ((int)blockIdx.x >= scan_blocks(n)) return;
-    scan3_phase0(a, n, part, blockIdx.x, threadIdx.x, SASA_PIPE_B, r);
+    const long long n = *cell_total(a);
+    if (threadIdx.x == 0) blk_s = scan_take_block(a);
     __syncthreads();
-    scan3_phase1(part, part2, threadIdx.x);
+    const int blk = blk_s;
+    if (blk >= scan_blocks(n)) return;
+    scan_phase0(a, n, part, blk, threadIdx.x, SASA_PIPE_B, r);
     __syncthreads();
-    scan3_phase2(part2, threadIdx.x);
+    scan_phase1(part, part2, threadIdx.x);
     __syncthreads();
-    scan3_phase3(a, n, part, part2, blockIdx.x, threadIdx.x, SASA_PIPE_B, r);
+    scan_phase2(a, part2, &before, blk, threadIdx.x);
+    __syncthreads();
+    scan_phase3(a, n, part, part2, &before, blk, threadIdx.x, SASA_PIPE_B, r);
 }
 
 __global__ __launch_bounds__(SASA_PIPE_B) void k_scatter(PipeArgs a)
@@ -256,7 +245,7 @@ __global__ __launch_bounds__(SORT_B) void k_sort_struct(PipeArgs a)
             }
             /* (compact cell table: a structure's cells start at a multiple of 32, its table words are its own) */
             const long long take = a.cell_tbl ? ((nc + 1 + 31) & ~31LL) : nc + 1;
-            const long long base = (long long)atomicAdd((unsigned long long *)&a.ncells[a.n_structs], (unsigned long long)take);
+            const long long base = (long long)atomicAdd((unsigned long long *)cell_total(a), (unsigned long long)take);
             if (base + nc + 1 > a.max_cells) { atomicMax(&a.status[ST_ERROR], (int)ERR_GRID_TOO_BIG); nc = -1; }
             else if (nc > (1LL << SORT_CELL_BITS)) { atomicOr(&a.status[ST_RETRY], 2); nc = -1; }
             else if (a.cells_cap > 0 && base + nc + 1 > a.cells_cap) { atomicOr(&a.status[ST_RETRY], 1); nc = -1; }
@@ -689,14 +678,13 @@ hipError_t kl_prep_general(const PipeArgs &pa, long long cells_cap, hipStream_t 
 {
     const int nblk_scan = (int)((cells_cap + 1 + (long long)SASA_PIPE_B * SASA_SCAN_ITEMS - 1) / ((long long)SASA_PIPE_B * SASA_SCAN_ITEMS));
     const int nblk_atoms = (pa.n_atoms + SASA_PIPE_B - 1) / SASA_PIPE_B;
-    hipLaunchKernelGGL(k_bounds, dim3(pa.n_chunks), dim3(SASA_PIPE_B), 0, st, pa);
-    hipLaunchKernelGGL(k_grid, dim3((pa.n_structs + 63) / 64), dim3(64), 0, st, pa);
-    hipLaunchKernelGGL(k_cell_base, dim3(1), dim3(SASA_PIPE_B), 0, st, pa);
-    hipLaunchKernelGGL(k_zero_cells, dim3((unsigned)((cells_cap + 2 + 16LL * SASA_PIPE_B - 1) / (16LL * SASA_PIPE_B))), dim3(SASA_PIPE_B), 0, st, pa);
+    /* four launches (nine until round 6): bounds + grids + cell bases + clearing, count, chained scan, scatter.  The first
+       gets one extra workgroup per 64 KB of histogram to clear (at most 2048) beside its one per chunk of atoms */
+    long long zb = (pa.zero_n * 4 + 65535) / 65536;
+    if (zb > 2048) zb = 2048;
+    hipLaunchKernelGGL(k_prep_general, dim3((unsigned)(pa.n_chunks + zb)), dim3(SASA_PIPE_B), 0, st, pa);
     hipLaunchKernelGGL(k_count, dim3(nblk_atoms), dim3(SASA_PIPE_B), 0, st, pa);
-    hipLaunchKernelGGL(k_scan1, dim3(nblk_scan), dim3(SASA_PIPE_B), 0, st, pa);
-    hipLaunchKernelGGL(k_scan2, dim3(1), dim3(SASA_PIPE_B), 0, st, pa);
-    hipLaunchKernelGGL(k_scan3, dim3(nblk_scan), dim3(SASA_PIPE_B), 0, st, pa);
+    hipLaunchKernelGGL(k_scan, dim3(nblk_scan), dim3(SASA_PIPE_B), 0, st, pa);
     hipLaunchKernelGGL(k_scatter, dim3(nblk_atoms), dim3(SASA_PIPE_B), 0, st, pa);
     return hipGetLastError();
 }

@@ -45,6 +45,8 @@ inline int atomic_max(int *p, int v) { int o = *p; if (v > o) *p = v; return o; 
 #define SASA_ATOMIC_ADD_GLB(p, v) sasa_emu::atomic_add((p), (v))
 #define SASA_ATOMIC_MAX_GLB(p, v) sasa_emu::atomic_max((p), (v))
 #define SASA_ATOMIC_MAX_LDS(p, v) sasa_emu::atomic_max((p), (v))
+#define SASA_LOAD_ACQ64(p) (*(p))
+#define SASA_STORE_REL64(p, v) (*(p) = (v))
 #define SASA_RSQ(x) (1.0 / sqrt(x))
 #define SASA_FMA_K(p, z, k) fma((p), (z), (k))
 #define SASA_RCP(x) (1.0 / (x))
@@ -61,6 +63,9 @@ inline int atomic_max(int *p, int v) { int o = *p; if (v > o) *p = v; return o; 
 #define SASA_ATOMIC_ADD_GLB(p, v) atomicAdd((p), (v))
 #define SASA_ATOMIC_MAX_GLB(p, v) atomicMax((p), (v))
 #define SASA_ATOMIC_MAX_LDS(p, v) atomicMax((p), (v))
+/* a 64-bit word handed from one workgroup to another (the chained scan's block descriptors): device scope */
+#define SASA_LOAD_ACQ64(p) __hip_atomic_load((p), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)
+#define SASA_STORE_REL64(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT)
 #define SASA_RSQ(x) __builtin_amdgcn_rsq(x)
 /* p*z + k with the constant k held in an SGPR pair: one v_fma_f64 per Horner step and no VGPRs
    spent on coefficients (hipcc otherwise copies each coefficient into a VGPR pair and issues
@@ -127,11 +132,16 @@ enum {
     ST_OCC_N = 5,      /* ... and how many atoms were sampled: local density -> first launch shape */
     ST_OVF3_ATOMS = 6, /* L&R (lr2_kernels.h): atoms handed to the last (slab) launch */
     ST_RETRY = 7,      /* the batch needs more cells than the table was sized for: nothing after K2 ran, the host
-                          redoes the batch with a table of ncells[n_structs] cells (gpu_engine.hip) */
+                          redoes the batch with a table of status[ST_CELLS] cells (gpu_engine.hip) */
     ST_HIST = 8,       /* [64] tiles by neighbor records needed, bins of hist_bin_width(TA) */
     ST_SPLIT = 72,     /* [64] L&R (lr2_kernels.h): tiles redone as two halves, counted in 64 buckets */
     ST_FAR = 136,      /* L&R (lr2_kernels.h): tiles of the main launch with an atom beyond LR2_WALK_Z (slice planes walked as the reference walks them) */
-    ST_WORDS = 137
+    ST_TICKET_PREP = 137, /* general cell sort: workgroups of k_prep_general that are through (the last one derives the grids) */
+    ST_TICKET_SCAN = 138, /* ... and the order in which the workgroups of the chained scan took their blocks */
+    ST_CELLS = 140,    /* [2] one long long (8-byte aligned): cells of the whole batch - the general cell sort's total, the fused
+                          sort's running counter - read back with the other words in ONE copy (round 6; until then a slot
+                          behind ncells[] with a clearing fill and a device-to-host copy of its own per batch) */
+    ST_WORDS = 142
 };
 enum {
     ERR_NONE = 0,
@@ -174,7 +184,7 @@ struct PipeArgs {
     double *bpart;            /* [n_chunks*7] per-chunk min xyz, max xyz, max radius */
     /* per structure */
     GridS *grid;
-    long long *ncells; /* [n_structs] cells of each structure; [n_structs] = total after K2 */
+    long long *ncells; /* [n_structs] cells of each structure (the batch's total: status[ST_CELLS], see cell_total) */
     long long cells_cap; /* > 0: cells the table cell_start[] has room for (K2 raises ST_RETRY beyond it) */
     /* per atom, original order */
     int *sid;     /* structure of atom i */
@@ -189,7 +199,9 @@ struct PipeArgs {
        gathered from by every tile.  null: the dense table. */
     unsigned long long *cell_tbl; /* [total cells / 32 + 1] bits | occupied cells before the word << 32; a structure's cells start at a multiple of 32 */
     int *cell_first;              /* [n_atoms + n_structs] first atom of an occupied cell; structure s uses entries offsets[s] + s ...; behind its last: its end */
-    int *blk_sums;   /* scan scratch */
+    unsigned long long *scan_desc; /* [scan blocks] the chained scan's block descriptors: value | state << 32 | epoch << 34 */
+    int scan_epoch;  /* 1 .. 2^30 - 1, another one for every batch of a context: descriptors of earlier batches read as "not yet" */
+    long long zero_n; /* words of cell_start[] the first kernel of the general pipeline clears (the table's capacity + 2) */
     /* per atom, cell-sorted order */
     Quad *sq; /* (x, y, z, radius + probe) (ref: src/sasa_lr.c:136, sasa_sr.c:144): one 32-byte record per atom - two
                  16-byte accesses where four arrays took four, one pointer where they took four */
@@ -198,6 +210,7 @@ struct PipeArgs {
 };
 
 #define SASA_PIPE_B 256
+SASA_D long long *cell_total(const PipeArgs &a) { return (long long *)(a.status + ST_CELLS); }
 
 /* K1a: one workgroup per CHUNK of at most SASA_BOUNDS_CHUNK atoms of one structure (a 200k-atom
  * structure is 49 chunks, not one serial workgroup).  red = LDS doubles [7][B]; the chunk's
@@ -211,18 +224,27 @@ SASA_D void bounds_phase0(const PipeArgs &a, double *red, int chunk, int tid, in
     double lo0 = INFINITY, lo1 = INFINITY, lo2 = INFINITY;
     double hi0 = -INFINITY, hi1 = -INFINITY, hi2 = -INFINITY, rmax = 0; /* ref: src/nb.c:246 */
     int bad = 0;
-    for (int64_t i = b + tid; i < e; i += B) {
-        const double x = a.xyz[3 * i], y = a.xyz[3 * i + 1], z = a.xyz[3 * i + 2];
-        lo0 = fmin(x, lo0); hi0 = fmax(x, hi0);
-        lo1 = fmin(y, lo1); hi1 = fmax(y, hi1);
-        lo2 = fmin(z, lo2); hi2 = fmax(z, hi2);
-        const double rr = a.radii[a.shared_radii ? i - b0 : i];
-        rmax = fmax(rr + a.probe, rmax);
-        a.sid[i] = s;
-        /* fmin/fmax drop NaN and the float-to-int conversion of a NaN is 0 on gfx950 (INT_MIN on x86): a
-           non-finite coordinate or radius is flagged here, explicitly (v - v is NaN for NaN and +-inf) */
-        if (!(x - x == 0) || !(y - y == 0) || !(z - z == 0)) bad = ERR_BAD_COORD;
-        if (!(rr - rr == 0)) bad = bad ? bad : ERR_BAD_RADIUS;
+    /* four atoms per trip, their sixteen loads in flight together (round 6: one atom per trip made a chunk of 4096 atoms
+       sixteen dependent round trips to memory, ~25 us of the first kernel of the general cell sort) */
+    for (int64_t i0 = b + tid; i0 < e; i0 += 4 * (int64_t)B) {
+        double x[4], y[4], z[4], rr[4];
+        for (int k = 0; k < 4; ++k) {
+            const int64_t i = i0 + k * (int64_t)B < e ? i0 + k * (int64_t)B : i0; /* (beyond the chunk: the first atom again - harmless) */
+            x[k] = a.xyz[3 * i]; y[k] = a.xyz[3 * i + 1]; z[k] = a.xyz[3 * i + 2];
+            rr[k] = a.radii[a.shared_radii ? i - b0 : i];
+        }
+        for (int k = 0; k < 4; ++k) {
+            lo0 = fmin(x[k], lo0); hi0 = fmax(x[k], hi0);
+            lo1 = fmin(y[k], lo1); hi1 = fmax(y[k], hi1);
+            lo2 = fmin(z[k], lo2); hi2 = fmax(z[k], hi2);
+            rmax = fmax(rr[k] + a.probe, rmax);
+            /* fmin/fmax drop NaN and the float-to-int conversion of a NaN is 0 on gfx950 (INT_MIN on x86): a
+               non-finite coordinate or radius is flagged here, explicitly (v - v is NaN for NaN and +-inf) */
+            if (!(x[k] - x[k] == 0) || !(y[k] - y[k] == 0) || !(z[k] - z[k] == 0)) bad = ERR_BAD_COORD;
+            if (!(rr[k] - rr[k] == 0)) bad = bad ? bad : ERR_BAD_RADIUS;
+        }
+        for (int k = 0; k < 4; ++k)
+            if (i0 + k * (int64_t)B < e) a.sid[i0 + k * (int64_t)B] = s;
     }
     if (bad) SASA_ATOMIC_MAX_GLB(&a.status[ST_ERROR], bad);
     red[0 * B + tid] = lo0; red[1 * B + tid] = lo1; red[2 * B + tid] = lo2;
@@ -230,21 +252,50 @@ SASA_D void bounds_phase0(const PipeArgs &a, double *red, int chunk, int tid, in
     red[6 * B + tid] = rmax;
 }
 
-SASA_D void bounds_phase1(const PipeArgs &a, const double *red, int chunk, int tid, int B)
+/* the B values of each of the 7 quantities in two levels of 16 (B = 256): 7 x 16 threads fold 16 values each into
+   red2[7][16], then 7 threads fold those (round 6: one level - 7 threads walking 255 values each, a chain of dependent
+   LDS reads - took 25 of the 39 us the first kernel of the general cell sort ran on a 200 000-atom structure) */
+SASA_D void bounds_phase1(const double *red, double *red2, int tid, int B)
+{
+    if (tid >= 7 * 16) return;
+    const int q = tid >> 4, g = tid & 15, per = B / 16;
+    const double *r = red + q * B + g * per;
+    double v = r[0];
+    for (int t = 1; t < per; ++t) v = q < 3 ? fmin(r[t], v) : fmax(r[t], v);
+    red2[tid] = v;
+}
+SASA_D void bounds_phase2(const PipeArgs &a, const double *red2, int chunk, int tid)
 {
     if (tid >= 7) return;
-    double v = red[tid * B];
-    for (int t = 1; t < B; ++t) {
-        const double w = red[tid * B + t];
-        v = tid < 3 ? fmin(w, v) : fmax(w, v);
-    }
+    double v = red2[tid * 16];
+    for (int t = 1; t < 16; ++t) v = tid < 3 ? fmin(red2[tid * 16 + t], v) : fmax(red2[tid * 16 + t], v);
     a.bpart[(size_t)chunk * 7 + tid] = v;
 }
 
-/* K1b: one thread per structure: combine its chunks, derive the cell grid. */
-SASA_D void grid_struct(const PipeArgs &a, int s)
+/* K1b: a structure's chunks combined, its cell grid derived.  SIXTEEN threads share a structure (round 6: one thread
+ * walked all of a structure's chunks - 49 dependent round trips for 200 000 atoms, the other ~30 us of that kernel):
+ * thread g of the group folds chunks c0 + g, c0 + g + 16, ... into gpart[slot][g][7] (LDS, slot = the structure's
+ * place among the 16 the workgroup does at a time), then one thread per structure folds the 16 and derives the grid. */
+#define SASA_GRID_GROUP 16
+SASA_D void grid_phase0(const PipeArgs &a, double *gpart, int s_first, int tid)
 {
-    if (s >= a.n_structs) return;
+    const int slot = tid / SASA_GRID_GROUP, g = tid % SASA_GRID_GROUP, s = s_first + slot;
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, rmax = 0;
+    if (s < a.n_structs) {
+        const int c0 = a.struct_chunk0[s], c1 = a.struct_chunk0[s + 1];
+        for (int c = c0 + g; c < c1; c += SASA_GRID_GROUP) {
+            const double *q = a.bpart + (size_t)c * 7;
+            for (int k = 0; k < 3; ++k) { lo[k] = fmin(q[k], lo[k]); hi[k] = fmax(q[3 + k], hi[k]); }
+            rmax = fmax(q[6], rmax);
+        }
+    }
+    double *o = gpart + (size_t)tid * 7;
+    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2]; o[6] = rmax;
+}
+SASA_D void grid_phase1(const PipeArgs &a, const double *gpart, int s_first, int tid)
+{
+    const int s = s_first + tid;
+    if (tid >= SASA_PIPE_B / SASA_GRID_GROUP || s >= a.n_structs) return;
     GridS g;
     const int c0 = a.struct_chunk0[s], c1 = a.struct_chunk0[s + 1];
     if (c1 <= c0) { /* empty structure */
@@ -254,8 +305,8 @@ SASA_D void grid_struct(const PipeArgs &a, int s)
         return;
     }
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, rmax = 0;
-    for (int c = c0; c < c1; ++c) {
-        const double *q = a.bpart + (size_t)c * 7;
+    for (int c = 0; c < SASA_GRID_GROUP; ++c) {
+        const double *q = gpart + ((size_t)tid * SASA_GRID_GROUP + c) * 7;
         for (int k = 0; k < 3; ++k) { lo[k] = fmin(q[k], lo[k]); hi[k] = fmax(q[3 + k], hi[k]); }
         rmax = fmax(q[6], rmax);
     }
@@ -288,7 +339,7 @@ SASA_D void grid_struct(const PipeArgs &a, int s)
     a.ncells[s] = nc;
 }
 
-/* K2: one workgroup; exclusive scan of ncells[] -> grid[].cell_base, total -> ncells[n_structs].
+/* K2: one workgroup; exclusive scan of ncells[] -> grid[].cell_base, total -> status[ST_CELLS].
  * part = LDS long long [B]. */
 SASA_D void cellbase_phase0(const PipeArgs &a, long long *part, int tid, int B)
 {
@@ -297,19 +348,28 @@ SASA_D void cellbase_phase0(const PipeArgs &a, long long *part, int tid, int B)
     for (int k = tid * per; k < (tid + 1) * per && k < a.n_structs; ++k) s += a.ncells[k];
     part[tid] = s;
 }
-SASA_D void cellbase_phase1(const PipeArgs &a, long long *part, int tid, int B)
+/* (the B partial sums in two levels of 16, as everywhere: one thread walking all 256 through LDS took ~15 us) */
+SASA_D void cellbase_phase1(long long *part, long long *part2, int tid, int B)
+{
+    const int G = B / 16;
+    if (tid >= 16) return;
+    long long run = 0;
+    for (int t = 0; t < G; ++t) { const long long v = part[tid * G + t]; part[tid * G + t] = run; run += v; }
+    part2[tid] = run;
+}
+SASA_D void cellbase_phase1b(const PipeArgs &a, long long *part2, int tid)
 {
     if (tid != 0) return;
     long long run = 0;
-    for (int t = 0; t < B; ++t) { long long v = part[t]; part[t] = run; run += v; }
-    a.ncells[a.n_structs] = run;
+    for (int t = 0; t < 16; ++t) { const long long v = part2[t]; part2[t] = run; run += v; }
+    *cell_total(a) = run;
     if (run > a.max_cells) SASA_ATOMIC_MAX_GLB(&a.status[ST_ERROR], (int)ERR_GRID_TOO_BIG);
     else if (a.cells_cap > 0 && run > a.cells_cap) a.status[ST_RETRY] = 1;
 }
-SASA_D void cellbase_phase2(const PipeArgs &a, const long long *part, int tid, int B)
+SASA_D void cellbase_phase2(const PipeArgs &a, const long long *part, const long long *part2, int tid, int B)
 {
     const int per = (a.n_structs + B - 1) / B;
-    long long run = part[tid];
+    long long run = part2[tid / (B / 16)] + part[tid];
     for (int k = tid * per; k < (tid + 1) * per && k < a.n_structs; ++k) {
         a.grid[k].cell_base = (int)run;
         run += a.ncells[k];
@@ -379,11 +439,16 @@ SASA_D void count_phase2(const PipeArgs &a, const int *cells, const int *base, i
 }
 
 /* K4: exclusive scan of cell_start[0..n) in place, n = total cells; cell_start[n] = total.
- * Three launches: scan1 (block sums), scan2 (scan of block sums, one block), scan3 (apply).
- * Each thread owns SCAN_ITEMS consecutive cells, moved as four 16-byte words and kept in
- * registers between the phases of scan3 (a sparse batch has ~10 cells per atom, so these two
- * kernels stream more bytes than the rest of the pipeline together).  The B partial sums of a
- * block are combined in two levels of SASA_SCAN_GROUP. */
+ * ONE launch (round 6; until then three: block sums, scan of the block sums by one workgroup, apply): the blocks are
+ * chained ("decoupled look-back"): a workgroup takes the next block of SCAN_ITEMS x B cells from a ticket counter -
+ * so a block's predecessors are always held by workgroups that are already running -, adds its cells up, publishes
+ * the sum in the block's descriptor, then walks back over its predecessors' descriptors - a sum, or an inclusive
+ * prefix, which ends the walk - and publishes its own inclusive prefix.  A descriptor is one 64-bit word (value |
+ * state << 32 | epoch << 34) stored and loaded with release / acquire at device scope; the epoch is the context's
+ * batch number, so the words need no clearing between batches (a word of an earlier batch reads as "not yet").
+ * Each thread owns SCAN_ITEMS consecutive cells, moved as four 16-byte words and kept in registers between the
+ * phases (a sparse batch has ~10 cells per atom: this kernel streams more bytes than the rest of the cell sort
+ * together).  The B partial sums of a block are combined in two levels of SASA_SCAN_GROUP. */
 #define SASA_SCAN_ITEMS 16
 #define SASA_SCAN_GROUP 16 /* B == GROUP * GROUP */
 struct __attribute__((aligned(16))) Int4 { int x, y, z, w; };
@@ -402,56 +467,14 @@ SASA_D int scan_load(const PipeArgs &a, long long n, int blk, int tid, int B, Sc
     for (int k = 0; k < SASA_SCAN_ITEMS / 4; ++k) s += (r.v[k].x + r.v[k].y) + (r.v[k].z + r.v[k].w);
     return s;
 }
-SASA_D void scan1_phase0(const PipeArgs &a, long long n, int *part, int blk, int tid, int B)
-{
-    ScanRegs r;
-    part[tid] = scan_load(a, n, blk, tid, B, r);
-}
-/* group sums: thread g < GROUP adds the partials of threads [g*GROUP, (g+1)*GROUP) */
-SASA_D void scan_group_sums(const int *part, int *part2, int tid)
-{
-    if (tid >= SASA_SCAN_GROUP) return;
-    int run = 0;
-    for (int t = 0; t < SASA_SCAN_GROUP; ++t) run += part[tid * SASA_SCAN_GROUP + t];
-    part2[tid] = run;
-}
-SASA_D void scan1_phase2(const PipeArgs &a, const int *part2, int blk, int tid)
-{
-    if (tid != 0) return;
-    int run = 0;
-    for (int t = 0; t < SASA_SCAN_GROUP; ++t) run += part2[t];
-    a.blk_sums[blk] = run;
-}
-/* one block; nblk block sums -> exclusive */
-SASA_D void scan2_phase0(const PipeArgs &a, int nblk, int *part, int tid, int B)
-{
-    const int per = (nblk + B - 1) / B;
-    int s = 0;
-    for (int k = tid * per; k < (tid + 1) * per && k < nblk; ++k) s += a.blk_sums[k];
-    part[tid] = s;
-}
-SASA_D void scan2_phase1(int *part, int tid, int B)
-{
-    if (tid != 0) return;
-    int run = 0;
-    for (int t = 0; t < B; ++t) { int v = part[t]; part[t] = run; run += v; }
-}
-SASA_D void scan2_phase2(const PipeArgs &a, int nblk, const int *part, int tid, int B)
-{
-    const int per = (nblk + B - 1) / B;
-    int run = part[tid];
-    for (int k = tid * per; k < (tid + 1) * per && k < nblk; ++k) {
-        int v = a.blk_sums[k];
-        a.blk_sums[k] = run;
-        run += v;
-    }
-}
-SASA_D void scan3_phase0(const PipeArgs &a, long long n, int *part, int blk, int tid, int B, ScanRegs &r)
+/* the block this workgroup scans (thread 0 takes the ticket; the kernel hands it to the others through LDS) */
+SASA_D int scan_take_block(const PipeArgs &a) { return SASA_ATOMIC_ADD_GLB(&a.status[ST_TICKET_SCAN], 1); }
+SASA_D void scan_phase0(const PipeArgs &a, long long n, int *part, int blk, int tid, int B, ScanRegs &r)
 {
     part[tid] = scan_load(a, n, blk, tid, B, r);
 }
 /* exclusive scan inside each group, group totals to part2 */
-SASA_D void scan3_phase1(int *part, int *part2, int tid)
+SASA_D void scan_phase1(int *part, int *part2, int tid)
 {
     if (tid >= SASA_SCAN_GROUP) return;
     int run = 0;
@@ -462,17 +485,34 @@ SASA_D void scan3_phase1(int *part, int *part2, int tid)
     }
     part2[tid] = run;
 }
-SASA_D void scan3_phase2(int *part2, int tid)
+#define SASA_SCAN_SUM 1ULL  /* descriptor states: the block's own sum is known ... */
+#define SASA_SCAN_INCL 2ULL /* ... the sum of every cell up to the block's end is known */
+/* thread 0: exclusive scan of the group totals; the block's sum into its descriptor; the cells before the block
+   (*before, LDS) from the predecessors' descriptors; the block's inclusive prefix into its descriptor */
+SASA_D void scan_phase2(const PipeArgs &a, int *part2, int *before, int blk, int tid)
 {
     if (tid != 0) return;
     int run = 0;
     for (int t = 0; t < SASA_SCAN_GROUP; ++t) { const int v = part2[t]; part2[t] = run; run += v; }
+    const unsigned long long ep = (unsigned long long)(unsigned)a.scan_epoch << 34;
+    int excl = 0;
+    if (blk > 0) {
+        SASA_STORE_REL64(&a.scan_desc[blk], ep | (SASA_SCAN_SUM << 32) | (unsigned long long)(unsigned)run);
+        for (int p = blk - 1;; --p) {
+            unsigned long long d;
+            do { d = SASA_LOAD_ACQ64(&a.scan_desc[p]); } while ((d >> 34) != (ep >> 34) || ((d >> 32) & 3ULL) == 0); /* (the predecessor's workgroup is running: it took its ticket first) */
+            excl += (int)(unsigned)d;
+            if (((d >> 32) & 3ULL) == SASA_SCAN_INCL) break;
+        }
+    }
+    SASA_STORE_REL64(&a.scan_desc[blk], ep | (SASA_SCAN_INCL << 32) | (unsigned long long)(unsigned)(excl + run));
+    *before = excl;
 }
-SASA_D void scan3_phase3(const PipeArgs &a, long long n, const int *part, const int *part2, int blk, int tid, int B,
-                         ScanRegs &r)
+SASA_D void scan_phase3(const PipeArgs &a, long long n, const int *part, const int *part2, const int *before, int blk, int tid, int B,
+                        ScanRegs &r)
 {
     const long long base = ((long long)blk * B + tid) * SASA_SCAN_ITEMS;
-    int run = a.blk_sums[blk] + part2[tid / SASA_SCAN_GROUP] + part[tid];
+    int run = *before + part2[tid / SASA_SCAN_GROUP] + part[tid];
     if (base + SASA_SCAN_ITEMS <= n) {
         Int4 *p = (Int4 *)(a.cell_start + base);
         for (int k = 0; k < SASA_SCAN_ITEMS / 4; ++k) {

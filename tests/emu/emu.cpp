@@ -232,25 +232,32 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
     pa.n_chunks = (int)cs.size(); pa.chunk_struct = cs.data(); pa.chunk_begin = cb.data(); pa.chunk_len = cl.data();
     pa.struct_chunk0 = sc0.data(); pa.bpart = bpart.data();
     { /* k_bounds + k_grid */
-        std::vector<double> red(7 * PB);
+        std::vector<double> red(7 * PB), red2(7 * 16);
         for (int ch = 0; ch < pa.n_chunks; ++ch) {
             for (int t = 0; t < PB; ++t) bounds_phase0(pa, red.data(), ch, t, PB);
-            for (int t = 0; t < PB; ++t) bounds_phase1(pa, red.data(), ch, t, PB);
+            for (int t = 0; t < PB; ++t) bounds_phase1(red.data(), red2.data(), t, PB);
+            for (int t = 0; t < PB; ++t) bounds_phase2(pa, red2.data(), ch, t);
         }
-        for (int s = 0; s < n_structs; ++s) grid_struct(pa, s);
+        std::vector<double> gpart(7 * PB);
+        for (int s0 = 0; s0 < n_structs; s0 += PB / SASA_GRID_GROUP) {
+            for (int t = 0; t < PB; ++t) grid_phase0(pa, gpart.data(), s0, t);
+            for (int t = 0; t < PB; ++t) grid_phase1(pa, gpart.data(), s0, t);
+        }
     }
     { /* k_cell_base */
-        std::vector<long long> part(PB);
+        std::vector<long long> part(PB), part2(16);
         for (int t = 0; t < PB; ++t) cellbase_phase0(pa, part.data(), t, PB);
-        for (int t = 0; t < PB; ++t) cellbase_phase1(pa, part.data(), t, PB);
-        for (int t = 0; t < PB; ++t) cellbase_phase2(pa, part.data(), t, PB);
+        for (int t = 0; t < PB; ++t) cellbase_phase1(part.data(), part2.data(), t, PB);
+        for (int t = 0; t < PB; ++t) cellbase_phase1b(pa, part2.data(), t);
+        for (int t = 0; t < PB; ++t) cellbase_phase2(pa, part.data(), part2.data(), t, PB);
     }
     stats_out[0] = status[ST_ERROR];
     if (status[ST_ERROR]) return -1;
-    const long long total_cells = ncells[n_structs];
+    const long long total_cells = *cell_total(pa);
     const int nblk_scan = (int)((total_cells + 1 + (long long)PB * SASA_SCAN_ITEMS - 1) / ((long long)PB * SASA_SCAN_ITEMS));
-    std::vector<int> cell_start(total_cells + 2, 0), blk_sums(nblk_scan + 1);
-    pa.cell_start = cell_start.data(); pa.blk_sums = blk_sums.data();
+    std::vector<int> cell_start(total_cells + 2, 0);
+    std::vector<unsigned long long> scan_desc(nblk_scan + 1, 0ULL); /* (fresh descriptors are cleared once: gpu_engine.hip) */
+    pa.cell_start = cell_start.data(); pa.scan_desc = scan_desc.data(); pa.scan_epoch = 1;
 
     const int nblk_atoms = (n + PB - 1) / PB;
     for (int b = 0; b < nblk_atoms; ++b)
@@ -260,22 +267,16 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
         for (int t = 0; t < PB; ++t) count_phase1(pa, cells.data(), base.data(), t, PB);
         for (int t = 0; t < PB; ++t) count_phase2(pa, cells.data(), base.data(), b * PB + t, t);
     }
-    {
+    { /* k_scan: the chained scan, its workgroups one after the other (every look-back finds its predecessors done) */
         std::vector<int> part(PB), part2(SASA_SCAN_GROUP);
         std::vector<ScanRegs> regs(PB);
-        for (int b = 0; b < nblk_scan; ++b) {
-            for (int t = 0; t < PB; ++t) scan1_phase0(pa, total_cells, part.data(), b, t, PB);
-            for (int t = 0; t < PB; ++t) scan_group_sums(part.data(), part2.data(), t);
-            for (int t = 0; t < PB; ++t) scan1_phase2(pa, part2.data(), b, t);
-        }
-        for (int t = 0; t < PB; ++t) scan2_phase0(pa, nblk_scan, part.data(), t, PB);
-        for (int t = 0; t < PB; ++t) scan2_phase1(part.data(), t, PB);
-        for (int t = 0; t < PB; ++t) scan2_phase2(pa, nblk_scan, part.data(), t, PB);
-        for (int b = 0; b < nblk_scan; ++b) {
-            for (int t = 0; t < PB; ++t) scan3_phase0(pa, total_cells, part.data(), b, t, PB, regs[t]);
-            for (int t = 0; t < PB; ++t) scan3_phase1(part.data(), part2.data(), t);
-            for (int t = 0; t < PB; ++t) scan3_phase2(part2.data(), t);
-            for (int t = 0; t < PB; ++t) scan3_phase3(pa, total_cells, part.data(), part2.data(), b, t, PB, regs[t]);
+        for (int w = 0; w < nblk_scan; ++w) {
+            const int b = scan_take_block(pa);
+            int before = 0;
+            for (int t = 0; t < PB; ++t) scan_phase0(pa, total_cells, part.data(), b, t, PB, regs[t]);
+            for (int t = 0; t < PB; ++t) scan_phase1(part.data(), part2.data(), t);
+            for (int t = 0; t < PB; ++t) scan_phase2(pa, part2.data(), &before, b, t);
+            for (int t = 0; t < PB; ++t) scan_phase3(pa, total_cells, part.data(), part2.data(), &before, b, t, PB, regs[t]);
         }
     }
     for (int b = 0; b < nblk_atoms; ++b)
