@@ -322,17 +322,24 @@ def driver_workloads(fa, tools, local_rank, scratch):
                     fr = tools.jitter(base, 100 + f, 0.5)
                     fr.tofile(a); fr.astype(np.float32).tofile(c)
         res = {}
-        for tag, path, is32 in (("f64", f64, False), ("f32", f32, True)):
+        for tag, path, is32, o32 in (("f64", f64, False, False), ("f64_out_f32", f64, False, True), ("f32", f32, True, False)):
             tp, sp = os.path.join(scratch, f"tot_{tag}.bin"), os.path.join(scratch, f"sasa_{tag}.bin")
-            fa.trajectory_file(path, r, tp, sp, f32=is32, n_frames=24, device=local_rank)                    # warm-up
-            t0 = time.perf_counter(); done, got = fa.trajectory_file(path, r, tp, sp, f32=is32, device=local_rank); dt = time.perf_counter() - t0
+            fa.trajectory_file(path, r, tp, sp, f32=is32, out_f32=o32, n_frames=104, device=local_rank)   # warm-up: 8 shards, so that EVERY lane's context, page-locked staging and tile shape exist (24 frames - two shards - left the third lane cold in rounds 4 and 5: ~50 ms of a 0.38 s run)
+            for q in (tp, sp):   # fresh result files: until round 6 the timed call began by TRUNCATING the warm-up's (rounds 4-5: the full
+                if os.path.exists(q): os.unlink(q)   # previous run's) 0.8 GB file - freeing its page-cache pages took ~50 ms of a 0.35 s run, and was read as "page-cache writes bind"
+            t0 = time.perf_counter(); done, got = fa.trajectory_file(path, r, tp, sp, f32=is32, out_f32=o32, device=local_rank); dt = time.perf_counter() - t0
             res[tag] = {"value": n_atoms * n_frames / dt, "unit": "atom-frames/s", "seconds": dt, "frames": int(got), "complete": bool(done),
-                        "in_GB_per_s": (12 if is32 else 24) * n_atoms * n_frames / dt / 1e9, "out_GB_per_s": 8 * n_atoms * n_frames / dt / 1e9}
+                        "in_GB_per_s": (12 if is32 else 24) * n_atoms * n_frames / dt / 1e9,
+                        "writer_GB_per_s": (4 if o32 else 8) * n_atoms * n_frames / dt / 1e9}
+        tp = os.path.join(scratch, "tot_only.bin")
+        t0 = time.perf_counter(); fa.trajectory_file(f64, r, tp, None, device=local_rank); dt = time.perf_counter() - t0
+        res["totals_only"] = {"value": n_atoms * n_frames / dt, "unit": "atom-frames/s", "seconds": dt}
         t64 = np.fromfile(os.path.join(scratch, "tot_f64.bin"))
         res["value"], res["unit"] = res["f64"]["value"], "atom-frames/s"
         res["mean_total_A2"] = float(t64.mean())
         res["workload"] = (f"{n_frames} frames x {n_atoms} atoms (globule + 0.5 A jitter) from a raw frame file (page cache warm), freesasa_gpu_trajectory_file: "
-                           "totals file + per-atom areas file (8 B per atom-frame) written; fp64 frames, and fp32 frames widened on the device; 3 host lanes")
+                           "totals file + per-atom areas file written (8 B per atom-frame; f64_out_f32: narrowed on the device to 4 B, an output "
+                           "format); fp64 frames, and fp32 frames widened on the device; 3 host lanes, all warm")
         out["trajectory_file"] = res
         for q in (f64, f32):
             pass

@@ -351,20 +351,22 @@ def trajectory(xyz_frames, radii, alg=LEE_RICHARDS, probe=1.4, resolution=20, fr
 
 def trajectory_file(frames_path, radii, totals_path, sasa_path=None, done_path=None, f32=False, header_bytes=0,
                     n_frames=0, alg=LEE_RICHARDS, probe=1.4, resolution=20, frames_per_batch=0, max_new_shards=0, device=-1,
-                    devices=None):
+                    devices=None, out_f32=False):
     """freesasa_gpu_trajectory_file(): raw frame file -> totals file (+ per-atom file), resumable through the
-    done-list at done_path.  Returns (complete, n_frames): complete is False when max_new_shards stopped the run."""
+    done-list at done_path.  Returns (complete, n_frames): complete is False when max_new_shards stopped the run.
+    f32: the frames are floats (an input format); out_f32: the per-atom file holds floats (an output format)."""
     radii = _f64(radii)
+    f32 = (1 if f32 else 0) | (2 if out_f32 else 0)
     err = C.create_string_buffer(512)
     total = C.c_longlong(0)
     enc = lambda p: None if p is None else str(p).encode()
     if devices is None:
-        ret = lib().freesasa_gpu_trajectory_file(enc(frames_path), 1 if f32 else 0, header_bytes, radii.ctypes.data_as(_dp), radii.size,
+        ret = lib().freesasa_gpu_trajectory_file(enc(frames_path), f32, header_bytes, radii.ctypes.data_as(_dp), radii.size,
                                                  n_frames, alg, probe, resolution, frames_per_batch, enc(totals_path), enc(sasa_path),
                                                  enc(done_path), max_new_shards, device, C.byref(total), err, 512)
     else:
         keep, dp_, nd = _devs(devices, device)
-        ret = lib().freesasa_gpu_trajectory_file_devices(enc(frames_path), 1 if f32 else 0, header_bytes, radii.ctypes.data_as(_dp), radii.size,
+        ret = lib().freesasa_gpu_trajectory_file_devices(enc(frames_path), f32, header_bytes, radii.ctypes.data_as(_dp), radii.size,
                                                          n_frames, alg, probe, resolution, frames_per_batch, enc(totals_path), enc(sasa_path),
                                                          enc(done_path), max_new_shards, dp_, nd, C.byref(total), err, 512)
     if ret < 0:

@@ -54,6 +54,7 @@ hipError_t kl_residue_areas(const double *d_sasa, const unsigned char *d_class, 
                             const short *d_ref_row, const double *d_ref_table, double *d_abs, double *d_rel, int n_res, hipStream_t st);
 hipError_t kl_arc_kat(const double *d_arcs, const int *d_first, int n_sets, double *d_out, hipStream_t st);
 hipError_t kl_widen_f32(const float *d_in, double *d_out, long long n, hipStream_t st);
+hipError_t kl_narrow_f64(const double *d_in, float *d_out, long long n, hipStream_t st);
 void kl_dump_phase_clocks(void); /* (dev builds with -DSASA_PHASE_TIMING; else nothing) */
 
 /* ------------------------------------------------------------------ context (gpu_engine.hip) */

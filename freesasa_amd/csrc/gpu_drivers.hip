@@ -28,6 +28,7 @@
 #include <string>
 #include <sys/stat.h>
 #include <thread>
+#include <time.h>
 #include <unistd.h>
 #include <vector>
 
@@ -464,6 +465,7 @@ struct TrajIO {
     int fd_totals = -1, fd_sasa = -1;
     int fd_done = -1;               /* done-list (append) */
     std::vector<char> done;         /* shards already recorded */
+    int out_f32 = 0;                /* per-atom areas written as fp32 (narrowed on the device; an output format) */
 };
 
 /* returns 0: all shards done, 1: stopped after max_new shards (more left), -1: error */
@@ -475,8 +477,11 @@ int traj_run(TrajIO &io, const double *radii, int n_atoms, long long n_frames, i
     const long long n_shards = (n_frames + frames_per_batch - 1) / frames_per_batch;
     if (io.done.size() < (size_t)n_shards) io.done.resize((size_t)n_shards, 0);
     if (lanes_per_device <= 0) {
-        /* three lanes keep one device's PCIe in, kernels and PCIe out busy (measured, round 2); with several devices
-           the lanes also share the granted CPUs (a lane reads, copies and writes on the host): two each at least */
+        /* three lanes keep one device's PCIe in, kernels and PCIe out busy (measured, round 2; round 6, from and to files on the
+           MI355X box, 600 frames x 100 000 atoms: 3 lanes 2.97e8, 6 lanes 3.10e8 atom-frames/s with two of the three contexts
+           cold - the kernel trace shows the tile kernels of the lanes back to back, 2.9 ms per shard of 1.2e6 atoms: the
+           driver runs at the rate of the kernels); with several devices the lanes also share the granted
+           CPUs (a lane reads, copies and writes on the host): two each at least */
         lanes_per_device = 3;
         if (n_devices > 1) {
             const int per = freesasa_ingest_usable_cpus() / n_devices;
@@ -498,6 +503,10 @@ int traj_run(TrajIO &io, const double *radii, int n_atoms, long long n_frames, i
     std::atomic<int> stopped(0);
     std::mutex done_mu;
     FirstError fe;
+    /* dev aid (FREESASA_AMD_TRAJ_PROFILE): where the lanes' host time goes - read, waiting for the device, write, flush */
+    const bool prof = getenv("FREESASA_AMD_TRAJ_PROFILE") != nullptr;
+    std::atomic<long long> t_read(0), t_dev(0), t_write(0), t_flush(0);
+    auto now_ns = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (long long)ts.tv_sec * 1000000000LL + ts.tv_nsec; };
     auto lane = [&](int id) noexcept {
       try {
         PoolLease lease(devices[id % n_devices]); /* lanes 0 .. n_devices-1 open one device each, the next n_devices the second lane of each, ... */
@@ -517,13 +526,14 @@ int traj_run(TrajIO &io, const double *radii, int n_atoms, long long n_frames, i
             do {
                 if (hipSetDevice(c->device) != hipSuccess) { ctx_fail(c, "hipSetDevice failed"); break; }
                 if (ensure(c, c->h_xyz, 24 * n * FB) || ensure(c, c->h_radii, 8 * n) || ensure(c, c->h_sasa, 8 * n * FB) ||
-                    ensure(c, c->h_totals, 8 * FB) || (io.in_f32 && ensure(c, c->h_counts, 12 * n * FB)))
+                    ensure(c, c->h_totals, 8 * FB) || ((io.in_f32 || io.out_f32) && ensure(c, c->h_counts, (io.in_f32 ? 12 * n * FB : 0) + (io.out_f32 ? 4 * n * FB : 0))))
                     break;
                 if (!radii_up) { /* once per lane: the radii of the system */
                     if (hipMemcpyAsync(c->h_radii.p, radii, 8 * n, hipMemcpyHostToDevice, c->stream) != hipSuccess) { ctx_fail(c, "radii upload failed"); break; }
                     radii_up = true;
                 }
                 const void *src;
+                long long tp0 = prof ? now_ns() : 0;
                 if (io.mem_in && in_pinned) {
                     src = io.mem_in + 3 * n * (size_t)f0;
                 } else {
@@ -535,6 +545,7 @@ int traj_run(TrajIO &io, const double *radii, int n_atoms, long long n_frames, i
                     }
                     src = c->stage_in;
                 }
+                if (prof) { const long long t = now_ns(); t_read += t - tp0; tp0 = t; }
                 if (io.in_f32) {
                     if (hipMemcpyAsync(c->h_counts.p, src, in_bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) { ctx_fail(c, "host-to-device copy failed"); break; }
                     if (kl_widen_f32((const float *)c->h_counts.p, (double *)c->h_xyz.p, (long long)(3 * na), c->stream) != hipSuccess) { ctx_fail(c, "widening launch failed"); break; }
@@ -549,23 +560,35 @@ int traj_run(TrajIO &io, const double *radii, int n_atoms, long long n_frames, i
                 if (rb) break;
                 double *dst_tot = io.totals_mem ? io.totals_mem + f0 : nullptr, *dst_sasa = io.sasa_mem ? io.sasa_mem + n * (size_t)f0 : nullptr;
                 const bool staged = !(io.totals_mem && out_pinned);
+                const size_t eb = io.out_f32 ? 4 : 8; /* bytes per per-atom area in the result file */
                 if (staged) {
                     if (ensure_pinned(c, &c->stage_out, &c->stage_out_cap, 8 * (size_t)nf + (want_sasa ? 8 * na : 0))) break;
                     dst_tot = (double *)c->stage_out;
                     dst_sasa = want_sasa ? (double *)c->stage_out + nf : nullptr;
                 }
+                const void *d_areas = c->h_sasa.p;
+                if (want_sasa && io.out_f32) { /* (file output only) narrowed on the device: half the bytes over PCIe and into the file */
+                    if (ensure(c, c->h_counts, 4 * n * FB + (io.in_f32 ? 12 * n * FB : 0))) break;
+                    float *d32 = (float *)((char *)c->h_counts.p + (io.in_f32 ? 12 * n * FB : 0));
+                    if (kl_narrow_f64((const double *)c->h_sasa.p, d32, (long long)na, c->stream) != hipSuccess) { ctx_fail(c, "narrowing launch failed"); break; }
+                    d_areas = d32;
+                }
                 bool ok = hipMemcpyAsync(dst_tot, c->h_totals.p, 8 * (size_t)nf, hipMemcpyDeviceToHost, c->stream) == hipSuccess;
-                if (ok && want_sasa) ok = hipMemcpyAsync(dst_sasa, c->h_sasa.p, 8 * na, hipMemcpyDeviceToHost, c->stream) == hipSuccess;
+                if (ok && want_sasa) ok = hipMemcpyAsync(dst_sasa, d_areas, eb * na, hipMemcpyDeviceToHost, c->stream) == hipSuccess;
                 if (!ok) { ctx_fail(c, "device-to-host copy failed"); break; }
                 if (hipStreamSynchronize(c->stream) != hipSuccess) { ctx_fail(c, "stream synchronize failed"); break; }
+                if (prof) { const long long t = now_ns(); t_dev += t - tp0; tp0 = t; }
+                const long long sasa_off = (long long)eb * (long long)n * f0;
                 if (staged) {
                     if (io.totals_mem) memcpy(io.totals_mem + f0, dst_tot, 8 * (size_t)nf);
                     if (io.sasa_mem) memcpy(io.sasa_mem + n * (size_t)f0, dst_sasa, 8 * na);
                     if (io.fd_totals >= 0 && !pwrite_all(io.fd_totals, dst_tot, 8 * (size_t)nf, 8 * f0)) { ctx_fail(c, "could not write the totals file"); break; }
-                    if (io.fd_sasa >= 0 && !pwrite_all(io.fd_sasa, dst_sasa, 8 * na, 8 * (long long)n * f0)) { ctx_fail(c, "could not write the per-atom file"); break; }
+                    if (io.fd_sasa >= 0 && !pwrite_all(io.fd_sasa, dst_sasa, eb * na, sasa_off)) { ctx_fail(c, "could not write the per-atom file"); break; }
                 }
+                if (prof) { const long long t = now_ns(); t_write += t - tp0; tp0 = t; }
                 if (io.fd_done >= 0) { /* results first, then the record: a shard is listed only when its numbers are on disk */
-                    if ((io.fd_totals >= 0 && fdatasync(io.fd_totals) != 0) || (io.fd_sasa >= 0 && fdatasync(io.fd_sasa) != 0)) {
+                    const bool flushed = (io.fd_totals < 0 || fdatasync(io.fd_totals) == 0) && (io.fd_sasa < 0 || fdatasync(io.fd_sasa) == 0);
+                    if (!flushed) {
                         ctx_fail(c, "could not flush the result files: the shard is not listed as done"); break;
                     }
                     char line[96];
@@ -573,6 +596,7 @@ int traj_run(TrajIO &io, const double *radii, int n_atoms, long long n_frames, i
                     std::lock_guard<std::mutex> lk(done_mu);
                     if (write(io.fd_done, line, (size_t)len) != len || fdatasync(io.fd_done) != 0) { ctx_fail(c, "could not append to the done-list"); break; }
                 }
+                if (prof) t_flush += now_ns() - tp0;
                 io.done[(size_t)k] = 1;
                 rc = 0;
             } while (0);
@@ -593,6 +617,8 @@ int traj_run(TrajIO &io, const double *radii, int n_atoms, long long n_frames, i
             if (!tg.spawn(lane, k)) { fe.set("could not start a worker thread"); break; }
         if (!fe.failed.load()) lane(0);
     }
+    if (prof) fprintf(stderr, "trajectory lanes %d: per lane, ms: read %.1f  device (copies + kernels) %.1f  write %.1f  flush + done-list %.1f\n", n_lanes,
+                      1e-6 * t_read.load() / n_lanes, 1e-6 * t_dev.load() / n_lanes, 1e-6 * t_write.load() / n_lanes, 1e-6 * t_flush.load() / n_lanes);
     if (fe.failed.load()) return set_err(err_out, err_len, fe.text);
     return stopped.load() ? 1 : 0;
     });
@@ -700,7 +726,7 @@ extern "C" int freesasa_gpu_trajectory_file_devices(const char *frames_path, int
         if (io.fd_in < 0) { set_err(err_out, err_len, "cannot open the frame file"); break; }
         struct stat st;
         if (fstat(io.fd_in, &st) != 0) { set_err(err_out, err_len, "cannot stat the frame file"); break; }
-        const long long frame_bytes = (frames_f32 ? 12LL : 24LL) * n_atoms;
+        const long long frame_bytes = ((frames_f32 & 1) ? 12LL : 24LL) * n_atoms;
         const long long in_file = ((long long)st.st_size - header_bytes) / frame_bytes;
         if (n_frames <= 0) n_frames = in_file;
         if (n_frames <= 0 || n_frames > in_file) { set_err(err_out, err_len, "the frame file holds fewer frames than asked for"); break; }
@@ -708,7 +734,8 @@ extern "C" int freesasa_gpu_trajectory_file_devices(const char *frames_path, int
         if (frames_per_batch <= 0) frames_per_batch = (int)(1250000 / n_atoms) + 1;
         if (frames_per_batch > n_frames) frames_per_batch = (int)n_frames;
         if ((long long)frames_per_batch * n_atoms > (1LL << 30)) { set_err(err_out, err_len, "batch too large"); break; }
-        io.in_f32 = frames_f32 ? 1 : 0; io.in_header = header_bytes;
+        io.in_f32 = (frames_f32 & 1) ? 1 : 0; io.in_header = header_bytes;
+        io.out_f32 = (frames_f32 & 2) ? 1 : 0;
         const long long n_shards = (n_frames + frames_per_batch - 1) / frames_per_batch;
         io.done.assign((size_t)n_shards, 0);
         unsigned long long hr = 1469598103934665603ULL; /* FNV-1a over the radii */
@@ -716,7 +743,7 @@ extern "C" int freesasa_gpu_trajectory_file_devices(const char *frames_path, int
         char head[384];
         snprintf(head, sizeof head, "freesasa_amd trajectory done-list v2 n_atoms=%d n_frames=%lld frames_per_batch=%d alg=%d resolution=%d probe=%.17g f32=%d "
                  "header_bytes=%lld frames_size=%lld frames_mtime=%lld.%09ld radii=%016llx\n",
-                 n_atoms, n_frames, frames_per_batch, alg, resolution, probe, io.in_f32, header_bytes, (long long)st.st_size,
+                 n_atoms, n_frames, frames_per_batch, alg, resolution, probe, io.in_f32 | (io.out_f32 << 1), header_bytes, (long long)st.st_size,
                  (long long)st.st_mtim.tv_sec, (long)st.st_mtim.tv_nsec, hr);
         bool resume = false;
         if (done_path) {

@@ -731,6 +731,17 @@ hipError_t kl_widen_f32(const float *d_in, double *d_out, long long n, hipStream
     hipLaunchKernelGGL(k_widen_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_in, d_out, n);
     return hipGetLastError();
 }
+/* ... and per-atom areas narrowed to fp32 for the trajectory drivers' compact output format (an OUTPUT format: computed in fp64) */
+__global__ __launch_bounds__(256) void k_narrow_f64(const double *in, float *out, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (float)in[i];
+}
+hipError_t kl_narrow_f64(const double *d_in, float *d_out, long long n, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_narrow_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_in, d_out, n);
+    return hipGetLastError();
+}
 
 void kl_dump_phase_clocks(void)
 {

@@ -245,9 +245,11 @@ int freesasa_gpu_calc_batch(const double *xyz, const double *radii, const int64_
    array is page-locked), totals_out [n_frames], sasa_out NULL or [n_frames*n_atoms].  Returns 0 / -1.
 
    freesasa_gpu_trajectory_file: frames from a file of raw little-endian frames (3*n_atoms doubles, or floats when
-   frames_f32 != 0 — an input format: they are widened on the device and all arithmetic is fp64 — at byte
+   bit 0 of frames_f32 is set — an input format: they are widened on the device and all arithmetic is fp64 — at byte
    header_bytes + f * frame size), results to files: totals_path (one double per frame at byte 8*f) and, unless
-   NULL, sasa_path (n_atoms doubles per frame).  done_path (may be NULL) is the done-list: a text file whose first
+   NULL, sasa_path (n_atoms doubles per frame; n_atoms FLOATS per frame when bit 1 of frames_f32 is set — an output
+   format, round 6: the areas are computed in fp64 and narrowed on the device, half the bytes over PCIe and on disk).
+   done_path (may be NULL) is the done-list: a text file whose first
    line holds the run's parameters, followed by one line "shard <k> <first frame> <frames>" per finished shard,
    appended after that shard's results are on disk.  A call that finds the done-list of the same run skips the
    shards listed there, so an interrupted run (crash, kill, max_new_shards) resumes where it stopped and ends

@@ -869,6 +869,12 @@ def test_trajectory_file_resumes_bit_for_bit(fa, tmp_path):
     w_tot, w_sasa = fa.trajectory(frames.astype(np.float32).astype(np.float64), r, frames_per_batch=5)
     done, _ = fa.trajectory_file(f32, r, tmp_path / "t2.bin", tmp_path / "s2.bin", f32=True, frames_per_batch=5)
     assert done and np.array_equal(read(tmp_path / "t2.bin", (nf,)), w_tot) and np.array_equal(read(tmp_path / "s2.bin", (nf, n)), w_sasa)
+    # fp32 per-atom areas are an OUTPUT format (round 6): the fp64 areas narrowed (on the device), nothing else changes
+    done, _ = fa.trajectory_file(f64, r, tmp_path / "t4.bin", tmp_path / "s4.bin", tmp_path / "d4.txt", frames_per_batch=3, out_f32=True)
+    assert done and np.array_equal(read(tmp_path / "t4.bin", (nf,)), want_tot)
+    assert np.array_equal(np.fromfile(tmp_path / "s4.bin", dtype=np.float32).reshape(nf, n), want_sasa.astype(np.float32))
+    with pytest.raises(RuntimeError, match="other parameters"):      # the done-list names the output format too
+        fa.trajectory_file(f64, r, tmp_path / "t4.bin", tmp_path / "s4.bin", tmp_path / "d4.txt", frames_per_batch=3)
     # killed for real: a child process is shot with SIGKILL once the done-list shows a few shards
     big = tmp_path / "big.f64"
     many = np.concatenate([frames] * 12)               # 276 frames

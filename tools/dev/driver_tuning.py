@@ -15,17 +15,22 @@ base, r = tools.globule(n_atoms, 5)
 f64 = os.path.join(scratch, "frames.f64")
 with open(f64, "wb") as a:
     for f in range(n_frames): tools.jitter(base, 100 + f, 0.5).tofile(a)
-for lanes in (3, 4, 5, 6, 8):
+for lanes in (3, 4, 5, 6, 8, 12):
     os.environ["FREESASA_AMD_TRAJ_LANES"] = str(lanes)
     fa.lib().freesasa_gpu_release_pool()
-    fa.trajectory_file(f64, r, os.path.join(scratch, "t.bin"), os.path.join(scratch, "s.bin"), n_frames=24)
+    fa.trajectory_file(f64, r, os.path.join(scratch, "t.bin"), os.path.join(scratch, "s.bin"), n_frames=26 * lanes)  # (every lane warm)
     best = 1e9
     for _ in range(2):
+        for q in ("t.bin", "s.bin"):
+            if os.path.exists(os.path.join(scratch, q)): os.unlink(os.path.join(scratch, q))   # (fresh result files: truncating the old ones inside the call costs ~50 ms)
         t0 = time.perf_counter(); fa.trajectory_file(f64, r, os.path.join(scratch, "t.bin"), os.path.join(scratch, "s.bin")); best = min(best, time.perf_counter() - t0)
     print(f"trajectory_file lanes {lanes}: {n_atoms * n_frames / best:.3e} atom-frames/s ({best:.3f} s)", flush=True)
+    t0 = time.perf_counter(); fa.trajectory_file(f64, r, os.path.join(scratch, "t.bin"), os.path.join(scratch, "s32.bin"), out_f32=True); dt = time.perf_counter() - t0
+    print(f"   fp32 per-atom output: {n_atoms * n_frames / dt:.3e}", flush=True)
     t0 = time.perf_counter(); fa.trajectory_file(f64, r, os.path.join(scratch, "t.bin"), None); dt = time.perf_counter() - t0
     print(f"   totals only: {n_atoms * n_frames / dt:.3e}", flush=True)
 os.environ.pop("FREESASA_AMD_TRAJ_LANES")
+if len(sys.argv) > 1 and sys.argv[1] == "traj": sys.exit(0)
 # cache sweep
 px, pr, poffs, per, reps = bench.real_pdb_batch(12_000_000)
 pdb_dir = os.path.join(ROOT, "tests", "golden", "pdb")
