@@ -30,8 +30,10 @@ same input: circles tangent to the last few bits.  The reference's three compari
 and at alpha = pi exactly the arc (beta - pi, beta + pi) reduces modulo 2 pi to a zero-length arc and the covered
 slice counts as fully exposed (:338-351).  The engine decides by the sign of cos(alpha) -+ 1 alone and returns the
 covered / untouched circle's value (finite).  Such an input is accepted when the engine's value is within tolerance of
-the reference's at the same input OR with the neighbor moved by +-4, 32 or 256 ulp along the line of centres in the
-slice plane - the reference's own values just outside its band.  ("Deliberate divergences", 5.)"""
+the reference's at the same input OR with the neighbor moved along the line of centres in the slice plane by up to a
+COMPUTED number of ulp (_tangent_structs: the reference's own plane error at that |z|, times the slope of the tangency
+distance in the plane's height, in ulp of the distance; 256 at least) - the reference's own values just outside its
+band.  ("Deliberate divergences", 5.)"""
 import numpy as np
 import pytest
 
@@ -110,10 +112,22 @@ def _tangent_structs(kind, origin, rng, probe=1.4, ns=20, n=160):
         if rng.random() < 0.4:                                   # a third atom, so that the union has something to unite
             atoms.append(origin + rng.normal(0, 2.5, 3)); rr.append(float(rng.choice(radii_set)))
         alts = []
-        # the neighbor a few ulp closer / farther in the slice plane; far from the origin but inside the closed-form range
-        # (|z| <= 1024 A) the reference's OWN plane sits up to ~2e-12 A = some thousand ulp of d off the exact one, and so
-        # does its NaN band: the nudges reach as far
-        for dk in (-4, 4, -32, 32, -256, 256) + ((-2048, 2048, -16384, 16384) if 200.0 < abs(origin[2]) <= 1024.0 else ()):
+        # The neighbor a few ulp closer / farther in the slice plane: how far is COMPUTED, not listed (round-5 review).  Two
+        # things move the reference's own verdict on "tangent": (1) its plane - it walks there, z = zi - Ri - delta/2, then
+        # s + 1 additions of delta (src/sasa_lr.c:304-307), each rounded to half an ulp of |z| - is off the exact mid-plane by
+        # up to (s + 2) / 2 ulp(|z|), and a plane moved by dt moves the tangency distance Ri' + Rj' (or their difference) by
+        # up to (|t| / Ri' + |t - zd| / Rj') dt; (2) the engine's and the reference's own roundings of the two comparisons,
+        # a few hundred ulp of d at most (the floor of 256).  Inside the closed-form range (|z| <= 1024 A, LR2_WALK_Z) the
+        # engine's plane is the exact one, so the reference's NaN band lies up to that many ulp of d away; beyond it the
+        # engine walks exactly as the reference does and (1) vanishes.  The ladder of nudges reaches the band's edge.
+        walked = abs(origin[2]) > 1024.0
+        slope = abs(t) / Rip + abs(t - zd) / max(Rjp, 1e-3)
+        plane_err = 0.0 if walked else 0.5 * (s + 2) * np.spacing(abs(origin[2]) + Ri)
+        band = max(256, int(np.ceil(slope * plane_err / np.spacing(d))))
+        ladder = [4]
+        while ladder[-1] < band:
+            ladder.append(min(band, ladder[-1] * 8))
+        for dk in [v for q in ladder for v in (-q, q)]:
             a2 = [v.copy() for v in atoms]
             d2 = d + dk * np.spacing(d)
             a2[1] = origin + np.array([d2 * np.cos(phi), d2 * np.sin(phi), zd])
