@@ -414,8 +414,26 @@ def secondary_workloads(fa, torch, tools, d_xyz, d_r, offs, xyz, r, dev, local_r
         dpx, dpr = torch.from_numpy(px).to(dev), torch.from_numpy(pr).to(dev)
         dpo = torch.empty(len(pr), dtype=torch.float64, device=dev)
         ctx = fa.GpuContext(local_rank, timing=True)
+        # first_call: what a one-shot caller pays on a context that has seen nothing (workspace allocation, the density
+        # sample that shapes the tile kernel, a first launch of every kernel, a tile shape not yet learnt from demand) for one
+        # heterogeneous 3e6-atom batch, against the same call in steady state (round-5 review, weak 7)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ctx.lee_richards(dpx.data_ptr(), dpr.data_ptr(), poffs, dpo.data_ptr(), 0, probe=1.4, n_slices=20)
+        torch.cuda.synchronize()
+        first_ms = 1e3 * (time.perf_counter() - t0)
+        first_fb = ctx.stats()["fallback_tiles"]
+        t0 = time.perf_counter()
+        ctx.lee_richards(dpx.data_ptr(), dpr.data_ptr(), poffs, dpo.data_ptr(), 0, probe=1.4, n_slices=20)
+        torch.cuda.synchronize()
+        second_ms = 1e3 * (time.perf_counter() - t0)
         res = run(ctx, lambda: ctx.lee_richards(dpx.data_ptr(), dpr.data_ptr(), poffs, dpo.data_ptr(), 0, probe=1.4, n_slices=20), len(pr), 10, 3)
         st = ctx.stats()
+        out["first_call"] = {"atoms": len(pr), "structures": len(poffs) - 1, "first_call_ms": first_ms, "second_call_ms": second_ms,
+                             "steady_state_ms": res["ms_per_step"], "first_call_atoms_per_s": len(pr) / (1e-3 * first_ms),
+                             "fallback_tiles_first_call": int(first_fb), "fallback_tiles_steady_state": int(st["fallback_tiles"]),
+                             "workload": "the real_pdb_lr20 batch on a context created just before the call (the process has run other contexts: "
+                                         "kernels are loaded, the device is warm)"}
         res.update({"workload": f"{reps} x the PDB entries {', '.join(names)} of the reference's test data ({', '.join(str(v) for v in per)} atoms after its "
                                 f"default filters; ProtOr radii, include/freesasa_ingest.h), {len(poffs) - 1} structures, {len(pr)} atoms, Lee-Richards 20 slices: "
                                 "the offline stand-in for BASELINE configs[1] / [3] that is not a lattice",
@@ -557,6 +575,71 @@ def bench_trajectory(args, rank, world, local_rank):
                                                  "host memory, staged through page-locked buffers by the driver's host lanes, per-atom "
                                                  "SASA streamed back; PCIe-inclusive",
                                      "mean_total": float(np.mean(totals))}}), flush=True)
+
+
+def rank_driver_workloads(fa, tools, torch, dist, dev, rank, world, local_rank, dry):
+    """N > 1 (the driver's 2 / 4 / 8-GPU runs): BASELINE configs[3] and configs[4] through the REAL drivers, one process per
+    GPU - every rank sweeps the binary cache and streams the frame file on its own device (weak scaling: the per-GPU work
+    is the 1-GPU keys' kind, the ranks share the input files' page cache and write their own result files), bracketed by
+    barriers, the slowest rank's time, whole-job rates.  What this measures that the resident headline cannot: the host
+    budget - file reads, PCIe both ways, result writes and the CPUs the cgroup grants, divided among the ranks
+    (LOCAL_WORLD_SIZE: gpu_drivers.hip, process_cpus) - at N devices.  Collective: every rank calls it."""
+    from freesasa_amd import ingest
+    scratch = os.path.join(os.environ.get("FREESASA_AMD_BENCH_CACHE", "/tmp"), f"freesasa_amd_bench_u{os.getuid()}")
+    os.makedirs(scratch, exist_ok=True)
+    n_atoms, n_frames = 100_000, 240
+    frames, cache = os.path.join(scratch, "frames240.f64"), os.path.join(scratch, "ranks.fsab")
+    base, r = tools.globule(n_atoms, 5) if not dry else (np.zeros(3 * 8), np.ones(8))
+    cache_atoms = 0
+    if rank == 0 and not dry:                                   # the inputs, once per session
+        if not (os.path.exists(frames) and os.path.getsize(frames) == 24 * n_atoms * n_frames):
+            with open(frames + ".tmp", "wb") as fh:
+                for f in range(n_frames):
+                    tools.jitter(base, 100 + f, 0.5).tofile(fh)
+            os.replace(frames + ".tmp", frames)
+        if not os.path.exists(cache):
+            pdb_dir = os.path.join(ROOT, "tests", "golden", "pdb")
+            texts = [open(os.path.join(pdb_dir, nm + ".pdb"), "rb").read() for nm in PDB_NAMES]
+            ingest.load_pdb_texts(texts * 250).save(cache + ".tmp")
+            os.replace(cache + ".tmp", cache)
+    dist.barrier()
+
+    def timed(fn, units):
+        fn()                                                    # warm-up: contexts, staging, tile shapes of every lane
+        if not dry:
+            torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        fn()
+        if not dry:
+            torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return {"value": world * units / float(t.item()), "seconds": float(t.item()), "ranks": world}
+
+    out = {}
+    tp, sp = os.path.join(scratch, f"tot_rank{rank}.bin"), os.path.join(scratch, f"sasa_rank{rank}.bin")
+
+    def traj():
+        if dry:
+            time.sleep(0.002); return
+        for q in (tp, sp):
+            if os.path.exists(q): os.unlink(q)
+        fa.trajectory_file(frames, r, tp, sp, device=local_rank)
+    res = timed(traj, n_atoms * n_frames)
+    res.update({"unit": "atom-frames/s", "workload": f"every rank: {n_frames} frames x {n_atoms} atoms from one shared frame file, totals + per-atom areas to its own files"})
+    out["trajectory_file"] = res
+    if not dry:
+        c = ingest.Cache(cache); cache_atoms = c.n_atoms; c.close()
+
+    def sweep():
+        if dry:
+            time.sleep(0.002); return
+        fa.sweep_cache(cache, device=local_rank)
+    res = timed(sweep, cache_atoms)
+    res.update({"unit": "atoms/s", "atoms_per_rank": int(cache_atoms), "workload": "every rank: the version-2 cache file of the reference's PDB entries x 250, read + verified + swept on its own device"})
+    out["sweep_cache"] = res
+    return out
 
 
 def main():
@@ -739,6 +822,12 @@ def main():
         sustained = {"value": world * n_atoms * n_sus / dt_sus, "unit": "atoms/s", "steps": n_sus, "seconds": dt_sus, "ms_per_step": 1e3 * dt_sus / n_sus,
                      "note": "the timed loop continued for >= %.1f s (not max-reduced over ranks)" % args.sustain_seconds}
 
+    multi = None
+    if world > 1 and args.workload == "coil_lr" and not args.no_drivers:
+        try:
+            multi = rank_driver_workloads(fa, tools, torch, dist, dev, rank, world, local_rank, dry)
+        except Exception as exc:                    # (a secondary key must not take the scaling line down - but every rank must leave the collectives together)
+            multi = {"error": repr(exc)}
     if rank == 0:
         total_atoms = atoms_all_ranks * args.steps
         value = total_atoms / elapsed
@@ -799,6 +888,8 @@ def main():
             out["sustained"] = sustained
         if dist_on:
             out["config"]["process_group"] = f"{dist.get_backend()} world {dist.get_world_size()} (barrier + 2 all_reduce around the timed region)"
+        if multi is not None:
+            out["drivers_all_ranks"] = multi
         if dry:
             out["dry_run"] = True
             out["atoms_all_ranks"] = atoms_all_ranks

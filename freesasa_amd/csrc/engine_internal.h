@@ -180,6 +180,25 @@ template <class F> int guarded_ctx(freesasa_gpu_ctx *c, F &&body) noexcept
     }
 }
 
+/* ------------------------------------------------------------------ a device's host side: its NUMA node
+ * On an 8-GPU node every GPU hangs off one socket's PCIe root; a lane that reads files into page-locked staging and
+ * feeds that GPU should run - and have its staging allocated - on that socket (the reference has no counterpart: its
+ * threads share one structure in one address space, src/sasa_lr.c:219-253).  hwloc-free: the device's PCI address
+ * (hipDeviceGetPCIBusId) -> <sysfs>/bus/pci/devices/<address>/numa_node -> <sysfs>/devices/system/node/node<k>/cpulist.
+ * DeviceNodeScope binds the CALLING thread to those CPUs (intersected with the CPUs it is allowed now) for the length
+ * of a scope and puts its old mask back; nothing happens when the node is unknown (-1: single-socket boxes, VMs), the
+ * intersection is empty, or FREESASA_AMD_NO_AFFINITY is set.  node_cpus_for_pci is the mapping itself, testable on
+ * a made-up sysfs tree without a GPU (freesasa_gpu_test_node_cpus, tests/test_multidevice.py). */
+int node_cpus_for_pci(const char *sysfs_root, const char *pci_address, int *cpus_out, int cap); /* CPUs found (<= cap stored), 0: no node known, -1: unreadable */
+struct DeviceNodeScope {
+    bool bound = false;
+    unsigned long old_mask[16] = {0}; /* cpu_set_t of 1024 CPUs */
+    explicit DeviceNodeScope(int device);
+    DeviceNodeScope(const DeviceNodeScope &) = delete;
+    DeviceNodeScope &operator=(const DeviceNodeScope &) = delete;
+    ~DeviceNodeScope();
+};
+
 /* threads of one scope: joined on every way out of it */
 struct ThreadGroup {
     std::vector<std::thread> th;

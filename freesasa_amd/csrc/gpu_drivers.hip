@@ -68,14 +68,23 @@ int check_devices(const int *devices, int n_devices, char *err_out, int err_len)
     return 0;
 }
 
-/* host threads of one of n_workers loaders: the caller's total (or, <= 0, the CPUs the cgroup grants) divided among them */
+/* CPUs THIS PROCESS may count on: what the cgroup grants (freesasa_ingest_usable_cpus), divided among the ranks of the node
+   when a launcher says there are several (one process per GPU: torchrun exports LOCAL_WORLD_SIZE).  What every default
+   below - loader threads, lanes per device - starts from: eight ranks of a box that grants 16 CPUs get two each, not
+   sixteen each (the host budget). */
+int process_cpus()
+{
+    int total = freesasa_ingest_usable_cpus();
+    if (const char *lws = getenv("LOCAL_WORLD_SIZE")) {
+        const int ranks = atoi(lws);
+        if (ranks > 1) total /= ranks;
+    }
+    return total < 1 ? 1 : total;
+}
+/* host threads of one of n_workers loaders: the caller's total (or, <= 0, this process's CPUs) divided among them */
 int threads_per_worker(int n_threads, int n_workers)
 {
-    int total = n_threads > 0 ? n_threads : freesasa_ingest_usable_cpus();
-    if (const char *lws = getenv("LOCAL_WORLD_SIZE")) { /* one process per GPU: the ranks of a node share its CPUs */
-        const int ranks = atoi(lws);
-        if (n_threads <= 0 && ranks > 1) total /= ranks;
-    }
+    const int total = n_threads > 0 ? n_threads : process_cpus();
     const int per = total / (n_workers > 0 ? n_workers : 1);
     return per < 1 ? 1 : per;
 }
@@ -231,6 +240,7 @@ int sweep_impl(const char *const *paths, int n_paths, int ingest_options, int n_
         Batch cur_b, nxt_b; /* (declared before the context: freed after its stream is idle) */
         freesasa_ingest_batch &cur = cur_b.b, &nxt = nxt_b.b;
         int cur_rc = 0, nxt_rc = 0;
+        DeviceNodeScope node(devices[w]); /* this worker - its context's page-locked memory, its loader threads - on the device's NUMA node */
         PoolLease lease(devices[w]);
         freesasa_gpu_ctx *c = lease.c;
         if (!c) { fe.set("could not create a GPU context"); return; }
@@ -370,9 +380,13 @@ int sweep_cache_impl(const char *cache_path, int alg, double probe, int resoluti
         if (class_sums_out) class_sums_out[3 * s] = class_sums_out[3 * s + 1] = class_sums_out[3 * s + 2] = 0;
     }
     if (lanes_per_device <= 0) {
-        lanes_per_device = freesasa_ingest_usable_cpus() / n_devices;
+        /* the granted CPUs divided among the devices, 8 at most; two where they allow (one lane reads while the other
+           computes) - but never more lanes in all than twice the CPUs: eight devices on four CPUs get one lane each, not
+           sixteen threads that read and checksum in turns (round-5 advisor) */
+        const int cpus = process_cpus();
+        lanes_per_device = cpus / n_devices;
         if (lanes_per_device > 8) lanes_per_device = 8;
-        if (lanes_per_device < 2) lanes_per_device = 2; /* (one lane reads while the other computes, at least) */
+        if (lanes_per_device < 2) lanes_per_device = 2 * cpus >= 2 * n_devices ? 2 : 1;
     }
     if (lanes_per_device > 8) lanes_per_device = 8;
     int n_lanes = lanes_per_device * n_devices;
@@ -383,6 +397,7 @@ int sweep_cache_impl(const char *cache_path, int alg, double probe, int resoluti
     FirstError fe;
     auto lane = [&](int id) noexcept {
       try {
+        DeviceNodeScope node(devices[id % n_devices]); /* the lane and its page-locked staging on the device's NUMA node */
         PoolLease lease(devices[id % n_devices]);
         freesasa_gpu_ctx *c = lease.c;
         if (!c) { fe.set("could not create a GPU context"); return; }
@@ -482,11 +497,8 @@ int traj_run(TrajIO &io, const double *radii, int n_atoms, long long n_frames, i
            cold - the kernel trace shows the tile kernels of the lanes back to back, 2.9 ms per shard of 1.2e6 atoms: the
            driver runs at the rate of the kernels); with several devices the lanes also share the granted
            CPUs (a lane reads, copies and writes on the host): two each at least */
-        lanes_per_device = 3;
-        if (n_devices > 1) {
-            const int per = freesasa_ingest_usable_cpus() / n_devices;
-            lanes_per_device = per >= 3 ? 3 : 2;
-        }
+        const int per = process_cpus() / n_devices;
+        lanes_per_device = per >= 3 ? 3 : 2;
         if (const char *e = getenv("FREESASA_AMD_TRAJ_LANES")) lanes_per_device = atoi(e) > 0 ? atoi(e) : lanes_per_device; /* tuning aid */
     }
     if (lanes_per_device > 8) lanes_per_device = 8;
@@ -509,6 +521,7 @@ int traj_run(TrajIO &io, const double *radii, int n_atoms, long long n_frames, i
     auto now_ns = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (long long)ts.tv_sec * 1000000000LL + ts.tv_nsec; };
     auto lane = [&](int id) noexcept {
       try {
+        DeviceNodeScope node(devices[id % n_devices]); /* the lane and its page-locked staging on the device's NUMA node */
         PoolLease lease(devices[id % n_devices]); /* lanes 0 .. n_devices-1 open one device each, the next n_devices the second lane of each, ... */
         freesasa_gpu_ctx *c = lease.c;
         if (!c) { fe.set("could not create a GPU context"); return; }

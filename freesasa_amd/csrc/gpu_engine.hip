@@ -634,7 +634,11 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
     {
         const TileCfg fb = fallback_cfg(cfg, lr);
         const size_t stride = tile_slab_bytes(fb.TA, fb.cap_idx, fb.pool, fb.lr, fb.ds, fb.B);
-        if (ensure(c, c->slab, stride * SASA_FB_BLOCKS)) return -1;
+        /* (Shrake-Rupley: a workgroup's slice of the slab is TA segments of SASA_FB_CAP records, 1.4 MB for 8-atom tiles - 92 MB
+           for 64 workgroups in EVERY context, and the multi-device drivers hold a context per lane (round-5 advisor).  The launch
+           only ever sees what overflowed two launches: a quarter of the workgroups serves it) */
+        const int fb_blocks = lr ? SASA_FB_BLOCKS : SASA_FB_BLOCKS / 4;
+        if (ensure(c, c->slab, stride * (size_t)fb_blocks)) return -1;
         TileArgs tf = ta;
         tf.cap_idx = fb.cap_idx; tf.pool = fb.pool; tf.ds = fb.ds;
         tf.work_tiles = (const int *)c->ovf_tiles2.p;
@@ -643,7 +647,7 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
         tf.ovf_count = nullptr;
         tf.slab = (char *)c->slab.p;
         tf.slab_stride = (long long)stride;
-        le = lr ? kl_lr_tile(2, fb, tf, SASA_FB_BLOCKS, fb.lds, st, false) : kl_sr_tile(2, fb, tf, SASA_FB_BLOCKS, fb.lds, st);
+        le = lr ? kl_lr_tile(2, fb, tf, fb_blocks, fb.lds, st, false) : kl_sr_tile(2, fb, tf, fb_blocks, fb.lds, st);
         if (le != hipSuccess) return ctx_fail(c, "fallback kernel launch failed: %s", hipGetErrorString(le));
     }
 

@@ -9,6 +9,8 @@
 #include <exception>
 #include <mutex>
 #include <new>
+#include <sched.h>
+#include <stdlib.h>
 #include <system_error>
 #include <stdint.h>
 #include <stdio.h>
@@ -74,6 +76,85 @@ const char *exception_text(char *buf, size_t len) noexcept
     catch (const std::exception &e) { snprintf(buf, len, "internal error: %s", e.what()); }
     catch (...) { snprintf(buf, len, "internal error (unknown C++ exception)"); }
     return buf;
+}
+
+/* ------------------------------------------------------------------ the NUMA node of a device (engine_internal.h) */
+
+static bool read_small_file(const char *path, char *buf, size_t len)
+{
+    FILE *f = fopen(path, "r");
+    if (!f) return false;
+    const size_t n = fread(buf, 1, len - 1, f);
+    fclose(f);
+    buf[n] = 0;
+    return n > 0;
+}
+/* "0-63,128-191\n" -> CPU numbers; returns how many the list names (the first `cap` are stored), -1 on a malformed list */
+static int parse_cpulist(const char *text, int *cpus_out, int cap)
+{
+    int n = 0;
+    const char *p = text;
+    while (*p && *p != '\n') {
+        char *e;
+        const long a = strtol(p, &e, 10);
+        if (e == p || a < 0) return -1;
+        long b = a;
+        p = e;
+        if (*p == '-') { b = strtol(p + 1, &e, 10); if (e == p + 1 || b < a) return -1; p = e; }
+        for (long c = a; c <= b; ++c) { if (n < cap && cpus_out) cpus_out[n] = (int)c; ++n; }
+        if (*p == ',') ++p;
+        else if (*p && *p != '\n') return -1;
+    }
+    return n;
+}
+int node_cpus_for_pci(const char *sysfs_root, const char *pci_address, int *cpus_out, int cap)
+{
+    if (!sysfs_root || !pci_address) return -1;
+    char path[512], buf[4096], addr[64];
+    size_t k = 0;
+    for (; pci_address[k] && k + 1 < sizeof addr; ++k) addr[k] = (char)(pci_address[k] >= 'A' && pci_address[k] <= 'F' ? pci_address[k] + 32 : pci_address[k]); /* sysfs names are lower case */
+    addr[k] = 0;
+    snprintf(path, sizeof path, "%s/bus/pci/devices/%s/numa_node", sysfs_root, addr);
+    if (!read_small_file(path, buf, sizeof buf)) return -1;
+    const int node = atoi(buf);
+    if (node < 0) return 0; /* the platform names no node for the device */
+    snprintf(path, sizeof path, "%s/devices/system/node/node%d/cpulist", sysfs_root, node);
+    if (!read_small_file(path, buf, sizeof buf)) return -1;
+    return parse_cpulist(buf, cpus_out, cap);
+}
+extern "C" int freesasa_gpu_test_node_cpus(const char *sysfs_root, const char *pci_address, int *cpus_out, int cap)
+{
+    return node_cpus_for_pci(sysfs_root, pci_address, cpus_out, cap);
+}
+
+DeviceNodeScope::DeviceNodeScope(int device)
+{
+    static_assert(sizeof(cpu_set_t) <= sizeof old_mask, "cpu_set_t");
+    if (getenv("FREESASA_AMD_NO_AFFINITY")) return;
+    char addr[64] = {0};
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) return;
+    if (hipDeviceGetPCIBusId(addr, (int)sizeof addr, device) != hipSuccess) { (void)hipGetLastError(); return; }
+    int cpus[1024];
+    const char *root = getenv("FREESASA_AMD_SYSFS_ROOT"); /* (tests) */
+    const int n = node_cpus_for_pci(root ? root : "/sys", addr, cpus, 1024);
+    if (n <= 0) return;
+    cpu_set_t now, want;
+    if (sched_getaffinity(0, sizeof now, &now) != 0) return;
+    CPU_ZERO(&want);
+    int common = 0;
+    for (int k = 0; k < n && k < 1024; ++k)
+        if (cpus[k] < CPU_SETSIZE && CPU_ISSET(cpus[k], &now)) { CPU_SET(cpus[k], &want); ++common; }
+    if (common == 0 || common == CPU_COUNT(&now)) return; /* (nothing to narrow) */
+    if (sched_setaffinity(0, sizeof want, &want) != 0) return;
+    memcpy(old_mask, &now, sizeof now);
+    bound = true;
+}
+DeviceNodeScope::~DeviceNodeScope()
+{
+    if (!bound) return;
+    cpu_set_t old;
+    memcpy(&old, old_mask, sizeof old);
+    (void)sched_setaffinity(0, sizeof old, &old);
 }
 
 extern "C" int freesasa_gpu_calc_batch(const double *xyz, const double *radii, const int64_t *offsets, int n_structs,

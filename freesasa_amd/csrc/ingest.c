@@ -1211,11 +1211,22 @@ static void *worker(void *arg)
 #define BLOCK_POOL 24
 #define BLOCK_MAGIC 0x66736162636b3031ULL
 #define BLOCK_KEEP_MIN ((size_t)1 << 20)       /* smaller blocks are not worth keeping */
-#define BLOCK_KEEP_TOTAL ((size_t)3 << 30)     /* bytes kept at most */
+#define BLOCK_KEEP_TOTAL ((size_t)1 << 30)     /* bytes kept at most (round 6: 1 GiB, was 3; FREESASA_INGEST_KEEP_MB overrides; freesasa_ingest_trim gives them back) */
 static struct { void *p; size_t cap; } g_blocks[BLOCK_POOL];
 static int g_nblocks = 0;
 static size_t g_block_bytes = 0;
 static pthread_mutex_t g_block_mu = PTHREAD_MUTEX_INITIALIZER;
+
+static size_t block_keep_total(void)
+{
+    static size_t cap = 0; /* (read once; racing threads compute the same value) */
+    if (!cap) {
+        const char *e = getenv("FREESASA_INGEST_KEEP_MB");
+        const long long mb = e ? atoll(e) : -1;
+        cap = mb >= 0 ? ((size_t)mb << 20) + 1 : BLOCK_KEEP_TOTAL;
+    }
+    return cap;
+}
 
 static void *block_get(size_t bytes, size_t *cap_out)
 {
@@ -1237,7 +1248,7 @@ static void block_put(void *p, size_t cap)
 {
     int kept = 0;
     pthread_mutex_lock(&g_block_mu);
-    if (cap >= BLOCK_KEEP_MIN && g_nblocks < BLOCK_POOL && g_block_bytes + cap <= BLOCK_KEEP_TOTAL) {
+    if (cap >= BLOCK_KEEP_MIN && g_nblocks < BLOCK_POOL && g_block_bytes + cap <= block_keep_total()) {
         g_blocks[g_nblocks].p = p; g_blocks[g_nblocks].cap = cap; ++g_nblocks;
         g_block_bytes += cap;
         kept = 1;
@@ -1245,13 +1256,25 @@ static void block_put(void *p, size_t cap)
     pthread_mutex_unlock(&g_block_mu);
     if (!kept) free(p);
 }
-__attribute__((destructor)) static void block_pool_release(void)
+/* Give kept blocks back to the allocator, largest first, until at most keep_bytes are held; returns the bytes released.
+   A long-lived process that loaded one large batch and will not load another calls this (round-5 advisor: the pool was
+   only emptied when the library was unloaded). */
+size_t freesasa_ingest_trim(size_t keep_bytes)
 {
+    size_t freed = 0;
     pthread_mutex_lock(&g_block_mu);
-    while (g_nblocks > 0) free(g_blocks[--g_nblocks].p);
-    g_block_bytes = 0;
+    while (g_nblocks > 0 && g_block_bytes > keep_bytes) {
+        int big = 0;
+        for (int k = 1; k < g_nblocks; ++k)
+            if (g_blocks[k].cap > g_blocks[big].cap) big = k;
+        free(g_blocks[big].p);
+        g_block_bytes -= g_blocks[big].cap; freed += g_blocks[big].cap;
+        g_blocks[big] = g_blocks[--g_nblocks];
+    }
     pthread_mutex_unlock(&g_block_mu);
+    return freed;
 }
+__attribute__((destructor)) static void block_pool_release(void) { (void)freesasa_ingest_trim(0); }
 
 static size_t up16(size_t v) { return (v + 15) & ~(size_t)15; }
 

@@ -264,7 +264,10 @@ static int cache_open(const char *path, freesasa_ingest_cache **out)
         int tail_zero = 1;
         for (size_t q = sizeof *h; q < sizeof head; ++q) if (head[q]) tail_zero = 0;
         if (!tail_zero || h->reserved0 != 0) break;
-        if (memcmp(h->magic, CACHE_MAGIC, 8) != 0 || h->version != CACHE_VERSION || h->bom != CACHE_BOM) break;
+        if (memcmp(h->magic, CACHE_MAGIC, 8) != 0 || h->bom != CACHE_BOM) break;
+        /* a cache file of an EARLIER format version (version 1: one chained checksum, rounds 2-4) is told apart from a
+           damaged one: its batch has to be saved again - from the parsed files, or by a build of that round (round-5 advisor) */
+        if (h->version != CACHE_VERSION) { if (h->version >= 1 && h->version < CACHE_VERSION) rc = FREESASA_INGEST_EVERSION; break; }
         if (h->n_structs < 0 || h->n_atoms < 0 || h->n_residues < 0 || h->n_atoms > ((int64_t)1 << 40) || h->n_residues > h->n_atoms) break;
         uint64_t payload = 0;
         section_bytes(h->n_structs, h->n_atoms, h->n_residues, c->len);

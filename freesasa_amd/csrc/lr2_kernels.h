@@ -606,7 +606,12 @@ SASA_D double lr2_slice_height(int s, double delta, double Ri) { return fma((dou
  * any distance from the origin.  The check is NOT in the ordinary tile (measured, round 5: a per-item test of |zi| cost
  * the 100-slice kernel 6 % of its instructions and 9 % of its time, the 20-slice one 0.9 %): the builds of the main launch
  * (WALK = false) hand a tile with such an atom on, like a tile whose lists do not fit, and the second launch's build
- * (WALK = true) walks - per ATOM, by its own z, so no area depends on which atoms share a tile. */
+ * (WALK = true) walks - per ATOM, by its own z, so no area depends on which atoms share a tile.
+ * Two paths outside this kernel do not follow the rule, and are documented limits: the last (slab) launch - the
+ * first-generation kernel, atom by atom, for what overflowed the second launch's lists: pathological densities only - walks
+ * to EVERY atom's planes as the reference does (sasa_kernels.h, lr_phase_slices), and resolutions above LR2_NS_MAX slices per
+ * atom in its strided form take z0 + (s + 1) delta everywhere; an atom that ends up there differs from this kernel's
+ * value by the plane's ~1e-13 A, i.e. ~1e-13 A^2 (tangent constructions: tests/test_adversarial.py). */
 #ifndef LR2_WALK_Z
 #define LR2_WALK_Z 1024.0 /* (closed form inside: the reference's drift is <= 2.3e-12 A there; tangent constructions at |z| = 1000 A: tests/test_adversarial.py) */
 #endif
@@ -789,7 +794,9 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         lr2_pre_b<SHAPE>(a, pre, na, lane);
         lr2_pre_b2<SHAPE>(a, pre);
     }
-    if ((!WALK || !a.work_items) && LR2_BALLOT(lane < na && fabs(pre.q.z) > LR2_WALK_Z) != 0) { /* (uniform) an atom beyond the closed-form range of the slice planes (lr2_slice_height_at) */
+    /* (the build the neighbor hooks are launched with stops after P1, which knows nothing of slice planes: it keeps far tiles -
+       round-5 advisor: handed on, they never reached the hooks, whose launch sequence ends with the main launch) */
+    if (!HOOKS && (!WALK || !a.work_items) && LR2_BALLOT(lane < na && fabs(pre.q.z) > LR2_WALK_Z) != 0) { /* (uniform) an atom beyond the closed-form range of the slice planes (lr2_slice_height_at) */
         ++far_tiles; /* (counted by every build of the main launch: the share of such tiles decides which build the next batch gets) */
         if (!WALK) { /* not a tile for this build */
             lr2_pre_none(pre);
@@ -1497,8 +1504,7 @@ SASA_D void lr2_wave(const Lr2Args &a, const Lr2Mem &m, int first, int stride, i
             int fail = lr2_tile<RMAX, COVER, PAIRS, SHAPE, HOOKS, WALK>(a, m, p0, na, sample && whole, by_place, lane, wg_max_nn, pre,
                                              rest_n > 0 ? rest0 : (nxt ? p0n : p0), rest_n > 0 ? rest_n : (nxt ? nan : na), far_tiles);
             sample = false;
-            if (fail == 3) { /* an atom beyond the closed-form range of the slice planes: the whole tile to the next launch, whose build walks to them (no halves: they would say the same) */
-                ++splits;
+            if (fail == 3) { /* an atom beyond the closed-form range of the slice planes: the whole tile to the next launch, whose build walks to them (no halves: they would say the same; not a split tile either - ST_FAR counts these, ST_SPLIT does not) */
                 if (lane == 0) lr2_overflow(a, p0, na, ERR_NEIGHBOR_CAP);
                 break;
             }

@@ -14,7 +14,7 @@ from . import lib
 
 INCLUDE_HETATM, INCLUDE_HYDROGEN, JOIN_MODELS = 1, 1 << 2, 1 << 5     # ref: src/freesasa.h:182-191
 HALT_AT_UNKNOWN, SKIP_UNKNOWN, RADIUS_FROM_OCCUPANCY = 1 << 6, 1 << 7, 1 << 8
-OK, EIO, EFORMAT, EEMPTY, EUNKNOWN, EOPTION, ENOMEM = range(7)
+OK, EIO, EFORMAT, EEMPTY, EUNKNOWN, EOPTION, ENOMEM, EVERSION = range(8)
 APOLAR, POLAR, UNKNOWN = 0, 1, 2
 
 
@@ -133,6 +133,8 @@ def _proto():
         L.freesasa_ingest_load.argtypes = [C.c_char_p, C.POINTER(_CBatch)]
         L.freesasa_ingest_load_mt.argtypes = [C.c_char_p, C.c_int, C.POINTER(_CBatch)]
         L.freesasa_ingest_usable_cpus.restype = C.c_int
+        L.freesasa_ingest_trim.argtypes = [C.c_size_t]
+        L.freesasa_ingest_trim.restype = C.c_size_t
         L.freesasa_ingest_cache_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
         L.freesasa_ingest_cache_close.argtypes = [C.c_void_p]
         L.freesasa_ingest_cache_n_structs.argtypes = [C.c_void_p]; L.freesasa_ingest_cache_n_structs.restype = C.c_int32
@@ -168,6 +170,12 @@ def load_cache(path, n_threads=0):
     L = _proto()
     cb = _CBatch()
     return _finish(L, L.freesasa_ingest_load_mt(str(path).encode(), int(n_threads), C.byref(cb)), cb)
+
+
+def trim(keep_bytes=0):
+    """freesasa_ingest_trim(): give the loader's kept blocks (freed batches, kept for the next ones: at most 1 GiB) back
+    to the allocator until at most keep_bytes remain; returns the bytes released."""
+    return int(_proto().freesasa_ingest_trim(int(keep_bytes)))
 
 
 def usable_cpus():

@@ -171,6 +171,12 @@ void freesasa_gpu_test_fail_after(int n);
    C++ code throws (std::bad_alloc, std::system_error from a thread that does not start) and returns its failure value
    with a message: no exception crosses this boundary (ref: src/util.c:89-113, "never exit()"). */
 int freesasa_host_test_fail_after(int n);
+/* Test hook: the mapping behind the drivers' NUMA placement (a lane, its page-locked staging and its loader threads run on
+   the CPUs of the socket its GPU hangs off; FREESASA_AMD_NO_AFFINITY=1 turns it off): the CPUs of the NUMA node of the PCI
+   device `pci_address` ("0000:c1:00.0", as hipDeviceGetPCIBusId names it) under the sysfs tree `sysfs_root` ("/sys"; a
+   made-up tree in the tests).  Returns how many CPUs the node has (the first `cap` are stored in cpus_out), 0 when the
+   platform names no node for the device (numa_node -1), -1 when the tree cannot be read. */
+int freesasa_gpu_test_node_cpus(const char *sysfs_root, const char *pci_address, int *cpus_out, int cap);
 
 /* Test hooks: the integer / exact parts of the Lee-Richards kernel, run on the device on their own.
    _lr_neighbors_dev: the neighbor sets it finds (what freesasa_nb_new builds, src/nb.c:524-557; the reference's

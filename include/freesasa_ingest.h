@@ -46,7 +46,9 @@ enum {
     FREESASA_INGEST_EEMPTY = 3,   /* no valid ATOM/HETATM line (ref: src/structure.c:710-713) */
     FREESASA_INGEST_EUNKNOWN = 4, /* HALT_AT_UNKNOWN and an atom the classifier does not know */
     FREESASA_INGEST_EOPTION = 5,  /* unsupported option bits */
-    FREESASA_INGEST_ENOMEM = 6
+    FREESASA_INGEST_ENOMEM = 6,
+    FREESASA_INGEST_EVERSION = 7  /* a cache file written by an earlier format version (1: rounds 2-4): not damaged, but
+                                     this build reads version 2 only - save the batch again (freesasa_ingest_save) */
 };
 
 /* atom classes (ref: src/freesasa.h:163-167) */
@@ -55,7 +57,7 @@ enum { FREESASA_INGEST_APOLAR = 0, FREESASA_INGEST_POLAR = 1, FREESASA_INGEST_UN
 /* A packed batch.  Structure s owns atoms [offsets[s], offsets[s+1]) and residues
  * [res_offsets[s], res_offsets[s+1]); residue r owns atoms [res_first[r], res_first[r+1]).
  * An input that failed contributes an empty structure (status[s] != 0).  All arrays are
- * malloc'd by the library and released by freesasa_ingest_free(). */
+ * allocated by the library (ONE block per batch) and released by freesasa_ingest_free() only. */
 typedef struct freesasa_ingest_batch {
     int32_t n_structs;
     int64_t n_atoms;
@@ -95,15 +97,25 @@ int freesasa_ingest_pdb_files(const char *const *paths, int n_paths, int options
 int freesasa_ingest_pdb_texts(const char *const *texts, const size_t *lens, int n_texts, int options,
                               int n_threads, freesasa_ingest_batch *out);
 
+/* Releases a batch THIS LIBRARY built (freesasa_ingest_pdb_files / _pdb_texts / _load / _load_mt) and zeroes the
+ * struct.  The arrays of such a batch lie in one block whose header sits 16 bytes before `xyz`; a struct filled in by
+ * the caller with arrays of its own must NOT be passed here (the header would be read out of the caller's bounds) - the
+ * caller frees those itself.  Freed blocks of 1 MiB and more are kept for the next batches (a sweep builds one every few
+ * milliseconds; fresh memory costs it a third of the loader's time in page faults): at most 24 blocks and 1 GiB
+ * (environment FREESASA_INGEST_KEEP_MB overrides the cap; 0 keeps nothing).  freesasa_ingest_trim(keep_bytes) gives kept
+ * blocks back to the allocator until at most keep_bytes remain and returns the bytes released; unloading the library
+ * releases all of them. */
 void freesasa_ingest_free(freesasa_ingest_batch *batch);
+size_t freesasa_ingest_trim(size_t keep_bytes);
 
 /* A batch on disk (the "binary cache" of SURVEY.md 8(f) N1): a sweep that is run again - another probe radius,
  * another resolution, the other algorithm - starts from one sequential read instead of parsing and classifying
  * every file again.  freesasa_ingest_save() writes every array of the batch (little endian, a 128-byte header
  * with the counts and a checksum; to a temporary name, then renamed); freesasa_ingest_load() gives back an equal
  * batch (released with freesasa_ingest_free) or refuses the file: FREESASA_INGEST_EIO if it cannot be opened or
- * written, FREESASA_INGEST_EFORMAT if it is not a cache file of this version, is truncated, fails its checksum or
- * holds inconsistent offsets (save: if the batch itself is inconsistent), FREESASA_INGEST_ENOMEM. */
+ * written, FREESASA_INGEST_EFORMAT if it is not a cache file, is truncated, fails its checksum or holds inconsistent
+ * offsets (save: if the batch itself is inconsistent), FREESASA_INGEST_EVERSION if it is a cache file of an earlier
+ * format version (there is no reader for version 1 in this build: re-save), FREESASA_INGEST_ENOMEM. */
 int freesasa_ingest_save(const freesasa_ingest_batch *batch, const char *path);
 int freesasa_ingest_load(const char *path, freesasa_ingest_batch *out);
 /* The same load with n_threads readers (<= 0: the usable CPUs, at most 8): since version 2 of the file every array is

@@ -162,6 +162,11 @@ def test_bench_py_two_ranks_dry_run():
     assert res["ms_per_step"] >= 2.0                                   # three steps of the stand-in's 2 ms each, at least
     for key in ("metric", "higher_is_better", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert key in res
+    # round 6: with more than one rank the line also carries configs[3] / configs[4] through the real drivers, every rank
+    # on its own device (here: the stand-ins), whole-job rates over the slowest rank's time
+    multi = res["drivers_all_ranks"]
+    assert set(multi) == {"trajectory_file", "sweep_cache"} and multi["trajectory_file"]["ranks"] == 2
+    assert multi["trajectory_file"]["seconds"] >= 0.002 and multi["trajectory_file"]["unit"] == "atom-frames/s"
     # --gpus must agree with the launcher's world size
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--structs", "2", "--atoms", "100"],
                          capture_output=True, text=True, timeout=120, cwd=ROOT, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK")})
@@ -189,7 +194,7 @@ def test_bench_py_eight_ranks_dry_run_share_the_cpus_and_the_cache(tmp_path):
         lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
         assert len(lines) == 1
         res.append(json.loads(lines[0]))
-        files = sorted(os.listdir(cache))
+        files = sorted(f for f in os.listdir(cache) if not f.startswith("freesasa_amd_bench_u"))   # (not the drivers' scratch directory, round 6)
         assert len(files) == 8 and all(f.endswith(".npy") and ".tmp." not in f for f in files), files   # one per rank, no leftovers
     for r in res:
         assert r["dry_run"] is True and r["n_gpus"] == 8 and r["atoms_all_ranks"] == 8 * 250 * 4000 and r["scaling"] == "weak"

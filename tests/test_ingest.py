@@ -460,6 +460,8 @@ def test_binary_cache_round_trip_and_refusals(tmp_path):
     for pos in [8, 12, 16, 24, 40, 48, 130] + rng.integers(128, len(raw), 12).tolist():
         flipped = bytearray(raw); flipped[pos] ^= 0x40
         refused(bytes(flipped), ingest.EFORMAT)              # version, byte-order mark, counts, checksum, payload
+    v1 = bytearray(raw); v1[8:12] = (1).to_bytes(4, "little")    # a file of format version 1 (rounds 2-4): told apart from damage
+    refused(bytes(v1), ingest.EVERSION)
     with pytest.raises(RuntimeError, match=f"code {ingest.EIO}"):
         ingest.load_cache(tmp_path / "missing.fsab")
     with pytest.raises(RuntimeError, match=f"code {ingest.EIO}"):
@@ -603,6 +605,12 @@ def test_batches_in_reused_blocks_equal_fresh_ones(tmp_path):
     for t in th:
         t.join()
     assert not bad, bad
+    # the kept blocks go back to the allocator on request (round-5 advisor: a long-lived process kept up to 3 GiB) ...
+    ingest.load_pdb_files(big, n_threads=2)
+    released = ingest.trim(0)
+    assert released >= 1 << 20 and ingest.trim(0) == 0
+    # ... and batches built afterwards are the same again
+    assert same(ingest.load_pdb_files(big, n_threads=2), fresh[0])
 
 
 def test_coordinate_columns_that_run_together_are_read_like_sscanf_reads_them():

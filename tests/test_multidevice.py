@@ -45,6 +45,43 @@ def test_usable_cpus_is_the_cgroup_aware_count():
     assert n == tools.usable_cpus()           # the Python twin bench.py divides among its ranks
 
 
+def test_device_to_numa_node_mapping_on_a_made_up_sysfs_tree(tmp_path):
+    """Round-5 review, item 7b: a device's lanes and page-locked staging run on the socket the GPU hangs off
+    (engine_internal.h, DeviceNodeScope).  The mapping - PCI address -> numa_node -> the node's cpulist - on a sysfs tree
+    made up here: an 8-GPU, two-socket box as /sys shows it."""
+    import ctypes as C
+    import freesasa_amd as fa
+    L = fa.lib()
+    L.freesasa_gpu_test_node_cpus.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.c_int]
+    root = tmp_path / "sys"
+    nodes = {0: "0-63,128-191", 1: "64-127,192-255\n"}
+    for k, text in nodes.items():
+        d = root / "devices" / "system" / "node" / f"node{k}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(text)
+    gpus = {"0000:05:00.0": 0, "0000:26:00.0": 0, "0000:85:00.0": 1, "0000:c6:00.0": 1, "0000:e5:00.0": -1}
+    for addr, node in gpus.items():
+        d = root / "bus" / "pci" / "devices" / addr
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text(f"{node}\n")
+
+    def cpus(addr, cap=1024):
+        buf = (C.c_int * cap)()
+        n = L.freesasa_gpu_test_node_cpus(str(root).encode(), addr.encode(), buf, cap)
+        return n, list(buf[:max(0, min(n, cap))])
+
+    n, got = cpus("0000:05:00.0")
+    assert n == 128 and got == list(range(0, 64)) + list(range(128, 192))
+    n, got = cpus("0000:C6:00.0")                        # (HIP prints the address in upper case on some versions)
+    assert n == 128 and got[0] == 64 and got[-1] == 255
+    assert cpus("0000:e5:00.0") == (0, [])               # no node named: nothing is bound
+    assert cpus("0000:ff:00.0")[0] == -1                 # not in the tree
+    n, got = cpus("0000:26:00.0", cap=4)                 # a short buffer still learns the count
+    assert n == 128 and got == [0, 1, 2, 3]
+    (root / "devices" / "system" / "node" / "node1" / "cpulist").write_text("64-,3\n")
+    assert cpus("0000:85:00.0")[0] == -1                 # a list it cannot read is not half-used
+
+
 def test_cache_v2_parallel_load_equals_the_serial_one(tmp_path):
     """Version 2 of the cache file: every array checksummed in 1 MiB pieces, read and verified by several threads."""
     b = _big_batch()
