@@ -190,11 +190,16 @@ def sr_workloads(fa, torch, tools, d_xyz, d_r, offs, xyz, r, dev, local_rank, ch
         ctx.set_timing(False)                       # (the step's wall clock without the context's event records ...)
         call()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(10):
-            call()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 10
+        import gc
+        gc.collect(); gc.disable()                  # (see secondary_workloads.run)
+        try:
+            t0 = time.perf_counter()
+            for _ in range(10):
+                call()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 10
+        finally:
+            gc.enable()
         ctx.set_timing(True)                        # (... the kernels' own durations from three further calls)
         ks, ps = [], []
         for _ in range(3):
@@ -325,9 +330,11 @@ def driver_workloads(fa, tools, local_rank, scratch):
         for tag, path, is32, o32 in (("f64", f64, False, False), ("f64_out_f32", f64, False, True), ("f32", f32, True, False)):
             tp, sp = os.path.join(scratch, f"tot_{tag}.bin"), os.path.join(scratch, f"sasa_{tag}.bin")
             fa.trajectory_file(path, r, tp, sp, f32=is32, out_f32=o32, n_frames=104, device=local_rank)   # warm-up: 8 shards, so that EVERY lane's context, page-locked staging and tile shape exist (24 frames - two shards - left the third lane cold in rounds 4 and 5: ~50 ms of a 0.38 s run)
-            for q in (tp, sp):   # fresh result files: until round 6 the timed call began by TRUNCATING the warm-up's (rounds 4-5: the full
-                if os.path.exists(q): os.unlink(q)   # previous run's) 0.8 GB file - freeing its page-cache pages took ~50 ms of a 0.35 s run, and was read as "page-cache writes bind"
-            t0 = time.perf_counter(); done, got = fa.trajectory_file(path, r, tp, sp, f32=is32, out_f32=o32, device=local_rank); dt = time.perf_counter() - t0
+            dt = 1e9
+            for _ in range(2):       # the better of two runs (0.3 s each, on a box shared with other tenants' jobs)
+                for q in (tp, sp):   # fresh result files: until round 6 the timed call began by TRUNCATING the warm-up's (rounds 4-5: the full
+                    if os.path.exists(q): os.unlink(q)   # previous run's) 0.8 GB file - freeing its page-cache pages took ~50 ms of a 0.35 s run, and was read as "page-cache writes bind"
+                t0 = time.perf_counter(); done, got = fa.trajectory_file(path, r, tp, sp, f32=is32, out_f32=o32, device=local_rank); dt = min(dt, time.perf_counter() - t0)
             res[tag] = {"value": n_atoms * n_frames / dt, "unit": "atom-frames/s", "seconds": dt, "frames": int(got), "complete": bool(done),
                         "in_GB_per_s": (12 if is32 else 24) * n_atoms * n_frames / dt / 1e9,
                         "writer_GB_per_s": (4 if o32 else 8) * n_atoms * n_frames / dt / 1e9}
@@ -365,11 +372,23 @@ def secondary_workloads(fa, torch, tools, d_xyz, d_r, offs, xyz, r, dev, local_r
         ctx.set_timing(False)
         call()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            call()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
+        # (the interpreter's cyclic garbage collector off for the timed loop: round 6 caught it stopping ONE of ten 6 ms calls
+        # for 32 ms - this process holds millions of objects by now - which read as "real_pdb_lr20 3.2e8" in two sessions)
+        import gc
+        gc.collect(); gc.disable()
+        try:
+            t0 = time.perf_counter()
+            per_call = []
+            for _ in range(steps):
+                tc = time.perf_counter()
+                call()
+                per_call.append(1e3 * (time.perf_counter() - tc))
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+        finally:
+            gc.enable()
+        if os.environ.get("FREESASA_AMD_BENCH_DEBUG"):
+            print("run(): per call ms " + " ".join(f"{v:.2f}" for v in per_call), file=sys.stderr, flush=True)
         ctx.set_timing(True)
         ks = []
         for _ in range(3):
@@ -781,6 +800,8 @@ def main():
     for _ in range(args.warmup):
         step()
     drain()
+    import gc
+    gc.collect(); gc.disable()              # (no cyclic-collector pause inside the timed region: see secondary_workloads.run)
     barrier()
     k_ms, prep_ms = [], []
     t0 = time.perf_counter()
@@ -792,6 +813,7 @@ def main():
     drain()
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if use_async:
         st = ctx.stats()
         k_ms = k_ms[2:] + [st["ms_kernel"]] if len(k_ms) > 2 else [st["ms_kernel"]]

@@ -89,6 +89,7 @@ struct freesasa_gpu_ctx {
         double *d_sasa = nullptr, *d_totals = nullptr;
         /* what completing it needs */
         int n = 0, TA = 0, mw = 0, ds = 0, lds = 0;
+        bool walk = false; /* the main launch was the walking build (far tiles stay in it: statistics) */
     } pend[2];
     /* workspace */
     DevBuf offsets, grid, ncells, sid, cell_of, rank, cell_start, blk_sums, cell_tbl, cell_first;

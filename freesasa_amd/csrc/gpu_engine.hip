@@ -220,6 +220,7 @@ static int complete_batch(freesasa_gpu_ctx *c, int n, int n_structs, int tile_at
     S.n_atoms = n; S.n_cells = total_cells; S.n_structs = n_structs;
     S.max_neighbors = status_h[ST_MAX_NN]; S.fallback_tiles = status_h[ST_OVF_TILES];
     for (int k = 0; k < 64; ++k) S.fallback_tiles += status_h[ST_SPLIT + k]; /* (L&R: tiles redone as halves) */
+    if (!c->pend[c->slot].walk) S.fallback_tiles += status_h[ST_FAR]; /* (... and tiles with an atom beyond LR2_WALK_Z, which an ordinary build of the main launch hands to the second - counted on their own since round 6, not as split tiles; the walking build keeps them) */
     S.tile_atoms = tile_atoms; S.block_threads = block_threads; S.lds_bytes = lds;
     S.ms_prep = S.ms_kernel = S.ms_total = 0;
     if (c->timing) {
@@ -373,7 +374,7 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
     }
     if (enqueue_tail(c, pa, n_structs, d_sasa, d_totals)) return -1;
     freesasa_gpu_ctx::Pend &P = c->pend[c->slot];
-    P.n = n; P.TA = cfg.TA; P.mw = cfg.mw; P.ds = cfg.ds; P.lds = cfg.lds; P.n_structs = n_structs; P.resolution = resolution;
+    P.n = n; P.TA = cfg.TA; P.mw = cfg.mw; P.ds = cfg.ds; P.lds = cfg.lds; P.n_structs = n_structs; P.resolution = resolution; P.walk = la.walk != 0;
     if (defer) return 0;
     const int rc = complete_batch(c, n, n_structs, cfg.TA, 64, cfg.lds);
     if (rc) return rc;
@@ -457,6 +458,8 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
     pa.sq = (Quad *)c->sq.p;
     pa.s_idx = (SortIdx *)c->s_idx.p;
     pa.status = (int *)c->status.p;
+    pa.cells_total = (long long *)((int *)c->status.p + ST_CELLS);
+    pa.cells_total_at = pa.cells_total - pa.ncells; /* (both 8-byte aligned device addresses) */
     if (probe != c->hint_probe) { /* launch-shape history is per (resolution, probe radius) */
         c->hint_res[0] = c->hint_res[1] = 0;
         c->hint_pool2 = 0;

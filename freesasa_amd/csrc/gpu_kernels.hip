@@ -245,7 +245,10 @@ __global__ __launch_bounds__(SORT_B) void k_sort_struct(PipeArgs a)
             }
             /* (compact cell table: a structure's cells start at a multiple of 32, its table words are its own) */
             const long long take = a.cell_tbl ? ((nc + 1 + 31) & ~31LL) : nc + 1;
-            const long long base = (long long)atomicAdd((unsigned long long *)cell_total(a), (unsigned long long)take);
+            /* (the counter lives in the status words, sasa_kernels.h ST_CELLS - addressed as an element of ncells[], the form this
+               kernel had until round 6: through a pointer of its own the compiler, at the 128-register limit of a 1024-thread
+               workgroup, put 125 registers into scratch and the kernel went from 0.28 to 0.50 ms per 1e7 atoms) */
+            const long long base = (long long)atomicAdd((unsigned long long *)&a.ncells[a.cells_total_at], (unsigned long long)take);
             if (base + nc + 1 > a.max_cells) { atomicMax(&a.status[ST_ERROR], (int)ERR_GRID_TOO_BIG); nc = -1; }
             else if (nc > (1LL << SORT_CELL_BITS)) { atomicOr(&a.status[ST_RETRY], 2); nc = -1; }
             else if (a.cells_cap > 0 && base + nc + 1 > a.cells_cap) { atomicOr(&a.status[ST_RETRY], 1); nc = -1; }

@@ -199,18 +199,23 @@ struct PipeArgs {
        gathered from by every tile.  null: the dense table. */
     unsigned long long *cell_tbl; /* [total cells / 32 + 1] bits | occupied cells before the word << 32; a structure's cells start at a multiple of 32 */
     int *cell_first;              /* [n_atoms + n_structs] first atom of an occupied cell; structure s uses entries offsets[s] + s ...; behind its last: its end */
-    unsigned long long *scan_desc; /* [scan blocks] the chained scan's block descriptors: value | state << 32 | epoch << 34 */
-    int scan_epoch;  /* 1 .. 2^30 - 1, another one for every batch of a context: descriptors of earlier batches read as "not yet" */
-    long long zero_n; /* words of cell_start[] the first kernel of the general pipeline clears (the table's capacity + 2) */
+    int *blk_sums_unused_; /* (keeps the layout the fused sort kernel was tuned with: see the end of the struct) */
     /* per atom, cell-sorted order */
     Quad *sq; /* (x, y, z, radius + probe) (ref: src/sasa_lr.c:136, sasa_sr.c:144): one 32-byte record per atom - two
                  16-byte accesses where four arrays took four, one pointer where they took four */
     SortIdx *s_idx;
     int *status;
+    /* (round 6; behind everything else: k_sort_struct sits at the 128-register limit of its 1024-thread workgroups, and
+       with these in the middle of the struct the compiler put 125 registers into scratch - 0.28 -> 0.50 ms per 1e7 atoms) */
+    long long *cells_total; /* = (long long *)(status + ST_CELLS): the batch's cell total / the fused sort's running counter */
+    long long cells_total_at; /* ... and where it lies seen from ncells[]: &ncells[cells_total_at] == cells_total (k_sort_struct addresses it this way: see there) */
+    unsigned long long *scan_desc; /* [scan blocks] the chained scan's block descriptors: value | state << 32 | epoch << 34 */
+    int scan_epoch;  /* 1 .. 2^30 - 1, another one for every batch of a context: descriptors of earlier batches read as "not yet" */
+    long long zero_n; /* words of cell_start[] the first kernel of the general pipeline clears (the table's capacity + 2) */
 };
 
 #define SASA_PIPE_B 256
-SASA_D long long *cell_total(const PipeArgs &a) { return (long long *)(a.status + ST_CELLS); }
+SASA_D long long *cell_total(const PipeArgs &a) { return a.cells_total; } /* = (long long *)(status + ST_CELLS) */
 
 /* K1a: one workgroup per CHUNK of at most SASA_BOUNDS_CHUNK atoms of one structure (a 200k-atom
  * structure is 49 chunks, not one serial workgroup).  red = LDS doubles [7][B]; the chunk's

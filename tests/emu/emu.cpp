@@ -215,7 +215,7 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
     pa.probe = probe; pa.max_cells = 1LL << 28;
     pa.grid = grid.data(); pa.ncells = ncells.data(); pa.sid = sid.data(); pa.cell_of = cell_of.data();
     pa.rank = rank.data(); pa.sq = sq.data();
-    pa.s_idx = s_idx.data(); pa.status = status.data();
+    pa.s_idx = s_idx.data(); pa.status = status.data(); pa.cells_total = (long long *)(status.data() + ST_CELLS);
 
     /* chunk table, as gpu_engine.hip builds it */
     std::vector<int> cs, cl, sc0(n_structs + 1);

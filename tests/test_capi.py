@@ -165,6 +165,10 @@ def test_hot_kernels_do_not_spill(L):
     main = [n for n in seen if n.startswith("_Z10k_lr2_tileILi4ELi0ELi4E")]
     assert main, "main L&R kernel not found in the report"
     assert seen[main[0]][0] <= 128 and seen[main[0]][1] == 0, seen[main[0]]
+    # the cell sort of a structure in one 1024-thread workgroup sits at the same limit: round 6 saw an innocent change of how
+    # one counter is ADDRESSED put 125 registers into scratch (0.28 -> 0.50 ms per 1e7 atoms) with every test green
+    sort = [n for n in seen if "k_sort_struct" in n]
+    assert sort and seen[sort[0]][0] <= 128 and seen[sort[0]][1] == 0, seen[sort[0]] if sort else None
     for n, (v, sc) in seen.items():
         if "k_lr2_tileILi" in n and "ELi0ELi4E" in n:          # every main-launch variant
             assert v <= 128 and sc == 0, (n, v, sc)
