@@ -19,7 +19,7 @@ all: $(LIBDIR)/libfreesasa_amd.so $(LIBDIR)/libfreesasa_amd_seam.a
 # Device code lives in ONE translation unit (gpu_kernels.hip); the compiler's per-kernel resource report (registers,
 # scratch, LDS) is kept next to its object: tests/test_capi.py checks that the hot kernels do not spill.  The other
 # .hip files are host code over the HIP runtime (engine_internal.h says who holds what).
-ENGINE_HDRS = $(CSRC)/engine_internal.h $(CSRC)/sasa_kernels.h $(CSRC)/lr2_kernels.h include/freesasa_gpu.h include/freesasa_ingest.h
+ENGINE_HDRS = $(CSRC)/engine_internal.h $(CSRC)/sasa_kernels.h $(CSRC)/lr2_kernels.h $(CSRC)/gpu_parse.h $(CSRC)/protor_table.h include/freesasa_gpu.h include/freesasa_ingest.h
 $(LIBDIR)/gpu_kernels.o: $(CSRC)/gpu_kernels.hip $(ENGINE_HDRS)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(LIBDIR)/kernel_resources.txt; rc=$$?; \
@@ -27,7 +27,7 @@ $(LIBDIR)/gpu_kernels.o: $(CSRC)/gpu_kernels.hip $(ENGINE_HDRS)
 $(LIBDIR)/gpu_%.o: $(CSRC)/gpu_%.hip $(ENGINE_HDRS)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-GPU_OBJS = $(LIBDIR)/gpu_kernels.o $(LIBDIR)/gpu_engine.o $(LIBDIR)/gpu_ops.o $(LIBDIR)/gpu_hostbatch.o $(LIBDIR)/gpu_drivers.o
+GPU_OBJS = $(LIBDIR)/gpu_kernels.o $(LIBDIR)/gpu_engine.o $(LIBDIR)/gpu_ops.o $(LIBDIR)/gpu_hostbatch.o $(LIBDIR)/gpu_drivers.o $(LIBDIR)/gpu_parse.o
 
 $(LIBDIR)/seam.o: $(CSRC)/seam.c include/freesasa_amd.h include/freesasa_gpu.h
 	@mkdir -p $(LIBDIR)

@@ -374,6 +374,38 @@ def trajectory_file(frames_path, radii, totals_path, sasa_path=None, done_path=N
     return ret == 0, int(total.value)
 
 
+def parse_files_dev(paths, ingest_options=0, n_threads=0, device=0):
+    """freesasa_gpu_parse_files(): the device-side PDB / mmCIF parser on its own -> (xyz [atoms, 3], radii, classes,
+    offsets [n + 1], status [n], refused [n]); a refused file (the sweep hands it to the host parser) contributes no atoms."""
+    L = lib()
+    L.freesasa_gpu_parse_files.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, C.POINTER(C.c_ubyte),
+                                           C.c_longlong, _lp, _ip, _ip, C.c_char_p, C.c_int]
+    L.freesasa_gpu_parse_files.restype = C.c_longlong
+    n = len(paths)
+    arr = (C.c_char_p * n)(*[str(p).encode() for p in paths])
+    offs, status, host = np.zeros(n + 1, dtype=np.int64), np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+    err = C.create_string_buffer(512)
+    cap = 1 << 16
+    while True:
+        xyz, r, cls = np.empty(3 * cap), np.empty(cap), np.empty(cap, dtype=np.uint8)
+        got = L.freesasa_gpu_parse_files(arr, n, ingest_options, n_threads, device, xyz.ctypes.data_as(_dp), r.ctypes.data_as(_dp),
+                                         cls.ctypes.data_as(C.POINTER(C.c_ubyte)), cap, offs.ctypes.data_as(_lp), status.ctypes.data_as(_ip),
+                                         host.ctypes.data_as(_ip), err, 512)
+        if got == -2:
+            cap = int(offs[-1]) + 16
+            continue
+        if got < 0:
+            raise RuntimeError("freesasa_gpu_parse_files: " + err.value.decode())
+        return xyz[:3 * got].reshape(-1, 3).copy(), r[:got].copy(), cls[:got].copy(), offs, status, host
+
+
+def sweep_parse_stats():
+    """(files parsed on the device, files left to the host parser) by this process's sweeps since the last call."""
+    a, b = C.c_longlong(0), C.c_longlong(0)
+    lib().freesasa_gpu_sweep_parse_stats(C.byref(a), C.byref(b))
+    return int(a.value), int(b.value)
+
+
 def host_test_fail_after(n):
     """freesasa_host_test_fail_after(): the n-th host allocation / thread creation of the library's own code fails
     (n <= 0: off); returns what was left of the previous countdown (tests/test_hostfault.py)."""

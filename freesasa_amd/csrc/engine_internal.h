@@ -117,6 +117,12 @@ struct freesasa_gpu_ctx {
     double hint_split2 = 0;   /* ... the share of its tiles above the 16-tiles-per-CU pool */
     bool hint_far = false;    /* ... a quarter or more of its tiles had an atom beyond LR2_WALK_Z: the next batch gets the walking build of the main launch */
     int hint_pool2 = 0, hint_ta2 = 0, hint_mw2 = 0; /* ... and the pool the last batch's demand histogram asks for, for tiles of that shape */
+    /* the device-side parser's workspace and what its two phases hand each other (gpu_parse.hip) */
+    DevBuf parse[11];
+    std::vector<long long> parse_off;
+    long long parse_atoms = 0;
+    int parse_lines = 0, parse_files = 0, parse_options = 0;
+    unsigned parse_T = 0;
     int *dbg_nn = nullptr, *dbg_nb = nullptr; /* test hook: freesasa_gpu_lr_neighbors_dev */
     int dbg_cap = 0;
 };

@@ -33,6 +33,7 @@
 #include <vector>
 
 #include "engine_internal.h"
+#include "gpu_parse.h"
 
 namespace {
 
@@ -113,6 +114,84 @@ struct Cache {
     ~Cache() { if (c) freesasa_ingest_cache_close(c); }
 };
 
+/* ---- the device-side parser's input (gpu_parse.hip): a batch's files read - not parsed - into page-locked memory */
+struct Staged {
+    unsigned char *text = nullptr; /* page-locked: the files one after the other, each in a slot of its size + 1 and ending with '\n' */
+    size_t cap = 0, T = 0;
+    std::vector<ParseFile> files;  /* [n + 1] */
+    int rc = 0;                    /* -1: no page-locked memory */
+    Staged() = default;
+    Staged(const Staged &) = delete;
+    Staged &operator=(const Staged &) = delete;
+    ~Staged() { if (text) (void)hipHostFree(text); }
+    void swap(Staged &o) { std::swap(text, o.text); std::swap(cap, o.cap); std::swap(T, o.T); files.swap(o.files); std::swap(rc, o.rc); }
+};
+/* n files -> out, with `threads` readers (each file: one pread loop, then the one-line-at-a-time look at an mmCIF file's text
+   before its _atom_site loop: freesasa_ingest_cif_locate); a file that cannot be read is left to the host parser, which
+   reports it */
+void stage_files(const char *const *paths, int n, int options, int threads, Staged *out)
+{
+    out->rc = 0;
+    out->files.assign((size_t)n + 1, ParseFile());
+    std::vector<long long> size((size_t)n, 0);
+    size_t T = 0;
+    for (int f = 0; f < n; ++f) {
+        struct stat st;
+        size[f] = (paths[f] && stat(paths[f], &st) == 0 && st.st_size > 0) ? (long long)st.st_size : 0;
+        out->files[f].beg = (unsigned)T;
+        T += (size_t)size[f] + 1;
+    }
+    if (T >= (1ULL << 31)) { out->rc = -2; return; }
+    out->files[n].beg = (unsigned)T;
+    out->T = T;
+    if (T + 64 > out->cap) {
+        if (out->text) (void)hipHostFree(out->text);
+        out->text = nullptr; out->cap = 0;
+        const size_t want = T + T / 8 + 4096;
+        if (host_malloc((void **)&out->text, want) != hipSuccess) { out->rc = -1; return; }
+        out->cap = want;
+    }
+    std::atomic<int> next(0);
+    auto reader = [&]() noexcept {
+        for (;;) {
+            const int f = next.fetch_add(1);
+            if (f >= n) break;
+            ParseFile &pf = out->files[f];
+            unsigned char *dst = out->text + pf.beg;
+            const size_t slot = (size_t)size[f] + 1;
+            size_t got = 0;
+            bool ok = false;
+            if (paths[f]) {
+                const int fd = open(paths[f], O_RDONLY);
+                if (fd >= 0) {
+                    ok = true;
+                    while (got < (size_t)size[f]) {
+                        const ssize_t r = pread(fd, dst + got, (size_t)size[f] - got, (off_t)got);
+                        if (r < 0) { ok = false; break; }
+                        if (r == 0) break;
+                        got += (size_t)r;
+                    }
+                    close(fd);
+                }
+            }
+            pf.no_final_nl = (got > 0 && dst[got - 1] != '\n') ? 1 : 0;
+            memset(dst + got, '\n', slot - got); /* (the slot's spare byte, and whatever a file that shrank left) */
+            pf.kind = PARSE_HOST; pf.ncol = 0; pf.row0 = 0;
+            if (!ok || (long long)got != size[f] || (options & FREESASA_INGEST_RADIUS_FROM_OCCUPANCY)) continue;
+            int ncol = 0;
+            size_t row0 = 0;
+            const int kind = freesasa_ingest_cif_locate((const char *)dst, got, &ncol, pf.slot, &row0);
+            if (kind == 0) pf.kind = PARSE_PDB;
+            else if (kind == 1) { pf.kind = PARSE_CIF; pf.ncol = (short)ncol; pf.row0 = pf.beg + (unsigned)row0; }
+        }
+    };
+    ThreadGroup tg;
+    for (int t = 1; t < threads && t < n; ++t)
+        if (!tg.spawn(reader)) break; /* (fewer readers then) */
+    reader();
+}
+std::atomic<long long> g_parse_dev_files(0), g_parse_host_files(0);
+
 /* first failure of a set of workers wins; the others stop taking work */
 struct FirstError {
     std::mutex mu;
@@ -154,7 +233,14 @@ int sweep_impl(const char *const *paths, int n_paths, int ingest_options, int n_
     if (alg != 0 && alg != 1) return set_err(err_out, err_len, "unknown algorithm");
     if (check_devices(devices, n_devices, err_out, err_len)) return -1;
     if (n_paths == 0) return 0;
-    if (batch_atoms <= 0) batch_atoms = 2000000;
+    /* (round 6, measured on the MI355X box, 1.2e7 protein atoms in 7172 files, 16 CPUs: batches of 5e5 / 1e6 / 2e6 atoms with two
+       workers on the device: parser on the device 1.57 / 1.49 / 1.08e8 atoms/s, host parser 1.25 / 1.34 / 1.31e8; one worker:
+       1.24 / 1.19 / 1.07e8 and 0.91 / 1.03 / 1.02e8) */
+    if (batch_atoms <= 0) batch_atoms = (ingest_options & FREESASA_INGEST_PARSE_ON_DEVICE) ? 500000 : 1000000;
+    /* ONE device in the list: two workers on it, so that the upload of one batch runs under the kernels of the other (a
+       worker's batch is a chain on one stream: text or arrays over PCIe, parse, cell sort, tile kernels) */
+    const int two[2] = {devices[0], devices[0]};
+    if (n_devices == 1 && !getenv("FREESASA_AMD_SWEEP_ONE_WORKER")) { devices = two; n_devices = 2; }
     return guarded(err_out, err_len, [&]() -> int {
     /* batches of roughly batch_atoms atoms, estimated from the file sizes (~81 bytes per ATOM line) */
     std::vector<int> cut(1, 0);
@@ -185,7 +271,7 @@ int sweep_impl(const char *const *paths, int n_paths, int ingest_options, int n_
         }
         char head[256];
         snprintf(head, sizeof head, "freesasa_amd sweep done-list v2 n_files=%d batches=%d files=%016llx options=%d alg=%d resolution=%d probe=%.17g\n",
-                 n_paths, n_batches, h, ingest_options, alg, resolution, probe);
+                 n_paths, n_batches, h, ingest_options & ~FREESASA_INGEST_PARSE_ON_DEVICE, alg, resolution, probe); /* (who parses does not change a result: not part of the run's name) */
         const std::string res_path = std::string(done_path) + ".bin";
         bool resume = false;
         if (FILE *fp = fopen(done_path, "r")) {
@@ -234,7 +320,127 @@ int sweep_impl(const char *const *paths, int n_paths, int ingest_options, int n_
     std::mutex done_mu;
     FirstError fe;
 
+    const bool dev_parse = (ingest_options & FREESASA_INGEST_PARSE_ON_DEVICE) != 0;
+    ingest_options &= ~FREESASA_INGEST_PARSE_ON_DEVICE;
+    /* the results of a finished batch to the result file, then its line in the done-list (both modes) */
+    auto record = [&](freesasa_gpu_ctx *c, int b, int first, int ns, const long long *atoms, const double *cls_src) -> int {
+        std::vector<SweepRec> recs((size_t)ns);
+        for (int k = 0; k < ns; ++k) {
+            SweepRec &r = recs[(size_t)k];
+            memset(&r, 0, sizeof r);
+            r.total = totals_out[first + k]; r.status = status_out[first + k];
+            r.atoms = atoms ? atoms[k] : 0;
+            if (cls_src) for (int q = 0; q < 3; ++q) r.cls[q] = cls_src[3 * k + q];
+        }
+        char line[96];
+        const int len = snprintf(line, sizeof line, "shard %d %d %d\n", b, first, ns);
+        std::lock_guard<std::mutex> lk(done_mu); /* (the records of a batch lie at their own offset; the list is appended to by one worker at a time) */
+        if (!pwrite_all(fd_res, recs.data(), sizeof(SweepRec) * recs.size(), (long long)sizeof(SweepRec) * first) || fdatasync(fd_res) != 0 ||
+            write(fd_done, line, (size_t)len) != len || fdatasync(fd_done) != 0)
+            return ctx_fail(c, "could not record the finished batch in the done-list");
+        return 0;
+    };
+
+    /* The sweep with the parser ON THE DEVICE (FREESASA_INGEST_PARSE_ON_DEVICE; gpu_parse.hip): the loader threads only READ the
+       next batch's files into page-locked memory while this batch's text is uploaded, parsed, classified and swept on the GPU.
+       Files the device refuses are read by the host parser and appended to the batch as further structures. */
+    auto worker_dev = [&](int w) noexcept {
+      try {
+        Staged cur_s, nxt_s;
+        DeviceNodeScope node(devices[w]);
+        PoolLease lease(devices[w]);
+        freesasa_gpu_ctx *c = lease.c;
+        if (!c) { fe.set("could not create a GPU context"); return; }
+        auto stage = [&](int b, Staged *out) noexcept {
+            try { stage_files(paths + cut[b], cut[b + 1] - cut[b], ingest_options, loader_threads, out); } catch (...) { out->rc = -3; }
+        };
+        size_t ti = next.fetch_add(1);
+        if (ti < todo.size()) stage(todo[ti], &cur_s);
+        while (ti < todo.size() && !fe.failed.load()) {
+            const int b = todo[ti];
+            const size_t tn = next.fetch_add(1);
+            ThreadGroup loader;
+            if (tn < todo.size() && !loader.spawn(stage, todo[tn], &nxt_s)) { fe.set("could not start a loader thread"); break; }
+            const int first = cut[b], ns = cut[b + 1] - cut[b];
+            std::vector<int> atoms((size_t)ns), status((size_t)ns), host((size_t)ns);
+            std::vector<long long> atoms64((size_t)ns, 0);
+            std::vector<double> tot, cls;
+            std::vector<int> fb;  /* the files the device left to the host parser ... */
+            Batch hb;             /* ... as the host read them (alive until the stream is idle: its arrays are copied from) */
+            int ret = -1;
+            do {
+                if (cur_s.rc) { ctx_fail(c, cur_s.rc == -1 ? "out of page-locked host memory (file staging)" : (cur_s.rc == -2 ? "a batch of files larger than 2 GB: use a smaller batch_atoms" : "out of host memory (file staging)")); break; }
+                if (hipSetDevice(c->device) != hipSuccess) { ctx_fail(c, "hipSetDevice failed"); break; }
+                long long total = 0;
+                if (parse_batch_dev_begin(c, cur_s.text, cur_s.T, cur_s.files.data(), ns, ingest_options, atoms.data(), status.data(), host.data(), &total)) break;
+                /* the files the device left to the host parser: read now, appended behind the device's atoms */
+                for (int k = 0; k < ns; ++k) if (host[(size_t)k]) fb.push_back(k);
+                g_parse_dev_files += ns - (long long)fb.size(); g_parse_host_files += (long long)fb.size();
+                if (!fb.empty()) {
+                    std::vector<const char *> fp;
+                    for (int k : fb) fp.push_back(paths[first + k]);
+                    const int lrc = freesasa_ingest_pdb_files(fp.data(), (int)fp.size(), ingest_options, loader_threads, &hb.b);
+                    if (lrc) { ctx_fail(c, "loader failed with code %d", lrc); break; }
+                }
+                const long long extra = hb.b.n_atoms, n_all = total + extra;
+                if (parse_batch_dev_finish(c, extra)) break;
+                const int nst = ns + (int)fb.size();
+                std::vector<int64_t> off((size_t)nst + 1);
+                off[0] = 0;
+                for (int k = 0; k < ns; ++k) off[(size_t)k + 1] = off[(size_t)k] + atoms[(size_t)k];
+                for (size_t j = 0; j < fb.size(); ++j) off[(size_t)ns + j + 1] = total + hb.b.offsets[j + 1];
+                for (int k = 0; k < ns; ++k) {
+                    status_out[first + k] = status[(size_t)k];
+                    totals_out[first + k] = 0;
+                    atoms64[(size_t)k] = atoms[(size_t)k];
+                    if (class_sums_out) class_sums_out[3 * (first + k)] = class_sums_out[3 * (first + k) + 1] = class_sums_out[3 * (first + k) + 2] = 0;
+                }
+                for (size_t j = 0; j < fb.size(); ++j) { status_out[first + fb[j]] = hb.b.status[j]; atoms64[(size_t)fb[j]] = hb.b.offsets[j + 1] - hb.b.offsets[j]; }
+                if (atoms_out) for (int k = 0; k < ns; ++k) atoms_out[first + k] = atoms64[(size_t)k];
+                if (n_all == 0) { ret = 0; break; }
+                if (extra > 0 &&
+                    (hipMemcpyAsync((double *)c->h_xyz.p + 3 * total, hb.b.xyz, 24 * (size_t)extra, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                     hipMemcpyAsync((double *)c->h_radii.p + total, hb.b.radii, 8 * (size_t)extra, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                     hipMemcpyAsync((unsigned char *)c->h_counts.p + total, hb.b.atom_class, (size_t)extra, hipMemcpyHostToDevice, c->stream) != hipSuccess)) {
+                    ctx_fail(c, "host-to-device copy failed");
+                    break;
+                }
+                if (ensure(c, c->h_sasa, 8 * (size_t)n_all) || ensure(c, c->h_totals, 8 * 4 * (size_t)nst)) break;
+                double *d_tot = (double *)c->h_totals.p, *d_cls = d_tot + nst;
+                if (run_batch(c, alg == 0, (double *)c->h_xyz.p, (double *)c->h_radii.p, off.data(), nst, probe, resolution,
+                              alg == 1 ? tp.data() : nullptr, (double *)c->h_sasa.p, nullptr, d_tot))
+                    break;
+                tot.resize((size_t)nst);
+                if (want_cls) {
+                    cls.resize(3 * (size_t)nst);
+                    if (freesasa_gpu_class_sums_dev(c, (double *)c->h_sasa.p, (const unsigned char *)c->h_counts.p, off.data(), nst, d_cls)) break;
+                    if (hipMemcpyAsync(cls.data(), d_cls, 8 * 3 * (size_t)nst, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { ctx_fail(c, "device-to-host copy failed"); break; }
+                }
+                if (hipMemcpyAsync(tot.data(), d_tot, 8 * (size_t)nst, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { ctx_fail(c, "device-to-host copy failed"); break; }
+                if (hipStreamSynchronize(c->stream) != hipSuccess) { ctx_fail(c, "stream synchronize failed"); break; }
+                /* structure k of the batch is file k; structure ns + j is the j-th file the host read */
+                for (int k = 0; k < ns; ++k) totals_out[first + k] = tot[(size_t)k];
+                for (size_t j = 0; j < fb.size(); ++j) totals_out[first + fb[j]] = tot[(size_t)ns + j];
+                if (want_cls) {
+                    for (size_t j = 0; j < fb.size(); ++j) for (int q = 0; q < 3; ++q) cls[3 * (size_t)fb[j] + q] = cls[3 * ((size_t)ns + j) + q];
+                    if (class_sums_out) memcpy(class_sums_out + 3 * (size_t)first, cls.data(), 8 * 3 * (size_t)ns);
+                }
+                ret = 0;
+            } while (0);
+            if (ret) (void)hipStreamSynchronize(c->stream);
+            if (!ret && fd_done >= 0 && record(c, b, first, ns, atoms64.data(), cls.empty() ? nullptr : cls.data())) ret = -1;
+            if (ret) fe.set(c->err[0] ? c->err : "GPU sweep failed");
+            loader.join();
+            cur_s.swap(nxt_s);
+            ti = tn;
+        }
+      } catch (...) {
+        fe.set_exception();
+      }
+    };
+
     auto worker = [&](int w) noexcept {
+      if (dev_parse) { worker_dev(w); return; }
       try {
         std::vector<double> cls_tmp;
         Batch cur_b, nxt_b; /* (declared before the context: freed after its stream is idle) */
@@ -292,25 +498,11 @@ int sweep_impl(const char *const *paths, int n_paths, int ingest_options, int n_
                 ret = 0;
             } while (0);
             if (ret) (void)hipStreamSynchronize(c->stream); /* no copy may still read the batch when it is freed */
-            if (!ret && fd_done >= 0) { /* the batch's results to the result file, then its line in the done-list */
-                std::vector<SweepRec> recs((size_t)ns);
-                const bool have_cls = cur.n_atoms > 0;
-                const double *cls_src = class_sums_out ? class_sums_out + 3 * (size_t)first : (have_cls ? cls_tmp.data() : nullptr);
-                for (int k = 0; k < ns; ++k) {
-                    SweepRec &r = recs[(size_t)k];
-                    memset(&r, 0, sizeof r);
-                    r.total = totals_out[first + k]; r.status = status_out[first + k];
-                    r.atoms = cur.offsets ? cur.offsets[k + 1] - cur.offsets[k] : 0;
-                    if (cls_src) for (int q = 0; q < 3; ++q) r.cls[q] = cls_src[3 * k + q];
-                }
-                char line[96];
-                const int len = snprintf(line, sizeof line, "shard %d %d %d\n", b, first, ns);
-                std::lock_guard<std::mutex> lk(done_mu); /* (the records of a batch lie at their own offset; the list is appended to by one worker at a time) */
-                if (!pwrite_all(fd_res, recs.data(), sizeof(SweepRec) * recs.size(), (long long)sizeof(SweepRec) * first) || fdatasync(fd_res) != 0 ||
-                    write(fd_done, line, (size_t)len) != len || fdatasync(fd_done) != 0) {
-                    ctx_fail(c, "could not record the finished batch in the done-list");
-                    ret = -1;
-                }
+            if (!ret && fd_done >= 0) {
+                std::vector<long long> at((size_t)ns, 0);
+                if (cur.offsets) for (int k = 0; k < ns; ++k) at[(size_t)k] = cur.offsets[k + 1] - cur.offsets[k];
+                const double *cls_src = class_sums_out ? class_sums_out + 3 * (size_t)first : (cur.n_atoms > 0 ? cls_tmp.data() : nullptr);
+                if (record(c, b, first, ns, at.data(), cls_src)) ret = -1;
             }
             if (ret) fe.set(c->err[0] ? c->err : "GPU sweep failed");
             loader.join();
@@ -640,6 +832,53 @@ int traj_run(TrajIO &io, const double *radii, int n_atoms, long long n_frames, i
 } /* namespace */
 
 /* ------------------------------------------------------------------ entry points: sweeps */
+
+/* The device-side parser on its own (tests, tools): n files -> coordinates, radii and classes of the atoms it keeps (host
+   arrays of `cap` atoms), offsets_out [n + 1], status_out [n] (the loader's codes), host_out [n] (1: the device refuses the
+   file - the sweep would hand it to the host parser - and it contributes nothing here).  Returns the atoms written, -1 on
+   error, -2 if cap is too small (offsets_out[n] says how many are needed). */
+extern "C" long long freesasa_gpu_parse_files(const char *const *paths, int n_paths, int ingest_options, int n_threads, int device,
+                                              double *xyz_out, double *radii_out, unsigned char *class_out, long long cap,
+                                              long long *offsets_out, int *status_out, int *host_out, char *err_out, int err_len)
+{
+    if (err_out && err_len > 0) err_out[0] = 0;
+    if (!paths || n_paths <= 0 || !offsets_out || !status_out || !host_out) return set_err(err_out, err_len, "bad argument");
+    if (check_devices(&device, 1, err_out, err_len)) return -1;
+    long long written = -1;
+    const int rc = guarded(err_out, err_len, [&]() -> int {
+        Staged s;
+        PoolLease lease(device);
+        freesasa_gpu_ctx *c = lease.c;
+        if (!c) return set_err(err_out, err_len, "could not create a GPU context");
+        if (hipSetDevice(c->device) != hipSuccess) return set_err(err_out, err_len, "hipSetDevice failed");
+        stage_files(paths, n_paths, ingest_options & ~FREESASA_INGEST_PARSE_ON_DEVICE, threads_per_worker(n_threads, 1), &s);
+        if (s.rc) return set_err(err_out, err_len, "could not stage the files");
+        std::vector<int> atoms((size_t)n_paths);
+        long long total = 0;
+        if (parse_batch_dev_begin(c, s.text, s.T, s.files.data(), n_paths, ingest_options & ~FREESASA_INGEST_PARSE_ON_DEVICE, atoms.data(), status_out, host_out, &total) ||
+            parse_batch_dev_finish(c, 0))
+            return set_err(err_out, err_len, c->err);
+        offsets_out[0] = 0;
+        for (int k = 0; k < n_paths; ++k) offsets_out[k + 1] = offsets_out[k] + atoms[(size_t)k];
+        if (total > cap) { written = -2; return 0; }
+        if (total > 0 &&
+            ((xyz_out && hipMemcpyAsync(xyz_out, c->h_xyz.p, 24 * (size_t)total, hipMemcpyDeviceToHost, c->stream) != hipSuccess) ||
+             (radii_out && hipMemcpyAsync(radii_out, c->h_radii.p, 8 * (size_t)total, hipMemcpyDeviceToHost, c->stream) != hipSuccess) ||
+             (class_out && hipMemcpyAsync(class_out, c->h_counts.p, (size_t)total, hipMemcpyDeviceToHost, c->stream) != hipSuccess) ||
+             hipStreamSynchronize(c->stream) != hipSuccess))
+            return set_err(err_out, err_len, "device-to-host copy failed");
+        written = total;
+        return 0;
+    });
+    return rc ? -1 : written;
+}
+
+/* files the sweeps of this process parsed on the device / left to the host parser since the last call (FREESASA_INGEST_PARSE_ON_DEVICE) */
+extern "C" void freesasa_gpu_sweep_parse_stats(long long *device_files, long long *host_files)
+{
+    if (device_files) *device_files = g_parse_dev_files.exchange(0);
+    if (host_files) *host_files = g_parse_host_files.exchange(0);
+}
 
 extern "C" int freesasa_gpu_sweep_files(const char *const *paths, int n_paths, int ingest_options, int n_threads,
                                         int alg, double probe, int resolution, long long batch_atoms,

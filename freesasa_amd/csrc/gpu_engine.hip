@@ -112,7 +112,7 @@ extern "C" freesasa_gpu_ctx *freesasa_gpu_ctx_create(int device, void *stream)
             return nullptr;
         }
     }
-    if (host_malloc((void **)&c->pinned, sizeof(int) * 2 * (ST_WORDS + 4)) != hipSuccess) {
+    if (host_malloc((void **)&c->pinned, sizeof(int) * (2 * (ST_WORDS + 4) + 4)) != hipSuccess) { /* (two sets of status words, four words for the parser's read-backs) */
         freesasa_gpu_ctx_destroy(c);
         return nullptr;
     }
@@ -130,6 +130,8 @@ extern "C" void freesasa_gpu_ctx_destroy(freesasa_gpu_ctx *c)
                      &c->h_xyz, &c->h_radii, &c->h_sasa, &c->h_counts, &c->h_totals};
     for (DevBuf *b : all)
         if (b->p) (void)hipFree(b->p);
+    for (DevBuf &b : c->parse)
+        if (b.p) (void)hipFree(b.p);
     for (int s_ = 0; s_ < 2; ++s_) {
         for (int k = 0; k < 4; ++k)
             if (c->evs[s_][k]) (void)hipEventDestroy(c->evs[s_][k]);

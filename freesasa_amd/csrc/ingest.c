@@ -1026,6 +1026,87 @@ static int looks_like_cif(const char *text, size_t len)
     return t.type == T_DATA;
 }
 
+/* For the device-side parser (gpu_parse.hip): what kind of text this is and, for mmCIF in its everyday form, where the rows
+ * of its _atom_site loop begin and which of the loop's columns are the twelve the reader wants (cif_cols' order).
+ * 0: read as PDB; 1: mmCIF, ONE data block so far, whose first item carrying _atom_site.group_PDB is a loop with all twelve
+ * columns, one tag per header line (*row0 = offset of the line behind the header); 2: mmCIF that the host parser has to
+ * read (pair form, a block without the category before another block, several tokens on a header line, no loop at all).
+ * A LINE scan of the text before the loop - text fields (';' in column one) are stepped over, tags, values and other
+ * loops are not looked into -: what is left of the host's share of an mmCIF file when the device parses it. */
+int freesasa_ingest_cif_locate(const char *text, size_t len, int *ncol_out, signed char slot_out[12], size_t *row0_out)
+{
+    if (!looks_like_cif(text, len)) return 0;
+    size_t pos = 0;
+    int in_text = 0, n_data = 0;
+    while (pos < len) {
+        const char *line = text + pos;
+        const char *nl = memchr(line, '\n', len - pos);
+        const size_t n = nl ? (size_t)(nl - line) : len - pos;
+        const size_t next = pos + n + (nl ? 1 : 0);
+        if (in_text) {
+            if (n > 0 && line[0] == ';') {
+                in_text = 0;
+                for (size_t i = 1; i < n; ++i) if (!cif_ws[(unsigned char)line[i]]) return 2; /* something behind the closing ';': host */
+            }
+            pos = next;
+            continue;
+        }
+        if (n > 0 && line[0] == ';') { in_text = 1; pos = next; continue; }
+        size_t s = 0;
+        while (s < n && cif_ws[(unsigned char)line[s]]) ++s;
+        if (s == n || line[s] == '#') { pos = next; continue; }
+        size_t e = s;
+        while (e < n && !cif_ws[(unsigned char)line[e]]) ++e;
+        const size_t tl = e - s;
+        if (line[s] == '_') {
+            if (tl == 20 && ieq_n(line + s, "_atom_site.group_pdb", 20)) return 2; /* the pair form decides: host */
+            pos = next;
+            continue;
+        }
+        if (tl >= 5 && line[s + 4] == '_' && ieq_n(line + s, "data_", 5)) {
+            if (++n_data > 1) return 2; /* a second block (the first had no _atom_site loop): host */
+            pos = next;
+            continue;
+        }
+        if (!(tl == 5 && ieq_n(line + s, "loop_", 5))) { pos = next; continue; } /* values, save_ frames */
+        for (size_t i = e; i < n; ++i) if (!cif_ws[(unsigned char)line[i]]) return 2; /* tags on the loop_ line: host */
+        /* the loop's header: one tag per line (blank lines and comments between them are stepped over) */
+        int ncol = 0, col[12], has_first = 0;
+        for (int k = 0; k < 12; ++k) col[k] = -1;
+        size_t q = next;
+        while (q < len) {
+            const char *hl = text + q;
+            const char *hn = memchr(hl, '\n', len - q);
+            const size_t m = hn ? (size_t)(hn - hl) : len - q;
+            size_t a = 0;
+            while (a < m && cif_ws[(unsigned char)hl[a]]) ++a;
+            if (a == m || hl[a] == '#') { q += m + (hn ? 1 : 0); continue; }
+            if (hl[a] != '_') break; /* the first row (or whatever follows) */
+            size_t b = a;
+            while (b < m && !cif_ws[(unsigned char)hl[b]]) ++b;
+            for (size_t i = b; i < m; ++i) if (!cif_ws[(unsigned char)hl[i]]) return 2; /* two tokens on a header line: host */
+            const cif_tok t = {hl + a, b - a, T_TAG};
+            const int k = cif_col_of(&t);
+            if (k >= 0) {
+                if (k == 0) has_first = 1;
+                if (col[k] < 0) col[k] = ncol;
+            }
+            ++ncol;
+            q += m + (hn ? 1 : 0);
+        }
+        if (has_first) { /* this loop is the block's _atom_site category */
+            for (int k = 0; k < 12; ++k) if (col[k] < 0 || col[k] >= 64) return 2; /* incomplete (no atoms for the reference), or wider than the device's table: host */
+            if (ncol < 1 || ncol > 64) return 2;
+            *ncol_out = ncol;
+            for (int k = 0; k < 12; ++k) slot_out[k] = (signed char)col[k];
+            *row0_out = q;
+            return 1;
+        }
+        pos = q; /* another category's loop: its rows are stepped over line by line */
+    }
+    return 2;
+}
+
 static void parse_any(const char *text, size_t len, int options, parsed *p)
 {
     if (looks_like_cif(text, len)) parse_cif(text, len, options, p);

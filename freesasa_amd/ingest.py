@@ -14,6 +14,7 @@ from . import lib
 
 INCLUDE_HETATM, INCLUDE_HYDROGEN, JOIN_MODELS = 1, 1 << 2, 1 << 5     # ref: src/freesasa.h:182-191
 HALT_AT_UNKNOWN, SKIP_UNKNOWN, RADIUS_FROM_OCCUPANCY = 1 << 6, 1 << 7, 1 << 8
+PARSE_ON_DEVICE = 1 << 16       # sweep drivers only: the files' text is parsed by kernels (csrc/gpu_parse.hip)
 OK, EIO, EFORMAT, EEMPTY, EUNKNOWN, EOPTION, ENOMEM, EVERSION = range(8)
 APOLAR, POLAR, UNKNOWN = 0, 1, 2
 

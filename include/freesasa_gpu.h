@@ -229,6 +229,18 @@ int freesasa_gpu_sweep_files_resumable(const char *const *paths, int n_paths, in
    coordinates, radii and classes of their batch through page-locked staging; n_out = length of the output arrays
    (>= the cache's structure count); class_sums_out / atoms_out / status_out may be NULL.  Returns 0 / -1.
    _trajectory_devices, _trajectory_file_devices: as freesasa_gpu_trajectory / _trajectory_file. */
+/* ingest_options | FREESASA_INGEST_PARSE_ON_DEVICE (include/freesasa_ingest.h): the files' text is parsed ON THE DEVICE (round 6;
+   the host reads bytes, kernels do what src/structure.c:644-722, src/pdb.c:176-283, src/cif.cc:113-240, src/classifier.c:781-796
+   do); results are those of the host parser bit for bit, files the device refuses are read by it.  _sweep_parse_stats: files
+   parsed on the device / by the host in this process's sweeps since the last call. */
+void freesasa_gpu_sweep_parse_stats(long long *device_files, long long *host_files);
+/* The device-side parser on its own: n files -> coordinates [3 * atoms], radii, classes of the atoms it keeps (host arrays with
+   room for `cap` atoms; each may be NULL), offsets_out [n + 1], status_out [n] (FREESASA_INGEST_* codes), host_out [n] (1: the
+   device refuses the file, which then contributes nothing here; the sweep hands such a file to the host parser).  Returns the
+   atoms written, -1 on error, -2 when cap is too small (offsets_out[n] = atoms needed). */
+long long freesasa_gpu_parse_files(const char *const *paths, int n_paths, int ingest_options, int n_threads, int device,
+                                   double *xyz_out, double *radii_out, unsigned char *class_out, long long cap,
+                                   long long *offsets_out, int *status_out, int *host_out, char *err, int err_len);
 int freesasa_gpu_sweep_files_devices(const char *const *paths, int n_paths, int ingest_options, int n_threads,
                                      int alg, double probe_radius, int resolution, long long batch_atoms,
                                      double *totals_out, double *class_sums_out, long long *atoms_out, int *status_out,

@@ -85,6 +85,16 @@ typedef struct freesasa_ingest_batch {
  * the devices of the multi-device drivers (include/freesasa_gpu.h), start from. */
 int freesasa_ingest_usable_cpus(void);
 
+/* Option bit of the SWEEP drivers only (include/freesasa_gpu.h, freesasa_gpu_sweep_files*; outside the reference's
+ * freesasa_structure_options values): parse the files' text ON THE DEVICE.  Host threads only read the bytes into page-locked
+ * staging (and find an mmCIF file's _atom_site loop header); kernels find the lines, filter the records, convert the
+ * coordinates, classify the atoms and write the batch the tile kernels read (freesasa_amd/csrc/gpu_parse.hip).  Files the
+ * device refuses - coordinates that need strtod, lines beyond the reference's 119-byte chunks, RADIUS_FROM_OCCUPANCY,
+ * mmCIF outside its everyday one-block, one-row-per-line loop form - are read by the host parser, one by one. */
+#define FREESASA_INGEST_PARSE_ON_DEVICE (1 << 16)
+/* (what the device parser asks of the host per mmCIF file; see ingest.c) */
+int freesasa_ingest_cif_locate(const char *text, size_t len, int *ncol_out, signed char slot_out[12], size_t *row0_out);
+
 /* Read n_paths PDB or mmCIF files with n_threads host threads (<= 0: one per usable CPU -- divided by
  * LOCAL_WORLD_SIZE when a launcher exports it, so the ranks of a node share the cores --, at most 64
  * and at most one per four inputs) into one batch.

@@ -745,3 +745,41 @@ def test_mmcif_rows_by_template_equal_the_byte_at_a_time_tokenizer():
         assert a.n_atoms == b.n_atoms and a.n_atoms > 5000
         for f in BATCH_ARRAYS:
             assert np.array_equal(getattr(a, f), getattr(b, f)), (options, f)
+
+
+def test_cif_locate_finds_the_atom_site_loop_or_hands_the_file_to_the_host_parser():
+    """What the device-side parser (csrc/gpu_parse.hip) asks of the host per file: PDB or mmCIF, and for mmCIF in its everyday
+    form - one data block whose _atom_site category is one loop, one tag per header line - where the rows begin and which of
+    the loop's columns are the twelve wanted ones.  Everything else (pair form, a second block first, an incomplete loop)
+    must come back as 'host'.  The rows are NOT looked at here: oddities inside them are the device's to refuse."""
+    import ctypes as C
+    L = ingest._proto()
+    L.freesasa_ingest_cif_locate.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_byte), C.POINTER(C.c_size_t)]
+
+    def locate(text):
+        ncol, slot, row0 = C.c_int(0), (C.c_byte * 12)(), C.c_size_t(0)
+        kind = L.freesasa_ingest_cif_locate(text, len(text), C.byref(ncol), slot, C.byref(row0))
+        return kind, ncol.value, list(slot), row0.value
+
+    for name in ("1ubq.pdb", "empty.pdb", "syn_crlf.pdb"):
+        assert locate(open(fixture(name), "rb").read())[0] == 0, name
+    cols = ["group_PDB", "auth_asym_id", "auth_seq_id", "pdbx_PDB_ins_code", "auth_comp_id", "auth_atom_id", "label_alt_id", "type_symbol",
+            "Cartn_x", "Cartn_y", "Cartn_z", "pdbx_PDB_model_num"]
+    for name in ("1ubq.cif", "3bkr.cif", "5dx9.cif", "7cma-assembly1.cif", "syn_basic.cif", "syn_reordered_columns.cif", "syn_two_blocks_textfield.cif"):
+        text = open(fixture(name), "rb").read()
+        kind, ncol, slot, row0 = locate(text)
+        assert kind == 1, name
+        # the header as the file spells it: tag k of the loop is on line k behind "loop_"
+        head = text[:row0].decode().split("\n")
+        start = max(i for i, l in enumerate(head) if l.strip().lower() == "loop_")
+        tags = [l.strip() for l in head[start + 1:] if l.strip().startswith("_")]
+        assert len(tags) == ncol, name
+        for k, c in enumerate(cols):
+            assert tags[slot[k]].lower() == ("_atom_site." + c).lower(), (name, c)
+        assert text[row0 - 1:row0] == b"\n" and not text[row0:row0 + 1] in (b"_", b"#"), name     # the first row's line
+    for name in ("syn_pair_form.cif", "syn_pair_form_incomplete.cif", "syn_missing_column.cif", "syn_no_atoms.cif"):
+        assert locate(open(fixture(name), "rb").read())[0] == 2, name
+    # a text field that talks about loop_ and _atom_site.group_PDB before the real loop is stepped over
+    text = b"data_X\n_struct.title\n;loop_\n_atom_site.group_PDB\n;\n" + open(fixture("syn_basic.cif"), "rb").read().split(b"\n", 1)[1]
+    kind, ncol, slot, row0 = locate(text)
+    assert kind == 1 and text[row0:row0 + 4] == b"ATOM"

@@ -29,7 +29,8 @@ def main():
     ap.add_argument("paths", nargs="*")
     ap.add_argument("--replicate", type=int, default=200)
     ap.add_argument("--threads", type=int, default=0)
-    ap.add_argument("--batch-atoms", type=int, default=4_000_000)
+    ap.add_argument("--batch-atoms", type=int, default=0, help="atoms per batch (0: the driver's default: 5e5 with the parser on the device, 1e6 with the host parser)")
+    ap.add_argument("--host-parser", action="store_true", help="parse the files with the host loader (default: ON THE DEVICE, csrc/gpu_parse.hip; files it refuses go to the host parser anyway)")
     ap.add_argument("--slices", type=int, default=20)
     ap.add_argument("--no-gpu", action="store_true", help="time the loader only")
     ap.add_argument("--devices", default="", help="comma-separated device list (default: all visible devices)")
@@ -71,18 +72,22 @@ def main():
                     "failed_inputs": int((~ok).sum()), "seconds": dt, "end_to_end_atoms_per_s": float(atoms.sum()) / dt,
                     "structures_per_s": float(ok.sum()) / dt, "mean_total_A2": float(totals[ok].mean())})
     elif not args.no_gpu and args.engine == "c":
-        fa.sweep_files(chunks[0][:20], fa.LEE_RICHARDS, resolution=args.slices)                      # warm-up
+        popt = 0 if args.host_parser else ingest.PARSE_ON_DEVICE
+        fa.sweep_files(chunks[0][:20], fa.LEE_RICHARDS, resolution=args.slices, ingest_options=popt)                      # warm-up
+        fa.sweep_parse_stats()
         t0 = time.perf_counter()
         if args.done:
             complete, totals, _, atoms, status = fa.sweep_files_resumable(paths, args.done, fa.LEE_RICHARDS, resolution=args.slices, n_threads=args.threads,
-                                                                         batch_atoms=args.batch_atoms, devices=devices)
+                                                                         batch_atoms=args.batch_atoms, devices=devices, ingest_options=popt)
             out["complete"] = bool(complete)
         else:
             totals, _, atoms, status = fa.sweep_files(paths, fa.LEE_RICHARDS, resolution=args.slices, n_threads=args.threads,
-                                                      batch_atoms=args.batch_atoms, class_sums=True, devices=devices)
+                                                      batch_atoms=args.batch_atoms, class_sums=True, devices=devices, ingest_options=popt)
         dt = time.perf_counter() - t0
         ok = status == 0
-        out.update({"engine": "freesasa_gpu_sweep_files_devices", "atoms": int(atoms.sum()), "structures": int(ok.sum()),
+        on_dev, on_host = fa.sweep_parse_stats()
+        out.update({"engine": "freesasa_gpu_sweep_files_devices", "parser": "host" if args.host_parser else "device",
+                    "files_parsed_on_device": on_dev, "files_left_to_the_host_parser": on_host, "atoms": int(atoms.sum()), "structures": int(ok.sum()),
                     "failed_inputs": int((~ok).sum()), "seconds": dt, "end_to_end_atoms_per_s": float(atoms.sum()) / dt,
                     "structures_per_s": float(ok.sum()) / dt, "mean_total_A2": float(totals[ok].mean())})
     elif not args.no_gpu:
