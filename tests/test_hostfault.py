@@ -188,11 +188,13 @@ def _driver_walk(call, baseline):
 
 
 @gpu
-def test_file_sweep_on_a_device_list_survives_host_faults(tmp_path):
+@pytest.mark.parametrize("parser", ["host", "device"])
+def test_file_sweep_on_a_device_list_survives_host_faults(tmp_path, parser):
     files = FILES * 3
+    opt = ingest.PARSE_ON_DEVICE if parser == "device" else 0     # (the device-side parser: staging buffers, file tables, the host fallback's batch)
 
     def run():
-        t, c, a, s = fa.sweep_files(files, n_threads=4, batch_atoms=1500, devices=[0, 0, 0])
+        t, c, a, s = fa.sweep_files(files, n_threads=4, batch_atoms=1500, devices=[0, 0, 0], ingest_options=opt)
         return t, c, a, s
 
     def call():

@@ -2,7 +2,7 @@
 #   bash tools/gpu_round.sh r04        (outputs under gpurun_out/<tag>_*; copy the summaries into profiles/)
 # Build the phase-ablation variants first if the per-phase instruction counts are wanted:
 #   for k in 0 1 2 3 4 5; do bash tools/build_variant.sh stop$k -DLR2_STOP_AFTER=$k; done; bash tools/build_variant.sh pt -DSASA_PHASE_TIMING
-TAG=${1:-r05}
+TAG=${1:-r06}
 mkdir -p gpurun_out
 export PYTHONUNBUFFERED=1
 REPO=$(pwd)
@@ -38,13 +38,15 @@ cd $REPO
 python tools/pmc_summary.py $O/prof_$TAG all > $O/${TAG}_pmc_summary.txt
 python tools/hbm_counters.py $O/prof_$TAG > $O/${TAG}_hbm_counters.json
 # derived counters of the tile kernel (coils, then globules)
-(bash tools/gpu_derived.sh "0,0,-1,0"; echo "--- globules"; STRUCTS=g100 bash tools/gpu_derived.sh "0,0,-1,0") > $O/${TAG}_derived_counters.txt 2>&1
+(bash tools/gpu_derived.sh "0,0,-1,0"; echo "--- globules"; STRUCTS=g100 bash tools/gpu_derived.sh "0,0,-1,0"; echo "--- the reference PDB entries x 84"; STRUCTS=p84 bash tools/gpu_derived.sh "0,0,-1,0") > $O/${TAG}_derived_counters.txt 2>&1
 # VALU instructions by phase (cumulative builds), if the variants are there
 if [ -f freesasa_amd/lib/libvar_stop0.so ]; then
   (echo "coils (300 x 10 000 atoms, 5 launches): cumulative after P0 .. P5, then the whole kernel"
    bash tools/gpu_ablate.sh "0,0,-1,0" freesasa_amd/lib/libvar_stop0.so freesasa_amd/lib/libvar_stop1.so freesasa_amd/lib/libvar_stop2.so freesasa_amd/lib/libvar_stop3.so freesasa_amd/lib/libvar_stop4.so freesasa_amd/lib/libvar_stop5.so freesasa_amd/lib/libfreesasa_amd.so
+   echo "the reference's PDB entries x 84 (1.0e6 atoms, 5 launches)"
+   STRUCTS=p84 bash tools/gpu_ablate.sh "0,0,-1,0" freesasa_amd/lib/libvar_stop0.so freesasa_amd/lib/libvar_stop1.so freesasa_amd/lib/libvar_stop2.so freesasa_amd/lib/libvar_stop3.so freesasa_amd/lib/libvar_stop4.so freesasa_amd/lib/libvar_stop5.so freesasa_amd/lib/libfreesasa_amd.so
    echo "globules (100 x 10 000 atoms, 5 launches)"
-   STRUCTS=g100 bash tools/gpu_ablate.sh "0,0,-1,0" freesasa_amd/lib/libvar_stop0.so freesasa_amd/lib/libvar_stop1.so freesasa_amd/lib/libvar_stop2.so freesasa_amd/lib/libvar_stop3.so freesasa_amd/lib/libvar_stop4.so freesasa_amd/lib/libvar_stop5.so freesasa_amd/lib/libfreesasa_amd.so) 2>&1 | grep "==\|coils\|globules\|lr2_tile<4" | sed "s/vgpr[^ ]* //" > $O/${TAG}_phase_valu.txt
+   STRUCTS=g100 bash tools/gpu_ablate.sh "0,0,-1,0" freesasa_amd/lib/libvar_stop0.so freesasa_amd/lib/libvar_stop1.so freesasa_amd/lib/libvar_stop2.so freesasa_amd/lib/libvar_stop3.so freesasa_amd/lib/libvar_stop4.so freesasa_amd/lib/libvar_stop5.so freesasa_amd/lib/libfreesasa_amd.so) 2>&1 | grep "==\|coils\|globules\|PDB entries\|lr2_tile<4" | sed "s/vgpr[^ ]* //" > $O/${TAG}_phase_valu.txt
 fi
 # wall clock of a wave by phase (variant built with -DSASA_PHASE_TIMING)
 if [ -f freesasa_amd/lib/libvar_pt.so ]; then
@@ -62,5 +64,14 @@ fi
 (bash tools/gpu_sr.sh $TAG) > $O/${TAG}_sr_session.txt 2>&1
 if [ -f freesasa_amd/lib/libvar_srstop0.so ]; then (bash tools/gpu_sr_ablate.sh) > $O/${TAG}_sr_phase_ablation.txt 2>&1; fi
 (timeout 300 python tools/dev/driver_tuning.py) > $O/${TAG}_driver_tuning.txt 2>&1
+# round 6: the device-side parser's kernels (kernel trace of the bench's sweep_files key), the sweep's workers / batch sizes,
+# the 200 000-atom Shrake-Rupley step's timeline, the trajectory driver's kernel + copy trace and per-lane host time
+mkdir -p /tmp/fsbench
+(cd /tmp && TMPDIR=/tmp timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_sweep -o trace -- python $REPO/tools/dev/sweep_bench.py) > $O/${TAG}_sweep_files_key.txt 2>&1
+cp $O/prof_${TAG}_sweep/trace_kernel_stats.csv $O/${TAG}_sweep_kernel_stats.csv 2>/dev/null
+(timeout 300 python tools/dev/sweep_devparse.py 2>&1 | grep -v amdgpu) > $O/${TAG}_sweep_workers.txt
+(timeout 200 bash tools/dev/sr200k_timeline.sh 2>&1 | grep -v amdgpu) > $O/${TAG}_sr200k_timeline.txt
+(timeout 200 bash tools/dev/traj_trace.sh 2>&1 | grep -v amdgpu) > $O/${TAG}_trajectory_trace.txt
+(timeout 200 python tools/dev/traj_profile.py 2>&1 | grep -v amdgpu) > $O/${TAG}_trajectory_lanes.txt
 (timeout 120 tools/dev/ubench) > $O/${TAG}_ubench.txt 2>&1
 tail -2 $O/${TAG}_smoke.log; tail -4 $O/${TAG}_pytest_gpu.log; cut -c1-400 $O/${TAG}_bench.json; cat $O/${TAG}_kernel_stats.csv | cut -d, -f1-4 | head -12; cat $O/${TAG}_fetch_calibration.txt; cat $O/${TAG}_deep_parity.json

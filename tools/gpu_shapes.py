@@ -8,10 +8,16 @@ import freesasa_amd as fa, tools
 geom = "coil"
 if len(sys.argv) > 1 and sys.argv[1].startswith("g"):  # g100 = 100 protein-like globules of 10k atoms
     geom = "globule"; sys.argv[1] = sys.argv[1][1:]
+elif len(sys.argv) > 1 and sys.argv[1].startswith("p"):  # p84 = the reference's PDB entries x 84 (1e6 atoms; bench.real_pdb_batch)
+    geom = "pdb"; sys.argv[1] = sys.argv[1][1:]
 structs = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 specs = sys.argv[2:] or ["LR1", "0,0,-1,0", "4,0,-1,16", "5,0,-1,16", "6,0,-1,8", "6,0,-1,24", "6,0,2,16", "3,0,-1,16"]
 if geom == "coil":
     xyz, r, offs = tools.coil_batch(structs, 10000, seed0=1000)
+elif geom == "pdb":
+    import bench
+    xyz, r, offs, _, reps = bench.real_pdb_batch(structs * 12000)
+    structs = len(offs) - 1
 else:
     parts = [tools.globule(10000, 500 + k) for k in range(structs)]
     xyz = np.concatenate([p[0] for p in parts]); r = np.concatenate([p[1] for p in parts])
