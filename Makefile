@@ -19,7 +19,7 @@ all: $(LIBDIR)/libfreesasa_amd.so $(LIBDIR)/libfreesasa_amd_seam.a
 # Device code lives in ONE translation unit (gpu_kernels.hip); the compiler's per-kernel resource report (registers,
 # scratch, LDS) is kept next to its object: tests/test_capi.py checks that the hot kernels do not spill.  The other
 # .hip files are host code over the HIP runtime (engine_internal.h says who holds what).
-ENGINE_HDRS = $(CSRC)/engine_internal.h $(CSRC)/sasa_kernels.h $(CSRC)/lr2_kernels.h $(CSRC)/gpu_parse.h $(CSRC)/protor_table.h include/freesasa_gpu.h include/freesasa_ingest.h
+ENGINE_HDRS = $(CSRC)/engine_internal.h $(CSRC)/sasa_kernels.h $(CSRC)/sr_caps.h $(CSRC)/lr2_kernels.h $(CSRC)/gpu_parse.h $(CSRC)/protor_table.h include/freesasa_gpu.h include/freesasa_ingest.h
 $(LIBDIR)/gpu_kernels.o: $(CSRC)/gpu_kernels.hip $(ENGINE_HDRS)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(LIBDIR)/kernel_resources.txt; rc=$$?; \
@@ -73,7 +73,7 @@ emu: tests/emu/libsasa_emu.so tests/emu/libingest_scalar.so
 # the loader with its byte-at-a-time mmCIF tokenizer only: the differential twin of the SSE2 row scanner
 tests/emu/libingest_scalar.so: $(CSRC)/ingest.c $(CSRC)/hostfault.c $(CSRC)/hostfault.h $(CSRC)/protor_table.h include/freesasa_ingest.h
 	$(CC) $(CFLAGS) -DFREESASA_INGEST_NO_SIMD -Iinclude -pthread -shared -o $@ $(CSRC)/ingest.c $(CSRC)/hostfault.c -lm
-tests/emu/libsasa_emu.so: tests/emu/emu.cpp $(CSRC)/sasa_kernels.h $(CSRC)/lr2_kernels.h
+tests/emu/libsasa_emu.so: tests/emu/emu.cpp $(CSRC)/sasa_kernels.h $(CSRC)/sr_caps.h $(CSRC)/lr2_kernels.h
 	$(CXX) -O2 -std=c++17 -fPIC -ffp-contract=off -DSASA_EMU -shared -o $@ tests/emu/emu.cpp -lm
 
 # Sanitizer build of the HOST sources (the reference's CI runs its C under sanitizers): the parsers,

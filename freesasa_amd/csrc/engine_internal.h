@@ -99,6 +99,10 @@ struct freesasa_gpu_ctx {
     DevBuf status, ovf_tiles, ovf_tiles2, ovf_atoms, unit_pts, slab, seg;
     std::vector<int64_t> offsets_host; /* last uploaded offsets */
     std::vector<double> unit_host;     /* last uploaded S&R unit points */
+    /* S&R, third arrangement (sr_caps.h): the table of cap masks of unit_host, rebuilt when the points change */
+    DevBuf captab;
+    std::vector<sasa::SrCapEntry> captab_host;
+    int captab_n = 0, captab_l = 0;    /* its resolution; 0: no table for these points (more than 128, not unit vectors, switched off) */
     /* host staging for freesasa_gpu_calc_batch */
     DevBuf h_xyz, h_radii, h_sasa, h_counts, h_totals;
     void *stage_in = nullptr, *stage_out = nullptr; /* page-locked host staging of freesasa_gpu_calc_batch_pipelined */

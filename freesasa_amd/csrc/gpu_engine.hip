@@ -126,7 +126,7 @@ extern "C" void freesasa_gpu_ctx_destroy(freesasa_gpu_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->chunk_struct, &c->chunk_begin, &c->chunk_len, &c->struct_chunk0, &c->bpart, &c->offsets, &c->grid, &c->ncells, &c->sid, &c->cell_of, &c->rank, &c->cell_start,
                      &c->blk_sums, &c->cell_tbl, &c->cell_first, &c->sq, &c->s_idx,
-                     &c->status, &c->ovf_tiles, &c->ovf_tiles2, &c->ovf_atoms, &c->unit_pts, &c->slab, &c->seg,
+                     &c->status, &c->ovf_tiles, &c->ovf_tiles2, &c->ovf_atoms, &c->unit_pts, &c->captab, &c->slab, &c->seg,
                      &c->h_xyz, &c->h_radii, &c->h_sasa, &c->h_counts, &c->h_totals};
     for (DevBuf *b : all)
         if (b->p) (void)hipFree(b->p);
@@ -536,7 +536,7 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
         if (rcs) return rcs;
         if (status_h[ST_OCC_N] > 0) {
             const double nn_est = 3.1 * (double)status_h[ST_OCC_SUM] / (double)status_h[ST_OCC_N];
-            const TileCfg probe_cfg = choose_cfg(resolution, lr, 0);
+            const TileCfg probe_cfg = choose_cfg(resolution, lr, 0, !lr && resolution <= SR_CAP_POINTS_MAX);
             int pool = (int)(1.35 * nn_est * probe_cfg.TA + 16.0);
             pool = (pool + 1) & ~1;
             if (pool < 32) pool = 32;
@@ -551,7 +551,40 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
             if (lr) c->hint_bucket = nn_est > 30.0;
         }
     }
-    TileCfg cfg = choose_cfg(resolution, lr, c->hint_res[hi] == resolution ? c->hint_pool[hi] : 0);
+    if (!lr) {
+        if (!unit_points) return ctx_fail(c, "unit_points is null");
+        if (ensure(c, c->unit_pts, sizeof(double) * 3 * (size_t)resolution)) return -1;
+        /* pageable host-to-device copies stall the stream: upload the points only when they change */
+        if (c->unit_host.size() != 3 * (size_t)resolution ||
+            memcmp(c->unit_host.data(), unit_points, sizeof(double) * 3 * (size_t)resolution) != 0) {
+            c->unit_host.assign(unit_points, unit_points + 3 * (size_t)resolution);
+            if (hipMemcpyAsync(c->unit_pts.p, c->unit_host.data(), sizeof(double) * 3 * (size_t)resolution, hipMemcpyHostToDevice, st) != hipSuccess) {
+                c->unit_host.clear();
+                return ctx_fail(c, "upload of the test points failed");
+            }
+            /* the third arrangement's table of cap masks for these points (sr_caps.h; FREESASA_AMD_SR_CAPS=0 keeps the
+               second arrangement, "N,L" sets the table's resolution: tuning aids) */
+            int tn = SR_CAP_N_DEFAULT, tl = SR_CAP_L_DEFAULT;
+            if (const char *e = getenv("FREESASA_AMD_SR_CAPS")) {
+                int n_ = 0, l_ = 0;
+                if (sscanf(e, "%d,%d", &n_, &l_) == 2 && n_ >= 1 && n_ <= 64 && l_ >= 1 && l_ <= 256) { tn = n_; tl = l_; }
+                else if (atoi(e) == 0) tn = 0;
+            }
+            c->captab_n = c->captab_l = 0;
+            if (tn > 0 && sr_captab_build(c->unit_host.data(), resolution, tn, tl, c->captab_host)) {
+                const size_t bytes = sizeof(SrCapEntry) * c->captab_host.size();
+                if (ensure(c, c->captab, bytes)) { c->unit_host.clear(); return -1; }
+                if (hipMemcpyAsync(c->captab.p, c->captab_host.data(), bytes, hipMemcpyHostToDevice, st) != hipSuccess) {
+                    c->unit_host.clear();
+                    return ctx_fail(c, "upload of the cap table failed");
+                }
+                c->captab_n = tn; c->captab_l = tl;
+            }
+        }
+    }
+
+    const bool sr_caps = !lr && c->captab_n > 0;
+    TileCfg cfg = choose_cfg(resolution, lr, c->hint_res[hi] == resolution ? c->hint_pool[hi] : 0, sr_caps);
     if (const char *e = getenv("FREESASA_AMD_CFG")) { /* tuning aid: "B,TA,pool,ds" */
         int b = 0, t = 0, pl = 0, d = 0;
         if (sscanf(e, "%d,%d,%d,%d", &b, &t, &pl, &d) == 4 && (b == 64 || b == 128 || b == 256) && t >= 1 && t <= b &&
@@ -559,7 +592,7 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
             cfg.B = b; cfg.TA = t; cfg.pool = pl; cfg.ds = lr ? d : 0;
             if (!lr) { cfg.cap_idx = pl > 0 ? pl : cfg.cap_idx; cfg.pool = cfg.TA * cfg.cap_idx; } /* (S&R: "pool" = records per atom) */
             if (!lr) cfg.tab = sr_survivors_fit(cfg.TA, resolution) ? 1 : 0;
-            cfg.items = lr ? (cfg.tab ? cfg.TA * resolution : cfg.B) : (cfg.tab ? sr_items(cfg.TA, resolution) : 1);
+            cfg.items = lr ? (cfg.tab ? cfg.TA * resolution : cfg.B) : (cfg.tab ? sr_tile_items(cfg.TA, resolution, sr_caps) : 1);
             cfg.lds = tile_fixed_bytes(cfg.TA, cfg.items) + tile_list_bytes(cfg.TA, cfg.cap_idx, cfg.pool, cfg.lr, cfg.ds, cfg.B);
         }
     }
@@ -593,18 +626,8 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
     ta.work_count = nullptr;
     ta.status = (int *)c->status.p;
     if (!lr) {
-        if (!unit_points) return ctx_fail(c, "unit_points is null");
-        if (ensure(c, c->unit_pts, sizeof(double) * 3 * (size_t)resolution)) return -1;
-        /* pageable host-to-device copies stall the stream: upload the points only when they change */
-        if (c->unit_host.size() != 3 * (size_t)resolution ||
-            memcmp(c->unit_host.data(), unit_points, sizeof(double) * 3 * (size_t)resolution) != 0) {
-            c->unit_host.assign(unit_points, unit_points + 3 * (size_t)resolution);
-            if (hipMemcpyAsync(c->unit_pts.p, c->unit_host.data(), sizeof(double) * 3 * (size_t)resolution, hipMemcpyHostToDevice, st) != hipSuccess) {
-                c->unit_host.clear();
-                return ctx_fail(c, "upload of the test points failed");
-            }
-        }
         ta.unit_pts = (const double *)c->unit_pts.p;
+        if (sr_caps) { ta.captab = c->captab.p; ta.cap_n = c->captab_n; ta.cap_l = c->captab_l; }
     }
 
     /* workgroups loop over tiles (w, w + grid, ...): ~150k workgroups measured ~2% better than
@@ -652,6 +675,8 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
         tf.ovf_count = nullptr;
         tf.slab = (char *)c->slab.p;
         tf.slab_stride = (long long)stride;
+        tf.captab = nullptr; /* (segments of 4096 records in the slab: the second arrangement ... */
+        if (sr_caps) tf.tab = 0; /* ... without its survivor table: the tile's LDS is sized for the third's masks and list) */
         le = lr ? kl_lr_tile(2, fb, tf, fb_blocks, fb.lds, st, false) : kl_sr_tile(2, fb, tf, fb_blocks, fb.lds, st);
         if (le != hipSuccess) return ctx_fail(c, "fallback kernel launch failed: %s", hipGetErrorString(le));
     }

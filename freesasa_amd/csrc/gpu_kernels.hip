@@ -559,11 +559,14 @@ hipError_t kl_lr2_main(int rmax, int grid, size_t lds, hipStream_t st, const Lr2
     return hipGetLastError();
 }
 
-template <int B, bool GLOBAL, int TIER>
+template <int B, bool GLOBAL, int TIER, bool CAPS = false>
 #ifndef SR_WPE
 #define SR_WPE 7 /* waves per SIMD the S&R kernel's registers are capped for (72 registers: seven 256-thread tiles per CU, what their LDS allows; the kernel is latency-bound - 67 % of its issue slots used - and measured on the MI355X, round 5, PDB entries x 251 / coil batch: uncapped (92 registers, 5 waves) 4.52 / 12.2 ms, 6 waves 4.16 / 11.2, 7 waves 4.04 / 11.0, 8 waves 4.49 / 11.4) */
 #endif
-__global__ __launch_bounds__(B) __attribute__((amdgpu_waves_per_eu(SR_WPE, SR_WPE))) void k_sr_tile(TileArgs a, int items)
+#ifndef SR_CAPS_WPE
+#define SR_CAPS_WPE 5 /* ... and the third arrangement's (sr_caps.h; measured, round 6, PDB entries x 251 / coil batch at 128 threads x 6 atoms: 4 waves 3.48 / 8.8 ms, 5 waves 3.24 / 7.7, 6 waves 3.48 / 8.5, 7 waves 4.6 / 10.9) */
+#endif
+__global__ __launch_bounds__(B) __attribute__((amdgpu_waves_per_eu(CAPS ? SR_CAPS_WPE : SR_WPE, CAPS ? SR_CAPS_WPE : SR_WPE))) void k_sr_tile(TileArgs a, int items)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -578,25 +581,44 @@ __global__ __launch_bounds__(B) __attribute__((amdgpu_waves_per_eu(SR_WPE, SR_WP
 #define SR_STOP_AFTER 99
 #endif
         sr_phase_load(a, m, tile, tid, B);
+        if constexpr (CAPS) sr_caps_clear(a, m, tile, tid, B);
         __syncthreads();
         if (SR_STOP_AFTER == 0) continue;
         sr_phase_neighbors(a, m, tile, tid, B);
         __syncthreads();
         if (SR_STOP_AFTER == 1) continue;
-        sr_phase_lists(a, m, tid);
+        if constexpr (CAPS) sr_caps_lists(a, m, tid); else sr_phase_lists(a, m, tid);
         __syncthreads();
         sr_report<GLOBAL>(a, m, tile, tid, wg_max_nn);
-        if constexpr (GLOBAL) sr_order_serial(a, m, tid); /* (the slab launch: segments of 4096 records) */
-        else sr_order_wave(a, m, tid, B);                 /* (LDS launches: C <= 64 * SR_ORDER_RECS, see choose_cfg / mid_cfg) */
-        __syncthreads();
-        if (SR_STOP_AFTER == 2) continue;
-        sr_phase_points(a, m, tile, tid, B);
-        __syncthreads();
-        if (SR_STOP_AFTER == 3) continue;
-        sr_phase_points2(a, m, tid, B);
-        __syncthreads();
-        sr_phase_store(a, m, tile, tid);
-        __syncthreads();
+        if constexpr (CAPS) {
+            /* third arrangement (sr_caps.h): a thread per neighbor record looks the record's cap masks up and ORs what it
+               covers for sure into its atom's words; then the (neighbor, point) pairs that have to be asked the
+               reference's way are listed, and asked */
+            SrCapRegs regs;
+            sr_caps_lookup_pass(a, m, tid, B, regs);
+            __syncthreads();
+            if (SR_STOP_AFTER == 12) continue;
+            sr_caps_todo_pass(a, m, tid, B, items, regs);
+            __syncthreads();
+            if (SR_STOP_AFTER == 2) continue;
+            sr_caps_exact(a, m, tid, B, items);
+            __syncthreads();
+            if (SR_STOP_AFTER == 3) continue;
+            sr_caps_store(a, m, tile, tid);
+            __syncthreads();
+        } else {
+            if constexpr (GLOBAL) sr_order_serial(a, m, tid); /* (the slab launch: segments of 4096 records) */
+            else sr_order_wave(a, m, tid, B);                 /* (LDS launches: C <= 64 * SR_ORDER_RECS, see choose_cfg / mid_cfg) */
+            __syncthreads();
+            if (SR_STOP_AFTER == 2) continue;
+            sr_phase_points(a, m, tile, tid, B);
+            __syncthreads();
+            if (SR_STOP_AFTER == 3) continue;
+            sr_phase_points2(a, m, tid, B);
+            __syncthreads();
+            sr_phase_store(a, m, tile, tid);
+            __syncthreads();
+        }
     }
     tile_report_flush(a, tid, wg_max_nn);
 }
@@ -634,6 +656,19 @@ static hipError_t launch_lr(const TileCfg &c, const TileArgs &t, int grid, size_
 template <bool GLOBAL, int TIER>
 static hipError_t launch_sr(const TileCfg &c, const TileArgs &t, int grid, size_t lds, hipStream_t s)
 {
+    if constexpr (!GLOBAL) {
+        /* the third arrangement (sr_caps.h) where its table exists and a wave's lanes hold an atom's list (C <= 128) */
+        if (t.captab && t.tab && t.n_res <= SR_CAP_POINTS_MAX && sr_order_in_wave(c.cap_idx) && c.B >= 64) {
+            if (c.B == 256)
+                hipLaunchKernelGGL((k_sr_tile<256, false, TIER, true>), dim3(grid), dim3(256), lds, s, t, c.items);
+            else if (c.B == 128)
+                hipLaunchKernelGGL((k_sr_tile<128, false, TIER, true>), dim3(grid), dim3(128), lds, s, t, c.items);
+            else if (c.B == 64)
+                hipLaunchKernelGGL((k_sr_tile<64, false, TIER, true>), dim3(grid), dim3(64), lds, s, t, c.items);
+            else return hipErrorInvalidValue;
+            return hipGetLastError();
+        }
+    }
     if (c.B == 256)
         hipLaunchKernelGGL((k_sr_tile<256, GLOBAL, TIER>), dim3(grid), dim3(256), lds, s, t, c.items);
     else if (c.B == 128)
@@ -652,7 +687,9 @@ static void allow_large_lds()
                              (const void *)k_lr_tile<256, false, 1, 4>, (const void *)k_lr_tile<128, false, 1, 4>, (const void *)k_lr_tile<64, false, 1, 4>,
                              (const void *)k_lr_tile<64, false, 0, 4, true>, (const void *)k_lr_tile<64, false, 1, 4, true>,
                              (const void *)k_sr_tile<256, false, 0>, (const void *)k_sr_tile<128, false, 0>, (const void *)k_sr_tile<64, false, 0>,
-                             (const void *)k_sr_tile<256, false, 1>, (const void *)k_sr_tile<128, false, 1>, (const void *)k_sr_tile<64, false, 1>};
+                             (const void *)k_sr_tile<256, false, 1>, (const void *)k_sr_tile<128, false, 1>, (const void *)k_sr_tile<64, false, 1>,
+                             (const void *)k_sr_tile<256, false, 0, true>, (const void *)k_sr_tile<128, false, 0, true>, (const void *)k_sr_tile<64, false, 0, true>,
+                             (const void *)k_sr_tile<256, false, 1, true>, (const void *)k_sr_tile<128, false, 1, true>, (const void *)k_sr_tile<64, false, 1, true>};
         for (const void *fn : fns) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
 }

@@ -33,6 +33,7 @@
 
 #include <math.h>
 #include <stdint.h>
+#include <vector> /* (host side: sr_captab_build) */
 
 #ifdef SASA_EMU
 #define SASA_D inline
@@ -590,6 +591,9 @@ struct TileArgs {
     char *slab;
     long long slab_stride;
     int *status;
+    /* S&R, third arrangement (sr_caps.h): the table of cap masks for unit_pts, or null (the second arrangement) */
+    const void *captab;
+    int cap_n, cap_l; /* cube-map cells per face edge, intervals of g */
 };
 
 /* One neighbor record, 32 B, read with two ds_read_b128:
@@ -1708,6 +1712,10 @@ SASA_HD int sr_items(int TA, int n_points) { return (TA * n_points + 1) / 2; } /
    points and more failed the launch, and a narrow range below that overran the shrunk segment) */
 #define SR_SURVIVOR_BYTES_MAX (32 * 1024)
 SASA_HD bool sr_survivors_fit(int TA, int n_points) { return (long long)TA * n_points * 4 <= SR_SURVIVOR_BYTES_MAX; }
+SASA_HD int sr_tile_items(int TA, int n_points, bool caps) /* ... or the third arrangement's masks and list (sr_caps.h): 4 copies of 4 DEF words + 4 COV words per atom, 256 list entries (dwords / 2) */
+{
+    return caps ? 10 * TA + 128 : sr_items(TA, n_points);
+}
 SASA_HD int sr_hist_bin(int longest) { return longest >> 1; } /* demand histogram of S&R batches: tiles by their longest neighbor list, bins of 2 */
 template <bool GLOBAL>
 SASA_D void sr_report(const TileArgs &a, TileMem &m, int tile, int tid, int &wg_max_nn)
@@ -1856,6 +1864,8 @@ SASA_D void sr_phase_store(const TileArgs &a, TileMem &m, int tile, int tid)
         if (a.counts) a.counts[i] = n_surface;
     }
 }
+
+#include "sr_caps.h" /* the third arrangement (round 6): cap masks looked up, the reference's test for the doubtful points only */
 
 /* ---------------------------------------------------------------- per-structure totals */
 /* One workgroup of SASA_TOT_B threads per structure: each thread sums a contiguous chunk in
@@ -2017,7 +2027,7 @@ struct TileCfg {
 
 /* Pick workgroup size and atoms per tile so that TA*resolution work items fill whole rounds
  * of B threads (resolution 20 -> 16 atoms x 20 slices = 320 threads, one round). */
-static inline TileCfg choose_cfg(int resolution, bool lr, int pool_hint = 0)
+static inline TileCfg choose_cfg(int resolution, bool lr, int pool_hint = 0, bool sr_caps = false)
 {
     TileCfg c;
     c.tab = 1;
@@ -2055,9 +2065,13 @@ static inline TileCfg choose_cfg(int resolution, bool lr, int pool_hint = 0)
         int ta = 1024 / resolution;
         c.B = 256;
         c.TA = ta < 1 ? 1 : (ta > 8 ? 8 : ta);
+        /* up to 128 points the third arrangement runs (sr_caps.h): the point tests are all but gone and with them the reason
+           for 256 threads (sr_caps: the caller has the table for these points); measured on the MI355X, round 6 (PDB entries x 251 / coil batch, kernel ms): 256 x 8 3.75 / 9.7,
+           256 x 12 3.93 / 8.0, 128 x 4 3.50 / 9.4, 128 x 6 3.24 / 7.7, 128 x 8 3.55 / 8.0, 64 x 3 3.40 / 8.8, 64 x 4 3.37 / 8.2 */
+        if (sr_caps) { c.B = 128; c.TA = 6; }
     }
     if (!lr) c.tab = sr_survivors_fit(c.TA, resolution) ? 1 : 0; /* (S&R: tab = the tile has a survivor table) */
-    c.items = lr ? (c.tab ? c.TA * resolution : c.B) : (c.tab ? sr_items(c.TA, resolution) : 1);
+    c.items = lr ? (c.tab ? c.TA * resolution : c.B) : (c.tab ? sr_tile_items(c.TA, resolution, sr_caps) : 1);
     c.lr = lr ? 1 : 0;
     c.cap_idx = 128;
     c.pool = 64 * c.TA < 128 ? 128 : 64 * c.TA;

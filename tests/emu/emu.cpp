@@ -94,6 +94,20 @@ static void run_wave(void (*body)(int, void *), void *ctx)
 }
 } /* namespace sasa_emu */
 
+namespace sasa { long long sr_caps_count_emu[4]; }
+static int emu_sr_caps_n = SR_CAP_N_DEFAULT, emu_sr_caps_l = SR_CAP_L_DEFAULT; /* S&R: the third arrangement's table (0: the second arrangement) */
+extern "C" void emu_sr_caps_counts(long long *out, int reset) { for (int k = 0; k < 4; ++k) { out[k] = sasa::sr_caps_count_emu[k]; if (reset) sasa::sr_caps_count_emu[k] = 0; } }
+/* the table itself, for tests/test_sr_caps.py: 6 N^2 L entries of 8 words (DEF then BAND); 0 if these points get no table */
+extern "C" int emu_sr_captab(const double *unit, int np, int n, int l, unsigned *out)
+{
+    std::vector<SrCapEntry> t;
+    if (!sr_captab_build(unit, np, n, l, t)) return 0;
+    memcpy(out, t.data(), sizeof(SrCapEntry) * t.size());
+    return (int)t.size();
+}
+extern "C" int emu_sr_cap_cell(float vx, float vy, float vz, int n) { return sr_cap_cell(vx, vy, vz, n); }
+extern "C" int emu_sr_cap_level(float g, int l) { return sr_cap_level(g, l); }
+extern "C" void emu_set_sr_caps(int n, int l) { emu_sr_caps_n = n; emu_sr_caps_l = l; }
 static bool emu_bucket = true; /* the BUCKET kernel variant; emu_set_bucket(0) emulates the plain one */
 extern "C" void emu_set_bucket(int on) { emu_bucket = on != 0; }
 
@@ -113,8 +127,18 @@ static void emu_tile_kernel(bool lr, const TileCfg &cfg, TileArgs a, int grid)
             if (!lr) { /* Shrake-Rupley: records written by the neighbor phase, no offsets / pairs phases (gpu_kernels.hip, k_sr_tile) */
                 PHASE(sr_phase_load(a, m, tile, tid, B));
                 PHASE(sr_phase_neighbors(a, m, tile, tid, B));
-                PHASE(sr_phase_lists(a, m, tid));
+                const bool caps = !GLOBAL && a.captab && a.tab && sr_order_in_wave(a.cap_idx) && B >= 64; /* third arrangement (sr_caps.h), as launch_sr picks it */
+                if (caps) { PHASE(sr_caps_lists(a, m, tid)); } else { PHASE(sr_phase_lists(a, m, tid)); }
                 PHASE(sr_report<GLOBAL>(a, m, tile, tid, wg_max_nn[tid]));
+                if (caps) {
+                    PHASE(sr_caps_clear(a, m, tile, tid, B)); /* (the device clears beside the load phase: the words are not read before) */
+                    std::vector<SrCapRegs> regs(B);
+                    PHASE(sr_caps_lookup_pass(a, m, tid, B, regs[tid]));
+                    PHASE(sr_caps_todo_pass(a, m, tid, B, cfg.items, regs[tid]));
+                    PHASE(sr_caps_exact(a, m, tid, B, cfg.items));
+                    PHASE(sr_caps_store(a, m, tile, tid));
+                    continue;
+                }
                 PHASE(sr_order_serial(a, m, tid)); /* (the device orders a list with one wave's ballots: the same partition up to the order inside each part, which no count depends on) */
                 PHASE(sr_phase_points(a, m, tile, tid, B));
                 PHASE(sr_phase_points2(a, m, tid, B));
@@ -371,7 +395,7 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
         stats_out[8] = status[ST_OVF3_ATOMS]; stats_out[9] = status[ST_OVF2_TILES];
         return status[ST_ERROR] ? -1 : 0;
     }
-    TileCfg cfg = choose_cfg(resolution, lr != 0);
+    TileCfg cfg = choose_cfg(resolution, lr != 0, 0, !lr && emu_sr_caps_n > 0 && resolution <= SR_CAP_POINTS_MAX);
     if (force_cap_idx > 0) cfg.cap_idx = force_cap_idx;
     if (force_pool > 0) cfg.pool = force_pool;
     if (force_ds >= 0 && lr) cfg.ds = force_ds;
@@ -389,6 +413,10 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
     ta.unit_pts = unit_pts; ta.sasa = sasa; ta.counts = counts;
     ta.cap_idx = cfg.cap_idx; ta.pool = cfg.pool; ta.lr = cfg.lr; ta.ds = cfg.ds;
     ta.ovf_count = status.data() + ST_OVF_TILES; ta.ovf_tiles = ovf_tiles.data(); ta.status = status.data();
+    std::vector<SrCapEntry> captab;
+    if (!lr && emu_sr_caps_n > 0 && sr_captab_build(unit_pts, resolution, emu_sr_caps_n, emu_sr_caps_l, captab)) {
+        ta.captab = captab.data(); ta.cap_n = emu_sr_caps_n; ta.cap_l = emu_sr_caps_l;
+    }
 
     ta.work_tiles = nullptr; ta.work_count = nullptr;
     emu_tile_kernel<false>(lr != 0, cfg, ta, ((n_tiles + 7) / 8) * 8);
@@ -421,6 +449,7 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
         tf.work_tiles = ovf_tiles2.data(); tf.work_count = status.data() + ST_OVF2_TILES;
         tf.ovf_tiles = nullptr; tf.ovf_count = nullptr;
         tf.slab = slab.data(); tf.slab_stride = (long long)stride;
+        if (tf.captab) { tf.captab = nullptr; tf.tab = 0; } /* (as the engine: the slab launch runs the second arrangement without its survivor table) */
         emu_tile_kernel<true>(lr != 0, fb, tf, fb_blocks);
     }
     if (totals) {

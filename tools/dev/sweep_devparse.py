@@ -4,6 +4,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np, freesasa_amd as fa, bench
 from freesasa_amd import ingest
 d = "/tmp/fsbench/sweep_files"
+if not os.path.isdir(d):            # bench.py's own copies of the reference's structure files (tests/golden/structures)
+    import shutil
+    os.makedirs(d, exist_ok=True)
+    pdb_dir, cif_dir = os.path.join(bench.ROOT, "tests", "golden", "pdb"), os.path.join(bench.ROOT, "tests", "golden", "cif")
+    srcs = [os.path.join(pdb_dir, nm + ".pdb") for nm in bench.PDB_NAMES] + sorted(os.path.join(cif_dir, f) for f in os.listdir(cif_dir) if f.endswith(".cif"))[:4]
+    for k in range(163):
+        for sp in srcs: shutil.copyfile(sp, os.path.join(d, f"{k:04d}_{os.path.basename(sp)}"))
 paths = sorted(os.path.join(d, f) for f in os.listdir(d)) * 4
 n = None
 for opt, tag in ((ingest.PARSE_ON_DEVICE, "device"), (0, "host")):
