@@ -559,6 +559,9 @@ hipError_t kl_lr2_main(int rmax, int grid, size_t lds, hipStream_t st, const Lr2
     return hipGetLastError();
 }
 
+#ifndef SR_STOP_AFTER /* dev only (tools/build_variant.sh): leave the tile after phase k, for instruction / time attribution */
+#define SR_STOP_AFTER 99
+#endif
 template <int B, bool GLOBAL, int TIER, bool CAPS = false>
 #ifndef SR_WPE
 #define SR_WPE 7 /* waves per SIMD the S&R kernel's registers are capped for (72 registers: seven 256-thread tiles per CU, what their LDS allows; the kernel is latency-bound - 67 % of its issue slots used - and measured on the MI355X, round 5, PDB entries x 251 / coil batch: uncapped (92 registers, 5 waves) 4.52 / 12.2 ms, 6 waves 4.16 / 11.2, 7 waves 4.04 / 11.0, 8 waves 4.49 / 11.4) */
@@ -577,9 +580,6 @@ __global__ __launch_bounds__(B) __attribute__((amdgpu_waves_per_eu(CAPS ? SR_CAP
     for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
         const int tile = a.work_tiles ? a.work_tiles[w] : xcd_tile(w, a.n_tiles);
         if (tile >= a.n_tiles) continue;
-#ifndef SR_STOP_AFTER /* dev only (tools/build_variant.sh): leave the tile after phase k, for instruction / time attribution */
-#define SR_STOP_AFTER 99
-#endif
         sr_phase_load(a, m, tile, tid, B);
         if constexpr (CAPS) sr_caps_clear(a, m, tile, tid, B);
         __syncthreads();

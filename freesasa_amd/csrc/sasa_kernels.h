@@ -714,10 +714,12 @@ SASA_D void tile_phase_load(const TileArgs &a, TileMem &m, int tile, int tid, in
                the chain is three round trips (s_struct -> grid -> cell_start), not four */
             const int p = p0 + la;
             const SortIdx si = a.s_idx[p];
-            const int sid = si.strct;
             const long long cf = si.cell;
-            const int nx = a.grid[sid].nx, ny = a.grid[sid].ny;
             const int c = (int)(cf & 0xffffffffLL), fl = (int)(cf >> 32);
+            /* nx and ny ride in the record's flag word (cell_pack_grid): the chain is s_idx -> cell table, without the
+               grid in between (round 6, as the L&R kernel since round 4); 0: a grid of 8192 cells or more along x or y */
+            int nx = (fl >> 6) & 8191, ny = (fl >> 19) & 8191;
+            if (nx == 0) { nx = a.grid[si.strct].nx; ny = a.grid[si.strct].ny; }
             const int dy = (r % 3) - 1, dz = (r / 3) - 1;
             const bool out = (dy < 0 && (fl & CELL_Y0)) || (dy > 0 && (fl & CELL_Y1)) ||
                              (dz < 0 && (fl & CELL_Z0)) || (dz > 0 && (fl & CELL_Z1));
@@ -1574,6 +1576,10 @@ SASA_D void sr_phase_load(const TileArgs &a, TileMem &m, int tile, int tid, int 
     if (tid < a.TA) m.aoff[tid] = 0; /* (front cursor of sr_phase_order) */
 }
 
+/* (Round 6, measured and not kept: the NEXT tile's load phase fetched link by link between the phases of this one, as the
+ * L&R kernel does - lr2_pre_a .. c.  The load phase is 1.6 of 7.1 ms on the coil batch, but a 128-thread tile that carries
+ * six more registers through its neighbor phase spills at the five-waves cap: 2.77 -> 3.05 ms on the PDB entries, 7.1 -> 7.5
+ * on the coils; the second arrangement at its seven-waves cap 4.0 -> 4.95.) */
 /* contact test of the reference, operand for operand (src/nb.c:483-492, as nb_test); a neighbor's (x, y, z, R) is kept */
 SASA_D void sr_nb_test(const TileArgs &a, TileMem &m, int la, int p, int q, double xi, double yi,
                        double zi, double ri, double xq, double yq, double zq, double rq)

@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
 L=freesasa_amd/lib
-(timeout 600 bash tools/dev/sr_caps_ab.sh $L/libfreesasa_amd.so:16,32 $L/libvar_cp1.so:16,32 $L/libvar_cp2.so:16,32 2>&1) > gpurun_out/caps_ab11.txt
-cat gpurun_out/caps_ab11.txt
+(timeout 300 python -m pytest tests -m gpu -x -q -k "sr or shrake or deep or points" 2>&1 | tail -3)
+(timeout 600 bash tools/dev/sr_caps_ab.sh $L/libfreesasa_amd.so:16,32 $L/libfreesasa_amd.so:0 2>&1) > gpurun_out/caps_ab12.txt
+cat gpurun_out/caps_ab12.txt
