@@ -584,7 +584,7 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
     }
 
     const bool sr_caps = !lr && c->captab_n > 0;
-    TileCfg cfg = choose_cfg(resolution, lr, c->hint_res[hi] == resolution ? c->hint_pool[hi] : 0, sr_caps);
+    TileCfg cfg = choose_cfg(resolution, lr, c->hint_res[hi] == resolution ? c->hint_pool[hi] : 0, sr_caps, c->hint_res[hi] == resolution ? c->hint_ta[hi] : 0);
     if (const char *e = getenv("FREESASA_AMD_CFG")) { /* tuning aid: "B,TA,pool,ds" */
         int b = 0, t = 0, pl = 0, d = 0;
         if (sscanf(e, "%d,%d,%d,%d", &b, &t, &pl, &d) == 4 && (b == 64 || b == 128 || b == 256) && t >= 1 && t <= b &&

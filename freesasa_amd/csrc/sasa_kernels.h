@@ -2033,7 +2033,7 @@ struct TileCfg {
 
 /* Pick workgroup size and atoms per tile so that TA*resolution work items fill whole rounds
  * of B threads (resolution 20 -> 16 atoms x 20 slices = 320 threads, one round). */
-static inline TileCfg choose_cfg(int resolution, bool lr, int pool_hint = 0, bool sr_caps = false)
+static inline TileCfg choose_cfg(int resolution, bool lr, int pool_hint = 0, bool sr_caps = false, int sr_last_ta = 0)
 {
     TileCfg c;
     c.tab = 1;
@@ -2074,7 +2074,9 @@ static inline TileCfg choose_cfg(int resolution, bool lr, int pool_hint = 0, boo
         /* up to 128 points the third arrangement runs (sr_caps.h): the point tests are all but gone and with them the reason
            for 256 threads (sr_caps: the caller has the table for these points); measured on the MI355X, round 6 (PDB entries x 251 / coil batch, kernel ms): 256 x 8 3.75 / 9.7,
            256 x 12 3.93 / 8.0, 128 x 4 3.50 / 9.4, 128 x 6 3.24 / 7.7, 128 x 8 3.55 / 8.0, 64 x 3 3.40 / 8.8, 64 x 4 3.37 / 8.2 */
-        if (sr_caps) { c.B = 128; c.TA = 6; }
+        /* ... and the per-tile phases (a third of the kernel on sparse input) amortise over more atoms where the lists are
+           short: the final build, 128 x 5 / 6 / 8 / 10: PDB entries 2.78 / 2.85 / 3.19 / 3.59, coils 7.5 / 6.9 / 6.41 / 7.3 */
+        if (sr_caps) { c.B = 128; c.TA = pool_hint > 0 && pool_hint <= (sr_last_ta == 8 ? 56 : 48) ? 8 : 6; } /* (the longest list of a tile of 8 is a little longer than of 6: a batch stays with 8 up to 56) */
     }
     if (!lr) c.tab = sr_survivors_fit(c.TA, resolution) ? 1 : 0; /* (S&R: tab = the tile has a survivor table) */
     c.items = lr ? (c.tab ? c.TA * resolution : c.B) : (c.tab ? sr_tile_items(c.TA, resolution, sr_caps) : 1);
