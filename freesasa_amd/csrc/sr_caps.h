@@ -47,11 +47,13 @@ extern long long sr_caps_count_emu[4]; /* tests only: records looked up, points 
 #define SASA_ATOMIC_OR64_LDS(p, v) (*(p) |= (v))
 #define SASA_RCPF(x) (1.0f / (x))
 #define SASA_RSQF(x) (1.0f / sqrtf(x))
+#define SASA_WAVE_ANY(p) (p) /* (a thread of the emulation decides for itself) */
 #else
 #define SR_CAPS_COUNT(k, n) ((void)0)
 #define SASA_ATOMIC_OR64_LDS(p, v) atomicOr((p), (v))
 #define SASA_RCPF(x) __builtin_amdgcn_rcpf(x) /* 1 ulp: inside the margins (see above) */
 #define SASA_RSQF(x) __builtin_amdgcn_rsqf(x)
+#define SASA_WAVE_ANY(p) (__builtin_amdgcn_ballot_w64(p) != 0) /* (uniform: true if the predicate holds in any lane of the wave) */
 #define SASA_ATOMIC_OR_LDS(p, v) atomicOr((p), (v))
 #endif
 
@@ -100,11 +102,13 @@ SASA_D void sr_cap_lookup(const TileArgs &a, double xi, double yi, double zi, do
     const bool tab = ok && !all && !none;
     const int cell = sr_cap_cell(tab ? (float)dx : 1.0f, tab ? (float)dy : 0.0f, tab ? (float)dz : 0.0f, a.cap_n);
     const SrCapEntry e = ((const SrCapEntry *)a.captab)[cell * a.cap_l + sr_cap_level(tab ? g : 0.0f, a.cap_l)];
-    for (int w = 0; w < SR_CAP_WORDS; ++w) {
-        const unsigned full = sr_cap_full_word(a.n_res, w);
-        def[w] = tab ? e.def[w] : (all ? full : 0u);
-        band[w] = tab ? e.band[w] : (ok ? 0u : full); /* not ok: every point has to be asked */
-    }
+    for (int w = 0; w < SR_CAP_WORDS; ++w) { def[w] = e.def[w]; band[w] = e.band[w]; }
+    if (SASA_WAVE_ANY(!tab)) /* (rare, so a branch for the whole wave: nested spheres, and what the bound refuses) */
+        for (int w = 0; w < SR_CAP_WORDS; ++w) {
+            const unsigned full = sr_cap_full_word(a.n_res, w);
+            def[w] = tab ? def[w] : (all ? full : 0u);
+            band[w] = tab ? band[w] : (ok ? 0u : full); /* not ok: every point has to be asked */
+        }
 }
 
 /* LDS of the arrangement: the tile's survivor table of the second arrangement (TileMem::contrib, 2 * items dwords) holds
