@@ -750,7 +750,9 @@ SASA_D void nb_test(const TileArgs &a, TileMem &m, int la, int p, int q, double 
 /* phase N: neighbor discovery.  SUB = B/TA lanes share one atom and stride over the
  * concatenation of its 9 candidate runs, four candidates per trip so that sixteen loads are in
  * flight before the first test (a coil atom's ~70 candidates then take one round trip to memory). */
+#ifndef SASA_NB_UNROLL
 #define SASA_NB_UNROLL 3
+#endif
 SASA_D void tile_phase_neighbors(const TileArgs &a, TileMem &m, int tile, int tid, int B)
 {
     const int na = tile_atoms(a, tile), p0 = tile_first_atom(a, tile);

@@ -2,6 +2,7 @@
 #   bash tools/gpu_round.sh r04        (outputs under gpurun_out/<tag>_*; copy the summaries into profiles/)
 # Build the phase-ablation variants first if the per-phase instruction counts are wanted:
 #   for k in 0 1 2 3 4 5; do bash tools/build_variant.sh stop$k -DLR2_STOP_AFTER=$k; done; bash tools/build_variant.sh pt -DSASA_PHASE_TIMING
+#   for k in 0 1 12 2 3; do bash tools/build_variant.sh srstop$k -DSR_STOP_AFTER=$k; done
 TAG=${1:-r06}
 mkdir -p gpurun_out
 export PYTHONUNBUFFERED=1
