@@ -177,7 +177,7 @@ def test_hot_kernels_do_not_spill(L):
         if "k_sr_tileILi128ELb0ELi0ELb1" in n:
             # Shrake-Rupley, third arrangement (sr_caps.h; what runs for up to 128 test points): capped for FIVE waves per SIMD -
             # measured in round 6 (4 / 5 / 6 / 7 waves: 3.48 / 3.24 / 3.48 / 4.6 ms on the PDB entries): no register in scratch
-            assert v <= 96 and sc <= 48, (n, v, sc)
+            assert v <= 96 and sc == 0, (n, v, sc)
         if "k_sr_tileILi256ELb0ELi0ELb0" in n:
             # Shrake-Rupley is latency-bound (67 % of its issue slots used), so its registers are CAPPED for seven waves
             # per SIMD (gpu_kernels.hip, SR_WPE): measured on the MI355X in round 5, seven waves with a few spilled
