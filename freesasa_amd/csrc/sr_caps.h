@@ -119,7 +119,9 @@ SASA_D void sr_cap_lookup(const TileArgs &a, double xi, double yi, double zi, do
 #ifndef SR_CAP_COPIES
 #define SR_CAP_COPIES 4
 #endif
-#define SR_CAP_REG_TRIPS 2 /* records per thread whose BAND words stay in registers between the two passes (more: looked up again) */
+#ifndef SR_CAP_REG_TRIPS
+#define SR_CAP_REG_TRIPS 3 /* records per thread whose BAND words stay in registers between the two passes (more: looked up again; six atoms of a protein are ~260 records = three per thread of 128: measured 2 / 3 trips in registers 2.79 / 2.74 ms on the PDB entries) */
+#endif
 SASA_D unsigned *sr_caps_def(const TileMem &m, int la, int copy) { return (unsigned *)m.contrib + SR_CAP_WORDS * (SR_CAP_COPIES * la + copy); }
 SASA_D unsigned *sr_caps_cov(const TileArgs &a, const TileMem &m, int la) { return (unsigned *)m.contrib + SR_CAP_WORDS * (SR_CAP_COPIES * a.TA + la); }
 SASA_D unsigned *sr_caps_list(const TileArgs &a, const TileMem &m) { return (unsigned *)m.contrib + SR_CAP_WORDS * (SR_CAP_COPIES + 1) * a.TA; }
