@@ -96,7 +96,7 @@ SASA_D void sr_cap_lookup(const TileArgs &a, double xi, double yi, double zi, do
     const float ird = SASA_RCPF(fri * fd); /* (coincident centres: 0 * inf, not a number - and so is everything below) */
     const float bound = 1e-14f * (frq * (cabs + fri + frq) + fri * fri) * ird; /* of the reference's rounding, in g */
     const float g = 0.5f * (float)num * ird;
-    const bool ok = bound <= SR_CAP_DEV_MARGIN; /* (false for anything that is not a number; true: g is one, or +-inf) */
+    const bool ok = bound <= SR_CAP_DEV_MARGIN && fri * fd <= 1e30f && g == g; /* (false for anything that is not a number, and for R_i |v| so large that its reciprocal is zero; true: g is a number, or +-inf) */
     const bool all = ok && g < -1.0f - (float)SR_CAP_MARGIN;  /* sphere i inside sphere j */
     const bool none = ok && g > 1.0f + (float)SR_CAP_MARGIN;  /* sphere j inside sphere i: it covers no point of i's surface */
     const bool tab = ok && !all && !none;

@@ -142,6 +142,8 @@ def test_inputs_that_reach_the_guarded_branches():
     x2 = np.concatenate([xyz[:50], xyz[:50] + 1e-9, xyz[:50] + 1e-3, xyz[:50]])   # (nearly) coincident centres
     r2 = np.concatenate([r[:50], r[:50], r[:50] * 1.001, r[:50] * 0.5])
     _both(L, x2, r2, 100)
+    for scale in (1e12, 1e20):                            # absurd but finite: the reciprocal of R_i |v| underflows, the bound refuses
+        _both(L, xyz[:40] * scale, r[:40] * scale, 100, probe=0.0, tables=((16, 32),))
     xyz_c, r_c, _ = tools.coil_batch(1, 1500, seed0=77)
     _both(L, xyz_c.reshape(-1, 3), r_c, 100, tables=((16, 32), (2, 2)))
 
@@ -202,7 +204,8 @@ def test_device_third_arrangement_on_hostile_inputs():
     xyz, r = np.asarray(g["xyz"]).reshape(-1, 3), np.asarray(g["radii"])
     rng = np.random.default_rng(11)
     cases = [(xyz + 1e6, r, 1.4), (xyz + 1e12, r, 1.4), (xyz, rng.uniform(0.1, 10, len(r)), 0.0), (xyz, rng.uniform(0.1, 10, len(r)), 5.0),
-             (np.concatenate([xyz[:80], xyz[:80] + 1e-9, xyz[:80] + 1e-3, xyz[:80]]), np.concatenate([r[:80], r[:80], r[:80] * 1.001, r[:80] * 0.5]), 1.4)]
+             (np.concatenate([xyz[:80], xyz[:80] + 1e-9, xyz[:80] + 1e-3, xyz[:80]]), np.concatenate([r[:80], r[:80], r[:80] * 1.001, r[:80] * 0.5]), 1.4),
+             (xyz[:40] * 1e12, r[:40] * 1e12, 0.0), (xyz[:40] * 1e20, r[:40] * 1e20, 0.0)]
     for x, rad, probe in cases:
         s2, c2, _ = _gpu_sr(x, rad, [0, len(rad)], 100, "0", probe)
         s3, c3, _ = _gpu_sr(x, rad, [0, len(rad)], 100, None, probe)
