@@ -60,13 +60,12 @@ extern long long sr_caps_count_emu[4]; /* tests only: records looked up, points 
 /* cube-map cell of a direction (not normalised; not the zero vector) */
 SASA_HD int sr_cap_cell(float vx, float vy, float vz, int N)
 {
+    /* selects, no branches (the three cases are equally likely: a wave would run them all) */
     const float ax = fabsf(vx), ay = fabsf(vy), az = fabsf(vz);
-    int face;
-    float m, s, t;
-    if (ax >= ay && ax >= az) { face = vx < 0 ? 1 : 0; m = ax; s = vy; t = vz; }
-    else if (ay >= az) { face = vy < 0 ? 3 : 2; m = ay; s = vz; t = vx; }
-    else { face = vz < 0 ? 5 : 4; m = az; s = vx; t = vy; }
-    const float inv = SASA_RCPF(m), h = 0.5f * (float)N;
+    const bool fx = ax >= ay && ax >= az, fy = !fx && ay >= az;
+    const float major = fx ? vx : (fy ? vy : vz), s = fx ? vy : (fy ? vz : vx), t = fx ? vz : (fy ? vx : vy);
+    const int face = (fx ? 0 : (fy ? 2 : 4)) + (major < 0 ? 1 : 0);
+    const float inv = SASA_RCPF(fabsf(major)), h = 0.5f * (float)N;
     int ix = (int)((s * inv + 1.0f) * h), iy = (int)((t * inv + 1.0f) * h);
     ix = ix < 0 ? 0 : (ix > N - 1 ? N - 1 : ix);
     iy = iy < 0 ? 0 : (iy > N - 1 ? N - 1 : iy);
