@@ -1581,7 +1581,11 @@ SASA_D void sr_phase_load(const TileArgs &a, TileMem &m, int tile, int tid, int 
 /* (Round 6, measured and not kept: the NEXT tile's load phase fetched link by link between the phases of this one, as the
  * L&R kernel does - lr2_pre_a .. c.  The load phase is 1.6 of 7.1 ms on the coil batch, but a 128-thread tile that carries
  * six more registers through its neighbor phase spills at the five-waves cap: 2.77 -> 3.05 ms on the PDB entries, 7.1 -> 7.5
- * on the coils; the second arrangement at its seven-waves cap 4.0 -> 4.95.) */
+ * on the coils; the second arrangement at its seven-waves cap 4.0 -> 4.95.  Also measured and not kept: the atoms' candidate rows
+ * written by a kernel of their own before the tile kernel (72 bytes per atom; the tile's load phase then one read instead of a
+ * chain of three): the row kernel costs more than the tiles gain - 2.77 -> 2.90 ms on the PDB entries, 6.55 -> 6.9 on the coils.
+ * The chain's latency is hidden by the other resident tiles; what the cumulative "load phase only" build shows is the tile loop
+ * running empty, not a cost the full kernel pays.) */
 /* contact test of the reference, operand for operand (src/nb.c:483-492, as nb_test); a neighbor's (x, y, z, R) is kept */
 SASA_D void sr_nb_test(const TileArgs &a, TileMem &m, int la, int p, int q, double xi, double yi,
                        double zi, double ri, double xq, double yq, double zq, double rq)
