@@ -88,7 +88,13 @@ int freesasa_gpu_lr_batch_dev_async(freesasa_gpu_ctx *ctx, const double *d_xyz, 
 int freesasa_gpu_wait(freesasa_gpu_ctx *ctx);
 /* unit_points: HOST array [3*n_points] of unit test points (generate with
    freesasa_gpu_test_points for bit-exact parity with the reference).  d_counts [n_atoms]
-   exposed points per atom (may be NULL). */
+   exposed points per atom (may be NULL).
+   Any number of points is accepted (ref: src/sasa_sr.c:56-90, :168-224).  Up to 128 points that are unit vectors (to
+   4e-15 in |u|^2: what freesasa_gpu_test_points produces) run the round-6 arrangement: when a context first sees a set of
+   points it builds a table of cap masks for them (1.5 MB, a few milliseconds of host time, once per point set), the points
+   a neighbor covers are looked up, and only the doubtful (neighbor, point) pairs are put to the reference's test,
+   operand for operand (freesasa_amd/csrc/sr_caps.h: counts and areas identical by construction; checked against the
+   reference).  Other point sets run the arrangement that tests every point.  The choice changes no result. */
 int freesasa_gpu_sr_batch_dev(freesasa_gpu_ctx *ctx, const double *d_xyz, const double *d_radii,
                               const int64_t *offsets, int n_structs, double probe_radius,
                               int n_points, const double *unit_points, double *d_sasa,
