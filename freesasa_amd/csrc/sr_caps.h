@@ -329,12 +329,13 @@ static inline bool sr_captab_build(const double *unit, int np, int N, int L, std
                     if (ang > rho) rho = ang;
                 }
                 rho += SR_CAP_RHO_PAD;
-                for (int k = 0; k < np; ++k) { /* u_k . w over the cell's directions w lies in [lo, hi] */
+                const double cr = cos(rho), sr = sin(rho);
+                for (int k = 0; k < np; ++k) { /* u_k . w over the cell's directions w lies in [lo, hi] = [cos(phi + rho), cos(phi - rho)], phi the angle between u_k and c */
                     double d = c[0] * unit[3 * k] + c[1] * unit[3 * k + 1] + c[2] * unit[3 * k + 2];
                     d = d > 1 ? 1 : (d < -1 ? -1 : d);
-                    const double phi = acos(d);
-                    lo[k] = cos(phi + rho < SASA_PI ? phi + rho : SASA_PI);
-                    hi[k] = cos(phi - rho > 0 ? phi - rho : 0.0);
+                    const double sn = sqrt(1.0 - d * d);                  /* sin(phi) */
+                    lo[k] = d > -cr ? d * cr - sn * sr - 2e-8 : -1.0;     /* (phi + rho < pi; the 2e-8: this arithmetic's own rounding - sqrt(1 - d^2) is off by up to 1e-8 where u_k is the cell's centre or its antipode) */
+                    hi[k] = d < cr ? d * cr + sn * sr + 2e-8 : 1.0;       /* (phi > rho) */
                 }
                 SrCapEntry *E = out.data() + (size_t)((face * N + iy) * N + ix) * L;
                 for (int l = 0; l < L; ++l) {
