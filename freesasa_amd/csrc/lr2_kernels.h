@@ -1303,7 +1303,136 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     /* ------------------------------------------------------------ P6 arc pass */
     int maxd = 0;
     LR2_COUNT(6, nq); LR2_COUNT(8, 1);
-    if (COVER && nq * 2 <= LR2_LANES) {
+#if defined(SASA_EMU) && defined(LR2_EMU_DUMP) /* dev only (tools/dev/arc_sched_sim.py; built with -include cstdio -include cstdlib): the arc pass's work of every tile, for scheduling studies on the CPU */
+    if (lane == 0) {
+        static FILE *df = fopen(getenv("LR2_EMU_DUMP") ? getenv("LR2_EMU_DUMP") : "/tmp/lr2_dump.txt", "w");
+        fprintf(df, "T %d %d %d %d\n", nq, na, mwt, (int)(COVER && cover));
+        for (int qi = 0; qi < nq; ++qi) {
+            const int e = (int)m.queue[qi], my = e & 1023, la_ = e >> 10;
+            fprintf(df, "%d %d", my, m.aoff[la_ + 1] - m.aoff[la_]);
+            for (int wi = 0; wi < mw; ++wi) fprintf(df, " %x", wi < mwt ? m.it_mask[my * mw + wi] : 0u);
+            fprintf(df, "\n");
+        }
+        fflush(df);
+    }
+#endif
+#ifndef LR2_ARC_BALANCED
+#define LR2_ARC_BALANCED 1
+#endif
+    if (LR2_ARC_BALANCED && COVER && nq <= LR2_LANES) {
+        /* Dense tiles behind the cover filter: ~22 of 60 items are left on the reference's PDB entries, with 1 to 60 arcs
+           each (18 on average) - fewer items than lanes, and very unequal ones.  The 64 lanes are dealt out by ARCS: with g
+           the least number for which sum ceil(arcs_i / g) <= 64, item i gets n_i = ceil(arcs_i / g) neighboring lanes, and
+           lane k of them unites the arcs of ranks [arcs_i k / n_i, arcs_i (k + 1) / n_i) in the item's list - contiguous in
+           beta -; then the partial unions are merged pairwise, the higher into the lower: components of the higher part
+           arrive in ascending order and each contains a mid-point beyond every mid-point of the lower part, which is all
+           the stack union asks of its input (see lr2_union_step).  The components, and with them every bit of the area,
+           are the same however the arcs are dealt out (unions are minima and maxima of the same end points).
+           Round 6 (tools/dev/arc_sched_sim.py on the emulation's dump of 1a0q, 1ubq, 3bzd): 8.5 - 9.0 trips of the arc loop
+           per tile where two or four lanes per item by list POSITION (rounds 4 - 5) ran 15.5 - 16.1 and a perfect deal
+           6.3 - 6.6. */
+        Arc2 *stk = m.stack + lane;
+        int *const tbl = m.hist; /* [64] lane -> item of the queue | place among its lanes << 8 | its lanes << 16 (P5 is done with the histogram; the arc stack takes this space over behind the second fence below) */
+        int cnt = 0;
+        if (lane < nq) {
+            const int my_ = (int)m.queue[lane] & 1023;
+            for (int wi = 0; wi < mwt; ++wi) cnt += LR2_POPC32(m.it_mask[LR2_MUL24(my_, mw) + wi]);
+        }
+        const int total = LR2_READLANE(lr2_scan_add(cnt, lane), LR2_LANES - 1);
+        int g = total > LR2_LANES ? (total + LR2_LANES - 1) >> 6 : 1, n = 0, incl = 0;
+        for (;;) { /* (uniform; one to three trips) */
+            n = (int)(((float)(cnt + g - 1) + 0.5f) * LR2_RCPF((float)g)); /* ceil(cnt / g): small integers, the half keeps the 1-ulp reciprocal on the right side */
+            incl = lr2_scan_add(n, lane);
+            if (LR2_READLANE(incl, LR2_LANES - 1) <= LR2_LANES) break;
+            ++g;
+        }
+        int nmax;
+        { const int v = lr2_scan_max16(n, lane); const int a0 = LR2_READLANE(v, 15), a1 = LR2_READLANE(v, 31), a2 = LR2_READLANE(v, 47), a3 = LR2_READLANE(v, 63);
+          nmax = a0 > a1 ? a0 : a1; nmax = nmax > a2 ? nmax : a2; nmax = nmax > a3 ? nmax : a3; }
+        tbl[lane] = -1;
+        LR2_SYNC();
+        for (int j = 0; j < nmax; ++j) /* (uniform) */
+            if (j < n) tbl[incl - n + j] = lane | (j << 8) | (n << 16);
+        LR2_SYNC();
+        const int te = tbl[lane];
+        LR2_SYNC();
+        const bool valid = te >= 0;
+        const int k = valid ? (te >> 8) & 255 : 0, nk = valid ? te >> 16 : 1;
+        int my = 0, la = 0, pos0 = 0;
+        if (valid) { /* the first arc of this lane: the item's set bit of rank r0 = cnt k / nk */
+            const int e = (int)m.queue[te & 255];
+            my = e & 1023; la = e >> 10;
+            int c = 0;
+            for (int wi = 0; wi < mwt; ++wi) c += LR2_POPC32(m.it_mask[LR2_MUL24(my, mw) + wi]);
+            int r = (int)(((float)LR2_MUL24(c, k) + 0.5f) * LR2_RCPF((float)nk)); /* < c: k < nk */
+            unsigned w = m.it_mask[LR2_MUL24(my, mw)];
+            for (int wi = 1; wi < mwt; ++wi) { /* the word it lies in */
+                const int p = LR2_POPC32(w);
+                if (r >= p) { r -= p; pos0 += 32; w = m.it_mask[LR2_MUL24(my, mw) + wi]; }
+            }
+            for (int sz = 16; sz >= 1; sz >>= 1) { /* ... and its place there: the blocks of set bits before it are stepped over */
+                const int p = LR2_POPC32((w >> (pos0 & 31)) & ((1u << sz) - 1u));
+                if (r >= p) { r -= p; pos0 += sz; }
+            }
+        }
+        /* ... and the first of the lane above, where this one's part ends */
+        int pos1 = LR2_SHFL(pos0, lane + 1 < LR2_LANES ? lane + 1 : lane);
+        if (k + 1 >= nk) pos1 = 32 * mwt;
+        Lr2Union u;
+        lr2_union_reset(u);
+        int cnt_shared_ = 0; (void)cnt_shared_;
+        /* the lane's arcs as a window of 64 list positions from its first one (a part that spans more - an item with a
+           long list, few arcs and one lane - takes a second window) */
+        const bool again = LR2_BALLOT(valid && pos1 - pos0 > 64) != 0;
+        for (int win = 0; win < (again ? 2 : 1); ++win) { /* (uniform) */
+            unsigned long long W = 0;
+            int base = 0;
+            double t = 0, hh = 0;
+            if (valid) {
+                const int b0 = pos0 + 64 * win, len = pos1 - b0;
+                const int i0 = b0 >> 5, sh = b0 & 31;
+                const unsigned *const mk = m.it_mask + LR2_MUL24(my, mw);
+                const unsigned x0 = i0 < mwt ? mk[i0 < mwt ? i0 : 0] : 0u, x1 = i0 + 1 < mwt ? mk[i0 + 1 < mwt ? i0 + 1 : 0] : 0u, x2 = i0 + 2 < mwt ? mk[i0 + 2 < mwt ? i0 + 2 : 0] : 0u;
+                const unsigned lo32 = (unsigned)((((unsigned long long)x1 << 32) | x0) >> sh), hi32 = (unsigned)((((unsigned long long)x2 << 32) | x1) >> sh);
+                W = ((unsigned long long)hi32 << 32) | lo32;
+                if (len < 64) W &= len > 0 ? (1ull << len) - 1ull : 0ull;
+                base = m.aoff[la] + b0;
+                t = lr2_slice_height_at<WALK>(my - LR2_MUL24(la, ns), m.adel[la], m.atom[la].w, WALK ? m.atom[la].z : 0.0); /* as P4: bit for bit */
+                hh = m.it_tc[my];
+            }
+            const Ab16 *const Rab = m.ab + base;
+            const double *const Rbt = m.beta + base;
+            while (W != 0) { /* (the wave runs as many trips as its busiest lane) */
+                const int q = __builtin_ctzll(W);
+                W &= W - 1;
+#ifdef SASA_EMU
+                ++cnt_shared_;
+#endif
+                const Ab16 ab = Rab[q];
+                const double bt = Rbt[q];
+                const double alpha = lr2_arc_alpha(t, ab, hh);
+                lr2_union_step(bt - alpha, bt + alpha, u, stk, LR2_A_DS(a), maxd); /* ref: :338-339 */
+            }
+        }
+        LR2_COUNT_LANES(14, 15, cnt_shared_);
+        for (int st = 1; st < nmax; st <<= 1) { /* merge: lane k + st of an item into its lane k, for k a multiple of 2 st */
+            LR2_SYNC();
+            const int src = lane + st < LR2_LANES ? lane + st : lane;
+            const int d_s = LR2_SHFL(u.depth, src);
+            const double bs_s = lr2_shfl_f64(u.bs, src), be_s = lr2_shfl_f64(u.be, src);
+            const double ts_s = lr2_shfl_f64(u.ts, src), te_s = lr2_shfl_f64(u.te, src);
+            if (valid && (k & (2 * st - 1)) == 0 && k + st < nk) {
+                const Arc2 *col = m.stack + src;
+                for (int c = 0; c < d_s - 2; ++c) { /* (rare: the components below the two in registers) */
+                    const Arc2 kk = col[(c < LR2_A_DS(a) ? c : 0) * LR2_LANES];
+                    lr2_union_step(kk.s, kk.e, u, stk, LR2_A_DS(a), maxd);
+                }
+                if (d_s >= 2) lr2_union_step(bs_s, be_s, u, stk, LR2_A_DS(a), maxd);
+                if (d_s >= 1) lr2_union_step(ts_s, te_s, u, stk, LR2_A_DS(a), maxd);
+            }
+        }
+        if (valid && k == 0) m.it_tc[my] = m.adel[la] * m.atom[la].w * lr2_sweep(u, stk, LR2_A_DS(a)); /* ref: :360 */
+    } else if (COVER && nq * 2 <= LR2_LANES) {
         const int shb = nq * 4 <= LR2_LANES ? 2 : 1, share = 1 << shb; /* (uniform) 4 lanes per item, or 2 */
         /* Few items are left (dense tiles behind the cover filter: ~9 of 60, two of them with ~27 arcs): one item
            per lane would leave 55 lanes idle for as long as the longest item takes.  Four lanes (two, from 17 items)
