@@ -115,16 +115,22 @@ struct Cache {
 };
 
 /* ---- the device-side parser's input (gpu_parse.hip): a batch's files read - not parsed - into page-locked memory */
+/* The text lives in one of the worker's CONTEXT's two page-locked staging buffers (stage_in / stage_out: they stay with the
+   pooled context from call to call).  Until round 6's last session every sweep allocated and freed its own: hipHostMalloc
+   and hipHostFree of 50 MB take 5 - 7 ms each and hold the runtime's lock while they do - in the kernel trace of a 70 ms
+   sweep (tools/dev/sweep_trace.sh) the first 24 ms saw five batches where the steady state does twenty-two, and the last
+   batch's tile kernel waited 11 ms for the OTHER worker to free its buffers. */
 struct Staged {
     unsigned char *text = nullptr; /* page-locked: the files one after the other, each in a slot of its size + 1 and ending with '\n' */
-    size_t cap = 0, T = 0;
+    size_t T = 0;
+    void **slot = nullptr;         /* the context's buffer and its capacity */
+    size_t *slot_cap = nullptr;
     std::vector<ParseFile> files;  /* [n + 1] */
     int rc = 0;                    /* -1: no page-locked memory */
-    Staged() = default;
+    Staged(void **slot_, size_t *cap_) : slot(slot_), slot_cap(cap_) {}
     Staged(const Staged &) = delete;
     Staged &operator=(const Staged &) = delete;
-    ~Staged() { if (text) (void)hipHostFree(text); }
-    void swap(Staged &o) { std::swap(text, o.text); std::swap(cap, o.cap); std::swap(T, o.T); files.swap(o.files); std::swap(rc, o.rc); }
+    void swap(Staged &o) { std::swap(text, o.text); std::swap(T, o.T); std::swap(slot, o.slot); std::swap(slot_cap, o.slot_cap); files.swap(o.files); std::swap(rc, o.rc); }
 };
 /* n files -> out, with `threads` readers (each file: one pread loop, then the one-line-at-a-time look at an mmCIF file's text
    before its _atom_site loop: freesasa_ingest_cif_locate); a file that cannot be read is left to the host parser, which
@@ -144,13 +150,14 @@ void stage_files(const char *const *paths, int n, int options, int threads, Stag
     if (T >= (1ULL << 31)) { out->rc = -2; return; }
     out->files[n].beg = (unsigned)T;
     out->T = T;
-    if (T + 64 > out->cap) {
-        if (out->text) (void)hipHostFree(out->text);
-        out->text = nullptr; out->cap = 0;
+    if (T + 64 > *out->slot_cap) {
+        if (*out->slot) (void)hipHostFree(*out->slot);
+        *out->slot = nullptr; *out->slot_cap = 0;
         const size_t want = T + T / 8 + 4096;
-        if (host_malloc((void **)&out->text, want) != hipSuccess) { out->rc = -1; return; }
-        out->cap = want;
+        if (host_malloc(out->slot, want) != hipSuccess) { out->rc = -1; out->text = nullptr; return; }
+        *out->slot_cap = want;
     }
+    out->text = (unsigned char *)*out->slot;
     std::atomic<int> next(0);
     auto reader = [&]() noexcept {
         for (;;) {
@@ -233,10 +240,11 @@ int sweep_impl(const char *const *paths, int n_paths, int ingest_options, int n_
     if (alg != 0 && alg != 1) return set_err(err_out, err_len, "unknown algorithm");
     if (check_devices(devices, n_devices, err_out, err_len)) return -1;
     if (n_paths == 0) return 0;
-    /* (round 6, measured on the MI355X box, 1.2e7 protein atoms in 7172 files, 16 CPUs: batches of 5e5 / 1e6 / 2e6 atoms with two
-       workers on the device: parser on the device 1.57 / 1.49 / 1.08e8 atoms/s, host parser 1.25 / 1.34 / 1.31e8; one worker:
-       1.24 / 1.19 / 1.07e8 and 0.91 / 1.03 / 1.02e8) */
-    if (batch_atoms <= 0) batch_atoms = (ingest_options & FREESASA_INGEST_PARSE_ON_DEVICE) ? 500000 : 1000000;
+    /* (round 6, MI355X box, 1.2e7 protein atoms in 7172 files, 16 CPUs, two workers on the device, parser on the device,
+       batches of 5e5 / 1e6 / 1.5e6 / 2e6 atoms: 2.2 / 2.5 / 2.4 / 2.3e8 atoms/s once the workers' page-locked staging stays
+       with their contexts - tools/dev/sweep_profile.py; with a staging buffer allocated and freed per call, as until the
+       round's last session: 1.7 / 1.5 / - / 1.1e8; host parser 1.25 / 1.34 / - / 1.31e8) */
+    if (batch_atoms <= 0) batch_atoms = 1000000;
     /* ONE device in the list: two workers on it, so that the upload of one batch runs under the kernels of the other (a
        worker's batch is a chain on one stream: text or arrays over PCIe, parse, cell sort, tile kernels) */
     const int two[2] = {devices[0], devices[0]};
@@ -344,18 +352,28 @@ int sweep_impl(const char *const *paths, int n_paths, int ingest_options, int n_
     /* The sweep with the parser ON THE DEVICE (FREESASA_INGEST_PARSE_ON_DEVICE; gpu_parse.hip): the loader threads only READ the
        next batch's files into page-locked memory while this batch's text is uploaded, parsed, classified and swept on the GPU.
        Files the device refuses are read by the host parser and appended to the batch as further structures. */
+    /* dev aid (FREESASA_AMD_SWEEP_PROFILE): where a worker's wall clock goes - staging of its first batch, parse (upload, line
+       and atom counts back), the files left to the host parser, the tile kernels up to the totals, the done-list, waiting for
+       the loader of the next batch */
+    const bool sprof = getenv("FREESASA_AMD_SWEEP_PROFILE") != nullptr;
+    std::atomic<long long> tp_first(0), tp_parse(0), tp_host(0), tp_run(0), tp_rec(0), tp_join(0), tp_stage(0);
+    auto now_ns = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (long long)ts.tv_sec * 1000000000LL + ts.tv_nsec; };
     auto worker_dev = [&](int w) noexcept {
       try {
-        Staged cur_s, nxt_s;
         DeviceNodeScope node(devices[w]);
         PoolLease lease(devices[w]);
         freesasa_gpu_ctx *c = lease.c;
         if (!c) { fe.set("could not create a GPU context"); return; }
+        Staged cur_s(&c->stage_in, &c->stage_in_cap), nxt_s(&c->stage_out, &c->stage_out_cap);
         auto stage = [&](int b, Staged *out) noexcept {
+            const long long t0 = sprof ? now_ns() : 0;
             try { stage_files(paths + cut[b], cut[b + 1] - cut[b], ingest_options, loader_threads, out); } catch (...) { out->rc = -3; }
+            if (sprof) tp_stage += now_ns() - t0;
         };
         size_t ti = next.fetch_add(1);
-        if (ti < todo.size()) stage(todo[ti], &cur_s);
+        { const long long t0 = sprof ? now_ns() : 0;
+          if (ti < todo.size()) stage(todo[ti], &cur_s);
+          if (sprof) tp_first += now_ns() - t0; }
         while (ti < todo.size() && !fe.failed.load()) {
             const int b = todo[ti];
             const size_t tn = next.fetch_add(1);
@@ -372,7 +390,9 @@ int sweep_impl(const char *const *paths, int n_paths, int ingest_options, int n_
                 if (cur_s.rc) { ctx_fail(c, cur_s.rc == -1 ? "out of page-locked host memory (file staging)" : (cur_s.rc == -2 ? "a batch of files larger than 2 GB: use a smaller batch_atoms" : "out of host memory (file staging)")); break; }
                 if (hipSetDevice(c->device) != hipSuccess) { ctx_fail(c, "hipSetDevice failed"); break; }
                 long long total = 0;
+                long long tq = sprof ? now_ns() : 0;
                 if (parse_batch_dev_begin(c, cur_s.text, cur_s.T, cur_s.files.data(), ns, ingest_options, atoms.data(), status.data(), host.data(), &total)) break;
+                if (sprof) { const long long t1 = now_ns(); tp_parse += t1 - tq; tq = t1; }
                 /* the files the device left to the host parser: read now, appended behind the device's atoms */
                 for (int k = 0; k < ns; ++k) if (host[(size_t)k]) fb.push_back(k);
                 g_parse_dev_files += ns - (long long)fb.size(); g_parse_host_files += (long long)fb.size();
@@ -383,6 +403,7 @@ int sweep_impl(const char *const *paths, int n_paths, int ingest_options, int n_
                     if (lrc) { ctx_fail(c, "loader failed with code %d", lrc); break; }
                 }
                 const long long extra = hb.b.n_atoms, n_all = total + extra;
+                if (sprof) { const long long t1 = now_ns(); tp_host += t1 - tq; tq = t1; }
                 if (parse_batch_dev_finish(c, extra)) break;
                 const int nst = ns + (int)fb.size();
                 std::vector<int64_t> off((size_t)nst + 1);
@@ -425,12 +446,16 @@ int sweep_impl(const char *const *paths, int n_paths, int ingest_options, int n_
                     for (size_t j = 0; j < fb.size(); ++j) for (int q = 0; q < 3; ++q) cls[3 * (size_t)fb[j] + q] = cls[3 * ((size_t)ns + j) + q];
                     if (class_sums_out) memcpy(class_sums_out + 3 * (size_t)first, cls.data(), 8 * 3 * (size_t)ns);
                 }
+                if (sprof) tp_run += now_ns() - tq;
                 ret = 0;
             } while (0);
             if (ret) (void)hipStreamSynchronize(c->stream);
+            long long tr = sprof ? now_ns() : 0;
             if (!ret && fd_done >= 0 && record(c, b, first, ns, atoms64.data(), cls.empty() ? nullptr : cls.data())) ret = -1;
             if (ret) fe.set(c->err[0] ? c->err : "GPU sweep failed");
+            if (sprof) { const long long t1 = now_ns(); tp_rec += t1 - tr; tr = t1; }
             loader.join();
+            if (sprof) tp_join += now_ns() - tr;
             cur_s.swap(nxt_s);
             ti = tn;
         }
@@ -520,6 +545,10 @@ int sweep_impl(const char *const *paths, int n_paths, int ingest_options, int n_
             if (!tg.spawn(worker, w)) { fe.set("could not start a worker thread"); break; }
         if (!fe.failed.load()) worker(0);
     }
+    if (sprof && dev_parse)
+        fprintf(stderr, "sweep profile (%d workers, %zu batches, %d loader threads each; ms summed over the workers): first batch staged %.1f | parse %.1f | host parser %.1f | "
+                        "kernels to totals %.1f | done-list %.1f | waiting for the loader %.1f || staging itself (loader threads) %.1f\n",
+                n_workers, todo.size(), loader_threads, tp_first / 1e6, tp_parse / 1e6, tp_host / 1e6, tp_run / 1e6, tp_rec / 1e6, tp_join / 1e6, tp_stage / 1e6);
     if (fe.failed.load()) return set_err(err_out, err_len, fe.text);
     return stopped ? 1 : 0;
     });
@@ -846,10 +875,10 @@ extern "C" long long freesasa_gpu_parse_files(const char *const *paths, int n_pa
     if (check_devices(&device, 1, err_out, err_len)) return -1;
     long long written = -1;
     const int rc = guarded(err_out, err_len, [&]() -> int {
-        Staged s;
         PoolLease lease(device);
         freesasa_gpu_ctx *c = lease.c;
         if (!c) return set_err(err_out, err_len, "could not create a GPU context");
+        Staged s(&c->stage_in, &c->stage_in_cap);
         if (hipSetDevice(c->device) != hipSuccess) return set_err(err_out, err_len, "hipSetDevice failed");
         stage_files(paths, n_paths, ingest_options & ~FREESASA_INGEST_PARSE_ON_DEVICE, threads_per_worker(n_threads, 1), &s);
         if (s.rc) return set_err(err_out, err_len, "could not stage the files");

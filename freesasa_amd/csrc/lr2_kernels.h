@@ -1111,12 +1111,25 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     lr2_pre_a<SHAPE>(a, pre, p0n, nan, lane); /* the next tile's sort records: on their way while this tile is screened */
     /* ------------------------------------------------------------ P4 screening */
     const float inv_ns = LR2_RCPF((float)ns); /* index arithmetic only (one off either way is put right below) */
-    m.hist[lane] = 0;
-    LR2_SYNC();
+#ifndef LR2_ARC_BALANCED
+#define LR2_ARC_BALANCED 1
+#endif
+    /* (uniform) dense builds whose tile has an item per lane at most (3 atoms x 20 slices): the arc pass deals its lanes out
+       by the items' arc counts (P6, "balanced"), which every lane still holds in a register - no queue, no P5 */
+#if defined(SASA_EMU) && defined(LR2_EMU_DUMP)
+    const bool direct = false;
+#else
+    const bool direct = LR2_ARC_BALANCED && COVER && !PAIRS && items <= LR2_LANES;
+#endif
+    int dcnt = 0; /* direct: arcs of the lane's item behind the cover filter */
+    if (!direct) {
+        m.hist[lane] = 0;
+        LR2_SYNC();
+    }
     /* what is left to do for an item once its arcs are known: the cover filter (dense tiles), its word for the arc pass
        or its area, its place in the queue */
     int cnt_filter_[2] = {0, 0}, cnt_filter_k_ = 0, cnt_screen_ = 0; (void)cnt_filter_; (void)cnt_filter_k_; (void)cnt_screen_;
-    auto finish_item = [&](int it, int la, double t, double h2, double Ri, int o, int cnt, bool buried, bool circle) {
+    auto finish_item = [&](int it, int la, double t, double h2, double Ri, int o, int cnt, bool buried, bool circle) -> int {
         double area = 0;
         if (buried || !circle) cnt = 0; /* circle i inside a neighbor's: buried (ref: :327-330); no circle: ref :310-312 */
         else if (cnt == 0) area = m.adel[la] * Ri * SASA_TWOPI; /* ref: :360 with exposed_arc_length(n = 0) */
@@ -1147,6 +1160,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         ++cnt_filter_k_;
 #endif
         m.it_tc[it] = cnt == 0 ? area : 0.5 * h2; /* (an item with arcs: 1/(4 Ri') for the arc pass - see lr2_arc_alpha -, which puts the area in its place) */
+        if (direct) return cnt; /* (uniform) */
         unsigned short qt = 0xffff;
         if (cnt > 0) { /* queue: heaviest first (bin 0 = 63 arcs or more); inside a bin in order of arrival */
             const int bin = 63 - (cnt < 63 ? cnt : 63);
@@ -1154,6 +1168,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             qt = (unsigned short)((bin << 10) | ord); /* ord < items <= 512 */
         }
         m.qtmp[it] = qt;
+        return cnt;
     };
     const int hp = (ns + 1) >> 1; /* pairs of slices per atom */
     if (PAIRS) { /* (the launch's tile shape: lr2_pairs_shape) */
@@ -1258,7 +1273,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             }
             buried = vmin <= -T;
         }
-        finish_item(it, la, t, h2, Ri, o, cnt, buried, A > 0);
+        dcnt = finish_item(it, la, t, h2, Ri, o, cnt, buried, A > 0); /* (direct: the loop has one trip) */
     }
     LR2_SYNC();
 #ifdef SASA_EMU
@@ -1270,7 +1285,8 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     lr2_pre_b<SHAPE>(a, pre, nan, lane); /* the next tile's candidate rows (compact cell table: their table words): on their way while this tile's arcs are done */
     /* ------------------------------------------------------------ P5 queue */
     int nq;
-    {
+    if (direct) nq = LR2_POPC64(LR2_BALLOT(dcnt > 0));
+    else {
         const int hv = m.hist[lane];
         const int incl2 = lr2_scan_add(hv, lane);
         nq = LR2_READLANE(incl2, LR2_LANES - 1);
@@ -1293,8 +1309,8 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             { const int s = it - LR2_MUL24(la, ns); if (s < 0) --la; else if (s >= ns) ++la; }
             if (qt != 0xffffu) m.queue[m.hist[qt >> 10] + (qt & 1023u)] = (unsigned short)(it | (la << 10));
         }
+        LR2_SYNC();
     }
-    LR2_SYNC();
 
     LR2_STOP(5);
     LR2_MARK(5);
@@ -1316,9 +1332,6 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         fflush(df);
     }
 #endif
-#ifndef LR2_ARC_BALANCED
-#define LR2_ARC_BALANCED 1
-#endif
     if (LR2_ARC_BALANCED && COVER && nq <= LR2_LANES) {
         /* Dense tiles behind the cover filter: ~22 of 60 items are left on the reference's PDB entries, with 1 to 60 arcs
            each (18 on average) - fewer items than lanes, and very unequal ones.  The 64 lanes are dealt out by ARCS: with g
@@ -1333,8 +1346,8 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
            6.3 - 6.6. */
         Arc2 *stk = m.stack + lane;
         int *const tbl = m.hist; /* [64] lane -> item of the queue | place among its lanes << 8 | its lanes << 16 (P5 is done with the histogram; the arc stack takes this space over behind the second fence below) */
-        int cnt = 0;
-        if (lane < nq) {
+        int cnt = direct ? dcnt : 0; /* direct: lane = item; else lane = place in the queue */
+        if (!direct && lane < nq) {
             const int my_ = (int)m.queue[lane] & 1023;
             for (int wi = 0; wi < mwt; ++wi) cnt += LR2_POPC32(m.it_mask[LR2_MUL24(my_, mw) + wi]);
         }
@@ -1359,11 +1372,17 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         const bool valid = te >= 0;
         const int k = valid ? (te >> 8) & 255 : 0, nk = valid ? te >> 16 : 1;
         int my = 0, la = 0, pos0 = 0;
+        const int c_src = LR2_SHFL(cnt, valid ? te & 255 : lane); /* the item's arcs */
         if (valid) { /* the first arc of this lane: the item's set bit of rank r0 = cnt k / nk */
-            const int e = (int)m.queue[te & 255];
-            my = e & 1023; la = e >> 10;
-            int c = 0;
-            for (int wi = 0; wi < mwt; ++wi) c += LR2_POPC32(m.it_mask[LR2_MUL24(my, mw) + wi]);
+            if (direct) {
+                my = te & 255;
+                la = (int)(((float)my + 0.5f) * inv_ns);
+                { const int s_ = my - LR2_MUL24(la, ns); if (s_ < 0) --la; else if (s_ >= ns) ++la; }
+            } else {
+                const int e = (int)m.queue[te & 255];
+                my = e & 1023; la = e >> 10;
+            }
+            const int c = c_src;
             int r = (int)(((float)LR2_MUL24(c, k) + 0.5f) * LR2_RCPF((float)nk)); /* < c: k < nk */
             unsigned w = m.it_mask[LR2_MUL24(my, mw)];
             for (int wi = 1; wi < mwt; ++wi) { /* the word it lies in */

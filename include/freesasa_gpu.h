@@ -198,7 +198,7 @@ int freesasa_gpu_arc_union_dev(freesasa_gpu_ctx *ctx, const double *arcs, const 
 void freesasa_gpu_shard_cuts(const int64_t *offsets, int n_structs, int n_parts, int *cuts);
 
 /* Structure sweep (BASELINE configs[3]): PDB / mmCIF files -> per-structure totals.  The files are
-   read in batches of about batch_atoms atoms (<= 0: 2e6) by n_threads host threads
+   read in batches of about batch_atoms atoms (<= 0: 1e6) by n_threads host threads
    (include/freesasa_ingest.h; ingest_options are its option bits) while the previous batch is on
    the GPU.  totals_out[n_paths]; class_sums_out[3*n_paths] (apolar, polar, unknown) and
    atoms_out[n_paths] may be NULL; status_out[n_paths] receives the loader's per-input status
