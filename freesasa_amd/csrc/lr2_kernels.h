@@ -1401,14 +1401,18 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         lr2_union_reset(u);
         int cnt_shared_ = 0; (void)cnt_shared_;
         /* the lane's arcs as a window of 64 list positions from its first one (a part that spans more - an item with a
-           long list, few arcs and one lane - takes a second window) */
-        const bool again = LR2_BALLOT(valid && pos1 - pos0 > 64) != 0;
-        for (int win = 0; win < (again ? 2 : 1); ++win) { /* (uniform) */
+           long list, few arcs and one lane - takes a second window; LR2_ARC_WINDOW: tests build with a narrow window to
+           walk that path) */
+#ifndef LR2_ARC_WINDOW
+#define LR2_ARC_WINDOW 64
+#endif
+        const int nwin = LR2_ARC_WINDOW == 64 ? (LR2_BALLOT(valid && pos1 - pos0 > 64) != 0 ? 2 : 1) : (32 * mwt + LR2_ARC_WINDOW - 1) / LR2_ARC_WINDOW; /* (32 mwt <= 128 positions) */
+        for (int win = 0; win < nwin; ++win) { /* (uniform) */
             unsigned long long W = 0;
             int base = 0;
             double t = 0, hh = 0;
             if (valid) {
-                const int b0 = pos0 + 64 * win, len = pos1 - b0;
+                const int b0 = pos0 + LR2_ARC_WINDOW * win, len = pos1 - b0 < LR2_ARC_WINDOW ? pos1 - b0 : LR2_ARC_WINDOW;
                 const int i0 = b0 >> 5, sh = b0 & 31;
                 const unsigned *const mk = m.it_mask + LR2_MUL24(my, mw);
                 const unsigned x0 = i0 < mwt ? mk[i0 < mwt ? i0 : 0] : 0u, x1 = i0 + 1 < mwt ? mk[i0 + 1 < mwt ? i0 + 1 : 0] : 0u, x2 = i0 + 2 < mwt ? mk[i0 + 2 < mwt ? i0 + 2 : 0] : 0u;

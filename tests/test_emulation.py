@@ -411,6 +411,37 @@ def test_tiles_with_too_many_candidate_items_are_handed_on(tmp_path):
     assert outs[40]["slab"] > 500 and outs[40]["err"] < LR_TOL                                            # nearly every atom through the slab launch
 
 
+def test_arc_pass_lane_dealing_does_not_change_a_bit(tmp_path):
+    """Round 6: on dense tiles the arc pass deals its 64 lanes out by the items' arc counts (n_i = ceil(arcs_i / g) lanes per
+    item, every lane a run of consecutive arcs of the item's beta-sorted list, partial unions merged pairwise).  The union's
+    components are minima and maxima of the same end points however the arcs are dealt out, so three builds of the same
+    sources must give identical bits on protein-density input: the shipped one, one with the dealing switched off (rounds
+    4 - 5: two or four lanes per item by list position, or the queue), and one whose lanes see their arcs through windows
+    of 8 list positions instead of 64, so that every lane walks the several-windows path that the shipped build takes only
+    for an item with a list beyond 64 neighbors, few arcs and a single lane."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for tag, flags in (("shipped", []), ("fixed", ["-DLR2_ARC_BALANCED=0"]), ("window8", ["-DLR2_ARC_WINDOW=8"])):
+        so = str(tmp_path / f"libsasa_emu_{tag}.so")
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-DSASA_EMU"] + flags +
+                       ["-shared", "-o", so, os.path.join(root, "tests", "emu", "emu.cpp"), "-lm"], check=True)
+        code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+                "from conftest import load_golden; import emu; from emu import run_batch\n"
+                "L = emu._load(); res = []\n"
+                "for name, ta in (('1ubq', 3), ('1ubq', 4), ('1a0q', 3)):\n"
+                "    g = load_golden(name); L.emu_set_lr2(1, ta, 0); emu.set_lr2_opts(True, False)\n"
+                "    s, _, _, st = run_batch(True, g['xyz'], g['radii'], resolution=20, cap_idx=96)\n"
+                "    assert np.max(np.abs(s - g['lr20'])) < 1e-8 and st['TA'] == ta\n"
+                "    res.append(s)\n"
+                "np.save(sys.argv[1], np.concatenate(res))\n") % (os.path.join(root, "tests"), root)
+        out = str(tmp_path / f"{tag}.npy")
+        subprocess.run([sys.executable, "-c", code, out], check=True, env=dict(os.environ, SASA_EMU_SO=so))
+        outs[tag] = np.load(out)
+    assert np.array_equal(outs["shipped"], outs["fixed"])
+    assert np.array_equal(outs["shipped"], outs["window8"])
+
+
 def test_shape_builds_and_the_compact_cell_table_give_the_generic_bits(oracle_lib):
     """Round-4 advisor (low): the CPU emulation ran the Lee-Richards tile kernel only in its generic build (SHAPE 0) over
     the dense cell table.  Here the builds with a compile-time tile shape - 6 x 20 (coils), 3 x 100 (100 slices), 3 x 20
