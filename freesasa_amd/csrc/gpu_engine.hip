@@ -309,6 +309,12 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
     /* (hint_nn: what all but 4 % of the last batch's tiles needed per atom, or 1.25 x the density sample: coils ~30, proteins ~58) */
     la.cover = c->hint_nn >= 1.35 * LR2_COVER_DENSITY ? LR2_COVER_DENSITY : 0;
     if (const char *e = getenv("FREESASA_AMD_COVER")) la.cover = atoi(e); /* tuning aid: neighbor records per atom from which a tile runs the cover filter; 0: never */
+    /* contained caps (lr2_prune_contained): the largest caps an atom's hits are tested against */
+    {
+        int want = lr2_prune_want(resolution, cfg.mw), cap = LR2_PRUNE_MAX;
+        if (const char *e = getenv("FREESASA_AMD_PRUNE")) { want = 0; (void)sscanf(e, "%d,%d", &want, &cap); } /* tuning / test aid: "caps wanted per atom[,list capacity]"; 0: off */
+        la.prune = lr2_prune_arg(want, cfg.TA, cfg.pool, cap);
+    }
     la.sasa = d_sasa; la.status = (int *)c->status.p;
     la.inv_ns = 1.0 / (double)resolution;
     la.ovf_items = (long long *)c->ovf_tiles.p;

@@ -54,6 +54,7 @@ long long wave_exchange(long long v, int src);
 #define LR2_UMUL24(a, b) ((unsigned)(a) * (unsigned)(b))
 #define LR2_RCPF(x) (1.0f / (x))
 #define LR2_RSQF(x) (1.0f / sqrtf(x))
+#define LR2_SQRTF(x) sqrtf(x)
 #define LR2_ADD64_LDS(p, v) (*(p) += (v))
 #define LR2_OR_LDS(p, v) (*(p) |= (v))
 #define LR2_INC_LDS(p) (++*(p))
@@ -94,6 +95,7 @@ namespace sasa_emu { extern long long lr2_count[16]; } /* wave-level trip counts
 #define LR2_UMUL24(a, b) ((unsigned)__umul24((unsigned)(a), (unsigned)(b)))
 #define LR2_RCPF(x) __builtin_amdgcn_rcpf(x)
 #define LR2_RSQF(x) __builtin_amdgcn_rsqf(x)
+#define LR2_SQRTF(x) __builtin_amdgcn_sqrtf(x)
 #define LR2_ADD64_LDS(p, v) atomicAdd((p), (v))
 #define LR2_OR_LDS(p, v) atomicOr((p), (v))
 #define LR2_INC_LDS(p) ((void)__hip_atomic_fetch_add((p), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) /* result unused: ds_add_u32, nothing to wait for */
@@ -277,6 +279,7 @@ struct Lr2Args {
     int seg_grid, seg_tiles;
     int hooks; /* bit 0: nn_out is set, bit 1: nb_out is set (what the tile body tests; the pointers themselves are cold) */
     int walk;  /* host side only (kl_lr2_main): launch the main launch's walking build - most tiles of the last batch had an atom beyond LR2_WALK_Z */
+    int prune; /* contained caps (lr2_prune_contained): caps wanted in an atom's list | the list's capacity << 8 (lr2_prune_arg); 0: off */
 };
 #include <stddef.h>
 /* Arguments only rare paths need (overflow lists, statistics, the test hooks): read from the kernel-argument
@@ -681,6 +684,138 @@ SASA_D double lr2_acos_lower(double c)
     return (1.5707963267948966 - 1e-9) - fma(c * c2, fma(k5, c2, 1.0 / 6.0), c);
 }
 
+/* ---------------------------------------------------------------- contained caps (P1.5, round 6)
+ * Neighbor j cuts the cap { u : u . n_j >= cos(theta_j) } out of sphere i (n_j: direction of j, cos(theta_j) = (Ri^2 - Rj^2
+ * + d^2) / (2 Ri d), as the cover filter's bins).  Where cap j lies INSIDE the cap of another neighbor k - angle(n_j, n_k) +
+ * theta_j <= theta_k - the arc of j lies inside the arc of k on every slice that j cuts, and a slice that j buries k
+ * buries too: the union of the slice's arcs, whose components are minima and maxima of the arcs' end points
+ * (lr2_union_step), is the same with and without j, bit for bit, and so is every area.  On random coils and on the
+ * reference's PDB entries alike 45 % of all neighbor records are of this kind (42 % against the eight largest caps of
+ * their atom), and they carry a third of all arcs.  So the hits of P1 are tested against the largest caps of their atom,
+ * and those that lie inside one are dropped before the records are made: P3 ranks shorter lists, P4 screens fewer
+ * records per item and the arc pass unites fewer arcs, for ~10 instructions per (hit, cap) pair here.
+ *    The test is a SUFFICIENT one, in fp32: with c = cos(theta), s >= sin(theta) (from 1 - c^2 + 4e-6), cap j is dropped
+ * for k only if c_k <= c_j - 4e-6 (k is the larger cap) and n_j . n_k >= c_k c_j + s_k s_j + 8e-6, i.e. cos(angle) >=
+ * cos(theta_k - theta_j) + 8e-6.  The operands carry relative errors of a few 1e-7 (conversions, v_rsq_f32, three
+ * roundings each), both sides of the comparison less than 2e-6 in all, so what passes has angle(n_j, n_k) + theta_j <
+ * theta_k - 6e-6 rad: room to spare against the arcs' own rounding (1e-8 rad where acos is steep).  "Larger cap" is a
+ * strict order, so a dropped cap always lies inside one that stays.  Coincident centres (d = 0) give directions that
+ * are not numbers: such a record neither drops nor is dropped.
+ *    "Bit for bit" needs one more condition.  The arc pass works on RAW end points beta -+ alpha with beta in [0, 2 pi]
+ * (lr2_sweep folds what sticks out), so an arc that lies inside another ON THE CIRCLE may lie 2 pi away from it as an
+ * interval of numbers - j just above beta = 0, k just below 2 pi - and then j's end points do become a component's, and
+ * the sweep adds its 2 pi to other numbers (the same area to ~1e-14, not the same bits).  beta is atan2(yd, xd) + pi: the
+ * cut is the negative x axis.  A cap is therefore dropped only for a cap on the same side of the x axis (yd of equal
+ * sign), or when both look to the right (xd > 0): then |beta_j - beta_k| <= pi as numbers, the intervals are nested as
+ * numbers, and j's end points are never the least or the greatest of a component.  Which caps are in an atom's list (the bins that hold
+ * the `want` largest, at most `kmax`) only decides how many records are dropped, never an area:
+ * tests/test_emulation.py compares the bits with and without this phase, the GPU suite runs both (FREESASA_AMD_PRUNE). */
+#ifndef LR2_PRUNE
+#define LR2_PRUNE 1
+#endif
+#define LR2_PRUNE_MAX 12   /* caps in an atom's list at most */
+#define LR2_DEAD_TAG 0xff  /* tag of a dropped hit (atoms of a tile: < 8) */
+struct __attribute__((aligned(16))) Lr2Cap { float x, y, z, c; };
+SASA_HD int lr2_prune_arg(int want, int TA, int pool, int cap = LR2_PRUNE_MAX) /* Lr2Args::prune: want | kmax << 8; 0: the list would be too short to pay */
+{
+    int kmax = (8 * pool) / (20 * TA); /* the lists lie where P3's sort keys will be: 8 B per pool record, 20 B per cap */
+    if (kmax > cap) kmax = cap;
+    if (kmax > LR2_PRUNE_MAX) kmax = LR2_PRUNE_MAX;
+    if (want > kmax) want = kmax;
+    return want >= 2 ? (want | (kmax << 8)) : 0;
+}
+/* caps wanted per atom by tile shape (host side) */
+/* MI355X, kernel ms without / with the phase (tools/dev/prune_ab.sh, round 6): coils at 100 slices 2.98 / 2.62 (6 wanted, lists
+   of 12; 3 of 3: 2.79, 4 of 4: 2.74, 8 of 8: 2.64), at 50 slices 1.95 / 1.79, the reference's PDB entries at 100 slices
+   5.11 / 4.74; at 20 slices the phase costs what it saves - coils 2.88 / 2.89 - 2.94, PDB entries and lattice globules
+   +5 ... +10 % (their hits are many and their slices few) - so it runs from 32 slices on. */
+static inline int lr2_prune_want(int ns, int mw) { (void)mw; return ns >= 32 ? 6 : 0; }
+SASA_D int lr2_cap_bin(float c) { const int b = (int)fmaf(c, 10.0f, -2.0f); return b < 0 ? 0 : (b > 7 ? 7 : b); }
+template <int RMAX>
+SASA_D void lr2_prune_contained(const Lr2Mem &m, int nh, int TA, int pk, int lane)
+{
+    const int want = pk & 255, kmax = pk >> 8;
+    unsigned long long *const chist = (unsigned long long *)m.acell; /* [TA] over acell and lead (P0 / P1 only; P3 uses them the same way) */
+    Lr2Cap *const bigc = (Lr2Cap *)m.keys;                             /* [TA][kmax] the atoms' largest caps: direction, cosine ... */
+    float *const bigs = (float *)(bigc + LR2_MUL24(TA, kmax));         /* ... and the upper bound of the sine */
+    if (lane < TA) chist[lane] = 0;
+    LR2_SYNC();
+    float nx[RMAX], ny[RMAX], nz[RMAX], cc[RMAX]; /* (the hit's atom, its bin and its sine are read / made again where needed: registers are short here) */
+#define LR2_CAP_SIN(c) LR2_SQRTF(fmaf(-(c), (c), 1.0f + 4e-6f))
+#define LR2_CAP_BIN(c) lr2_cap_bin(c) /* the cover filter's bins: 0.1 wide from 0.2 */
+    for (int r = 0; r < RMAX; ++r) {
+        const int gp = lane + LR2_LANES * r;
+        nx[r] = ny[r] = nz[r] = cc[r] = 0.0f;
+        if (gp < nh) {
+            const Quad hq = m.hits[gp];
+            const int la = (int)m.tag[gp];
+            const double ri = m.atom[la].w;
+            const double d2 = hq.x * hq.x + hq.y * hq.y + hq.z * hq.z;
+            const double K = (ri * ri - hq.w * hq.w) + d2;
+            const float inv = LR2_RSQF((float)d2);
+            nx[r] = (float)hq.x * inv; ny[r] = (float)hq.y * inv; nz[r] = (float)hq.z * inv;
+            float c = (float)K * inv * LR2_RCPF(2.0f * (float)ri);
+            c = c < -1.0f ? -1.0f : (c > 1.0f ? 1.0f : c); /* (sphere i inside sphere j: the whole sphere, theta = pi) */
+            cc[r] = c;
+            LR2_ADD64_LDS(&chist[la], 1ull << (8 * LR2_CAP_BIN(c))); /* (a byte per bin; a carry only changes which caps are listed) */
+        }
+    }
+    LR2_SYNC();
+    if (lane < TA) { /* the last bin needed for `want` caps */
+        const unsigned long long h = chist[lane];
+        int cum = 0, tb = 7;
+        for (int b = 0; b < 8; ++b) {
+            cum += (int)((h >> (8 * b)) & 255u);
+            if (cum >= want && b < tb) tb = b;
+        }
+        m.aoff[lane] = tb; /* (aoff: free until P2) */
+    }
+    LR2_SYNC();
+    for (int r = 0; r < RMAX; ++r) {
+        const int gp = lane + LR2_LANES * r;
+        if (gp >= nh) continue;
+        const int la = (int)m.tag[gp];
+        if (LR2_CAP_BIN(cc[r]) <= m.aoff[la]) {
+            const int slot = SASA_ATOMIC_ADD_LDS(&m.gsz[la], 1); /* (gsz: zero since P0, and again below) */
+            if (slot < kmax) {
+                Lr2Cap q; q.x = nx[r]; q.y = ny[r]; q.z = nz[r]; q.c = cc[r];
+                bigc[LR2_MUL24(la, kmax) + slot] = q;
+                bigs[LR2_MUL24(la, kmax) + slot] = LR2_CAP_SIN(cc[r]);
+            }
+        }
+    }
+    LR2_SYNC();
+    for (int r = 0; r < RMAX; ++r) {
+        const int gp = lane + LR2_LANES * r;
+        if (gp >= nh) continue;
+        const int la = (int)m.tag[gp];
+        int nb = m.gsz[la];
+        nb = nb < kmax ? nb : kmax;
+        const Lr2Cap *const L = bigc + LR2_MUL24(la, kmax);
+        const float *const S = bigs + LR2_MUL24(la, kmax);
+        const float clim = cc[r] - 4e-6f;
+        const bool right = nx[r] > 0.0f;
+        const float sj = LR2_CAP_SIN(cc[r]);
+        bool inside = false;
+        for (int k = 0; k < nb; ++k) { /* (the wave runs as many trips as its longest list) */
+            const Lr2Cap q = L[k];
+            const float dot = fmaf(nz[r], q.z, fmaf(ny[r], q.y, nx[r] * q.x));
+            const float rhs = fmaf(sj, S[k], fmaf(cc[r], q.c, 8e-6f));
+            const bool same_side = ny[r] * q.y > 0.0f || (right && q.x > 0.0f); /* beta_j and beta_k less than pi apart AS NUMBERS (see above) */
+            inside = inside || (q.c <= clim && dot >= rhs && same_side); /* (a direction that is not a number compares false) */
+        }
+        if (inside) {
+            m.tag[gp] = (unsigned char)LR2_DEAD_TAG;
+            SASA_ATOMIC_ADD_LDS(&m.acnt[la], -1);
+        }
+    }
+#undef LR2_CAP_BIN
+#undef LR2_CAP_SIN
+    LR2_SYNC();
+    if (lane < TA) m.gsz[lane] = 0;
+    LR2_SYNC();
+}
+
 /* ---------------------------------------------------------------- P0's global loads, one tile ahead
  * What P0 needs from global memory is a chain: the atom's sort record -> (its structure's grid ->) the first atoms of
  * the cells at both ends of each of its 9 candidate rows.  Until round 3 every tile began by waiting for those round
@@ -938,6 +1073,13 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         LR2_SYNC();
         return 0;
     }
+    /* ------------------------------------------------------------ P1.5 contained caps */
+    if (LR2_PRUNE && !HOOKS && !PAIRS) { /* (PAIRS: the builds for at most 128 items - 20 slices or so -, where the phase costs what it saves; they are at their register cap) */
+        const int pk = LR2_COLD(a, prune);
+        if (pk > 0 && nh > 0 && nh <= a.pool && nh <= LR2_LANES * RMAX) /* (uniform; hits beyond the pool were not kept: P2 hands the tile on) */
+            lr2_prune_contained<RMAX>(m, nh, TA, pk, lane);
+    }
+    LR2_STOP(15);
     /* ------------------------------------------------------------ P2 offsets */
     /* offsets of the atoms' lists in the pool (lists padded to an even length): a prefix over the first lanes of
        the wave; whether the tile fits is a ballot, so every lane knows it without a flag in LDS */
@@ -954,7 +1096,8 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         if (lane == 0) {
             if (nn_max > wg_max_nn) wg_max_nn = nn_max;
             if (sample) { /* demand histogram for the next batch's pool size: 1 tile in 32 of the main launch */
-                const int need = total / hist_bin_width(TA);
+                const bool pruned = LR2_PRUNE && !HOOKS && !PAIRS && LR2_COLD(a, prune) > 0;
+                const int need = (pruned && nh > total ? nh : total) / hist_bin_width(TA); /* (the hits themselves need their places before any is dropped) */
                 SASA_ATOMIC_ADD_GLB(&LR2_COLD(a, status)[ST_HIST + (need < 63 ? need : 63)], 1);
             }
         }
@@ -992,6 +1135,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             if (gp < nh) {
                 const Quad hq = m.hits[gp];
                 const int la = (int)m.tag[gp];
+                if (la == LR2_DEAD_TAG) continue; /* a cap inside another (P1.5) */
                 const int sa = SASA_ATOMIC_ADD_LDS(&m.gsz[la], 1); /* place in the atom's list, in order of discovery (gsz: zero since P0) */
                 const int o = m.aoff[la];
                 const double ri = m.atom[la].w;
@@ -1321,7 +1465,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
     LR2_COUNT(6, nq); LR2_COUNT(8, 1);
 #if defined(SASA_EMU) && defined(LR2_EMU_DUMP) /* dev only (tools/dev/arc_sched_sim.py; built with -include cstdio -include cstdlib): the arc pass's work of every tile, for scheduling studies on the CPU */
     if (lane == 0) {
-        static FILE *df = fopen(getenv("LR2_EMU_DUMP") ? getenv("LR2_EMU_DUMP") : "/tmp/lr2_dump.txt", "w");
+        static FILE *df = fopen(getenv("LR2_EMU_DUMP") ? getenv("LR2_EMU_DUMP") : "/tmp/lr2_dump.txt", "a");
         fprintf(df, "T %d %d %d %d\n", nq, na, mwt, (int)(COVER && cover));
         for (int qi = 0; qi < nq; ++qi) {
             const int e = (int)m.queue[qi], my = e & 1023, la_ = e >> 10;

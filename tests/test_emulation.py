@@ -442,6 +442,50 @@ def test_arc_pass_lane_dealing_does_not_change_a_bit(tmp_path):
     assert np.array_equal(outs["shipped"], outs["window8"])
 
 
+def test_dropping_contained_caps_does_not_change_a_bit(tmp_path):
+    """Round 6, P1.5 (lr2_prune_contained): a neighbor whose cap on the atom's sphere lies inside another neighbor's cap cuts,
+    on every slice, an arc inside that neighbor's arc; its record is dropped before the pair records are made (45 % of all
+    records on coils and proteins alike).  The union's components are minima and maxima of end points that the dropped arcs
+    never supply - provided the two arcs are nested AS NUMBERS, hence the phase's same-side-of-the-cut rule -, so every
+    area must keep its bits whatever the phase drops: off, 3 caps per atom's list, 8, 12; at 20 and at 100 slices; on a
+    coil, on the reference's 1a0q at protein density (tile of three atoms: the cover filter and the dealt arc pass behind
+    it), and on hostile geometry - neighbors placed just either side of beta's cut (the negative x axis), spheres wholly
+    inside a neighbor's, twins at 1e-9 A, a ring of equal caps."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from conftest import load_golden; import emu, tools; from emu import run_batch\n"
+            "L = emu._load(); res = []\n"
+            "xyz, r = tools.coil(1500, 77)[:2]\n"
+            "for ns in (20, 100):\n"
+            "    emu.set_lr2_opts(True, False); L.emu_set_lr2(1, 3, 0)\n"
+            "    res.append(run_batch(True, xyz, r, resolution=ns)[0])\n"
+            "g = load_golden('1a0q')\n"
+            "s, _, _, st = run_batch(True, g['xyz'], g['radii'], resolution=20, cap_idx=96)\n"
+            "assert np.max(np.abs(s - g['lr20'])) < 1e-8 and st['TA'] == 3\n"
+            "res.append(s)\n"
+            "rng = np.random.default_rng(5)\n"
+            "pts = [(0.0, 0.0, 0.0, 1.8)]\n"
+            "for k in range(40):                      # around the cut of beta: directions (-1, +-tiny, z)\n"
+            "    d = 2.0 + 2.5 * rng.random(); e = (1 if k %% 2 else -1) * 10.0 ** rng.uniform(-12, -1)\n"
+            "    pts.append((-d, e * d, rng.uniform(-1.5, 1.5), rng.choice([1.2, 1.6, 1.9])))\n"
+            "pts += [(0.3, 0.1, 0.2, 3.5), (0.31, 0.1, 0.2, 3.5 + 1e-9), (0.3 + 1e-9, 0.1, 0.2, 3.5)]   # spheres that hold atom 0; twins\n"
+            "for k in range(12): pts.append((3.0 * np.cos(k * np.pi / 6), 3.0 * np.sin(k * np.pi / 6), 0.0, 1.7))   # a ring of equal caps\n"
+            "pts += [(6.0 + 3 * rng.random(), 4 * rng.random() - 2, 4 * rng.random() - 2, 1.5 + 0.5 * rng.random()) for _ in range(60)]\n"
+            "p = np.array(pts)\n"
+            "for ns in (20, 100):\n"
+            "    res.append(run_batch(True, p[:, :3].copy(), p[:, 3].copy(), resolution=ns)[0])\n"
+            "np.save(sys.argv[1], np.concatenate(res))\n") % (os.path.join(root, "tests"), root)
+    outs = {}
+    for want in ("0", "3", "8", "12"):
+        out = str(tmp_path / f"prune{want}.npy")
+        subprocess.run([sys.executable, "-c", code, out], check=True, env=dict(os.environ, EMU_LR2_PRUNE=want))
+        outs[want] = np.load(out)
+    assert np.all(np.isfinite(outs["0"][:1500 * 2]))
+    for want in ("3", "8", "12"):
+        assert np.array_equal(outs["0"], outs[want], equal_nan=True), (want, float(np.nanmax(np.abs(outs["0"] - outs[want]))))
+
+
 def test_shape_builds_and_the_compact_cell_table_give_the_generic_bits(oracle_lib):
     """Round-4 advisor (low): the CPU emulation ran the Lee-Richards tile kernel only in its generic build (SHAPE 0) over
     the dense cell table.  Here the builds with a compile-time tile shape - 6 x 20 (coils), 3 x 100 (100 slices), 3 x 20

@@ -355,6 +355,40 @@ def test_shape_builds_give_the_generic_builds_bits(fa, monkeypatch):
     monkeypatch.delenv("FREESASA_AMD_NO_SHAPE", raising=False)
 
 
+def test_dropping_contained_caps_leaves_every_bit_alone(fa, monkeypatch):
+    """Round 6, lr2_prune_contained (P1.5 of the Lee-Richards tile kernel; on from 32 slices): neighbors whose cap lies inside
+    another neighbor's are dropped before the pair records are made.  Their arcs lie inside the other's on every slice, so
+    the areas must be the same BITS with the phase off (FREESASA_AMD_PRUNE=0), as shipped, and with lists of 3 and of 12
+    caps per atom - at 20 slices too, where the phase is off by default - on coils, lattice globules and protein copies."""
+    import torch
+    dev = torch.device("cuda:0")
+    g = load_golden("1a0q")
+    prot = (g["xyz"].reshape(-1, 3), g["radii"])
+    sets = {"coils, 100 slices": ([tools.coil(5000, 510 + k) for k in range(4)], 100),
+            "coils, 48 slices": ([tools.coil(5000, 520 + k) for k in range(4)], 48),
+            "coils, 20 slices": ([tools.coil(5000, 530 + k) for k in range(6)], 20),
+            "globules, 20 slices": ([tools.globule(10000, 540 + k) for k in range(2)], 20),
+            "protein copies, 100 slices": ([(prot[0] + 70.0 * k, prot[1]) for k in range(6)], 100),
+            "protein copies, 20 slices": ([(prot[0] + 70.0 * k, prot[1]) for k in range(12)], 20)}
+    for name, (parts, ns) in sets.items():
+        xyz = np.concatenate([np.asarray(p[0]).reshape(-1, 3) for p in parts]); r = np.concatenate([p[1] for p in parts])
+        offs = np.concatenate([[0], np.cumsum([len(p[1]) for p in parts])]).astype(np.int64)
+        d_xyz, d_r = torch.from_numpy(np.ascontiguousarray(xyz)).to(dev), torch.from_numpy(np.ascontiguousarray(r)).to(dev)
+        d_out = torch.empty(len(r), dtype=torch.float64, device=dev)
+        got = {}
+        for spec in ("0", None, "3,3", "12,12"):
+            if spec is None: monkeypatch.delenv("FREESASA_AMD_PRUNE", raising=False)
+            else: monkeypatch.setenv("FREESASA_AMD_PRUNE", spec)
+            ctx = fa.GpuContext(0)
+            for _ in range(2):  # (the second batch runs with the shape learnt from the first one's demand)
+                ctx.lee_richards(d_xyz.data_ptr(), d_r.data_ptr(), offs, d_out.data_ptr(), 0, probe=1.4, n_slices=ns)
+            got[spec] = d_out.cpu().numpy().copy()
+            ctx.close()
+        for spec in (None, "3,3", "12,12"):
+            assert np.array_equal(got["0"], got[spec]), (name, spec, float(np.nanmax(np.abs(got["0"] - got[spec]))))
+    monkeypatch.delenv("FREESASA_AMD_PRUNE", raising=False)
+
+
 def test_asynchronous_batches_match_the_synchronous_ones(fa, oracle_lib):
     """freesasa_gpu_lr_batch_dev_async: batches enqueued back to back (two in flight, a third call collects the oldest),
     different inputs and output buffers per batch, offsets that change between batches (the tables of the batches in
