@@ -311,9 +311,9 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
     if (const char *e = getenv("FREESASA_AMD_COVER")) la.cover = atoi(e); /* tuning aid: neighbor records per atom from which a tile runs the cover filter; 0: never */
     /* contained caps (lr2_prune_contained): the largest caps an atom's hits are tested against */
     {
-        int want = lr2_prune_want(resolution, cfg.mw), cap = LR2_PRUNE_MAX;
-        if (const char *e = getenv("FREESASA_AMD_PRUNE")) { want = 0; (void)sscanf(e, "%d,%d", &want, &cap); } /* tuning / test aid: "caps wanted per atom[,list capacity]"; 0: off */
-        la.prune = lr2_prune_arg(want, cfg.TA, cfg.pool, cap);
+        int want = lr2_prune_want(resolution, cfg.mw);
+        if (const char *e = getenv("FREESASA_AMD_PRUNE")) want = atoi(e); /* tuning / test aid: caps wanted per list (at most LR2_PRUNE_LIST); 0: off */
+        la.prune = lr2_prune_arg(want, cfg.TA, cfg.pool);
     }
     la.sasa = d_sasa; la.status = (int *)c->status.p;
     la.inv_ns = 1.0 / (double)resolution;

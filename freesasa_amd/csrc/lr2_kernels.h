@@ -706,50 +706,58 @@ SASA_D double lr2_acos_lower(double c)
  * interval of numbers - j just above beta = 0, k just below 2 pi - and then j's end points do become a component's, and
  * the sweep adds its 2 pi to other numbers (the same area to ~1e-14, not the same bits).  beta is atan2(yd, xd) + pi: the
  * cut is the negative x axis.  A cap is therefore dropped only for a cap on the same side of the x axis (yd of equal
- * sign), or when both look to the right (xd > 0): then |beta_j - beta_k| <= pi as numbers, the intervals are nested as
- * numbers, and j's end points are never the least or the greatest of a component.  Which caps are in an atom's list (the bins that hold
+ * sign, neither zero): then |beta_j - beta_k| < pi as numbers, the intervals are nested as numbers, and j's end points are
+ * never the least or the greatest of a component.  Which caps are in an atom's list (the bins that hold
  * the `want` largest, at most `kmax`) only decides how many records are dropped, never an area:
  * tests/test_emulation.py compares the bits with and without this phase, the GPU suite runs both (FREESASA_AMD_PRUNE). */
 #ifndef LR2_PRUNE
 #define LR2_PRUNE 1
 #endif
-#define LR2_PRUNE_MAX 12   /* caps in an atom's list at most */
+#ifndef LR2_PRUNE_IN_PAIRS
+#define LR2_PRUNE_IN_PAIRS 0 /* (the builds for at most 128 items - 20 slices or so -, where the phase costs what it saves: coils 2.82 - 2.92 ms without, 2.78 - 2.88 with; they are at their register cap) */
+#endif
+#define LR2_PRUNE_PAIRS_OK (LR2_PRUNE_IN_PAIRS || !PAIRS)
+#define LR2_PRUNE_LIST 4   /* caps in one of an atom's two lists (lists of 6 and 8, all four read at once and tested in straight-line code: the same times) */
 #define LR2_DEAD_TAG 0xff  /* tag of a dropped hit (atoms of a tile: < 8) */
 struct __attribute__((aligned(16))) Lr2Cap { float x, y, z, c; };
-SASA_HD int lr2_prune_arg(int want, int TA, int pool, int cap = LR2_PRUNE_MAX) /* Lr2Args::prune: want | kmax << 8; 0: the list would be too short to pay */
+SASA_HD int lr2_prune_arg(int want, int TA, int pool) /* Lr2Args::prune: caps wanted per list; 0: off */
 {
-    int kmax = (8 * pool) / (20 * TA); /* the lists lie where P3's sort keys will be: 8 B per pool record, 20 B per cap */
-    if (kmax > cap) kmax = cap;
-    if (kmax > LR2_PRUNE_MAX) kmax = LR2_PRUNE_MAX;
-    if (want > kmax) want = kmax;
-    return want >= 2 ? (want | (kmax << 8)) : 0;
+    /* the lists lie where P3's sort keys will be (8 B per pool record): a histogram word per (atom, side), then 20 B per cap */
+    if (8 * pool < (16 + 20 * LR2_PRUNE_LIST) * 2 * TA) return 0;
+    return want > LR2_PRUNE_LIST ? LR2_PRUNE_LIST : (want < 0 ? 0 : want);
 }
-/* caps wanted per atom by tile shape (host side) */
-/* MI355X, kernel ms without / with the phase (tools/dev/prune_ab.sh, round 6): coils at 100 slices 2.98 / 2.62 (6 wanted, lists
-   of 12; 3 of 3: 2.79, 4 of 4: 2.74, 8 of 8: 2.64), at 50 slices 1.95 / 1.79, the reference's PDB entries at 100 slices
-   5.11 / 4.74; at 20 slices the phase costs what it saves - coils 2.88 / 2.89 - 2.94, PDB entries and lattice globules
-   +5 ... +10 % (their hits are many and their slices few) - so it runs from 32 slices on. */
-static inline int lr2_prune_want(int ns, int mw) { (void)mw; return ns >= 32 ? 6 : 0; }
-SASA_D int lr2_cap_bin(float c) { const int b = (int)fmaf(c, 10.0f, -2.0f); return b < 0 ? 0 : (b > 7 ? 7 : b); }
+/* caps wanted per list by tile shape (host side).
+   MI355X, kernel ms without / with the phase (tools/dev/prune_ab.sh, round 6; one list of 6 - 12 caps per atom, as first built):
+   coils at 100 slices 2.98 / 2.62 (3 of 3: 2.79, 4 of 4: 2.74, 8 of 8: 2.64), at 50 slices 1.95 / 1.79, the reference's PDB
+   entries at 100 slices 5.11 / 4.74; at 20 slices that form cost what it saved - coils 2.88 / 2.89 - 2.94, PDB entries and
+   lattice globules +5 ... +10 % (their hits are many and their slices few). */
+static inline int lr2_prune_want(int ns, int mw) { (void)mw; return ns >= 32 ? 4 : 0; }
+SASA_D int lr2_cap_bin(float c) { const int b = (int)fmaf(c, 10.0f, -2.0f); return b < 0 ? 0 : (b > 7 ? 7 : b); } /* the cover filter's bins: 0.1 wide from 0.2 */
+/* Two lists per atom, one for either side of the x axis (the same-side rule above): a hit is tested against the largest caps
+   of ITS side only - half the trips of one list for the same caps, and no side test inside the loop (per side the 4 largest
+   caps drop 38 % of all records on coils, 35 % on 1a0q; all pairs: 43 / 44 %). */
 template <int RMAX>
-SASA_D void lr2_prune_contained(const Lr2Mem &m, int nh, int TA, int pk, int lane)
+SASA_D void lr2_prune_contained(const Lr2Mem &m, int nh, int TA, int want, int lane)
 {
-    const int want = pk & 255, kmax = pk >> 8;
-    unsigned long long *const chist = (unsigned long long *)m.acell; /* [TA] over acell and lead (P0 / P1 only; P3 uses them the same way) */
-    Lr2Cap *const bigc = (Lr2Cap *)m.keys;                             /* [TA][kmax] the atoms' largest caps: direction, cosine ... */
-    float *const bigs = (float *)(bigc + LR2_MUL24(TA, kmax));         /* ... and the upper bound of the sine */
-    if (lane < TA) chist[lane] = 0;
+    constexpr int LK = LR2_PRUNE_LIST;
+    unsigned long long *const chist = (unsigned long long *)m.keys;  /* [2 TA] a byte per bin; then the list's last bin */
+    Lr2Cap *const bigc = (Lr2Cap *)(chist + 2 * TA);                 /* [2 TA][LK] the largest caps: direction, cosine ... */
+    Lr2Cap *const bigs = bigc + 2 * LK * TA;                         /* [2 TA] ... and the upper bounds of their sines, a list's four in one read */
+    int *const fill = m.acell;                                       /* [2 TA] over acell and lead (P0 / P1 only): caps in the list */
+    if (lane < 2 * TA) { chist[lane] = 0; fill[lane] = 0; }
     LR2_SYNC();
-    float nx[RMAX], ny[RMAX], nz[RMAX], cc[RMAX]; /* (the hit's atom, its bin and its sine are read / made again where needed: registers are short here) */
+    float nx[RMAX], ny[RMAX], nz[RMAX], cc[RMAX]; /* (the hit's bin and its sine are made again where needed: registers are short here) */
+    int lis[RMAX];
 #define LR2_CAP_SIN(c) LR2_SQRTF(fmaf(-(c), (c), 1.0f + 4e-6f))
-#define LR2_CAP_BIN(c) lr2_cap_bin(c) /* the cover filter's bins: 0.1 wide from 0.2 */
+/* the hit's list: 2 atom + side; -1: none (no hit, or yd = 0 / not a number: on the cut or beside it, never dropped, never listed) */
+#define LR2_CAP_LIST(r, gp) ((gp) < nh && ny[r] != 0.0f && ny[r] == ny[r] ? 2 * (int)m.tag[gp] + (ny[r] > 0.0f ? 1 : 0) : -1)
     for (int r = 0; r < RMAX; ++r) {
         const int gp = lane + LR2_LANES * r;
         nx[r] = ny[r] = nz[r] = cc[r] = 0.0f;
+        lis[r] = -1;
         if (gp < nh) {
             const Quad hq = m.hits[gp];
-            const int la = (int)m.tag[gp];
-            const double ri = m.atom[la].w;
+            const double ri = m.atom[(int)m.tag[gp]].w;
             const double d2 = hq.x * hq.x + hq.y * hq.y + hq.z * hq.z;
             const double K = (ri * ri - hq.w * hq.w) + d2;
             const float inv = LR2_RSQF((float)d2);
@@ -757,62 +765,57 @@ SASA_D void lr2_prune_contained(const Lr2Mem &m, int nh, int TA, int pk, int lan
             float c = (float)K * inv * LR2_RCPF(2.0f * (float)ri);
             c = c < -1.0f ? -1.0f : (c > 1.0f ? 1.0f : c); /* (sphere i inside sphere j: the whole sphere, theta = pi) */
             cc[r] = c;
-            LR2_ADD64_LDS(&chist[la], 1ull << (8 * LR2_CAP_BIN(c))); /* (a byte per bin; a carry only changes which caps are listed) */
+            const int li = lis[r] = LR2_CAP_LIST(r, gp);
+            if (li >= 0) LR2_ADD64_LDS(&chist[li], 1ull << (8 * lr2_cap_bin(c))); /* (a byte per bin; a carry only changes which caps are listed) */
         }
     }
     LR2_SYNC();
-    if (lane < TA) { /* the last bin needed for `want` caps */
+    if (lane < 2 * TA) { /* the last bin needed for `want` caps */
         const unsigned long long h = chist[lane];
         int cum = 0, tb = 7;
         for (int b = 0; b < 8; ++b) {
             cum += (int)((h >> (8 * b)) & 255u);
             if (cum >= want && b < tb) tb = b;
         }
-        m.aoff[lane] = tb; /* (aoff: free until P2) */
+        chist[lane] = (unsigned long long)tb;
     }
     LR2_SYNC();
     for (int r = 0; r < RMAX; ++r) {
-        const int gp = lane + LR2_LANES * r;
-        if (gp >= nh) continue;
-        const int la = (int)m.tag[gp];
-        if (LR2_CAP_BIN(cc[r]) <= m.aoff[la]) {
-            const int slot = SASA_ATOMIC_ADD_LDS(&m.gsz[la], 1); /* (gsz: zero since P0, and again below) */
-            if (slot < kmax) {
+        const int li = lis[r];
+        if (li < 0) continue;
+        if (lr2_cap_bin(cc[r]) <= (int)chist[li]) {
+            const int slot = SASA_ATOMIC_ADD_LDS(&fill[li], 1);
+            if (slot < LK) {
                 Lr2Cap q; q.x = nx[r]; q.y = ny[r]; q.z = nz[r]; q.c = cc[r];
-                bigc[LR2_MUL24(la, kmax) + slot] = q;
-                bigs[LR2_MUL24(la, kmax) + slot] = LR2_CAP_SIN(cc[r]);
+                bigc[LK * li + slot] = q;
+                ((float *)bigs)[LK * li + slot] = LR2_CAP_SIN(cc[r]);
             }
         }
     }
     LR2_SYNC();
     for (int r = 0; r < RMAX; ++r) {
         const int gp = lane + LR2_LANES * r;
-        if (gp >= nh) continue;
-        const int la = (int)m.tag[gp];
-        int nb = m.gsz[la];
-        nb = nb < kmax ? nb : kmax;
-        const Lr2Cap *const L = bigc + LR2_MUL24(la, kmax);
-        const float *const S = bigs + LR2_MUL24(la, kmax);
-        const float clim = cc[r] - 4e-6f;
-        const bool right = nx[r] > 0.0f;
-        const float sj = LR2_CAP_SIN(cc[r]);
+        const int li = lis[r];
+        if (li < 0) continue;
+        const Lr2Cap *const L = bigc + LK * li;
+        const float *const S = (const float *)bigs + LK * li;
+        const float clim = cc[r] - 4e-6f, sj = LR2_CAP_SIN(cc[r]);
         bool inside = false;
+        int nb = fill[li];
+        nb = nb < LK ? nb : LK;
         for (int k = 0; k < nb; ++k) { /* (the wave runs as many trips as its longest list) */
             const Lr2Cap q = L[k];
             const float dot = fmaf(nz[r], q.z, fmaf(ny[r], q.y, nx[r] * q.x));
             const float rhs = fmaf(sj, S[k], fmaf(cc[r], q.c, 8e-6f));
-            const bool same_side = ny[r] * q.y > 0.0f || (right && q.x > 0.0f); /* beta_j and beta_k less than pi apart AS NUMBERS (see above) */
-            inside = inside || (q.c <= clim && dot >= rhs && same_side); /* (a direction that is not a number compares false) */
+            inside = inside || (q.c <= clim && dot >= rhs); /* (a direction that is not a number compares false) */
         }
         if (inside) {
             m.tag[gp] = (unsigned char)LR2_DEAD_TAG;
-            SASA_ATOMIC_ADD_LDS(&m.acnt[la], -1);
+            SASA_ATOMIC_ADD_LDS(&m.acnt[li >> 1], -1);
         }
     }
-#undef LR2_CAP_BIN
+#undef LR2_CAP_LIST
 #undef LR2_CAP_SIN
-    LR2_SYNC();
-    if (lane < TA) m.gsz[lane] = 0;
     LR2_SYNC();
 }
 
@@ -1074,10 +1077,12 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         return 0;
     }
     /* ------------------------------------------------------------ P1.5 contained caps */
-    if (LR2_PRUNE && !HOOKS && !PAIRS) { /* (PAIRS: the builds for at most 128 items - 20 slices or so -, where the phase costs what it saves; they are at their register cap) */
+    if (LR2_PRUNE && !HOOKS && LR2_PRUNE_PAIRS_OK) { /* (PAIRS: the builds for at most 128 items - 20 slices or so -, where the phase costs what it saves; they are at their register cap) */
         const int pk = LR2_COLD(a, prune);
-        if (pk > 0 && nh > 0 && nh <= a.pool && nh <= LR2_LANES * RMAX) /* (uniform; hits beyond the pool were not kept: P2 hands the tile on) */
-            lr2_prune_contained<RMAX>(m, nh, TA, pk, lane);
+        /* (uniform; hits beyond the pool were not kept: P2 hands the tile on.  Two rounds of hits at most - the shapes the phase runs
+           for have 60 - 90 per tile -: with four the generic builds keep five registers in scratch; a tile with more is not pruned) */
+        if (pk > 0 && nh > 0 && nh <= a.pool && nh <= LR2_LANES * (RMAX < 2 ? RMAX : 2))
+            lr2_prune_contained<(RMAX < 2 ? RMAX : 2)>(m, nh, TA, pk, lane);
     }
     LR2_STOP(15);
     /* ------------------------------------------------------------ P2 offsets */
@@ -1096,7 +1101,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         if (lane == 0) {
             if (nn_max > wg_max_nn) wg_max_nn = nn_max;
             if (sample) { /* demand histogram for the next batch's pool size: 1 tile in 32 of the main launch */
-                const bool pruned = LR2_PRUNE && !HOOKS && !PAIRS && LR2_COLD(a, prune) > 0;
+                const bool pruned = LR2_PRUNE && !HOOKS && LR2_PRUNE_PAIRS_OK && LR2_COLD(a, prune) > 0;
                 const int need = (pruned && nh > total ? nh : total) / hist_bin_width(TA); /* (the hits themselves need their places before any is dropped) */
                 SASA_ATOMIC_ADD_GLB(&LR2_COLD(a, status)[ST_HIST + (need < 63 ? need : 63)], 1);
             }

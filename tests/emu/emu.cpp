@@ -324,7 +324,7 @@ extern "C" int emu_run_batch(int lr, const double *xyz, const double *radii, con
         la.grid = pa.grid; la.cell_start = pa.cell_start; la.n_atoms = n; la.n_tiles = n_tiles2;
         la.TA = c2.TA; la.ns = resolution; la.pool = c2.pool; la.mw = c2.mw; la.ds = c2.ds; la.refill = c2.refill; la.inv_ns = 1.0 / (double)resolution;
         la.cover = getenv("EMU_LR2_COVER") ? atoi(getenv("EMU_LR2_COVER")) : LR2_COVER_DENSITY;
-        la.prune = lr2_prune_arg(getenv("EMU_LR2_PRUNE") ? atoi(getenv("EMU_LR2_PRUNE")) : 8, c2.TA, c2.pool); /* (contained caps, P1.5: caps wanted per atom; 0: off) */
+        la.prune = lr2_prune_arg(getenv("EMU_LR2_PRUNE") ? atoi(getenv("EMU_LR2_PRUNE")) : 4, c2.TA, c2.pool); /* (contained caps, P1.5: caps wanted per atom; 0: off) */
         la.sasa = sasa; la.status = status.data();
         /* main launch: a tile that does not fit is split in place; halves that still do not fit go to the list */
         la.ovf_items = ovf2x.data(); la.ovf_count = status.data() + ST_OVF2_TILES; la.split_count = status.data() + ST_SPLIT;

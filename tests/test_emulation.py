@@ -447,7 +447,7 @@ def test_dropping_contained_caps_does_not_change_a_bit(tmp_path):
     on every slice, an arc inside that neighbor's arc; its record is dropped before the pair records are made (45 % of all
     records on coils and proteins alike).  The union's components are minima and maxima of end points that the dropped arcs
     never supply - provided the two arcs are nested AS NUMBERS, hence the phase's same-side-of-the-cut rule -, so every
-    area must keep its bits whatever the phase drops: off, 3 caps per atom's list, 8, 12; at 20 and at 100 slices; on a
+    area must keep its bits whatever the phase drops: off, 1, 2, 4 caps wanted per list; at 20 and at 100 slices; on a
     coil, on the reference's 1a0q at protein density (tile of three atoms: the cover filter and the dealt arc pass behind
     it), and on hostile geometry - neighbors placed just either side of beta's cut (the negative x axis), spheres wholly
     inside a neighbor's, twins at 1e-9 A, a ring of equal caps."""
@@ -477,12 +477,12 @@ def test_dropping_contained_caps_does_not_change_a_bit(tmp_path):
             "    res.append(run_batch(True, p[:, :3].copy(), p[:, 3].copy(), resolution=ns)[0])\n"
             "np.save(sys.argv[1], np.concatenate(res))\n") % (os.path.join(root, "tests"), root)
     outs = {}
-    for want in ("0", "3", "8", "12"):
+    for want in ("0", "1", "2", "4"):
         out = str(tmp_path / f"prune{want}.npy")
         subprocess.run([sys.executable, "-c", code, out], check=True, env=dict(os.environ, EMU_LR2_PRUNE=want))
         outs[want] = np.load(out)
     assert np.all(np.isfinite(outs["0"][:1500 * 2]))
-    for want in ("3", "8", "12"):
+    for want in ("1", "2", "4"):
         assert np.array_equal(outs["0"], outs[want], equal_nan=True), (want, float(np.nanmax(np.abs(outs["0"] - outs[want]))))
 
 
