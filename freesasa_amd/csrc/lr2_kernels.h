@@ -1263,6 +1263,9 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
 #ifndef LR2_ARC_BALANCED
 #define LR2_ARC_BALANCED 1
 #endif
+#ifndef LR2_SCREEN5
+#define LR2_SCREEN5 1 /* (0: the 3 x 100 shape screens one item per lane and round, like the generic builds) */
+#endif
     /* (uniform) dense builds whose tile has an item per lane at most (3 atoms x 20 slices): the arc pass deals its lanes out
        by the items' arc counts (P6, "balanced"), which every lane still holds in a register - no queue, no P5 */
 #if defined(SASA_EMU) && defined(LR2_EMU_DUMP)
@@ -1379,6 +1382,62 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
             }
             finish_item(it0, la, t0, circ0 ? h0 : 0.0, Ri, o, cnt0, vmin0 <= -T0, circ0);
             if (second) finish_item(it0 + 1, la, t1, circ1 ? h1 : 0.0, Ri, o, cnt1, vmin1 <= -T1, circ1);
+        }
+    } else if (LR2_SCREEN5 && SHAPE == 2) {
+        /* 3 atoms x 100 slices (BASELINE configs[2] as written): 300 items were 4.7 rounds of one item per lane, every round
+           walking its atoms' lists again.  Here a lane screens FIVE neighboring slices of one atom in one pass over the atom's
+           records (60 lanes, one round): a record is read once for the five, the loop's bookkeeping is shared - the PAIRS
+           arrangement above, wider.  The same values by the same operations as the generic loop below (the shape builds give
+           the generic builds' bits: tests/test_emulation.py, tests/test_gpu_parity.py).  Round 6, MI355X: the phase 739 ->
+           see DESIGN.md wave instructions per tile. */
+        constexpr int Q = 5, G = 100 / Q;
+        int ln = lane;
+        SASA_OPAQUE(ln); /* (as above: not computed once per wave and kept) */
+        if (ln < LR2_MUL24(na, G)) {
+            int la = (int)(((float)ln + 0.5f) * (1.0f / (float)G)), j = ln - LR2_MUL24(la, G);
+            if (j < 0) { --la; j += G; } else if (j >= G) { ++la; j -= G; }
+            const int s0 = Q * j, it0 = LR2_MUL24(la, ns) + s0;
+            const double Ri = m.atom[la].w, del = m.adel[la];
+            const double zi_ = WALK ? m.atom[la].z : 0.0;
+            double t[Q], T[Q], vmin[Q]; /* (1/(2 Ri') is made again for finish_item - the same operations, the same bits: five more doubles do not fit the registers) */
+            int cnt[Q];
+            for (int q = 0; q < Q; ++q) {
+                t[q] = lr2_slice_height_at<WALK>(s0 + q, del, Ri, zi_);
+                const double A = Ri * Ri - t[q] * t[q]; /* Ri'^2, ref: src/sasa_lr.c:309 */
+                double hq;
+                LR2_H2(A > 0 ? A : 1.0, hq);             /* 1/(2 Ri'); no circle (ref: :310-312): finish_item is told */
+                T[q] = lr2_arc_limit(A > 0 ? A : 1.0, hq);
+                vmin[q] = 0.0;
+                cnt[q] = 0;
+            }
+            const int o = m.aoff[la], nn = m.aoff[la + 1] - o;
+            for (int wi = 0; wi < mwt; ++wi) {
+                unsigned w[Q];
+                for (int q = 0; q < Q; ++q) w[q] = 0;
+                const int k1 = nn - 32 * wi < 32 ? nn - 32 * wi : 32;
+                const Ab16 *R = m.ab + (o + 32 * wi);
+                /* from the end: neighbor k lands on bit k; the next record is on its way while this one meets the five slices */
+                Ab16 rn = R[k1 > 0 ? k1 - 1 : 0];
+                for (int k = k1 - 1; k >= 0; --k) {
+                    const Ab16 ra = rn;
+                    rn = R[k > 0 ? k - 1 : 0];
+                    for (int q = 0; q < Q; ++q) {
+                        const double c = fma(t[q], ra.a, ra.b);
+                        vmin[q] = SASA_MIN(vmin[q], c);
+                        w[q] = LR2_SHIFT_IN_LT(w[q], c, T[q]);
+                    }
+                }
+                for (int q = 0; q < Q; ++q) {
+                    m.it_mask[LR2_MUL24(it0 + q, mw) + wi] = w[q];
+                    cnt[q] += LR2_POPC32(w[q]);
+                }
+            }
+            for (int q = 0; q < Q; ++q) {
+                const double A = Ri * Ri - t[q] * t[q];
+                double hq;
+                LR2_H2(A > 0 ? A : 1.0, hq);
+                finish_item(it0 + q, la, t[q], A > 0 ? hq : 0.0, Ri, o, cnt[q], vmin[q] <= -T[q], A > 0);
+            }
         }
     } else
     for (int it = lane; it < items; it += LR2_LANES) {
