@@ -311,7 +311,7 @@ static int run_lr2(freesasa_gpu_ctx *c, const PipeArgs &pa, int n, int n_structs
     if (const char *e = getenv("FREESASA_AMD_COVER")) la.cover = atoi(e); /* tuning aid: neighbor records per atom from which a tile runs the cover filter; 0: never */
     /* contained caps (lr2_prune_contained): the largest caps an atom's hits are tested against */
     {
-        int want = lr2_prune_want(resolution, cfg.mw);
+        int want = lr2_prune_want(resolution, la.cover > 0);
         if (const char *e = getenv("FREESASA_AMD_PRUNE")) want = atoi(e); /* tuning / test aid: caps wanted per list (at most LR2_PRUNE_LIST); 0: off */
         la.prune = lr2_prune_arg(want, cfg.TA, cfg.pool);
     }

@@ -713,10 +713,9 @@ SASA_D double lr2_acos_lower(double c)
 #ifndef LR2_PRUNE
 #define LR2_PRUNE 1
 #endif
-#ifndef LR2_PRUNE_IN_PAIRS
-#define LR2_PRUNE_IN_PAIRS 0 /* (the builds for at most 128 items - 20 slices or so -, where the phase costs what it saves: coils 2.82 - 2.92 ms without, 2.78 - 2.88 with; they are at their register cap) */
+#ifndef LR2_PRUNE_ROUNDS
+#define LR2_PRUNE_ROUNDS(pairs) ((pairs) ? 3 : 2) /* rounds of 64 hits a tile may have to be pruned: 6 atoms x 20 neighbors need two, often three; the builds for more than 128 items (60 - 90 hits per tile) keep registers in scratch with more than two */
 #endif
-#define LR2_PRUNE_PAIRS_OK (LR2_PRUNE_IN_PAIRS || !PAIRS)
 #define LR2_PRUNE_LIST 4   /* caps in one of an atom's two lists (lists of 6 and 8, all four read at once and tested in straight-line code: the same times) */
 #define LR2_DEAD_TAG 0xff  /* tag of a dropped hit (atoms of a tile: < 8) */
 struct __attribute__((aligned(16))) Lr2Cap { float x, y, z, c; };
@@ -726,12 +725,14 @@ SASA_HD int lr2_prune_arg(int want, int TA, int pool) /* Lr2Args::prune: caps wa
     if (8 * pool < (16 + 20 * LR2_PRUNE_LIST) * 2 * TA) return 0;
     return want > LR2_PRUNE_LIST ? LR2_PRUNE_LIST : (want < 0 ? 0 : want);
 }
-/* caps wanted per list by tile shape (host side).
-   MI355X, kernel ms without / with the phase (tools/dev/prune_ab.sh, round 6; one list of 6 - 12 caps per atom, as first built):
-   coils at 100 slices 2.98 / 2.62 (3 of 3: 2.79, 4 of 4: 2.74, 8 of 8: 2.64), at 50 slices 1.95 / 1.79, the reference's PDB
-   entries at 100 slices 5.11 / 4.74; at 20 slices that form cost what it saved - coils 2.88 / 2.89 - 2.94, PDB entries and
-   lattice globules +5 ... +10 % (their hits are many and their slices few). */
-static inline int lr2_prune_want(int ns, int mw) { (void)mw; return ns >= 32 ? 4 : 0; }
+/* caps wanted per list by tile shape and density (host side).
+   MI355X, kernel ms without / with the phase (tools/dev/prune_ab.sh, round 6): coils at 100 slices 3.04 / 2.62, at 50 slices
+   1.95 / 1.78, the reference's PDB entries at 100 slices 5.10 / 4.63 (4 wanted; 2 or 3: +1 %).  At 20 slices the arcs it
+   saves are a fifth as many and the phase costs the same: random coils (20 neighbors per atom, three rounds of hits per
+   tile of six atoms) 2.86 / 2.74 (mean of four runs each; 3 wanted; 2: 2.78, 4: 2.75), but at protein density (41 - 48
+   neighbors, the cover filter already takes 2 of 3 items before their arcs) the PDB entries 2.09 / 2.14 and the lattice
+   globules 2.15 / 2.22: there it stays off. */
+static inline int lr2_prune_want(int ns, bool dense) { return ns >= 32 ? 4 : (dense ? 0 : 3); }
 SASA_D int lr2_cap_bin(float c) { const int b = (int)fmaf(c, 10.0f, -2.0f); return b < 0 ? 0 : (b > 7 ? 7 : b); } /* the cover filter's bins: 0.1 wide from 0.2 */
 /* Two lists per atom, one for either side of the x axis (the same-side rule above): a hit is tested against the largest caps
    of ITS side only - half the trips of one list for the same caps, and no side test inside the loop (per side the 4 largest
@@ -1077,12 +1078,12 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         return 0;
     }
     /* ------------------------------------------------------------ P1.5 contained caps */
-    if (LR2_PRUNE && !HOOKS && LR2_PRUNE_PAIRS_OK) { /* (PAIRS: the builds for at most 128 items - 20 slices or so -, where the phase costs what it saves; they are at their register cap) */
+    if (LR2_PRUNE && !HOOKS) {
         const int pk = LR2_COLD(a, prune);
-        /* (uniform; hits beyond the pool were not kept: P2 hands the tile on.  Two rounds of hits at most - the shapes the phase runs
-           for have 60 - 90 per tile -: with four the generic builds keep five registers in scratch; a tile with more is not pruned) */
-        if (pk > 0 && nh > 0 && nh <= a.pool && nh <= LR2_LANES * (RMAX < 2 ? RMAX : 2))
-            lr2_prune_contained<(RMAX < 2 ? RMAX : 2)>(m, nh, TA, pk, lane);
+        /* (uniform; hits beyond the pool were not kept: P2 hands the tile on; a tile with more rounds of hits than the build holds is not pruned) */
+        constexpr int PR = RMAX < LR2_PRUNE_ROUNDS(PAIRS) ? RMAX : LR2_PRUNE_ROUNDS(PAIRS);
+        if (pk > 0 && nh > 0 && nh <= a.pool && nh <= LR2_LANES * PR)
+            lr2_prune_contained<PR>(m, nh, TA, pk, lane);
     }
     LR2_STOP(15);
     /* ------------------------------------------------------------ P2 offsets */
@@ -1101,7 +1102,7 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         if (lane == 0) {
             if (nn_max > wg_max_nn) wg_max_nn = nn_max;
             if (sample) { /* demand histogram for the next batch's pool size: 1 tile in 32 of the main launch */
-                const bool pruned = LR2_PRUNE && !HOOKS && LR2_PRUNE_PAIRS_OK && LR2_COLD(a, prune) > 0;
+                const bool pruned = LR2_PRUNE && !HOOKS && LR2_COLD(a, prune) > 0;
                 const int need = (pruned && nh > total ? nh : total) / hist_bin_width(TA); /* (the hits themselves need their places before any is dropped) */
                 SASA_ATOMIC_ADD_GLB(&LR2_COLD(a, status)[ST_HIST + (need < 63 ? need : 63)], 1);
             }
