@@ -771,13 +771,16 @@ SASA_D void lr2_prune_contained(const Lr2Mem &m, int nh, int TA, int want, int l
         }
     }
     LR2_SYNC();
-    if (lane < 2 * TA) { /* the last bin needed for `want` caps */
+    if (lane < 2 * TA) {
+        /* the last bin needed for `want` caps: the bins' running sums byte-parallel (x 0x01010101 adds every byte to the ones
+           above it; sums beyond 255 carry into the next byte and at worst list other caps - an atom with that many hits on
+           one side has left this launch long before), then the first byte that reaches `want` (its bit 7 after adding
+           128 - want) */
         const unsigned long long h = chist[lane];
-        int cum = 0, tb = 7;
-        for (int b = 0; b < 8; ++b) {
-            cum += (int)((h >> (8 * b)) & 255u);
-            if (cum >= want && b < tb) tb = b;
-        }
+        const unsigned lo = (unsigned)h * 0x01010101u, hi = (unsigned)(h >> 32) * 0x01010101u + (lo >> 24) * 0x01010101u;
+        const unsigned add = (unsigned)(128 - want) * 0x01010101u;
+        const unsigned mlo = (lo + add) & 0x80808080u, mhi = (hi + add) & 0x80808080u;
+        const int tb = mlo ? __builtin_ctz(mlo) >> 3 : (mhi ? 4 + (__builtin_ctz(mhi) >> 3) : 7);
         chist[lane] = (unsigned long long)tb;
     }
     LR2_SYNC();

@@ -480,6 +480,7 @@ extern "C" void emu_lr2_shape(int ns, double nn_hint, int nn_max_hint, int last_
 }
 extern "C" int emu_lr2_pool_from_hist(const int *hist, int TA, int ns, int mw, int ds) { return lr2_pool_from_hist(hist, TA, ns, mw, ds); }
 extern "C" int emu_lr2_lds(int TA, int ns, int pool, int mw, int ds) { return lr2_layout(TA, ns, pool, mw, ds).total; }
+extern "C" int emu_lr2_prune(int ns, int dense, int TA, int pool) { return lr2_prune_arg(lr2_prune_want(ns, dense != 0), TA, pool); } /* what gpu_engine.hip puts into Lr2Args::prune */
 
 extern "C" void emu_segsum_small(const double *sasa, const int64_t *seg, int n_segs, double *out)
 {

@@ -442,6 +442,22 @@ def test_arc_pass_lane_dealing_does_not_change_a_bit(tmp_path):
     assert np.array_equal(outs["shipped"], outs["window8"])
 
 
+def test_contained_caps_chooser_and_the_room_of_its_lists():
+    """Host side of P1.5 (lr2_prune_want / lr2_prune_arg, what gpu_engine.hip puts into Lr2Args::prune): 4 caps wanted per list
+    from 32 slices on, 3 on sparse input below, none at protein density below (measured: DESIGN.md 4); never more than a
+    list holds; and off when the two lists per atom (a histogram word and four caps of 20 bytes each) do not fit where
+    P3's sort keys will be (8 bytes per record of the pool)."""
+    L = emu._load()
+    assert L.emu_lr2_prune(100, 0, 3, 104) == 4 and L.emu_lr2_prune(100, 1, 2, 120) == 4 and L.emu_lr2_prune(32, 0, 6, 224) == 4
+    assert L.emu_lr2_prune(20, 0, 6, 224) == 3 and L.emu_lr2_prune(31, 0, 4, 200) == 3
+    assert L.emu_lr2_prune(20, 1, 3, 230) == 0 and L.emu_lr2_prune(20, 1, 4, 230) == 0
+    for ta in range(1, 8):
+        need = (16 + 20 * 4) * 2 * ta      # bytes of the lists
+        assert L.emu_lr2_prune(100, 0, ta, need // 8) == 4 and L.emu_lr2_prune(100, 0, ta, need // 8 - 1) == 0
+        # ... and the layout really has that room: the keys' region is 8 bytes per pool record
+        assert 8 * (need // 8) >= need
+
+
 def test_dropping_contained_caps_does_not_change_a_bit(tmp_path):
     """Round 6, P1.5 (lr2_prune_contained): a neighbor whose cap on the atom's sphere lies inside another neighbor's cap cuts,
     on every slice, an arc inside that neighbor's arc; its record is dropped before the pair records are made (45 % of all
