@@ -707,9 +707,16 @@ SASA_D double lr2_acos_lower(double c)
  * the sweep adds its 2 pi to other numbers (the same area to ~1e-14, not the same bits).  beta is atan2(yd, xd) + pi: the
  * cut is the negative x axis.  A cap is therefore dropped only for a cap on the same side of the x axis (yd of equal
  * sign, neither zero): then |beta_j - beta_k| < pi as numbers, the intervals are nested as numbers, and j's end points are
- * never the least or the greatest of a component.  Which caps are in an atom's list (the bins that hold
- * the `want` largest, at most `kmax`) only decides how many records are dropped, never an area:
- * tests/test_emulation.py compares the bits with and without this phase, the GPU suite runs both (FREESASA_AMD_PRUNE). */
+ * never the least or the greatest of a component.  Which caps are in an atom's lists only decides how many records are
+ * dropped, never an area; it is nevertheless a function of the atom's neighbors alone (all hits of the leading bins of
+ * cos(theta) that together are no more than a list holds - not the first that arrive), so that what is dropped, and with it
+ * every path the tile takes afterwards (an arc stack that proves too short sends it to another launch), does not depend on
+ * the tile's shape.  The phase runs BEHIND P2's decision whether the tile fits the launch: lists as found decide that, so
+ * the same atoms take the same launches with the phase on and off.  (What remains: an item with more disjoint arc pieces
+ * than any launch's stack holds goes to the last launch, whose first-generation arithmetic equals this kernel's to ~1e-11,
+ * not to the bit; with contained arcs gone the stack may suffice.  Inputs of > 100 neighbors per atom: tools/dev/
+ * prune_fuzz.py counts them.)  tests/test_emulation.py compares the bits with and without this phase, the GPU suite runs
+ * both (FREESASA_AMD_PRUNE). */
 #ifndef LR2_PRUNE
 #define LR2_PRUNE 1
 #endif
@@ -719,19 +726,19 @@ SASA_D double lr2_acos_lower(double c)
 #define LR2_PRUNE_LIST 4   /* caps in one of an atom's two lists (lists of 6 and 8, all four read at once and tested in straight-line code: the same times) */
 #define LR2_DEAD_TAG 0xff  /* tag of a dropped hit (atoms of a tile: < 8) */
 struct __attribute__((aligned(16))) Lr2Cap { float x, y, z, c; };
-SASA_HD int lr2_prune_arg(int want, int TA, int pool) /* Lr2Args::prune: caps wanted per list; 0: off */
+SASA_HD int lr2_prune_arg(int want, int TA, int pool) /* Lr2Args::prune: > 0 on (the chooser's figure, at most what a list holds), 0: off */
 {
     /* the lists lie where P3's sort keys will be (8 B per pool record): a histogram word per (atom, side), then 20 B per cap */
     if (8 * pool < (16 + 20 * LR2_PRUNE_LIST) * 2 * TA) return 0;
     return want > LR2_PRUNE_LIST ? LR2_PRUNE_LIST : (want < 0 ? 0 : want);
 }
-/* caps wanted per list by tile shape and density (host side).
+/* on (> 0) or off by tile shape and density (host side; the figure was the number of caps wanted per list while the lists
+   were filled in order of arrival, and is only a switch since they are chosen by the bins alone).
    MI355X, kernel ms without / with the phase (tools/dev/prune_ab.sh, round 6): coils at 100 slices 3.04 / 2.62, at 50 slices
-   1.95 / 1.78, the reference's PDB entries at 100 slices 5.10 / 4.63 (4 wanted; 2 or 3: +1 %).  At 20 slices the arcs it
-   saves are a fifth as many and the phase costs the same: random coils (20 neighbors per atom, three rounds of hits per
-   tile of six atoms) 2.86 / 2.74 (mean of four runs each; 3 wanted; 2: 2.78, 4: 2.75), but at protein density (41 - 48
-   neighbors, the cover filter already takes 2 of 3 items before their arcs) the PDB entries 2.09 / 2.14 and the lattice
-   globules 2.15 / 2.22: there it stays off. */
+   1.95 / 1.78, the reference's PDB entries at 100 slices 5.10 / 4.63.  At 20 slices the arcs it saves are a fifth as many
+   and the phase costs the same: random coils (20 neighbors per atom, three rounds of hits per tile of six atoms) 2.86 /
+   2.74 (mean of four runs each), but at protein density (41 - 48 neighbors, the cover filter already takes 2 of 3 items
+   before their arcs) the PDB entries 2.09 / 2.14 and the lattice globules 2.15 / 2.22: there it stays off. */
 static inline int lr2_prune_want(int ns, bool dense) { return ns >= 32 ? 4 : (dense ? 0 : 3); }
 SASA_D int lr2_cap_bin(float c) { const int b = (int)fmaf(c, 10.0f, -2.0f); return b < 0 ? 0 : (b > 7 ? 7 : b); } /* the cover filter's bins: 0.1 wide from 0.2 */
 /* Two lists per atom, one for either side of the x axis (the same-side rule above): a hit is tested against the largest caps
@@ -741,6 +748,7 @@ template <int RMAX>
 SASA_D void lr2_prune_contained(const Lr2Mem &m, int nh, int TA, int want, int lane)
 {
     constexpr int LK = LR2_PRUNE_LIST;
+    (void)want; /* (on / off since the lists are chosen by the bins alone) */
     unsigned long long *const chist = (unsigned long long *)m.keys;  /* [2 TA] a byte per bin; then the list's last bin */
     Lr2Cap *const bigc = (Lr2Cap *)(chist + 2 * TA);                 /* [2 TA][LK] the largest caps: direction, cosine ... */
     Lr2Cap *const bigs = bigc + 2 * LK * TA;                         /* [2 TA] ... and the upper bounds of their sines, a list's four in one read */
@@ -772,23 +780,26 @@ SASA_D void lr2_prune_contained(const Lr2Mem &m, int nh, int TA, int want, int l
     }
     LR2_SYNC();
     if (lane < 2 * TA) {
-        /* the last bin needed for `want` caps: the bins' running sums byte-parallel (x 0x01010101 adds every byte to the ones
-           above it; sums beyond 255 carry into the next byte and at worst list other caps - an atom with that many hits on
-           one side has left this launch long before), then the first byte that reaches `want` (its bit 7 after adding
-           128 - want) */
+        /* The list: ALL hits of the leading bins that together hold no more than the list does - a set that depends on the
+           atom's neighbors alone, not on the order in which a tile of some shape found them: what is dropped, and with it
+           every path a tile takes from here on (an arc stack that is too short sends it to another launch), is the same
+           for every tile shape.  The bins' running sums byte-parallel (x 0x01010101 adds every byte to the ones above it;
+           sums beyond 255 carry into the next byte and at worst list nothing - an atom with that many hits on one side has
+           left this launch long before), then the first byte that exceeds the list (its bit 7 after adding 127 - LK); the
+           bins before it are listed (-1: none, the first bin alone is too many). */
         const unsigned long long h = chist[lane];
         const unsigned lo = (unsigned)h * 0x01010101u, hi = (unsigned)(h >> 32) * 0x01010101u + (lo >> 24) * 0x01010101u;
-        const unsigned add = (unsigned)(128 - want) * 0x01010101u;
+        const unsigned add = (unsigned)(127 - LK) * 0x01010101u;
         const unsigned mlo = (lo + add) & 0x80808080u, mhi = (hi + add) & 0x80808080u;
-        const int tb = mlo ? __builtin_ctz(mlo) >> 3 : (mhi ? 4 + (__builtin_ctz(mhi) >> 3) : 7);
-        chist[lane] = (unsigned long long)tb;
+        const int tb = (mlo ? __builtin_ctz(mlo) >> 3 : (mhi ? 4 + (__builtin_ctz(mhi) >> 3) : 8)) - 1;
+        chist[lane] = (unsigned long long)(long long)tb;
     }
     LR2_SYNC();
     for (int r = 0; r < RMAX; ++r) {
         const int li = lis[r];
         if (li < 0) continue;
         if (lr2_cap_bin(cc[r]) <= (int)chist[li]) {
-            const int slot = SASA_ATOMIC_ADD_LDS(&fill[li], 1);
+            const int slot = SASA_ATOMIC_ADD_LDS(&fill[li], 1); /* (< LK by the choice of the bins; the order of the places does not matter: the test below asks for any) */
             if (slot < LK) {
                 Lr2Cap q; q.x = nx[r]; q.y = ny[r]; q.z = nz[r]; q.c = cc[r];
                 bigc[LK * li + slot] = q;
@@ -1080,15 +1091,6 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         LR2_SYNC();
         return 0;
     }
-    /* ------------------------------------------------------------ P1.5 contained caps */
-    if (LR2_PRUNE && !HOOKS) {
-        const int pk = LR2_COLD(a, prune);
-        /* (uniform; hits beyond the pool were not kept: P2 hands the tile on; a tile with more rounds of hits than the build holds is not pruned) */
-        constexpr int PR = RMAX < LR2_PRUNE_ROUNDS(PAIRS) ? RMAX : LR2_PRUNE_ROUNDS(PAIRS);
-        if (pk > 0 && nh > 0 && nh <= a.pool && nh <= LR2_LANES * PR)
-            lr2_prune_contained<PR>(m, nh, TA, pk, lane);
-    }
-    LR2_STOP(15);
     /* ------------------------------------------------------------ P2 offsets */
     /* offsets of the atoms' lists in the pool (lists padded to an even length): a prefix over the first lanes of
        the wave; whether the tile fits is a ballot, so every lane knows it without a flag in LDS */
@@ -1105,19 +1107,38 @@ SASA_D int lr2_tile(const Lr2Args &a, const Lr2Mem &m, int p0, int na, bool samp
         if (lane == 0) {
             if (nn_max > wg_max_nn) wg_max_nn = nn_max;
             if (sample) { /* demand histogram for the next batch's pool size: 1 tile in 32 of the main launch */
-                const bool pruned = LR2_PRUNE && !HOOKS && LR2_COLD(a, prune) > 0;
-                const int need = (pruned && nh > total ? nh : total) / hist_bin_width(TA); /* (the hits themselves need their places before any is dropped) */
+                const int need = total / hist_bin_width(TA);
                 SASA_ATOMIC_ADD_GLB(&LR2_COLD(a, status)[ST_HIST + (need < 63 ? need : 63)], 1);
             }
         }
     }
     LR2_SYNC();
     if (ovf) { LR2_COUNT(9, 1); return 1; } /* (uniform) */
+    LR2_STOP(2);
+    /* ------------------------------------------------------------ P1.5 contained caps */
+    /* Behind the decision whether the tile fits: a tile whose lists AS FOUND are too long for this launch is handed on
+       whatever could be dropped from them, so the same atoms go through the same launches with the phase on and off (the
+       last launch, for atoms with lists beyond any tile's, has the first-generation kernel's arithmetic: equal to 1e-11,
+       not to the bit), and the pool's demand statistics are those of the lists as found. */
+    if (LR2_PRUNE && !HOOKS) {
+        const int pk = LR2_COLD(a, prune);
+        /* (uniform; a tile with more rounds of hits than the build holds in registers is not pruned) */
+        constexpr int PR = RMAX < LR2_PRUNE_ROUNDS(PAIRS) ? RMAX : LR2_PRUNE_ROUNDS(PAIRS);
+        if (pk > 0 && nh > 0 && nh <= LR2_LANES * PR) {
+            lr2_prune_contained<PR>(m, nh, TA, pk, lane);
+            const int c = lane < TA ? m.acnt[lane] : 0, pc = (c + 1) & ~1; /* the offsets again, of the lists that are left */
+            const int incl = lr2_scan_add(pc, lane), cmax = lr2_scan_max16(c, lane);
+            if (lane < TA) m.aoff[lane] = incl - pc;
+            if (lane == TA - 1) m.aoff[TA] = incl;
+            nn_max = LR2_READLANE(cmax, TA - 1);
+            LR2_SYNC();
+        }
+    }
+    LR2_STOP(15);
     const int mwt = (nn_max + 31) >> 5; /* mask words this tile's longest list needs (<= mw; one on most coil tiles) */
     const bool cover = COVER && a.cover > 0 && nh >= LR2_MUL24(a.cover, na); /* (uniform) dense enough for the cover filter; COVER: the launch
                                                                                   was built with it (launches over sparse batches are not) */
 
-    LR2_STOP(2);
     LR2_MARK(2);
     /* ------------------------------------------------------------ P3 pair records */
     {

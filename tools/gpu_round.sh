@@ -1,7 +1,7 @@
 # Full GPU session for a round: everything profiles/ and DESIGN.md quote, in one gpurun call.
 #   bash tools/gpu_round.sh r04        (outputs under gpurun_out/<tag>_*; copy the summaries into profiles/)
 # Build the phase-ablation variants first if the per-phase instruction counts are wanted:
-#   for k in 0 1 15 2 3 4 5; do bash tools/build_variant.sh stop$k -DLR2_STOP_AFTER=$k; done; bash tools/build_variant.sh pt -DSASA_PHASE_TIMING    (15: behind P1.5, the contained caps)
+#   for k in 0 1 2 15 3 4 5; do bash tools/build_variant.sh stop$k -DLR2_STOP_AFTER=$k; done; bash tools/build_variant.sh pt -DSASA_PHASE_TIMING    (15: behind the contained caps, which follow P2)
 #   for k in 0 1 12 2 3; do bash tools/build_variant.sh srstop$k -DSR_STOP_AFTER=$k; done
 TAG=${1:-r06}
 mkdir -p gpurun_out
@@ -42,12 +42,12 @@ python tools/hbm_counters.py $O/prof_$TAG > $O/${TAG}_hbm_counters.json
 (bash tools/gpu_derived.sh "0,0,-1,0"; echo "--- globules"; STRUCTS=g100 bash tools/gpu_derived.sh "0,0,-1,0"; echo "--- the reference PDB entries x 84"; STRUCTS=p84 bash tools/gpu_derived.sh "0,0,-1,0") > $O/${TAG}_derived_counters.txt 2>&1
 # VALU instructions by phase (cumulative builds), if the variants are there
 if [ -f freesasa_amd/lib/libvar_stop0.so ]; then
-  (echo "coils (300 x 10 000 atoms, 5 launches): cumulative after P0, P1, P1.5, P2 .. P5, then the whole kernel"
-   bash tools/gpu_ablate.sh "0,0,-1,0" freesasa_amd/lib/libvar_stop0.so freesasa_amd/lib/libvar_stop1.so freesasa_amd/lib/libvar_stop15.so freesasa_amd/lib/libvar_stop2.so freesasa_amd/lib/libvar_stop3.so freesasa_amd/lib/libvar_stop4.so freesasa_amd/lib/libvar_stop5.so freesasa_amd/lib/libfreesasa_amd.so
+  (echo "coils (300 x 10 000 atoms, 5 launches): cumulative after P0, P1, P2, the contained caps (stop 15), P3 .. P5, then the whole kernel"
+   bash tools/gpu_ablate.sh "0,0,-1,0" freesasa_amd/lib/libvar_stop0.so freesasa_amd/lib/libvar_stop1.so freesasa_amd/lib/libvar_stop2.so freesasa_amd/lib/libvar_stop15.so freesasa_amd/lib/libvar_stop3.so freesasa_amd/lib/libvar_stop4.so freesasa_amd/lib/libvar_stop5.so freesasa_amd/lib/libfreesasa_amd.so
    echo "the reference's PDB entries x 84 (1.0e6 atoms, 5 launches)"
-   STRUCTS=p84 bash tools/gpu_ablate.sh "0,0,-1,0" freesasa_amd/lib/libvar_stop0.so freesasa_amd/lib/libvar_stop1.so freesasa_amd/lib/libvar_stop15.so freesasa_amd/lib/libvar_stop2.so freesasa_amd/lib/libvar_stop3.so freesasa_amd/lib/libvar_stop4.so freesasa_amd/lib/libvar_stop5.so freesasa_amd/lib/libfreesasa_amd.so
+   STRUCTS=p84 bash tools/gpu_ablate.sh "0,0,-1,0" freesasa_amd/lib/libvar_stop0.so freesasa_amd/lib/libvar_stop1.so freesasa_amd/lib/libvar_stop2.so freesasa_amd/lib/libvar_stop15.so freesasa_amd/lib/libvar_stop3.so freesasa_amd/lib/libvar_stop4.so freesasa_amd/lib/libvar_stop5.so freesasa_amd/lib/libfreesasa_amd.so
    echo "globules (100 x 10 000 atoms, 5 launches)"
-   STRUCTS=g100 bash tools/gpu_ablate.sh "0,0,-1,0" freesasa_amd/lib/libvar_stop0.so freesasa_amd/lib/libvar_stop1.so freesasa_amd/lib/libvar_stop15.so freesasa_amd/lib/libvar_stop2.so freesasa_amd/lib/libvar_stop3.so freesasa_amd/lib/libvar_stop4.so freesasa_amd/lib/libvar_stop5.so freesasa_amd/lib/libfreesasa_amd.so) 2>&1 | grep "==\|coils\|globules\|PDB entries\|lr2_tile<4" | sed "s/vgpr[^ ]* //" > $O/${TAG}_phase_valu.txt
+   STRUCTS=g100 bash tools/gpu_ablate.sh "0,0,-1,0" freesasa_amd/lib/libvar_stop0.so freesasa_amd/lib/libvar_stop1.so freesasa_amd/lib/libvar_stop2.so freesasa_amd/lib/libvar_stop15.so freesasa_amd/lib/libvar_stop3.so freesasa_amd/lib/libvar_stop4.so freesasa_amd/lib/libvar_stop5.so freesasa_amd/lib/libfreesasa_amd.so) 2>&1 | grep "==\|coils\|globules\|PDB entries\|lr2_tile<4" | sed "s/vgpr[^ ]* //" > $O/${TAG}_phase_valu.txt
 fi
 # wall clock of a wave by phase (variant built with -DSASA_PHASE_TIMING)
 if [ -f freesasa_amd/lib/libvar_pt.so ]; then
@@ -56,8 +56,8 @@ if [ -f freesasa_amd/lib/libvar_pt.so ]; then
 fi
 # configs[2] as written (L&R 100 slices, TA 3): VALU instructions by phase
 if [ -f freesasa_amd/lib/libvar_stop0.so ]; then
-  (echo "coils, Lee-Richards 100 slices (100 x 10 000 atoms, 5 launches): cumulative after P0, P1, P1.5, P2 .. P5, then the whole kernel"
-   SLICES=100 STRUCTS=100 bash tools/gpu_ablate.sh "0,0,-1,0" freesasa_amd/lib/libvar_stop0.so freesasa_amd/lib/libvar_stop1.so freesasa_amd/lib/libvar_stop15.so freesasa_amd/lib/libvar_stop2.so freesasa_amd/lib/libvar_stop3.so freesasa_amd/lib/libvar_stop4.so freesasa_amd/lib/libvar_stop5.so freesasa_amd/lib/libfreesasa_amd.so) 2>&1 | grep "==\|coils\|lr2_tile<" | sed "s/vgpr[^ ]* //" > $O/${TAG}_lr100_phase_valu.txt
+  (echo "coils, Lee-Richards 100 slices (100 x 10 000 atoms, 5 launches): cumulative after P0, P1, P2, the contained caps (stop 15), P3 .. P5, then the whole kernel"
+   SLICES=100 STRUCTS=100 bash tools/gpu_ablate.sh "0,0,-1,0" freesasa_amd/lib/libvar_stop0.so freesasa_amd/lib/libvar_stop1.so freesasa_amd/lib/libvar_stop2.so freesasa_amd/lib/libvar_stop15.so freesasa_amd/lib/libvar_stop3.so freesasa_amd/lib/libvar_stop4.so freesasa_amd/lib/libvar_stop5.so freesasa_amd/lib/libfreesasa_amd.so) 2>&1 | grep "==\|coils\|lr2_tile<" | sed "s/vgpr[^ ]* //" > $O/${TAG}_lr100_phase_valu.txt
 fi
 (timeout 600 python tools/deep_parity.py 120 24 2>/dev/null | tail -1) > $O/${TAG}_deep_parity.json
 (timeout 900 python tools/deep_parity.py 500 100 2>/dev/null | tail -1) > $O/${TAG}_deep_parity_large.json
@@ -75,6 +75,7 @@ cp $O/prof_${TAG}_sweep/trace_kernel_stats.csv $O/${TAG}_sweep_kernel_stats.csv 
 (timeout 200 bash tools/dev/traj_trace.sh 2>&1 | grep -v amdgpu) > $O/${TAG}_trajectory_trace.txt
 (timeout 200 python tools/dev/traj_profile.py 2>&1 | grep -v amdgpu) > $O/${TAG}_trajectory_lanes.txt
 (timeout 120 tools/dev/ubench) > $O/${TAG}_ubench.txt 2>&1
-# round 6: the contained caps (P1.5) off / 2 / 3 / 4 wanted per list, kernel ms on the L&R workloads
-(WL="c20 c50 c100 pdb pdb100 glob" timeout 900 bash tools/dev/prune_ab.sh "0 2 3 4 0" 2>&1 | grep "==\|slices\|PDB\|globules\|kernel_ms" | cut -c1-130) > $O/${TAG}_prune_ab.txt
+# round 6: the contained caps off / on / off / on, kernel ms on the L&R workloads; the same on random inputs, bit for bit
+(WL="c20 c50 c100 pdb pdb100 glob" timeout 900 bash tools/dev/prune_ab.sh "0 4 0 4" 2>&1 | grep "==\|slices\|PDB\|globules\|kernel_ms" | cut -c1-130) > $O/${TAG}_prune_ab.txt
+(timeout 900 python tools/dev/prune_fuzz.py 3000 777 2>&1 | grep -v amdgpu | tail -3) > $O/${TAG}_prune_fuzz.txt
 tail -2 $O/${TAG}_smoke.log; tail -4 $O/${TAG}_pytest_gpu.log; cut -c1-400 $O/${TAG}_bench.json; cat $O/${TAG}_kernel_stats.csv | cut -d, -f1-4 | head -12; cat $O/${TAG}_fetch_calibration.txt; cat $O/${TAG}_deep_parity.json
