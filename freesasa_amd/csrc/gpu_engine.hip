@@ -502,12 +502,17 @@ static int run_batch_once(freesasa_gpu_ctx *c, bool lr, const double *d_xyz, con
         pa.cell_tbl = (unsigned long long *)c->cell_tbl.p;
         pa.cell_first = (int *)c->cell_first.p;
     } else {
-        const void *const desc_was = c->blk_sums.p;
+        const size_t desc_cap_was = c->blk_sums.cap;
         if (ensure(c, c->cell_start, sizeof(int) * ((size_t)cells_cap + 4)) || ensure(c, c->blk_sums, sizeof(unsigned long long) * ((size_t)nblk_scan + 1)))
             return -1;
         /* the chained scan's block descriptors carry the batch's epoch (sasa_kernels.h, K4): fresh memory must not look
-           like a descriptor of this epoch, so a new array is cleared once (epoch 0 is never used) */
-        if (c->blk_sums.p != desc_was) HIP_TRY(c, hipMemsetAsync(c->blk_sums.p, 0, c->blk_sums.cap, st));
+           like a descriptor of this epoch, so a new array is cleared once (epoch 0 is never used).  "New" is a new
+           CAPACITY, not a new address: the allocator may hand the grown array the address of the one just freed, and the
+           part beyond the old length then holds whatever was there before - an earlier context's descriptors with small
+           epochs like this one's (round 6, tools/dev/prune_fuzz.py: a batch that is redone with a larger cell table -
+           ST_RETRY - scanned with such descriptors as its predecessors', scattered atoms out of bounds, and the GPU
+           faulted; one batch in a few thousand random ones, and only behind certain other batches) */
+        if (c->blk_sums.cap != desc_cap_was) HIP_TRY(c, hipMemsetAsync(c->blk_sums.p, 0, c->blk_sums.cap, st));
     }
     pa.cell_start = (int *)c->cell_start.p;
     pa.scan_desc = (unsigned long long *)c->blk_sums.p;

@@ -390,6 +390,26 @@ def test_dropping_contained_caps_leaves_every_bit_alone(fa, monkeypatch):
     monkeypatch.delenv("FREESASA_AMD_PRUNE", raising=False)
 
 
+def test_random_batches_with_and_without_the_contained_caps_and_a_redone_cell_table():
+    """tools/dev/prune_fuzz.py inside the suite, two ways.  (1) Rounds 39 and 41 of seed 777: a dense batch on one context,
+    then - on a NEW context, whose allocations may get the addresses the first one freed - a sparse batch (radii down to
+    0.43 A, no probe: 32 cells per atom) that the general cell sort must redo with a larger cell table (ST_RETRY).  Until
+    round 6 the redone pass could find the grown array of scan descriptors at the freed one's address, took that for "not a
+    new array", did not clear it, and the chained scan read an earlier context's descriptors (same small epochs) as its
+    predecessors' sums: atoms scattered out of bounds, a GPU memory fault - found by this fuzz, five times out of five with
+    these two rounds.  (2) Forty random batches of another seed: identical bits with the contained caps dropped and not."""
+    import subprocess, sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "dev", "prune_fuzz.py")
+    env = dict(os.environ, FUZZ_ONLY="39,41")
+    env.pop("FREESASA_AMD_PRUNE", None)
+    for _ in range(2):
+        r = subprocess.run([sys.executable, tool, "42", "777"], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "identical areas" in r.stdout, (r.returncode, r.stdout[-400:], r.stderr[-400:])
+    env.pop("FUZZ_ONLY")
+    r = subprocess.run([sys.executable, tool, "40", "20261001"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "identical areas" in r.stdout, (r.returncode, r.stdout[-400:], r.stderr[-400:])
+
+
 def test_asynchronous_batches_match_the_synchronous_ones(fa, oracle_lib):
     """freesasa_gpu_lr_batch_dev_async: batches enqueued back to back (two in flight, a third call collects the oldest),
     different inputs and output buffers per batch, offsets that change between batches (the tables of the batches in

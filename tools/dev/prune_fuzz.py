@@ -51,7 +51,10 @@ for k in range(rounds):
     offs = np.concatenate([[0], np.cumsum([len(p[1]) for p in parts])]).astype(np.int64)
     ns = int(rng.choice([1, 7, 20, 20, 20, 32, 33, 50, 64, 100, 100, 128, 200, 256]))
     probe = float(rng.choice([0.0, 1.0, 1.4, 1.4, 2.5]))
+    if k < int(os.environ.get("FUZZ_FROM", "0")) or (os.environ.get("FUZZ_ONLY") and str(k) not in os.environ["FUZZ_ONLY"].split(",")): continue
+    if os.environ.get("FUZZ_TRACE"): print(f"round {k}: kind {kind} structs {nst} atoms {len(r)} slices {ns} probe {probe}", flush=True)
     a0, st0 = run(xyz, r, offs, ns, probe, "0")
+    if os.environ.get("FUZZ_TRACE"): print("  off done", flush=True)
     for env in (None, "4"):
         a1, st1 = run(xyz, r, offs, ns, probe, env)
         if not np.array_equal(a0, a1, equal_nan=True):
