@@ -12,7 +12,9 @@
  *   P1 neighbors   atoms of the tile that share a cell share their candidates: every candidate is
  *                  loaded ONCE and tested against all of them (ref predicate, src/nb.c:483-492);
  *                  hits keep (xd, yd, zd, Rj) in LDS — no second fetch of a neighbor
- *   P2 offsets
+ *   P2 offsets     the atoms' lists in the pool; whether the tile fits the launch
+ *   (caps)         round 6, "P1.5" in the tables: hits whose cap on the atom's sphere lies inside another hit's cap are
+ *                  dropped - their arcs lie inside the other's on every slice (lr2_prune_contained); offsets again
  *   P3 pairs       per (atom, neighbor): beta = atan2(yd, xd) + pi and the two coefficients of
  *                  2 Ri' cos(alpha) = b' + a' t, LINEAR in the slice height t (see lr2_record);
  *                  lists sorted by beta
@@ -27,7 +29,8 @@
  * A tile that does not fit the LDS capacities of the launch is redone at once as two halves; what still does not
  * fit goes to the next launch's work list (larger LDS lists, then the slab-backed first-generation kernel, atom by atom).
  *
- * Arithmetic: fp64 only; -ffp-contract=off; fma only where written.
+ * Arithmetic: fp64 only (the contained-caps test is a sufficient one in fp32: it decides what is dropped, never a value);
+ * -ffp-contract=off; fma only where written.
  */
 #ifndef LR2_KERNELS_H
 #define LR2_KERNELS_H

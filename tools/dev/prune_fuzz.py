@@ -30,7 +30,7 @@ def run(xyz, r, offs, ns, probe, env):
     return out.cpu().numpy(), st
 
 
-atoms = moved = 0
+atoms = moved = refused = 0
 t0 = time.time()
 for k in range(rounds):
     kind = rng.integers(0, 4)
@@ -53,7 +53,12 @@ for k in range(rounds):
     probe = float(rng.choice([0.0, 1.0, 1.4, 1.4, 2.5]))
     if k < int(os.environ.get("FUZZ_FROM", "0")) or (os.environ.get("FUZZ_ONLY") and str(k) not in os.environ["FUZZ_ONLY"].split(",")): continue
     if os.environ.get("FUZZ_TRACE"): print(f"round {k}: kind {kind} structs {nst} atoms {len(r)} slices {ns} probe {probe}", flush=True)
-    a0, st0 = run(xyz, r, offs, ns, probe, "0")
+    try:
+        a0, st0 = run(xyz, r, offs, ns, probe, "0")
+    except RuntimeError as e:   # an input beyond the engine's stated capacity (4096 neighbors per atom): reported, not computed
+        if "more neighbors than" not in str(e): raise
+        refused += 1
+        continue
     if os.environ.get("FUZZ_TRACE"): print("  off done", flush=True)
     for env in (None, "4"):
         a1, st1 = run(xyz, r, offs, ns, probe, env)
@@ -68,4 +73,4 @@ for k in range(rounds):
             sys.exit(1)
     atoms += len(r)
 print(f"{rounds} rounds, {atoms} atoms: identical areas with the contained caps dropped (as shipped and forced on) and not; {moved} runs on inputs with more than "
-      f"100 neighbors per atom in which atoms moved from the last launch into the tile kernel (< 1e-9 A^2), {time.time() - t0:.0f} s")
+      f"100 neighbors per atom in which atoms moved from the last launch into the tile kernel (< 1e-9 A^2); {refused} inputs refused (an atom with more than 4096 neighbors), {time.time() - t0:.0f} s")
