@@ -737,11 +737,13 @@ SASA_HD int lr2_prune_arg(int want, int TA, int pool) /* Lr2Args::prune: > 0 on 
 }
 /* on (> 0) or off by tile shape and density (host side; the figure was the number of caps wanted per list while the lists
    were filled in order of arrival, and is only a switch since they are chosen by the bins alone).
-   MI355X, kernel ms without / with the phase (tools/dev/prune_ab.sh, round 6): coils at 100 slices 3.04 / 2.62, at 50 slices
-   1.95 / 1.78, the reference's PDB entries at 100 slices 5.10 / 4.63.  At 20 slices the arcs it saves are a fifth as many
-   and the phase costs the same: random coils (20 neighbors per atom, three rounds of hits per tile of six atoms) 2.86 /
-   2.74 (mean of four runs each), but at protein density (41 - 48 neighbors, the cover filter already takes 2 of 3 items
-   before their arcs) the PDB entries 2.09 / 2.14 and the lattice globules 2.15 / 2.22: there it stays off. */
+   MI355X, kernel ms without / with the phase (tools/dev/prune_ab.sh, profiles/r06_prune_ab.txt, final form): coils at 100
+   slices 2.93 / 2.56, at 50 slices 1.95 / 1.81, the reference's PDB entries at 100 slices 5.12 / 4.68.  At 20 slices the
+   arcs it saves are a fifth as many and the phase costs the same: random coils (20 neighbors per atom, two or three rounds
+   of hits per tile of six atoms) 2.86 / 2.76, but at protein density (41 - 48 neighbors, the cover filter already takes 2 of
+   3 items before their arcs) the PDB entries 2.09 / 2.04 and the lattice globules 2.13 / 2.13 under the tool, and no
+   difference in the bench line's keys (profiles/r06_prune_bench_ab.txt): there it stays off (the first form - one list per
+   atom, filled in order of arrival - lost 2 - 5 % there). */
 static inline int lr2_prune_want(int ns, bool dense) { return ns >= 32 ? 4 : (dense ? 0 : 3); }
 SASA_D int lr2_cap_bin(float c) { const int b = (int)fmaf(c, 10.0f, -2.0f); return b < 0 ? 0 : (b > 7 ? 7 : b); } /* the cover filter's bins: 0.1 wide from 0.2 */
 /* Two lists per atom, one for either side of the x axis (the same-side rule above): a hit is tested against the largest caps
