@@ -726,7 +726,9 @@ SASA_D double lr2_acos_lower(double c)
 #ifndef LR2_PRUNE_ROUNDS
 #define LR2_PRUNE_ROUNDS(pairs) ((pairs) ? 3 : 2) /* rounds of 64 hits a tile may have to be pruned: 6 atoms x 20 neighbors need two, often three; the builds for more than 128 items (60 - 90 hits per tile) keep registers in scratch with more than two */
 #endif
-#define LR2_PRUNE_LIST 4   /* caps in one of an atom's two lists (lists of 6 and 8, all four read at once and tested in straight-line code: the same times) */
+#ifndef LR2_PRUNE_LIST
+#define LR2_PRUNE_LIST 4   /* caps in one of an atom's two lists.  MI355X, final form, kernel ms on coils at 20 / 100 slices (mean of three runs): 2: 2.86 / 2.71, 3: 2.78 / 2.59, 4: 2.78 / 2.56, 6: 2.77 / 2.54 */
+#endif
 #define LR2_DEAD_TAG 0xff  /* tag of a dropped hit (atoms of a tile: < 8) */
 struct __attribute__((aligned(16))) Lr2Cap { float x, y, z, c; };
 SASA_HD int lr2_prune_arg(int want, int TA, int pool) /* Lr2Args::prune: > 0 on (the chooser's figure, at most what a list holds), 0: off */
