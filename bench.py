@@ -960,6 +960,26 @@ def main():
             dts = (time.perf_counter() - ts) / n_sync
             out["synchronous_entry"] = {"value": n_atoms / dts, "unit": "atoms/s", "ms_per_step": 1e3 * dts,
                                         "identical_outputs": bool(torch.equal(got_async, d_sasa))}
+            if not sr and "FREESASA_AMD_PRUNE" not in os.environ:
+                # round 6: the same batch with the kernel's contained-caps phase switched off (neighbors whose
+                # cap lies inside another neighbor's are dropped before the pair records are made) - the same bits, and
+                # what the phase is worth on this box (the variable is read per call; removed again before anything else runs)
+                os.environ["FREESASA_AMD_PRUNE"] = "0"
+                try:
+                    ctx.lee_richards(d_xyz.data_ptr(), d_r.data_ptr(), offs, d_sasa.data_ptr(), d_tot.data_ptr(), probe=1.4, n_slices=args.slices)
+                    torch.cuda.synchronize()
+                    ts = time.perf_counter()
+                    for _ in range(n_sync):
+                        ctx.lee_richards(d_xyz.data_ptr(), d_r.data_ptr(), offs, d_sasa.data_ptr(), d_tot.data_ptr(), probe=1.4, n_slices=args.slices)
+                    torch.cuda.synchronize()
+                    dto = (time.perf_counter() - ts) / n_sync
+                finally:
+                    del os.environ["FREESASA_AMD_PRUNE"]
+                out["contained_caps_off"] = {"value": n_atoms / dto, "unit": "atoms/s", "ms_per_step": 1e3 * dto,
+                                             "identical_outputs": bool(torch.equal(got_async, d_sasa)),
+                                             "note": "synchronous entry with FREESASA_AMD_PRUNE=0; compare with synchronous_entry"}
+                ctx.lee_richards(d_xyz.data_ptr(), d_r.data_ptr(), offs, d_sasa.data_ptr(), d_tot.data_ptr(), probe=1.4, n_slices=args.slices)  # (back to the shipped launch state)
+                torch.cuda.synchronize()
         if world == 1 and args.workload == "coil_lr" and not args.no_secondary and (args.structs, args.atoms, args.slices) == (1000, 10000, 20):
             out.update(secondary_workloads(fa, torch, tools, d_xyz, d_r, offs, xyz, r, dev, local_rank, check=not args.no_cpu_baseline))
         if world == 1 and args.workload == "coil_lr" and not args.no_secondary and (args.structs, args.atoms, args.slices) == (1000, 10000, 20):
